@@ -1,0 +1,264 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference).
+
+Development-container tool (the reference tree does not travel to the GPU box;
+the vectors it produces do).  Re-run with:  python oracle/gen_golden.py
+Every expected output in the fixtures is produced by the reference's own classes
+(pypbr.models.CookTorranceBRDF, pypbr.materials.*, pypbr.utils.*); inputs are
+seeded draws (recipe of SURVEY.md section 8c) or crops of the PNG fixtures the
+reference's own tests hold (tests/data/{tiles,rocks}).
+
+Output keys:  in_*  = inputs,  out_* = fp32 reference outputs,  f64_* = the same
+reference code evaluated in float64 (maps poked into material._maps)
+used only for the conditioning-aware criterion.
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_import import import_reference, REFERENCE_ROOT  # noqa: E402
+
+pypbr = import_reference()
+from pypbr.materials import BasecolorMetallicMaterial, DiffuseSpecularMaterial, MaterialBase  # noqa: E402
+from pypbr.models import CookTorranceBRDF  # noqa: E402
+from pypbr.utils import linear_to_srgb, srgb_to_linear  # noqa: E402
+from pypbr.io import load_material_from_folder  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+LIGHTS = {
+    # name: (light_type, light vector, light_size)
+    "pt1": ("point", [0.1, 0.1, 1.0], 1.0),
+    "pt5": ("point", [0.0, 10.0, 10.0], 5.0),
+    "dir": ("directional", [0.3, -0.2, 1.0], None),
+}
+VIEW0 = [0.0, 0.0, 1.0]
+INT0 = [1.0, 1.0, 1.0]
+VIEW1 = [0.2, -0.1, 1.0]
+INT1 = [2.0, 1.6, 1.2]
+
+
+def draw(seed, H, W):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(3, H, W, generator=g)
+    n = torch.rand(3, H, W, generator=g) * 2 - 1
+    r = torch.rand(1, H, W, generator=g)
+    m = torch.rand(1, H, W, generator=g)
+    s = torch.rand(3, H, W, generator=g)
+    return a, n, r, m, s
+
+
+def draw_realistic(seed, H, W):
+    """Criterion (i) inputs: roughness in [0.05,1], normals with z>0."""
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(3, H, W, generator=g)
+    nxy = torch.rand(2, H, W, generator=g) - 0.5
+    n = torch.cat([nxy, torch.ones(1, H, W)], dim=0)
+    n = n / n.norm(dim=0, keepdim=True)
+    r = torch.rand(1, H, W, generator=g) * 0.95 + 0.05
+    m = torch.rand(1, H, W, generator=g)
+    s = torch.rand(3, H, W, generator=g)
+    return a, n, r, m, s
+
+
+def make_material(kind, a, n, r, m, s, dtype=torch.float32, albedo_is_srgb=True, specular_is_srgb=True):
+    """Builds the reference material.  fp64: poke maps past the FloatTensor gate."""
+    if dtype == torch.float32:
+        if kind == "metallic":
+            mat = BasecolorMetallicMaterial(albedo=a, normal=n, roughness=r, metallic=m,
+                                            albedo_is_srgb=albedo_is_srgb)
+        else:
+            mat = DiffuseSpecularMaterial(albedo=a, normal=n, roughness=r, specular=s,
+                                          albedo_is_srgb=albedo_is_srgb, specular_is_srgb=specular_is_srgb)
+        if n is None:
+            mat.normal = None
+        return mat
+    if kind == "metallic":
+        mat = BasecolorMetallicMaterial(albedo_is_srgb=albedo_is_srgb)
+        mat._maps["metallic"] = m.double()
+    else:
+        mat = DiffuseSpecularMaterial(albedo_is_srgb=albedo_is_srgb, specular_is_srgb=specular_is_srgb)
+        mat._maps["specular"] = s.double()
+    mat._maps["albedo"] = a.double()
+    mat._maps["normal"] = None if n is None else n.double()
+    mat._maps["roughness"] = r.double()
+    return mat
+
+
+def render(mat, light_key, view=VIEW0, inten=INT0, return_srgb=True, dtype=torch.float32):
+    ltype, lvec, lsize = LIGHTS[light_key]
+    brdf = CookTorranceBRDF(light_type=ltype)
+    out = brdf(mat, torch.tensor(view, dtype=dtype), torch.tensor(lvec, dtype=dtype),
+               torch.tensor(inten, dtype=dtype), lsize, return_srgb=return_srgb)
+    assert out.dtype == dtype
+    return out
+
+
+def sha12(t):
+    return hashlib.sha1(np.ascontiguousarray(t).tobytes()).hexdigest()[:12]
+
+
+def random_set(name, a, n, r, m, s, manifest, with_f64=False, full=True):
+    d = {"in_albedo": a, "in_normal": n, "in_roughness": r, "in_metallic": m, "in_specular": s}
+    outs = {}
+    for kind in ("metallic", "specular"):
+        mat = make_material(kind, a, n, r, m, s)
+        for lk in LIGHTS:
+            for srgb in (True, False):
+                if not full and not srgb and lk == "pt5":
+                    continue
+                key = f"{kind}_{lk}_{'srgb' if srgb else 'lin'}"
+                outs[key] = render(mat, lk, return_srgb=srgb)
+        # non-trivial view direction + coloured, >1 intensity
+        outs[f"{kind}_pt1_srgb_view1"] = render(mat, "pt1", VIEW1, INT1)
+        outs[f"{kind}_dir_srgb_view1"] = render(mat, "dir", VIEW1, INT1)
+        # +Z default normal branch (cooktorrance.py:147-152; reachable after mat.normal = None)
+        mat0 = make_material(kind, a, None, r, m, s)
+        outs[f"{kind}_pt1_srgb_nonormal"] = render(mat0, "pt1")
+        outs[f"{kind}_dir_srgb_nonormal"] = render(mat0, "dir")
+        # stored maps already linear
+        matl = make_material(kind, a, n, r, m, s, albedo_is_srgb=False, specular_is_srgb=False)
+        outs[f"{kind}_pt1_srgb_linmaps"] = render(matl, "pt1")
+        if with_f64:
+            mat64 = make_material(kind, a, n, r, m, s, dtype=torch.float64)
+            for lk in ("pt1", "dir"):
+                d[f"f64_{kind}_{lk}_srgb"] = render(mat64, lk, dtype=torch.float64).numpy()
+                d[f"f64_{kind}_{lk}_lin"] = render(mat64, lk, return_srgb=False, dtype=torch.float64).numpy()
+    # metallic -> diffuse/specular conversion, then render (H13, quirk F6)
+    matm = make_material("metallic", a, n, r, m, s)
+    conv = matm.to_diffuse_specular_material()
+    assert conv.albedo_is_srgb is False and conv.specular_is_srgb is True
+    d["out_conv_diffuse"] = conv.albedo.numpy()
+    d["out_conv_specular"] = conv.specular.numpy()
+    outs["converted_dir_srgb_quirk"] = render(conv, "dir")
+    outs["converted_pt1_srgb_quirk"] = render(conv, "pt1")
+    conv.specular_is_srgb = False
+    outs["converted_dir_srgb_fixed"] = render(conv, "dir")
+    outs["converted_pt1_srgb_fixed"] = render(conv, "pt1")
+    # diffuse/specular -> basecolor/metallic (H14): raw specular, 3-channel metallic
+    mats = make_material("specular", a, n, r, m, s)
+    back = mats.to_basecolor_metallic_material()
+    d["out_back_basecolor"] = back.albedo.numpy()
+    d["out_back_metallic"] = back.metallic.numpy()
+    assert back.metallic.shape[0] == 3
+
+    for k, v in outs.items():
+        d["out_" + k] = v.numpy()
+    d = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+    np.savez(os.path.join(GOLDEN, name + ".npz"), **d)
+    manifest["sets"][name] = {
+        k: {"sha1_12": sha12(v), "mean": float(np.asarray(v, dtype=np.float64).mean()),
+            "shape": list(v.shape), "dtype": str(v.dtype)}
+        for k, v in d.items()}
+
+
+def fixture_set(name, folder, crop, manifest):
+    """96x96 crops of the maps the reference loads from its own PNG fixtures."""
+    y0, x0, hh, ww = crop
+    d = {}
+    for kind in ("metallic", "specular"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mat = load_material_from_folder(os.path.join(REFERENCE_ROOT, "tests", "data", folder),
+                                            preferred_workflow=kind)
+        maps = {k: v[:, y0:y0 + hh, x0:x0 + ww].contiguous() for k, v in mat._maps.items()
+                if v is not None and k in ("albedo", "normal", "roughness", "metallic", "specular")}
+        if kind == "metallic":
+            m2 = BasecolorMetallicMaterial(albedo=maps["albedo"], normal=None, roughness=maps["roughness"],
+                                           metallic=maps["metallic"])
+        else:
+            m2 = DiffuseSpecularMaterial(albedo=maps["albedo"], normal=None, roughness=maps["roughness"],
+                                         specular=maps["specular"])
+        m2._maps["normal"] = maps["normal"]  # keep the decoded map exactly as loaded
+        for k, v in maps.items():
+            d[f"in_{kind}_{k}"] = v.numpy()
+        for lk in ("pt1", "dir"):
+            d[f"out_{kind}_{lk}_srgb"] = render(m2, lk).numpy()
+            d[f"out_{kind}_{lk}_lin"] = render(m2, lk, return_srgb=False).numpy()
+        m64 = make_material(kind, maps["albedo"], maps["normal"], maps["roughness"],
+                            maps.get("metallic"), maps.get("specular"), dtype=torch.float64)
+        d[f"f64_{kind}_pt1_srgb"] = render(m64, "pt1", dtype=torch.float64).numpy()
+    np.savez_compressed(os.path.join(GOLDEN, name + ".npz"), **d)
+    manifest["sets"][name] = {
+        k: {"sha1_12": sha12(v), "mean": float(np.asarray(v, dtype=np.float64).mean()),
+            "shape": list(v.shape), "dtype": str(v.dtype)} for k, v in d.items()}
+
+
+def misc_set(manifest):
+    d = {}
+    x = torch.linspace(-0.25, 1.25, 1537)
+    g = torch.Generator().manual_seed(5)
+    xr = torch.rand(3, 33, 31, generator=g)
+    knees = torch.tensor([0.0, 0.0031307, 0.0031308, 0.0031309, 0.04044, 0.04045, 0.04046, 1.0])
+    for nm, t in (("ramp", x), ("rand", xr), ("knees", knees)):
+        d[f"in_colour_{nm}"] = t.numpy()
+        d[f"out_s2l_{nm}"] = srgb_to_linear(t).numpy()
+        d[f"out_l2s_{nm}"] = linear_to_srgb(t).numpy()
+    # normal decode (base.py:191-242)
+    n01 = torch.rand(3, 19, 23, generator=g)
+    nneg = torch.rand(3, 19, 23, generator=g) * 2 - 1
+    n2 = torch.rand(2, 19, 23, generator=g)
+    for nm, t in (("rgb01", n01), ("signed", nneg), ("xy", n2)):
+        mat = MaterialBase(normal=t)
+        d[f"in_normal_{nm}"] = t.numpy()
+        d[f"out_normal_{nm}"] = mat.normal.numpy()
+    # multi-light composition (H12) out of single reference calls
+    a, n, r, m, s = draw_realistic(21, 24, 40)
+    mat = make_material("metallic", a, n, r, m, s)
+    pos = torch.tensor([[np.cos(t), np.sin(t), 1.0] for t in np.linspace(0, 2 * np.pi, 4, endpoint=False)],
+                       dtype=torch.float32)
+    inten = torch.tensor([[0.9, 0.8, 0.7], [0.5, 0.6, 0.7], [0.3, 0.3, 0.3], [0.6, 0.2, 0.4]])
+    acc = torch.zeros(3, 24, 40)
+    for l in range(4):
+        acc = acc + CookTorranceBRDF("point")(mat, torch.tensor(VIEW0), pos[l], inten[l], 1.0, return_srgb=False)
+    acc = acc.clamp(0, 1)
+    for k, v in (("albedo", a), ("normal", n), ("roughness", r), ("metallic", m)):
+        d[f"in_ml_{k}"] = v.numpy()
+    d["in_ml_lights"] = pos.numpy()
+    d["in_ml_intensities"] = inten.numpy()
+    d["out_ml_lin"] = acc.numpy()
+    d["out_ml_srgb"] = linear_to_srgb(acc).numpy()
+    np.savez(os.path.join(GOLDEN, "misc.npz"), **d)
+    manifest["sets"]["misc"] = {
+        k: {"sha1_12": sha12(v), "mean": float(np.asarray(v, dtype=np.float64).mean()),
+            "shape": list(v.shape), "dtype": str(v.dtype)} for k, v in d.items()}
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(8)
+    manifest = {
+        "generator": "oracle/gen_golden.py",
+        "reference": "giuvecchio/PyPBR at /root/reference (imported, unmodified)",
+        "torch": torch.__version__,
+        "aten_threads": torch.get_num_threads(),
+        "lights": LIGHTS, "view0": VIEW0, "intensity0": INT0, "view1": VIEW1, "intensity1": INT1,
+        "sets": {},
+    }
+    random_set("rand64", *draw(1234, 64, 64), manifest, with_f64=True)
+    random_set("rand37x53", *draw(1234, 37, 53), manifest, full=False)
+    random_set("rand1x1", *draw(7, 1, 1), manifest, full=False)
+    random_set("rand1x17", *draw(7, 1, 17), manifest, full=False)
+    random_set("rand5x1", *draw(8, 5, 1), manifest, full=False)
+    random_set("real48", *draw_realistic(99, 48, 48), manifest, with_f64=True)
+    fixture_set("tiles96", "tiles", (300, 420, 96, 96), manifest)
+    fixture_set("rocks96", "rocks", (512, 100, 96, 96), manifest)
+    misc_set(manifest)
+    with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    tot = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))
+    print("golden fixtures written: %.1f KiB" % (tot / 1024))
+    # SURVEY.md 8c known answers
+    ka = manifest["sets"]["rand64"]
+    print("rand64 metallic_pt1_srgb", ka["out_metallic_pt1_srgb"]["sha1_12"], ka["out_metallic_pt1_srgb"]["mean"])
+
+
+if __name__ == "__main__":
+    main()

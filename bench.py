@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of fused Cook-Torrance evaluation on MI355X.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): one
+4096x4096 BasecolorMetallicMaterial per GPU (albedo sRGB, decoded normal, roughness,
+metallic; fp32 planar), point light, sRGB output.  A "step" is one pass of the hot
+path over that batch = ONE launch of the fused kernel through the C ABI
+(pbr_cook_torrance), inputs already resident in HBM.  With --gpus N every rank owns
+its own material (independent materials shard with no data-path collective, weak
+scaling); the light/view parameter block is broadcast once from rank 0 over RCCL.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--no-cpu-baseline]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
+  roofline     -- achieved algorithmic HBM GB/s of the kernel (44 B/pixel x pixels per launch /
+                  average launch duration from HIP events on the launch stream) vs 8 TB/s
+  cpu_baseline -- the ATen-level restatement of the reference's CPU path (oracle/torch_oracle.py,
+                  kind "port": bit-equal to the reference in the dev container) timed on this
+                  host's cores on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_BUFFER_SETS = 3              # rotate map sets: 704 MiB per step never re-hits the 256 MiB Infinity Cache anyway
+
+
+def synth_material(size, device, seed):
+    """SURVEY.md 8d config 2 recipe: U[0,1) albedo/metallic, roughness remapped to [0.05,1],
+    normal = normalize([U(-.5,.5), U(-.5,.5), 1]) stored decoded."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    H = W = size
+    albedo = torch.rand(3, H, W, device=device, generator=g)
+    nxy = torch.rand(2, H, W, device=device, generator=g) - 0.5
+    normal = torch.cat([nxy, torch.ones(1, H, W, device=device)], 0)
+    normal = normal / normal.norm(dim=0, keepdim=True)
+    rough = torch.rand(1, H, W, device=device, generator=g) * 0.95 + 0.05
+    metal = torch.rand(1, H, W, device=device, generator=g)
+    return albedo, normal, rough, metal
+
+
+def cpu_baseline(sample_size, passes):
+    """Times the ATen-level oracle (the reference's op sequence) on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch_oracle
+    a, n, r, m = [t.cpu() for t in synth_material(sample_size, "cpu", 99)]
+    kw = dict(view=torch.tensor([0.0, 0.0, 1.0]), light=torch.tensor([0.1, 0.1, 1.0]),
+              intensity=torch.tensor([1.0, 1.0, 1.0]), light_type="point", light_size=1.0)
+    small = [t[:, :512, :512].contiguous() for t in (a, n, r, m)]
+    torch_oracle.cook_torrance(*small, None, **kw)                                  # warm-up (cold first call ~1 s)
+    # ATen's intra-op pool defaults to every host core; the reference's op mix scales badly past a few
+    # threads, so give it its best thread count: probe on a 512x512 crop
+    best, best_t = torch.get_num_threads(), float("inf")
+    for nt in sorted({1, 4, 8, 16, 32, torch.get_num_threads()}):
+        if nt > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nt)
+        t0 = time.perf_counter()
+        torch_oracle.cook_torrance(*small, None, **kw)
+        dt = time.perf_counter() - t0
+        if dt < best_t:
+            best, best_t = nt, dt
+    torch.set_num_threads(best)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        torch_oracle.cook_torrance(a, n, r, m, None, **kw)
+    dt = time.perf_counter() - t0
+    return {"value": round(sample_size * sample_size * passes / dt / 1e6, 3), "unit": "Mpixels/s",
+            "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
+            "sample": f"{passes} passes of one {sample_size}x{sample_size} material, same recipe and light as the GPU "
+                      f"workload, oracle/torch_oracle.py (ATen ops of the reference) at its fastest ATen thread count, {dt:.1f} s"}
+
+
+def recorded_traffic(kernel_name):
+    """HBM bytes per launch from the PMC passes (rocprofv3 --pmc, collected separately and committed
+    under profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        ent = rec.get(kernel_name)
+        return None if ent is None else ent.get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-passes", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and not distributed:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+
+    from pypbr_amd import functional as F
+    from pypbr_amd.distributed import broadcast_light_block
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device; pypbr_amd has no CPU path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if distributed:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    # light/view parameters: owned by rank 0, broadcast over RCCL/xGMI (400 B, once per change)
+    params = dict(view_dir=[0.0, 0.0, 1.0], light=[[0.1, 0.1, 1.0]], light_intensity=[[1.0, 1.0, 1.0]], light_size=1.0)
+    if distributed:
+        params = broadcast_light_block(params if rank == 0 else None, device=device, src=0)
+
+    plans = []
+    for i in range(N_BUFFER_SETS):
+        a, n, r, m = synth_material(args.size, device, 1234 + rank * 16 + i)
+        plans.append(F.plan_cook_torrance(a, n, r, m, view_dir=params["view_dir"], light=params["light"],
+                                          light_intensity=params["light_intensity"], light_type="point",
+                                          light_size=params["light_size"]))
+    kernel = plans[0].kernel_name
+    bpp = plans[0].bytes_per_pixel
+    pixels = args.size * args.size
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    def barrier():
+        if distributed:
+            dist.barrier(device_ids=[local_rank])
+
+    for i in range(args.warmup):
+        plans[i % N_BUFFER_SETS].launch(stream)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                   # same stream the kernels are launched on
+    for i in range(args.steps):
+        plans[i % N_BUFFER_SETS].launch(stream)
+    ev1.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+
+    if distributed:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    out = plans[0].result
+    assert bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        value = world * pixels * args.steps / elapsed / 1e6
+        achieved = bpp * pixels / (kernel_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Mpixels/s Cook-Torrance eval, 4K maps",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Batch=1 {args.size}x{args.size} BasecolorMetallicMaterial per GPU, point light, "
+                                   f"fused HIP kernel, fp32 maps, sRGB in/out (BASELINE.json configs[1])",
+                       "kernel": kernel, "pixels_per_launch": pixels, "bytes_per_pixel": bpp,
+                       "parallelism": f"material-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(kernel),
+                         "kernel_us": round(kernel_ms * 1e3, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_passes)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+/*
+ * pbr_hip.h -- C ABI of libpbr_hip.so: fused Cook-Torrance evaluation of PBR
+ * material maps on AMD MI355X (gfx950), plus the map conversions the path pulls in.
+ *
+ * This is the drop-in boundary of the build.  The reference
+ * (giuvecchio/PyPBR) has no FFI: its hot path sits behind a Python callable,
+ *     pypbr.models.CookTorranceBRDF.forward      pypbr/models/cooktorrance.py:68-182
+ * and the entry points below are what a native binding for that path binds
+ * (INTEGRATION.md shows the ctypes stub a PyPBR maintainer would add).  Plain
+ * pointers and sizes only -- no torch types.  All map pointers are DEVICE pointers;
+ * light/view parameters are HOST values (they travel in the kernel-argument
+ * segment, i.e. in SGPRs: the wave-uniform broadcast is free).
+ *
+ * Threading: every call only enqueues work on `stream` (a hipStream_t passed as
+ * void*, NULL = the null stream); no call synchronises with the host, allocates
+ * device memory, or keeps state between calls (same contract as the reference:
+ * synchronous-looking, stateless, re-entrant).  Inputs are never written.
+ *
+ * Map layout (pypbr/materials/base.py: maps are (C,H,W) float32, channel-first):
+ * planar [B][C][H][W], rows contiguous (row stride == width).  `batch_stride`
+ * and `channel_stride` are in ELEMENTS, so a row band of a taller map, or one
+ * map shared by the whole batch (batch_stride = 0), is passed without a copy.
+ */
+#ifndef PBR_HIP_H
+#define PBR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBR_HIP_ABI_VERSION 1
+#define PBR_MAX_LIGHTS 16
+
+/* ---- status codes (negative = caller error, positive = HIP runtime error code + 1000) */
+enum {
+    PBR_OK = 0,
+    PBR_ERR_NULL_MAP = -1,        /* a required map pointer is NULL */
+    PBR_ERR_WORKFLOW = -2,        /* neither metallic nor specular: cooktorrance.py:115-118 ValueError */
+    PBR_ERR_LIGHT_TYPE = -3,      /* cooktorrance.py:62-65 ValueError */
+    PBR_ERR_SHAPE = -4,           /* non-positive extent, band outside the map, > PBR_MAX_LIGHTS */
+    PBR_ERR_DTYPE = -5,
+    PBR_ERR_CHANNELS = -6,        /* base.py:219 "Normal map must have 2 or 3 channels." */
+    PBR_ERR_NO_DEVICE = -7
+};
+
+enum { PBR_F32 = 0, PBR_F16 = 1 };                 /* storage type of maps */
+enum { PBR_LIGHT_DIRECTIONAL = 0, PBR_LIGHT_POINT = 1 };   /* cooktorrance.py:61-65 */
+enum {
+    PBR_WORKFLOW_METALLIC = 0,    /* BasecolorMetallicMaterial: cooktorrance.py:103-107 */
+    PBR_WORKFLOW_SPECULAR = 1,    /* DiffuseSpecularMaterial:   cooktorrance.py:108-114 */
+    PBR_WORKFLOW_CONVERTED = 2    /* metallic maps, converted in-kernel by
+                                     to_diffuse_specular_material (metallic.py:71-120),
+                                     rendered in the specular workflow (config 3) */
+};
+
+typedef struct pbr_map {
+    const void *data;             /* device pointer, NULL = map absent */
+    int64_t batch_stride;         /* elements between materials */
+    int64_t channel_stride;       /* elements between channel planes */
+} pbr_map;
+
+/*
+ * One evaluation = CookTorranceBRDF.forward for `batch` materials and `n_lights`
+ * lights.  Replaces cooktorrance.py:92-182 plus the lazy conversions it calls:
+ * MaterialBase.linear_albedo (base.py:262-277), DiffuseSpecularMaterial.linear_specular
+ * (diffuse.py:76-91), utils.srgb_to_linear / linear_to_srgb (utils/functions.py:31-66).
+ */
+typedef struct pbr_render_desc {
+    int32_t abi_version;          /* PBR_HIP_ABI_VERSION */
+    int32_t batch;                /* B >= 1.  The reference is unbatched (B = 1); B > 1 == a loop of calls */
+    int32_t height;               /* rows of this band */
+    int32_t width;                /* W */
+    int32_t height_total;         /* rows of the full map: the point-light y grid spans it (cooktorrance.py:133) */
+    int32_t y_offset;             /* first row of the band inside the full map (0 for a whole map) */
+
+    int32_t map_dtype;            /* PBR_F32 | PBR_F16: albedo/normal/roughness/metallic/specular */
+    int32_t out_dtype;            /* PBR_F32 | PBR_F16 */
+    int32_t workflow;             /* PBR_WORKFLOW_* */
+    int32_t light_type;           /* PBR_LIGHT_* */
+    int32_t n_lights;             /* L in [1, PBR_MAX_LIGHTS]; L > 1: per-light clamp, sum, clamp, encode */
+    int32_t albedo_is_srgb;       /* MaterialBase.albedo_is_srgb (base.py:72) */
+    int32_t specular_is_srgb;     /* DiffuseSpecularMaterial.specular_is_srgb (diffuse.py:64);
+                                     CONVERTED: 1 reproduces the upstream default of the converted
+                                     material (already-linear specular decoded again), 0 = decoded once */
+    int32_t return_srgb;          /* forward(..., return_srgb) cooktorrance.py:179-180 */
+
+    pbr_map albedo;               /* 3 channels, required */
+    pbr_map normal;               /* 3 channels, decoded to [-1,1]; data NULL = +Z (cooktorrance.py:147-152) */
+    pbr_map roughness;            /* 1 channel, required */
+    pbr_map metallic;             /* 1 channel: METALLIC / CONVERTED */
+    pbr_map specular;             /* 3 channels: SPECULAR */
+    void *out;                    /* [B][3][height][width], contiguous */
+
+    float view_dir[3];            /* un-normalised, as handed to forward (normalised like F.normalize, :95) */
+    float light_size;             /* point lights; <= 0 or NaN means "falsy": 1.0 (cooktorrance.py:130) */
+    float lights[PBR_MAX_LIGHTS][3];       /* direction (normalised here, :126) or position (:129) */
+    float intensities[PBR_MAX_LIGHTS][3];  /* light_intensity per light (:96) */
+} pbr_render_desc;
+
+/* Enqueue the fused kernel.  Returns PBR_OK or an error code; never blocks. */
+int pbr_cook_torrance(const pbr_render_desc *desc, void *stream);
+
+/* ---- stand-alone map conversions (same arithmetic as the fused kernel) ------------- */
+
+/* utils.srgb_to_linear, pypbr/utils/functions.py:31-47.  n elements, in-place allowed. */
+int pbr_srgb_to_linear(const void *src, void *dst, size_t n, int dtype, void *stream);
+/* utils.linear_to_srgb, pypbr/utils/functions.py:50-66. */
+int pbr_linear_to_srgb(const void *src, void *dst, size_t n, int dtype, void *stream);
+
+/*
+ * BasecolorMetallicMaterial.to_diffuse_specular_material, metallic.py:98-108:
+ * diffuse = a(1-m), specular = 0.04(1-m) + a m on LINEAR albedo (decoded here when
+ * albedo_is_srgb).  albedo [B][3][P], metallic [B][1][P] -> diffuse, specular [B][3][P].
+ */
+int pbr_metallic_to_specular(const void *albedo, const void *metallic, void *diffuse, void *specular,
+                             int32_t batch, int64_t pixels, int albedo_is_srgb, int dtype, void *stream);
+/*
+ * DiffuseSpecularMaterial.to_basecolor_metallic_material, diffuse.py:128-147 (raw
+ * specular, 3-channel metallic).  diffuse, specular [n] -> basecolor, metallic [n].
+ */
+int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *basecolor, void *metallic,
+                             size_t n, int albedo_is_srgb, int dtype, void *stream);
+/*
+ * MaterialBase._process_normal_map, base.py:191-242.  channels = 2 or 3, planar
+ * [channels][pixels] -> [3][pixels].  3 channels: kept as-is when any value is
+ * negative, else x*2-1 and unit length.  `workspace` = 4 bytes of device memory
+ * (the min<0 flag; zeroed by the call).
+ */
+int pbr_decode_normal(const void *src, void *dst, int32_t channels, int64_t pixels, int dtype,
+                      void *workspace, void *stream);
+
+/* ---- introspection / tuning (bench and tests only) --------------------------------- */
+int pbr_abi_version(void);
+/* sizeof(pbr_render_desc) as compiled: bindings check their struct layout against it. */
+size_t pbr_render_desc_size(void);
+const char *pbr_error_string(int code);
+/* Name of the kernel the descriptor dispatches to (no launch); NULL on a bad descriptor. */
+const char *pbr_kernel_name(const pbr_render_desc *desc);
+/* Algorithmic HBM bytes per pixel of that dispatch: reads + writes. */
+int pbr_bytes_per_pixel(const pbr_render_desc *desc);
+/* Tuning knobs for A/B runs inside one process; returns the previous value. */
+enum { PBR_TUNE_NONTEMPORAL = 0, PBR_TUNE_BLOCK_LOG2 = 1 };   /* nt hint on/off; workgroup = 1 << value lanes (6..8) */
+int pbr_set_tuning(int knob, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PBR_HIP_H */

@@ -1,0 +1,120 @@
+"""ctypes binding of libpbr_hip.so (the C ABI declared in include/pbr_hip.h).
+
+There is no Python/ATen fallback behind these calls: if the shared library is
+missing, or no HIP device is present when a kernel has to run, the call raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpbr_hip.so")
+
+ABI_VERSION = 1
+MAX_LIGHTS = 16
+
+F32, F16 = 0, 1
+LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
+WORKFLOW_METALLIC, WORKFLOW_SPECULAR, WORKFLOW_CONVERTED = 0, 1, 2
+TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2 = 0, 1
+
+OK = 0
+ERR_NULL_MAP, ERR_WORKFLOW, ERR_LIGHT_TYPE, ERR_SHAPE, ERR_DTYPE, ERR_CHANNELS, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
+
+# every symbol include/pbr_hip.h declares (tests/test_abi.py checks the export table against the header)
+EXPORTS = (
+    "pbr_cook_torrance", "pbr_srgb_to_linear", "pbr_linear_to_srgb", "pbr_metallic_to_specular",
+    "pbr_specular_to_metallic", "pbr_decode_normal", "pbr_abi_version", "pbr_error_string",
+    "pbr_kernel_name", "pbr_bytes_per_pixel", "pbr_set_tuning", "pbr_render_desc_size",
+)
+
+
+class PbrMap(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("batch_stride", ctypes.c_int64), ("channel_stride", ctypes.c_int64)]
+
+
+class RenderDesc(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32), ("batch", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("width", ctypes.c_int32), ("height_total", ctypes.c_int32), ("y_offset", ctypes.c_int32),
+        ("map_dtype", ctypes.c_int32), ("out_dtype", ctypes.c_int32), ("workflow", ctypes.c_int32),
+        ("light_type", ctypes.c_int32), ("n_lights", ctypes.c_int32), ("albedo_is_srgb", ctypes.c_int32),
+        ("specular_is_srgb", ctypes.c_int32), ("return_srgb", ctypes.c_int32),
+        ("albedo", PbrMap), ("normal", PbrMap), ("roughness", PbrMap), ("metallic", PbrMap), ("specular", PbrMap),
+        ("out", ctypes.c_void_p),
+        ("view_dir", ctypes.c_float * 3), ("light_size", ctypes.c_float),
+        ("lights", (ctypes.c_float * 3) * MAX_LIGHTS), ("intensities", (ctypes.c_float * 3) * MAX_LIGHTS),
+    ]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Loads libpbr_hip.so once.  torch is imported first so that the process keeps ONE
+    HIP runtime (torch's bundled libamdhip64.so.7; ours has the same soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads libamdhip64 before our library asks for it)
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pypbr_amd/csrc`.  pypbr_amd has no CPU fallback." % LIB_PATH)
+    try:
+        L = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+    L.pbr_cook_torrance.argtypes = [ctypes.POINTER(RenderDesc), vp]
+    L.pbr_cook_torrance.restype = ctypes.c_int
+    L.pbr_srgb_to_linear.argtypes = [vp, vp, sz, ctypes.c_int, vp]
+    L.pbr_linear_to_srgb.argtypes = [vp, vp, sz, ctypes.c_int, vp]
+    L.pbr_metallic_to_specular.argtypes = [vp, vp, vp, vp, i32, i64, ctypes.c_int, ctypes.c_int, vp]
+    L.pbr_specular_to_metallic.argtypes = [vp, vp, vp, vp, sz, ctypes.c_int, ctypes.c_int, vp]
+    L.pbr_decode_normal.argtypes = [vp, vp, i32, i64, ctypes.c_int, vp, vp]
+    for name in ("pbr_srgb_to_linear", "pbr_linear_to_srgb", "pbr_metallic_to_specular",
+                 "pbr_specular_to_metallic", "pbr_decode_normal", "pbr_abi_version", "pbr_set_tuning",
+                 "pbr_bytes_per_pixel"):
+        getattr(L, name).restype = ctypes.c_int
+    L.pbr_error_string.argtypes = [ctypes.c_int]
+    L.pbr_error_string.restype = ctypes.c_char_p
+    L.pbr_kernel_name.argtypes = [ctypes.POINTER(RenderDesc)]
+    L.pbr_kernel_name.restype = ctypes.c_char_p
+    L.pbr_bytes_per_pixel.argtypes = [ctypes.POINTER(RenderDesc)]
+    L.pbr_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.pbr_render_desc_size.restype = ctypes.c_size_t
+    if L.pbr_render_desc_size() != ctypes.sizeof(RenderDesc):
+        raise NativeLibraryError("pbr_render_desc layout mismatch: library %d bytes, binding %d"
+                                 % (L.pbr_render_desc_size(), ctypes.sizeof(RenderDesc)))
+    if L.pbr_abi_version() != ABI_VERSION:
+        raise NativeLibraryError("libpbr_hip.so ABI %d, binding expects %d" % (L.pbr_abi_version(), ABI_VERSION))
+    _lib = L
+    return L
+
+
+def error_string(code: int) -> str:
+    return lib().pbr_error_string(code).decode()
+
+
+def check(code: int):
+    """Maps C-ABI status codes onto the exceptions the reference raises for the same
+    condition (cooktorrance.py:62-65, :115-118; base.py:219)."""
+    if code == OK:
+        return
+    msg = error_string(code)
+    if code in (ERR_WORKFLOW, ERR_LIGHT_TYPE, ERR_CHANNELS, ERR_SHAPE, ERR_NULL_MAP):
+        raise ValueError(msg)
+    if code == ERR_DTYPE:
+        raise TypeError(msg)
+    raise RuntimeError("HIP error %d: %s" % (code, msg))
+
+
+def require_device():
+    """The product has no CPU path: anything that computes needs a ROCm device."""
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("pypbr_amd needs a ROCm/HIP device (MI355X); there is no CPU fallback")

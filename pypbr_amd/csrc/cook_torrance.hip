@@ -1,0 +1,219 @@
+// cook_torrance.hip -- launcher of the fused Cook-Torrance kernels (C ABI: pbr_cook_torrance).
+//
+// One launch replaces the ~130 whole-map ATen kernels of the reference's
+// CookTorranceBRDF.forward (/root/reference/pypbr/models/cooktorrance.py:92-182): sRGB
+// decode of albedo/specular, workflow switch (or the in-kernel metallic -> diffuse/specular
+// conversion), light geometry, normal normalisation, Fresnel/GGX/Smith, compositing, clamp
+// and sRGB encode, for a [B,C,H,W] planar batch and up to PBR_MAX_LIGHTS lights.
+//
+// Roofline: HBM-bound streaming kernel, zero reuse: 32 B read + 12 B written per pixel
+// (metallic workflow, fp32).  Design for that:
+//   * each lane owns 4 consecutive pixels of a row: one 16-byte load per input plane
+//     (8 x global_load_dwordx4 in flight per lane, 8 KiB per wave) and one 16-byte store
+//     per output plane; a wave covers 1 KiB-contiguous segments of every plane;
+//   * loads/stores carry the non-temporal hint (each byte is touched once; 4K maps are
+//     64 MiB per plane, nothing fits L2/MALL);
+//   * view / light / intensity / grid parameters live in the kernel-argument segment and
+//     are read with scalar loads: they sit in SGPRs, which IS the wave-wide broadcast on
+//     CDNA (a cross-lane shuffle would cost VALU/LDS slots for something the scalar unit
+//     gives for free).  Directional-light terms (L, V+L, Fresnel power) are pixel
+//     independent and are folded on the host; point-light row terms are shared by the 4
+//     pixels of a lane;
+//   * no LDS: there is no inter-pixel reuse to stage ("LDS staging").
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/pbr_hip.h"
+#include "ct_kernel.hpp"
+
+namespace pbr {
+
+// Measured A/B on MI355X, 4096x4096 point/metallic (tools/tune.py, DESIGN.md "Schedule experiments"):
+// nt hint on: -5 % time; one-wave workgroups: -2 % vs 256 lanes (no LDS/barrier, so nothing is lost).
+static int g_nontemporal = 1;
+static int g_block_log2 = 6;       // workgroup size: 64 (6), 128 (7) or 256 (8) lanes
+
+static inline void normalize_host(const float v[3], float o[3]) {   // F.normalize(v, dim=0), fp32
+    const float nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float d = nrm > 1e-12f ? nrm : 1e-12f;
+    o[0] = v[0] / d; o[1] = v[1] / d; o[2] = v[2] / d;
+}
+
+static int validate(const pbr_render_desc *d) {
+    if (!d) return PBR_ERR_NULL_MAP;
+    if (d->abi_version != PBR_HIP_ABI_VERSION) return PBR_ERR_SHAPE;
+    if (d->light_type != PBR_LIGHT_DIRECTIONAL && d->light_type != PBR_LIGHT_POINT) return PBR_ERR_LIGHT_TYPE;
+    if (d->workflow < 0 || d->workflow > PBR_WORKFLOW_CONVERTED) return PBR_ERR_WORKFLOW;
+    if (d->workflow == PBR_WORKFLOW_SPECULAR ? !d->specular.data : !d->metallic.data) return PBR_ERR_WORKFLOW;
+    if (!d->albedo.data || !d->roughness.data || !d->out) return PBR_ERR_NULL_MAP;
+    if (d->batch < 1 || d->height < 1 || d->width < 1 || d->y_offset < 0 ||
+        d->height_total < d->y_offset + d->height || d->n_lights < 1 || d->n_lights > PBR_MAX_LIGHTS)
+        return PBR_ERR_SHAPE;
+    if ((int64_t)d->batch * d->height > INT32_MAX) return PBR_ERR_SHAPE;
+    if ((d->map_dtype != PBR_F32 && d->map_dtype != PBR_F16) || (d->out_dtype != PBR_F32 && d->out_dtype != PBR_F16))
+        return PBR_ERR_DTYPE;
+    if (d->map_dtype == PBR_F32 && d->out_dtype == PBR_F16) return PBR_ERR_DTYPE;   // not built
+    return PBR_OK;
+}
+
+// 16-byte path: every plane start and every row start must be 16-byte (fp16: 8-byte) aligned.
+static int pick_vec(const pbr_render_desc *d) {
+    const int esz_in = d->map_dtype == PBR_F32 ? 4 : 2, esz_out = d->out_dtype == PBR_F32 ? 4 : 2;
+    if (d->width % 4) return 1;
+    auto ok = [&](const pbr_map &m, int esz, bool three) {
+        if (!m.data) return true;
+        const uintptr_t align = esz == 4 ? 15u : 7u;
+        if (reinterpret_cast<uintptr_t>(m.data) & align) return false;
+        if (m.batch_stride % 4) return false;
+        if (three && (m.channel_stride % 4)) return false;
+        return true;
+    };
+    if (!ok(d->albedo, esz_in, true) || !ok(d->normal, esz_in, true) || !ok(d->roughness, esz_in, false) ||
+        !ok(d->metallic, esz_in, false) || !ok(d->specular, esz_in, true))
+        return 1;
+    if (reinterpret_cast<uintptr_t>(d->out) & (esz_out == 4 ? 15u : 7u)) return 1;
+    return 4;
+}
+
+static void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
+    std::memset(&k, 0, sizeof(k));
+    k.albedo = d->albedo.data; k.normal = d->normal.data; k.rough = d->roughness.data;
+    k.metal = d->metallic.data; k.spec = d->specular.data; k.out = d->out;
+    k.a_bs = d->albedo.batch_stride; k.a_cs = d->albedo.channel_stride;
+    k.n_bs = d->normal.batch_stride; k.n_cs = d->normal.channel_stride;
+    k.r_bs = d->roughness.batch_stride; k.m_bs = d->metallic.batch_stride;
+    k.s_bs = d->specular.batch_stride; k.s_cs = d->specular.channel_stride;
+    k.o_cs = (int64_t)d->height * d->width; k.o_bs = 3 * k.o_cs;
+    k.rows = d->batch * d->height; k.H = d->height; k.W = d->width;
+    k.wv = d->width / vec;
+    k.bt_log2 = g_block_log2 < 6 ? 6 : (g_block_log2 > 8 ? 8 : g_block_log2);
+    int lg = 0;
+    while ((1 << lg) < k.wv && lg < k.bt_log2) ++lg;
+    k.bx_log2 = lg;
+    const int bx = 1 << lg, by = (1 << k.bt_log2) >> lg;
+    k.tiles_x = (k.wv + bx - 1) / bx;
+    const int64_t tiles = (int64_t)k.tiles_x * ((k.rows + by - 1) / by);
+    k.n_tiles = tiles > INT32_MAX ? INT32_MAX : (int32_t)tiles;
+    k.div_h.init((uint32_t)d->height);
+    k.div_tx.init((uint32_t)k.tiles_x);
+    k.y_offset = d->y_offset; k.H_total = d->height_total;
+    // `light_size or 1.0` (:130): 0 / NaN / negative are treated as "not given".
+    const float size = (d->light_size > 0.0f) ? d->light_size : 1.0f;
+    const float lo = (float)(-(double)size / 2), hi = (float)((double)size / 2);
+    k.x0 = lo; k.x1 = hi; k.xstep = d->width > 1 ? (hi - lo) / (float)(d->width - 1) : 0.0f;
+    k.y0 = lo; k.y1 = hi; k.ystep = d->height_total > 1 ? (hi - lo) / (float)(d->height_total - 1) : 0.0f;
+    if (d->width == 1) k.x1 = k.x0;          // torch.linspace(a, b, 1) == [a]
+    if (d->height_total == 1) k.y1 = k.y0;
+    normalize_host(d->view_dir, k.V);
+    k.n_lights = d->n_lights;
+    k.albedo_srgb = d->albedo_is_srgb != 0; k.spec_srgb = d->specular_is_srgb != 0;
+    k.out_srgb = d->return_srgb != 0; k.has_normal = d->normal.data != nullptr;
+    for (int i = 0; i < d->n_lights; ++i) {
+        LightU &u = k.lights[i];
+        for (int c = 0; c < 3; ++c) u.inten[c] = d->intensities[i][c];
+        if (d->light_type == PBR_LIGHT_DIRECTIONAL) {
+            normalize_host(d->lights[i], u.l);                                   // :126
+            float hn[3];
+            for (int c = 0; c < 3; ++c) u.h[c] = k.V[c] + u.l[c];                // :155
+            u.hh = u.h[0] * u.h[0] + u.h[1] * u.h[1] + u.h[2] * u.h[2];
+            normalize_host(u.h, hn);
+            float ct = hn[0] * k.V[0] + hn[1] * k.V[1] + hn[2] * k.V[2];          // :156-158
+            ct = ct < 0.0f ? 0.0f : (ct > 1.0f ? 1.0f : ct);
+            const float om = 1.0f - ct;
+            u.p5 = (om * om) * (om * om) * om;                                   // :196
+        } else {
+            for (int c = 0; c < 3; ++c) u.l[c] = d->lights[i][c];
+        }
+    }
+}
+
+using KernelFn = void (*)(const KArgs);
+struct KernelEntry { KernelFn fn; const char *name; };
+
+// Storage-type pairs built: (f32 -> f32), (f16 -> f32), (f16 -> f16).
+template <int LIGHT, int WF, typename TI, typename TO>
+static KernelFn pick_variant(int vec, bool multi, bool nt) {
+    if (vec == 1) return multi ? cook_torrance_kernel<LIGHT, WF, TI, TO, 1, true, false>
+                               : cook_torrance_kernel<LIGHT, WF, TI, TO, 1, false, false>;
+    if (multi) return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 4, true, true>
+                         : cook_torrance_kernel<LIGHT, WF, TI, TO, 4, true, false>;
+    return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 4, false, true>
+              : cook_torrance_kernel<LIGHT, WF, TI, TO, 4, false, false>;
+}
+
+template <int LIGHT, int WF>
+static KernelFn pick_types(int in_dt, int out_dt, int vec, bool multi, bool nt) {
+    if (in_dt == PBR_F32) return pick_variant<LIGHT, WF, float, float>(vec, multi, nt);
+    if (out_dt == PBR_F32) return pick_variant<LIGHT, WF, __half, float>(vec, multi, nt);
+    return pick_variant<LIGHT, WF, __half, __half>(vec, multi, nt);
+}
+
+static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
+    static thread_local char name[96];
+    static const char *const wf_names[3] = {"metallic", "specular", "converted"};
+    const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
+    const int idt = d->map_dtype, odt = d->out_dtype;
+    std::snprintf(name, sizeof(name), "ct_%s_%s_%s_%s_v%d%s", point ? "point" : "directional", wf_names[d->workflow],
+                  idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", vec, multi ? "_multi" : "");
+    KernelFn fn = nullptr;
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi, nt); break;
+        case 1: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi, nt); break;
+        case 2: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi, nt); break;
+        case 3: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi, nt); break;
+        case 4: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi, nt); break;
+        default: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi, nt); break;
+    }
+    return KernelEntry{fn, name};
+}
+
+}  // namespace pbr
+
+extern "C" {
+
+int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
+    using namespace pbr;
+    const int rc = validate(d);
+    if (rc != PBR_OK) return rc;
+    const int vec = pick_vec(d);
+    KArgs k;
+    fill_args(d, vec, k);
+    const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0);
+    // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane
+    hipLaunchKernelGGL(e.fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0,
+                       static_cast<hipStream_t>(stream), k);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
+
+const char *pbr_kernel_name(const pbr_render_desc *d) {
+    if (pbr::validate(d) != PBR_OK) return nullptr;
+    return pbr::pick_kernel(d, pbr::pick_vec(d), true).name;
+}
+
+int pbr_bytes_per_pixel(const pbr_render_desc *d) {
+    if (pbr::validate(d) != PBR_OK) return 0;
+    const int ein = d->map_dtype == PBR_F32 ? 4 : 2, eout = d->out_dtype == PBR_F32 ? 4 : 2;
+    int ch = 3 + 1;                                        // albedo + roughness
+    if (d->normal.data) ch += 3;
+    ch += d->workflow == PBR_WORKFLOW_SPECULAR ? 3 : 1;    // specular | metallic
+    return ch * ein + 3 * eout;
+}
+
+int pbr_set_tuning(int knob, int value) {
+    int *slot = nullptr;
+    switch (knob) {
+        case PBR_TUNE_NONTEMPORAL: slot = &pbr::g_nontemporal; break;
+        case PBR_TUNE_BLOCK_LOG2: slot = &pbr::g_block_log2; break;
+        default: return -1;
+    }
+    const int old = *slot;
+    *slot = value;
+    return old;
+}
+
+}  // extern "C"

@@ -1,0 +1,282 @@
+// map_ops.hip -- stand-alone map conversions (same arithmetic as the fused kernel) and the
+// small introspection entry points of the C ABI.  All kernels are HBM-bound streams:
+// 16-byte accesses per lane, grid-stride over the element count, non-temporal hints.
+//
+// Reference functions replaced (paths under /root/reference/pypbr/):
+//   utils/functions.py:31-47   srgb_to_linear
+//   utils/functions.py:50-66   linear_to_srgb
+//   materials/metallic.py:98-108   to_diffuse_specular_material (arithmetic part)
+//   materials/diffuse.py:128-147   to_basecolor_metallic_material (arithmetic part)
+//   materials/base.py:191-242      _process_normal_map / _compute_normal_map_z_component
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdint>
+
+#include "../../include/pbr_hip.h"
+#include "brdf_math.hpp"
+
+namespace pbr {
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float ld(const void *p, size_t i) { return static_cast<const float *>(p)[i]; }
+    static __device__ __forceinline__ void st(void *p, size_t i, float v) { static_cast<float *>(p)[i] = v; }
+};
+template <> struct Elem<__half> {
+    static __device__ __forceinline__ float ld(const void *p, size_t i) { return (float)static_cast<const _Float16 *>(p)[i]; }
+    static __device__ __forceinline__ void st(void *p, size_t i, float v) { static_cast<_Float16 *>(p)[i] = (_Float16)v; }
+};
+
+// 4 elements per lane when everything is 16-byte (fp32) / 8-byte (fp16) aligned.
+template <typename T> struct Quad;
+template <> struct Quad<float> {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void ld(const void *p, size_t q, float v[4]) {
+        v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p) + q);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void st(void *p, size_t q, const float v[4]) {
+        v4 t = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4 *>(p) + q);
+    }
+};
+template <> struct Quad<__half> {
+    typedef _Float16 v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void ld(const void *p, size_t q, float v[4]) {
+        v4 t = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(p) + q);
+        v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
+    }
+    static __device__ __forceinline__ void st(void *p, size_t q, const float v[4]) {
+        v4 t = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<v4 *>(p) + q);
+    }
+};
+
+// ---- colour transfer functions ---------------------------------------------------
+template <typename T, bool TO_LINEAR>
+__global__ __launch_bounds__(256) void colour_kernel(const void *src, void *dst, size_t n, int vec_ok) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nq = vec_ok ? n / 4 : 0;
+    for (size_t q = tid; q < nq; q += stride) {
+        float v[4];
+        Quad<T>::ld(src, q, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = TO_LINEAR ? srgb_to_linear(v[j]) : linear_to_srgb(v[j]);
+        Quad<T>::st(dst, q, v);
+    }
+    for (size_t i = nq * 4 + tid; i < n; i += stride) {
+        const float x = Elem<T>::ld(src, i);
+        Elem<T>::st(dst, i, TO_LINEAR ? srgb_to_linear(x) : linear_to_srgb(x));
+    }
+}
+
+// ---- metallic -> diffuse/specular (metallic.py:98-108) ---------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void metallic_to_specular_kernel(const void *albedo, const void *metallic,
+                                                                   void *diffuse, void *specular, int batch,
+                                                                   int64_t P, int albedo_srgb) {
+    const size_t total = (size_t)batch * (size_t)P;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const size_t b = i / (size_t)P, p = i - b * (size_t)P;
+        const float m = Elem<T>::ld(metallic, i), om = 1.0f - m;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t o = (b * 3 + c) * (size_t)P + p;
+            float a = Elem<T>::ld(albedo, o);
+            if (albedo_srgb) a = srgb_to_linear(a);
+            Elem<T>::st(diffuse, o, a * om);
+            Elem<T>::st(specular, o, fmaf(a, m, kDielectricF0 * om));
+        }
+    }
+}
+
+// ---- diffuse/specular -> basecolor/metallic (diffuse.py:128-147) -----------------
+// Thresholded selects (den < eps, metallic >= 0.95) make this one discontinuous, so the
+// divisions are done with a Newton-refined reciprocal: the quotient then rounds like the
+// reference's IEEE division except in rare half-ulp ties.
+__device__ __forceinline__ float div_refined(float a, float b) {
+    float r = rcp(b);
+    r = fmaf(fmaf(-b, r, 1.0f), r, r);
+    const float q = a * r;
+    return fmaf(fmaf(-b, q, a), r, q);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void specular_to_metallic_kernel(const void *diffuse, const void *specular,
+                                                                   void *basecolor, void *metallic, size_t n,
+                                                                   int albedo_srgb) {
+    const float eps = 1e-6f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        float d = Elem<T>::ld(diffuse, i);
+        if (albedo_srgb) d = srgb_to_linear(d);
+        const float s = Elem<T>::ld(specular, i);                   // RAW specular (diffuse.py:120-124)
+        const float num = s - kDielectricF0;
+        const float den = d - kDielectricF0 + eps;
+        float m = clamp01(div_refined(num, den + eps));
+        if (den < eps) m = 0.0f;
+        float bc = div_refined(d, 1.0f - m + eps);
+        if (m >= 0.95f) bc = s;
+        Elem<T>::st(basecolor, i, clamp01(bc));
+        Elem<T>::st(metallic, i, m);
+    }
+}
+
+// ---- normal decode (base.py:191-242) ---------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void any_negative_kernel(const void *src, size_t n, int *flag) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    bool neg = false;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        neg |= Elem<T>::ld(src, i) < 0.0f;
+    if (__ballot(neg) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void decode_normal_kernel(const void *src, void *dst, int64_t P, const int *flag) {
+    const bool keep = CH == 3 && *flag != 0;                        // base.py:212-213
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < (size_t)P; p += stride) {
+        float x = Elem<T>::ld(src, p), y = Elem<T>::ld(src, (size_t)P + p), z;
+        if (CH == 3) {
+            z = Elem<T>::ld(src, 2 * (size_t)P + p);
+            if (!keep) { x = fmaf(x, 2.0f, -1.0f); y = fmaf(y, 2.0f, -1.0f); z = fmaf(z, 2.0f, -1.0f); }
+        } else {
+            x = fmaf(x, 2.0f, -1.0f); y = fmaf(y, 2.0f, -1.0f);     // base.py:235
+            z = sqrt_hw(fmaxf(1.0f - (x * x + y * y), 1e-6f));      // base.py:238-240
+        }
+        if (!keep) {
+            const float r = rsq(fmaxf(fmaf(z, z, fmaf(y, y, x * x)), 1e-24f));   // F.normalize
+            x *= r; y *= r; z *= r;
+        }
+        Elem<T>::st(dst, p, x); Elem<T>::st(dst, (size_t)P + p, y); Elem<T>::st(dst, 2 * (size_t)P + p, z);
+    }
+}
+
+static inline unsigned stream_grid(size_t work_items) {
+    const size_t blocks = (work_items + 255) / 256;
+    const size_t cap = 256 * 8;                                     // 256 CUs x 8 blocks, grid-stride beyond
+    return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+static inline int hip_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+}
+
+static inline bool is_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
+
+}  // namespace pbr
+
+extern "C" {
+
+static int colour_launch(const void *src, void *dst, size_t n, int dtype, void *stream, bool to_linear) {
+    using namespace pbr;
+    if (!src || !dst) return PBR_ERR_NULL_MAP;
+    if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
+    if (n == 0) return PBR_OK;
+    const size_t al = dtype == PBR_F32 ? 16 : 8;
+    const int vec_ok = is_aligned(src, al) && is_aligned(dst, al);
+    const unsigned grid = stream_grid(vec_ok ? (n + 3) / 4 : n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == PBR_F32) {
+        if (to_linear) hipLaunchKernelGGL((colour_kernel<float, true>), dim3(grid), dim3(256), 0, s, src, dst, n, vec_ok);
+        else hipLaunchKernelGGL((colour_kernel<float, false>), dim3(grid), dim3(256), 0, s, src, dst, n, vec_ok);
+    } else {
+        if (to_linear) hipLaunchKernelGGL((colour_kernel<__half, true>), dim3(grid), dim3(256), 0, s, src, dst, n, vec_ok);
+        else hipLaunchKernelGGL((colour_kernel<__half, false>), dim3(grid), dim3(256), 0, s, src, dst, n, vec_ok);
+    }
+    return hip_status();
+}
+
+int pbr_srgb_to_linear(const void *src, void *dst, size_t n, int dtype, void *stream) {
+    return colour_launch(src, dst, n, dtype, stream, true);
+}
+
+int pbr_linear_to_srgb(const void *src, void *dst, size_t n, int dtype, void *stream) {
+    return colour_launch(src, dst, n, dtype, stream, false);
+}
+
+int pbr_metallic_to_specular(const void *albedo, const void *metallic, void *diffuse, void *specular,
+                             int32_t batch, int64_t pixels, int albedo_is_srgb, int dtype, void *stream) {
+    using namespace pbr;
+    if (!albedo || !metallic || !diffuse || !specular) return PBR_ERR_NULL_MAP;
+    if (batch < 1 || pixels < 1) return PBR_ERR_SHAPE;
+    if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
+    const unsigned grid = stream_grid((size_t)batch * (size_t)pixels);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == PBR_F32)
+        hipLaunchKernelGGL((metallic_to_specular_kernel<float>), dim3(grid), dim3(256), 0, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb);
+    else
+        hipLaunchKernelGGL((metallic_to_specular_kernel<__half>), dim3(grid), dim3(256), 0, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb);
+    return hip_status();
+}
+
+int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *basecolor, void *metallic,
+                             size_t n, int albedo_is_srgb, int dtype, void *stream) {
+    using namespace pbr;
+    if (!diffuse || !specular || !basecolor || !metallic) return PBR_ERR_NULL_MAP;
+    if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
+    if (n == 0) return PBR_OK;
+    const unsigned grid = stream_grid(n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == PBR_F32)
+        hipLaunchKernelGGL((specular_to_metallic_kernel<float>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb);
+    else
+        hipLaunchKernelGGL((specular_to_metallic_kernel<__half>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb);
+    return hip_status();
+}
+
+int pbr_decode_normal(const void *src, void *dst, int32_t channels, int64_t pixels, int dtype,
+                      void *workspace, void *stream) {
+    using namespace pbr;
+    if (channels != 2 && channels != 3) return PBR_ERR_CHANNELS;
+    if (!src || !dst || !workspace) return PBR_ERR_NULL_MAP;
+    if (pixels < 1) return PBR_ERR_SHAPE;
+    if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int *flag = static_cast<int *>(workspace);
+    if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) return hip_status();
+    const unsigned grid = stream_grid((size_t)pixels);
+    if (dtype == PBR_F32) {
+        if (channels == 3) {
+            hipLaunchKernelGGL((any_negative_kernel<float>), dim3(stream_grid((size_t)pixels * 3)), dim3(256), 0, s, src, (size_t)pixels * 3, flag);
+            hipLaunchKernelGGL((decode_normal_kernel<float, 3>), dim3(grid), dim3(256), 0, s, src, dst, pixels, flag);
+        } else {
+            hipLaunchKernelGGL((decode_normal_kernel<float, 2>), dim3(grid), dim3(256), 0, s, src, dst, pixels, flag);
+        }
+    } else {
+        if (channels == 3) {
+            hipLaunchKernelGGL((any_negative_kernel<__half>), dim3(stream_grid((size_t)pixels * 3)), dim3(256), 0, s, src, (size_t)pixels * 3, flag);
+            hipLaunchKernelGGL((decode_normal_kernel<__half, 3>), dim3(grid), dim3(256), 0, s, src, dst, pixels, flag);
+        } else {
+            hipLaunchKernelGGL((decode_normal_kernel<__half, 2>), dim3(grid), dim3(256), 0, s, src, dst, pixels, flag);
+        }
+    }
+    return hip_status();
+}
+
+int pbr_abi_version(void) { return PBR_HIP_ABI_VERSION; }
+
+size_t pbr_render_desc_size(void) { return sizeof(pbr_render_desc); }
+
+const char *pbr_error_string(int code) {
+    switch (code) {
+        case PBR_OK: return "ok";
+        case PBR_ERR_NULL_MAP: return "a required map pointer is NULL";
+        case PBR_ERR_WORKFLOW: return "Material must have either 'metallic' or 'specular' property.";
+        case PBR_ERR_LIGHT_TYPE: return "Unsupported light_type. Must be 'directional' or 'point'.";
+        case PBR_ERR_SHAPE: return "bad extents, band, light count or ABI version";
+        case PBR_ERR_DTYPE: return "unsupported map dtype";
+        case PBR_ERR_CHANNELS: return "Normal map must have 2 or 3 channels.";
+        case PBR_ERR_NO_DEVICE: return "no HIP device";
+        default: break;
+    }
+    if (code >= 1000) return hipGetErrorString(static_cast<hipError_t>(code - 1000));
+    return "unknown error";
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+"""Tensor-level entry points of the MI355X Cook-Torrance path.
+
+`cook_torrance` evaluates what the reference's CookTorranceBRDF.forward computes
+(/root/reference/pypbr/models/cooktorrance.py:92-182) on raw planar maps with ONE
+fused HIP kernel launch; the map-level classes in pypbr_amd.materials / .models
+call into it.  torch is used for device memory and streams only: every number is
+produced by libpbr_hip.so.
+
+Build extensions over the reference:
+  * a leading batch dimension: maps may be [B,C,H,W]; B > 1 equals a loop of calls;
+  * several lights: `light` [L,3] with `light_intensity` [L,3]; each light's linear
+    contribution is clamped to [0,1] (what one reference call does), contributions are
+    summed, clamped, and encoded once;
+  * fp16 map storage (fp32 arithmetic), optional fp16 output;
+  * row bands: (y_offset, height_total) evaluate rows of a taller map (multi-GPU
+    sharding of a single material);
+  * `convert_to_diffuse_specular`: to_diffuse_specular_material (metallic.py:71-120)
+    fused in front of the specular-workflow evaluation.
+"""
+import ctypes
+from typing import Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _native as N
+
+TensorLike = Union[torch.Tensor, Sequence[float]]
+
+_LIGHT_TYPES = {"directional": N.LIGHT_DIRECTIONAL, "point": N.LIGHT_POINT}
+_DTYPES = {torch.float32: N.F32, torch.float16: N.F16}
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _host_vec3(v: TensorLike, rows: Optional[int] = None):
+    """Light/view parameters travel in the kernel-argument segment, so they are host
+    values; a device tensor costs one small D2H copy (documented in DESIGN.md)."""
+    t = torch.as_tensor(v, dtype=torch.float32) if not isinstance(v, torch.Tensor) else v.detach().to("cpu", torch.float32)
+    if rows is None:
+        if t.numel() != 3:
+            raise ValueError("expected a vector of 3 components, got shape %s" % (tuple(t.shape),))
+        return [float(x) for x in t.reshape(3).tolist()]
+    t = t.reshape(-1, 3)
+    return [[float(x) for x in r] for r in t.tolist()]
+
+
+def _as_batched(t: Optional[torch.Tensor], channels: Tuple[int, ...], name: str):
+    if t is None:
+        return None
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.dim() != 4 or t.shape[1] not in channels:
+        raise ValueError("%s must be [%s,H,W] or [B,%s,H,W], got %s" % (name, channels, channels, tuple(t.shape)))
+    if t.stride(-1) != 1 or t.stride(-2) != t.shape[-1]:   # rows must be contiguous; planes/batches may be strided
+        t = t.contiguous()
+    return t
+
+
+def _pbr_map(t: Optional[torch.Tensor]) -> N.PbrMap:
+    if t is None:
+        return N.PbrMap(None, 0, 0)
+    return N.PbrMap(t.data_ptr(), t.stride(0) if t.shape[0] > 1 else 0, t.stride(1))
+
+
+def build_descriptor(albedo, normal, roughness, metallic, specular, out, *, view_dir, light, light_intensity,
+                     light_type, light_size, albedo_is_srgb, specular_is_srgb, return_srgb,
+                     convert_to_diffuse_specular, y_offset, height_total) -> N.RenderDesc:
+    """Fills the C-ABI descriptor (include/pbr_hip.h: pbr_render_desc) from [B,C,H,W] tensors.
+    Pure host logic: no device access, so it is testable without a GPU."""
+    lt = str(light_type).lower()
+    if lt not in _LIGHT_TYPES:   # cooktorrance.py:62-65
+        raise ValueError(f"Unsupported light_type: {lt}. Must be 'directional' or 'point'.")
+    if metallic is not None:
+        workflow = N.WORKFLOW_CONVERTED if convert_to_diffuse_specular else N.WORKFLOW_METALLIC
+    elif specular is not None:
+        if convert_to_diffuse_specular:
+            raise ValueError("convert_to_diffuse_specular needs a metallic map")
+        workflow = N.WORKFLOW_SPECULAR
+    else:                         # cooktorrance.py:115-118
+        raise ValueError("Material must have either 'metallic' or 'specular' property.")
+
+    B, _, H, W = albedo.shape
+    for name, t in (("normal", normal), ("roughness", roughness), ("metallic", metallic), ("specular", specular)):
+        if t is None:
+            continue
+        if t.shape[-2:] != (H, W) or t.shape[0] not in (1, B):
+            raise ValueError("%s %s does not match albedo %s" % (name, tuple(t.shape), tuple(albedo.shape)))
+        if t.dtype != albedo.dtype or t.device != albedo.device:
+            raise TypeError("all maps must share dtype and device (%s is %s on %s)" % (name, t.dtype, t.device))
+    if albedo.dtype not in _DTYPES or out.dtype not in _DTYPES:
+        raise TypeError("maps must be float32 or float16, got %s" % albedo.dtype)
+
+    lights = _host_vec3(light, rows=-1)
+    intens = _host_vec3(light_intensity, rows=-1)
+    if len(intens) == 1 and len(lights) > 1:
+        intens = intens * len(lights)
+    if len(lights) != len(intens):
+        raise ValueError("light [%d,3] and light_intensity [%d,3] disagree" % (len(lights), len(intens)))
+    if not 1 <= len(lights) <= N.MAX_LIGHTS:
+        raise ValueError("between 1 and %d lights are supported, got %d" % (N.MAX_LIGHTS, len(lights)))
+
+    d = N.RenderDesc()
+    d.abi_version = N.ABI_VERSION
+    d.batch, d.height, d.width = B, H, W
+    d.height_total = H if height_total is None else int(height_total)
+    d.y_offset = int(y_offset)
+    d.map_dtype, d.out_dtype = _DTYPES[albedo.dtype], _DTYPES[out.dtype]
+    d.workflow, d.light_type, d.n_lights = workflow, _LIGHT_TYPES[lt], len(lights)
+    d.albedo_is_srgb = int(bool(albedo_is_srgb))
+    d.specular_is_srgb = int(bool(specular_is_srgb))
+    d.return_srgb = int(bool(return_srgb))
+    d.albedo, d.normal, d.roughness = _pbr_map(albedo), _pbr_map(normal), _pbr_map(roughness)
+    d.metallic, d.specular = _pbr_map(metallic), _pbr_map(specular)
+    d.out = out.data_ptr()
+    v = _host_vec3(view_dir)
+    for c in range(3):
+        d.view_dir[c] = v[c]
+    d.light_size = float(light_size) if light_size else 0.0   # falsy -> 1.0 inside (cooktorrance.py:130)
+    for i, (l, it) in enumerate(zip(lights, intens)):
+        for c in range(3):
+            d.lights[i][c] = l[c]
+            d.intensities[i][c] = it[c]
+    return d
+
+
+class RenderPlan:
+    """A filled descriptor plus the tensors it points into: `launch()` is one C-ABI call
+    (ctypes + hipLaunchKernel, a few microseconds), for callers that evaluate the same
+    maps repeatedly (bench.py, a rendering-loss loop) and must not pay the Python-side
+    descriptor construction per step."""
+
+    def __init__(self, desc, out, keep_alive, squeeze):
+        self.desc, self.out, self._keep, self._squeeze = desc, out, keep_alive, squeeze
+        self.device = out.device
+        self._fn = N.lib().pbr_cook_torrance
+        self._ref = ctypes.byref(desc)
+
+    @property
+    def result(self) -> torch.Tensor:
+        return self.out[0] if self._squeeze else self.out
+
+    @property
+    def kernel_name(self) -> str:
+        return N.lib().pbr_kernel_name(self._ref).decode()
+
+    @property
+    def bytes_per_pixel(self) -> int:
+        return N.lib().pbr_bytes_per_pixel(self._ref)
+
+    def launch(self, stream: Optional[int] = None) -> torch.Tensor:
+        """Enqueue on `stream` (raw hipStream_t) or torch's current stream of the maps' device."""
+        rc = self._fn(self._ref, _stream_ptr(self.device) if stream is None else stream)
+        if rc != N.OK:
+            N.check(rc)
+        return self.result
+
+
+def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughness: torch.Tensor,
+                       metallic: Optional[torch.Tensor] = None, specular: Optional[torch.Tensor] = None, *,
+                       view_dir: TensorLike, light: TensorLike, light_intensity: TensorLike,
+                       light_type: str = "point", light_size: Optional[float] = None,
+                       albedo_is_srgb: bool = True, specular_is_srgb: bool = True, return_srgb: bool = True,
+                       convert_to_diffuse_specular: bool = False, y_offset: int = 0,
+                       height_total: Optional[int] = None, out_dtype: Optional[torch.dtype] = None,
+                       out: Optional[torch.Tensor] = None) -> RenderPlan:
+    """Validates the maps, allocates the output and fills the C-ABI descriptor; see `cook_torrance`."""
+    if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda:
+        raise RuntimeError("pypbr_amd.functional.cook_torrance needs maps on a ROCm device "
+                           "(use material.to('cuda')); there is no CPU path")
+    squeeze = albedo.dim() == 3
+    a = _as_batched(albedo, (3,), "albedo")
+    n = _as_batched(normal, (3,), "normal")
+    r = _as_batched(roughness, (1,), "roughness")
+    m = _as_batched(metallic, (1,), "metallic")
+    s = _as_batched(specular, (3,), "specular")
+    B, _, H, W = a.shape
+    if out is None:
+        out = torch.empty((B, 3, H, W), dtype=out_dtype or torch.float32, device=a.device)
+    elif tuple(out.shape[-3:]) != (3, H, W) or not out.is_contiguous() or out.device != a.device:
+        raise ValueError("out must be a contiguous [B,3,H,W] tensor on the maps' device")
+    desc = build_descriptor(a, n, r, m, s, out, view_dir=view_dir, light=light, light_intensity=light_intensity,
+                            light_type=light_type, light_size=light_size, albedo_is_srgb=albedo_is_srgb,
+                            specular_is_srgb=specular_is_srgb, return_srgb=return_srgb,
+                            convert_to_diffuse_specular=convert_to_diffuse_specular, y_offset=y_offset,
+                            height_total=height_total)
+    return RenderPlan(desc, out, (a, n, r, m, s), squeeze and out.dim() == 4)
+
+
+def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughness: torch.Tensor,
+                  metallic: Optional[torch.Tensor] = None, specular: Optional[torch.Tensor] = None,
+                  **kwargs) -> torch.Tensor:
+    """Fused Cook-Torrance evaluation on device-resident planar maps.
+
+    albedo/normal/specular: [3,H,W] or [B,3,H,W]; roughness/metallic: [1,H,W] or
+    [B,1,H,W]; all on one ROCm device, float32 or float16.  Keyword arguments:
+    view_dir, light, light_intensity (required), light_type="point", light_size=None,
+    albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True,
+    convert_to_diffuse_specular=False, y_offset=0, height_total=None, out_dtype=None, out=None.
+    Returns [3,H,W] or [B,3,H,W] (float32 unless `out_dtype`), on the same device,
+    enqueued on the current stream without synchronising.
+    """
+    plan = plan_cook_torrance(albedo, normal, roughness, metallic, specular, **kwargs)
+    with torch.cuda.device(plan.device):
+        return plan.launch()
+
+
+# ------------------------------------------------------------------ stand-alone conversions
+def _device_tensor(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("%s needs a tensor on a ROCm device; there is no CPU path" % what)
+    if t.dtype not in _DTYPES:
+        raise TypeError("%s supports float32/float16, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
+def srgb_to_linear(texture: torch.Tensor) -> torch.Tensor:
+    """utils.srgb_to_linear (pypbr/utils/functions.py:31-47) on the device."""
+    t = _device_tensor(texture, "srgb_to_linear")
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        N.check(N.lib().pbr_srgb_to_linear(t.data_ptr(), out.data_ptr(), t.numel(), _DTYPES[t.dtype], _stream_ptr(t.device)))
+    return out
+
+
+def linear_to_srgb(texture: torch.Tensor) -> torch.Tensor:
+    """utils.linear_to_srgb (pypbr/utils/functions.py:50-66) on the device."""
+    t = _device_tensor(texture, "linear_to_srgb")
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        N.check(N.lib().pbr_linear_to_srgb(t.data_ptr(), out.data_ptr(), t.numel(), _DTYPES[t.dtype], _stream_ptr(t.device)))
+    return out
+
+
+def metallic_to_diffuse_specular(albedo: torch.Tensor, metallic: torch.Tensor, albedo_is_srgb: bool = False):
+    """Arithmetic of to_diffuse_specular_material (metallic.py:98-108).  albedo [..,3,H,W],
+    metallic [..,1,H,W] -> (diffuse, specular) both [..,3,H,W] in linear space."""
+    a = _device_tensor(albedo, "metallic_to_diffuse_specular")
+    m = _device_tensor(metallic, "metallic_to_diffuse_specular")
+    if a.shape[-3] != 3 or m.shape[-3] != 1 or a.shape[-2:] != m.shape[-2:] or a.shape[:-3] != m.shape[:-3]:
+        raise ValueError("albedo [..,3,H,W] / metallic [..,1,H,W] expected, got %s / %s" % (tuple(a.shape), tuple(m.shape)))
+    diffuse, spec = torch.empty_like(a), torch.empty_like(a)
+    P = a.shape[-1] * a.shape[-2]
+    with torch.cuda.device(a.device):
+        N.check(N.lib().pbr_metallic_to_specular(a.data_ptr(), m.data_ptr(), diffuse.data_ptr(), spec.data_ptr(),
+                                                 a.numel() // (3 * P), P, int(albedo_is_srgb), _DTYPES[a.dtype],
+                                                 _stream_ptr(a.device)))
+    return diffuse, spec
+
+
+def diffuse_specular_to_basecolor_metallic(diffuse: torch.Tensor, specular: torch.Tensor, albedo_is_srgb: bool = False):
+    """Arithmetic of to_basecolor_metallic_material (diffuse.py:128-147): RAW specular in,
+    (basecolor, 3-channel metallic) out."""
+    d = _device_tensor(diffuse, "diffuse_specular_to_basecolor_metallic")
+    s = _device_tensor(specular, "diffuse_specular_to_basecolor_metallic")
+    if d.shape != s.shape:
+        raise ValueError("diffuse %s and specular %s must have the same shape" % (tuple(d.shape), tuple(s.shape)))
+    base, met = torch.empty_like(d), torch.empty_like(d)
+    with torch.cuda.device(d.device):
+        N.check(N.lib().pbr_specular_to_metallic(d.data_ptr(), s.data_ptr(), base.data_ptr(), met.data_ptr(),
+                                                 d.numel(), int(albedo_is_srgb), _DTYPES[d.dtype], _stream_ptr(d.device)))
+    return base, met
+
+
+def decode_normal(normal_map: torch.Tensor) -> torch.Tensor:
+    """MaterialBase._process_normal_map (base.py:191-242) on the device: (2|3,H,W) -> (3,H,W)."""
+    if normal_map.dim() != 3 or normal_map.shape[0] not in (2, 3):
+        raise ValueError("Normal map must have 2 or 3 channels.")
+    t = _device_tensor(normal_map, "decode_normal")
+    C, H, W = t.shape
+    out = torch.empty((3, H, W), dtype=t.dtype, device=t.device)
+    flag = torch.empty(1, dtype=torch.int32, device=t.device)
+    with torch.cuda.device(t.device):
+        N.check(N.lib().pbr_decode_normal(t.data_ptr(), out.data_ptr(), C, H * W, _DTYPES[t.dtype],
+                                          flag.data_ptr(), _stream_ptr(t.device)))
+    return out

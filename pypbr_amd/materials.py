@@ -1,0 +1,296 @@
+"""Material containers with the surface the Cook-Torrance path reads.
+
+Mirrors the part of pypbr.materials the hot path touches (SURVEY.md 8a rows H13-H16,
+8b "Material surface"): the name -> tensor dict `_maps`, attribute access to maps,
+`device`, `albedo_is_srgb` / `specular_is_srgb`, `linear_albedo` / `linear_specular`,
+`to()`, `to_linear()` / `to_srgb()`, the two workflow conversions, `tile()`.
+Reference: /root/reference/pypbr/materials/{base,metallic,diffuse}.py.
+
+Every computation (normal decode, colour transfer, workflow conversion) runs in
+libpbr_hip.so on a ROCm device.  Maps that live on the CPU are staged through the
+device and brought back; with no device present those calls raise -- there is no
+ATen/CPU arithmetic in this package.
+
+Differences from the reference, all supersets:
+  * maps may be any floating torch.Tensor on any device (the reference only files
+    CPU float32 `torch.FloatTensor`s into `_maps`) and may carry a
+    leading batch dimension [B,C,H,W] (F2);
+  * `to_diffuse_specular_material(specular_is_srgb=...)` exposes the flag the upstream
+    conversion forgets to set (F6); the default keeps upstream behaviour.
+"""
+import copy
+import enum
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _native
+from . import functional as F_
+
+
+class NormalConvention(enum.Enum):
+    """pypbr/utils/enums.py:12-14 (carried on materials; the BRDF never reads it)."""
+    OPENGL = "opengl"
+    DIRECTX = "directx"
+
+
+def _is_image(value) -> bool:
+    try:
+        from PIL import Image
+        return isinstance(value, Image.Image)
+    except ImportError:  # pragma: no cover
+        return False
+
+
+def _is_map_value(value) -> bool:
+    if value is None or isinstance(value, np.ndarray) or _is_image(value):
+        return True
+    return isinstance(value, torch.Tensor) and value.is_floating_point()
+
+
+def _image_to_tensor(image) -> torch.Tensor:
+    """PIL image -> (C,H,W) float32 in [0,1] (base.py:143-164: 16-bit modes / 65535,
+    mode F as is, RGBA -> RGB, everything else uint8 / 255)."""
+    if image.mode in ("I", "I;16", "I;16B", "I;16L", "I;16N"):
+        arr = np.array(image, dtype=np.uint16).astype(np.float32)
+        return (torch.from_numpy(arr) / 65535.0).unsqueeze(0)
+    if image.mode == "F":
+        return torch.from_numpy(np.array(image, dtype=np.float32)).unsqueeze(0)
+    if image.mode == "RGBA":
+        image = image.convert("RGB")
+    arr = np.asarray(image)
+    if arr.ndim == 2:
+        arr = arr[:, :, None]
+    t = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
+    return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t.to(torch.float32)
+
+
+def _through_device(t: torch.Tensor, fn):
+    """Runs a libpbr_hip op on `t`; CPU-resident maps are staged through the device."""
+    if t.is_cuda:
+        return fn(t)
+    _native.require_device()
+    res = fn(t.to("cuda"))
+    if isinstance(res, tuple):
+        return tuple(r.to(t.device) for r in res)
+    return res.to(t.device)
+
+
+class MaterialBase:
+    """Dynamic bag of texture maps (base.py:34-120)."""
+
+    def __init__(self, albedo=None, albedo_is_srgb: bool = True, normal=None, roughness=None,
+                 normal_convention: NormalConvention = NormalConvention.OPENGL,
+                 device: torch.device = torch.device("cpu"), **kwargs):
+        self.device = device
+        self.normal_convention = normal_convention
+        self._maps = {}
+        self.albedo_is_srgb = albedo_is_srgb
+        for name, value in (("albedo", albedo), ("normal", normal), ("roughness", roughness)):
+            if value is not None:
+                setattr(self, name, value)
+        for name, value in kwargs.items():
+            setattr(self, name, value)
+
+    # -- attribute protocol: map-like values are filed in _maps, the rest are plain attributes
+    def __setattr__(self, name, value):
+        if name in ("albedo_is_srgb", "_maps", "device", "normal_convention", "specular_is_srgb"):
+            object.__setattr__(self, name, value)
+        elif _is_map_value(value):
+            self._maps[name] = self._ingest(name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+    def __getattr__(self, name):
+        maps = self.__dict__.get("_maps", {})
+        if name in maps:
+            return maps[name]
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    def _ingest(self, name, value):
+        if value is None:
+            return None
+        if isinstance(value, torch.Tensor):
+            t = value.to(self.device)
+        elif isinstance(value, np.ndarray):
+            t = torch.from_numpy(value).float().to(self.device)
+        elif _is_image(value):
+            t = _image_to_tensor(value).to(self.device)
+        else:  # pragma: no cover  (guarded by _is_map_value)
+            raise TypeError(f"Unsupported image type: {type(value)}. Supported types are PIL.Image.Image, "
+                            "np.ndarray, and torch.FloatTensor.")
+        if name == "normal":
+            return self._process_normal_map(t)
+        return t
+
+    @staticmethod
+    def _process_normal_map(normal_map: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """base.py:191-242 on the device; a batch is decoded map by map (the "already
+        signed?" test of :212 is per map)."""
+        if normal_map is None:
+            return None
+        if normal_map.shape[-3] not in (2, 3):
+            raise ValueError("Normal map must have 2 or 3 channels.")
+        if normal_map.dim() == 4:
+            return torch.stack([_through_device(n, F_.decode_normal) for n in normal_map], dim=0)
+        return _through_device(normal_map, F_.decode_normal)
+
+    # -- device management (base.py:245-259)
+    def to(self, device):
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        for name, t in self._maps.items():
+            if t is not None:
+                self._maps[name] = t.to(self.device)
+        return self
+
+    # -- properties
+    @property
+    def linear_albedo(self):
+        """base.py:262-277: a fresh linear copy when the stored map is sRGB."""
+        albedo = self._maps.get("albedo")
+        if albedo is None:
+            return None
+        return _through_device(albedo, F_.srgb_to_linear) if self.albedo_is_srgb else albedo
+
+    @property
+    def normal_rgb(self):
+        normal = self._maps.get("normal")
+        return None if normal is None else (normal + 1.0) * 0.5
+
+    @property
+    def size(self) -> Optional[Tuple[int, int]]:
+        """(height, width) of the first map that is present (base.py:293-307)."""
+        for t in self._maps.values():
+            if t is not None:
+                return (t.shape[-2], t.shape[-1])
+        return None
+
+    def as_dict(self):
+        return dict(self._maps)
+
+    # -- colour space, in place, returning self (base.py:754-778)
+    def to_linear(self):
+        albedo = self._maps.get("albedo")
+        if albedo is not None and self.albedo_is_srgb:
+            self._maps["albedo"] = _through_device(albedo, F_.srgb_to_linear)
+            self.albedo_is_srgb = False
+        return self
+
+    def to_srgb(self):
+        albedo = self._maps.get("albedo")
+        if albedo is not None and not self.albedo_is_srgb:
+            self._maps["albedo"] = _through_device(albedo, F_.linear_to_srgb)
+            self.albedo_is_srgb = True
+        return self
+
+    # -- pure indexing (base.py:524-537); no arithmetic involved
+    def tile(self, num_tiles: int):
+        for name, t in self._maps.items():
+            if t is not None:
+                reps = (1,) * (t.dim() - 2) + (num_tiles, num_tiles)
+                self._maps[name] = t.repeat(*reps)
+        return self
+
+    def clone(self):
+        """Deep copy: tensors cloned, flags copied (base.py:880-912)."""
+        new = copy.copy(self)
+        object.__setattr__(new, "_maps", {k: (None if v is None else v.clone()) for k, v in self._maps.items()})
+        return new
+
+    def __repr__(self):
+        body = ", ".join(f"{k}={None if v is None else tuple(v.shape)}" for k, v in self._maps.items())
+        return f"{type(self).__name__}({body})"
+
+
+class BasecolorMetallicMaterial(MaterialBase):
+    """Metallic workflow (metallic.py:22-69)."""
+
+    def __init__(self, albedo=None, albedo_is_srgb: bool = True, normal=None, roughness=None, metallic=None,
+                 **kwargs):
+        super().__init__(albedo=albedo, albedo_is_srgb=albedo_is_srgb, normal=normal, roughness=roughness, **kwargs)
+        if metallic is not None:
+            self.metallic = metallic
+
+    @property
+    def basecolor(self):
+        return self.albedo
+
+    @basecolor.setter
+    def basecolor(self, value):
+        self.albedo = value
+
+    def to_diffuse_specular_material(self, albedo_is_srgb: bool = False, specular_is_srgb: bool = True):
+        """metallic.py:71-120.  The new material shares normal/roughness, holds LINEAR
+        diffuse and specular maps and -- as upstream -- is flagged specular_is_srgb=True
+        unless told otherwise."""
+        albedo, metallic = self._maps.get("albedo"), self._maps.get("metallic")
+        if albedo is None or metallic is None:
+            raise ValueError("Both albedo and metallic maps are required for conversion.")
+        if metallic.shape[-2:] != albedo.shape[-2:]:
+            raise NotImplementedError("metallic map of a different size: resize it first")
+        srgb = self.albedo_is_srgb
+        diffuse, specular = _through_device(
+            albedo, lambda a: F_.metallic_to_diffuse_specular(a, metallic.to(a.device), albedo_is_srgb=srgb))
+        return DiffuseSpecularMaterial(albedo=diffuse, specular=specular, normal=self._maps.get("normal"),
+                                       roughness=self._maps.get("roughness"), albedo_is_srgb=albedo_is_srgb,
+                                       specular_is_srgb=specular_is_srgb, device=self.device)
+
+
+class DiffuseSpecularMaterial(MaterialBase):
+    """Specular workflow (diffuse.py:23-91)."""
+
+    def __init__(self, albedo=None, albedo_is_srgb: bool = True, normal=None, roughness=None, specular=None,
+                 specular_is_srgb: bool = True, **kwargs):
+        super().__init__(albedo=albedo, albedo_is_srgb=albedo_is_srgb, normal=normal, roughness=roughness, **kwargs)
+        self.specular_is_srgb = specular_is_srgb
+        if specular is not None:
+            self.specular = specular
+
+    @property
+    def diffuse(self):
+        return self.albedo
+
+    @diffuse.setter
+    def diffuse(self, value):
+        self.albedo = value
+
+    @property
+    def linear_specular(self):
+        """diffuse.py:76-91."""
+        specular = self._maps.get("specular")
+        if specular is None:
+            return None
+        return _through_device(specular, F_.srgb_to_linear) if self.specular_is_srgb else specular
+
+    def to_basecolor_metallic_material(self, albedo_is_srgb: bool = False):
+        """diffuse.py:93-158: RAW specular (not linear_specular), 3-channel metallic."""
+        albedo, specular = self._maps.get("albedo"), self._maps.get("specular")
+        if albedo is None or specular is None:
+            raise ValueError("Both albedo (diffuse) and specular maps are required for conversion.")
+        if specular.shape[-2:] != albedo.shape[-2:]:
+            raise NotImplementedError("specular map of a different size: resize it first")
+        srgb = self.albedo_is_srgb
+        base, metallic = _through_device(
+            albedo, lambda d: F_.diffuse_specular_to_basecolor_metallic(d, specular.to(d.device), albedo_is_srgb=srgb))
+        return BasecolorMetallicMaterial(albedo=base, metallic=metallic, normal=self._maps.get("normal"),
+                                         roughness=self._maps.get("roughness"), albedo_is_srgb=albedo_is_srgb,
+                                         device=self.device)
+
+    def to_linear(self):
+        """diffuse.py:160-175."""
+        super().to_linear()
+        specular = self._maps.get("specular")
+        if specular is not None and self.specular_is_srgb:
+            self._maps["specular"] = _through_device(specular, F_.srgb_to_linear)
+            self.specular_is_srgb = False
+        return self
+
+    def to_srgb(self):
+        """diffuse.py:177-190."""
+        super().to_srgb()
+        specular = self._maps.get("specular")
+        if specular is not None and not self.specular_is_srgb:
+            self._maps["specular"] = _through_device(specular, F_.linear_to_srgb)
+            self.specular_is_srgb = True
+        return self

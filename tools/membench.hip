@@ -1,0 +1,138 @@
+// membench.hip -- stand-alone ceiling probe for the Cook-Torrance access pattern on MI355X:
+// 8 planar fp32 input planes -> 3 output planes, 16 B per lane per plane, optional synthetic
+// VALU work per pixel.  Tells how much of the fused kernel's time is the memory pattern
+// itself (no arithmetic) and how much VALU work that pattern hides.
+//   hipcc -O3 --offload-arch=gfx950 tools/membench.hip -o gpurun_out/membench && gpurun_out/membench
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+template <bool NT> __device__ __forceinline__ f4 ld(const f4 *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ void st(f4 *p, f4 v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+// FMAS: synthetic dependent-chain-free VALU work per pixel (transcendental every 10th op)
+template <int FMAS> __device__ __forceinline__ f4 work(f4 a, f4 b, f4 c) {
+    f4 r = a;
+#pragma unroll
+    for (int i = 0; i < FMAS; ++i) {
+        if (i % 10 == 9) { r.x = __builtin_amdgcn_rcpf(r.x + 2.0f); r.y = __builtin_amdgcn_rcpf(r.y + 2.0f); r.z = __builtin_amdgcn_rcpf(r.z + 2.0f); r.w = __builtin_amdgcn_rcpf(r.w + 2.0f); }
+        else r = r * b + c;
+    }
+    return r;
+}
+
+template <bool NT, int FMAS, int BLOCK, bool NTS = NT>
+__global__ __launch_bounds__(BLOCK) void oneshot(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size_t plane, size_t oplane) {
+    const size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nv) return;
+    f4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = ld<NT>(in + c * plane + i);
+    f4 r0 = work<FMAS>(v[0] + v[3] + v[6], v[6], v[7]);
+    f4 r1 = work<FMAS>(v[1] + v[4] + v[7], v[6], v[7]);
+    f4 r2 = work<FMAS>(v[2] + v[5], v[6], v[7]);
+    st<NTS>(out + i, r0); st<NTS>(out + oplane + i, r1); st<NTS>(out + 2 * oplane + i, r2);
+}
+
+template <bool NT, int FMAS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void persistent(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size_t plane) {
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nv) return;
+    f4 v[8], w[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = ld<NT>(in + c * plane + i);
+    while (true) {
+        const size_t n = i + stride;
+        if (n < nv) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) w[c] = ld<NT>(in + c * plane + n);
+        }
+        f4 r0 = work<FMAS>(v[0] + v[3] + v[6], v[6], v[7]);
+        f4 r1 = work<FMAS>(v[1] + v[4] + v[7], v[6], v[7]);
+        f4 r2 = work<FMAS>(v[2] + v[5], v[6], v[7]);
+        st<NT>(out + i, r0); st<NT>(out + plane + i, r1); st<NT>(out + 2 * plane + i, r2);
+        if (n >= nv) break;
+        i = n;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = w[c];
+    }
+}
+
+// read-only and write-only ceilings
+template <bool NT> __global__ __launch_bounds__(256) void readonly(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size_t plane) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nv) return;
+    f4 s = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += ld<NT>(in + c * plane + i);
+    if (s.x == 12345.678f) out[i] = s;
+}
+template <bool NT> __global__ __launch_bounds__(256) void writeonly(f4 *__restrict__ out, size_t nv, size_t plane) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nv) return;
+    f4 s = {1, 2, 3, 4};
+    st<NT>(out + i, s); st<NT>(out + plane + i, s); st<NT>(out + 2 * plane + i, s);
+}
+
+struct Result { const char *name; double us; double gbs; };
+
+template <typename L> static double time_us(L launch, int iters) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch(i);
+    std::vector<double> t;
+    for (int r = 0; r < 5; ++r) {
+        CHECK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) launch(i);
+        CHECK(hipEventRecord(e1, 0));
+        CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        t.push_back(ms * 1e3 / iters);
+    }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
+
+int main(int argc, char **argv) {
+    const size_t S = argc > 1 ? atoi(argv[1]) : 4096;
+    const size_t px = S * S, nv = px / 4, plane = nv;
+    const int NSETS = 3;
+    f4 *in[NSETS], *out[NSETS];
+    for (int s = 0; s < NSETS; ++s) {
+        CHECK(hipMalloc(&in[s], 8 * px * 4)); CHECK(hipMalloc(&out[s], 3 * px * 4));
+        CHECK(hipMemset(in[s], 0x3c, 8 * px * 4));
+    }
+    const double bytes_rw = 44.0 * px, bytes_r = 32.0 * px, bytes_w = 12.0 * px;
+    const int iters = 20;
+    auto report = [&](const char *name, double us, double bytes) { printf("%-44s %8.2f us  %7.1f GB/s\n", name, us, bytes / us / 1e3); fflush(stdout); };
+
+    report("read-only 8 planes nt", time_us([&](int i) { hipLaunchKernelGGL(readonly<true>, dim3((nv + 255) / 256), dim3(256), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_r);
+    report("read-only 8 planes", time_us([&](int i) { hipLaunchKernelGGL(readonly<false>, dim3((nv + 255) / 256), dim3(256), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_r);
+    report("write-only 3 planes nt", time_us([&](int i) { hipLaunchKernelGGL(writeonly<true>, dim3((nv + 255) / 256), dim3(256), 0, 0, out[i % NSETS], nv, plane); }, iters), bytes_w);
+    report("write-only 3 planes", time_us([&](int i) { hipLaunchKernelGGL(writeonly<false>, dim3((nv + 255) / 256), dim3(256), 0, 0, out[i % NSETS], nv, plane); }, iters), bytes_w);
+
+#define ONESHOT(NT, F, B) report("oneshot nt=" #NT " valu/px=" #F " block=" #B, time_us([&](int i) { hipLaunchKernelGGL((oneshot<NT, F, B>), dim3((nv + B - 1) / B), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane, plane); }, iters), bytes_rw)
+    ONESHOT(true, 0, 256); ONESHOT(false, 0, 256); ONESHOT(true, 0, 128); ONESHOT(true, 0, 512); ONESHOT(true, 0, 1024);
+    ONESHOT(true, 40, 256); ONESHOT(true, 80, 256);
+    report("oneshot loads nt, stores plain", time_us([&](int i) { hipLaunchKernelGGL((oneshot<true, 0, 256, false>), dim3((nv + 255) / 256), dim3(256), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane, plane); }, iters), bytes_rw);
+    report("oneshot loads plain, stores nt", time_us([&](int i) { hipLaunchKernelGGL((oneshot<false, 0, 256, true>), dim3((nv + 255) / 256), dim3(256), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane, plane); }, iters), bytes_rw);
+    // padded plane strides: do the 64 MiB-aligned planes camp on the same HBM channels/banks?
+    for (size_t pad : {(size_t)0, (size_t)16, (size_t)64, (size_t)272, (size_t)1040, (size_t)4112, (size_t)65552}) {   // in f4 units (16 B)
+        char nm[96]; snprintf(nm, sizeof(nm), "oneshot nt plane stride +%zu B", pad * 16);
+        if (8 * (plane + pad) * 16 > 8 * px * 4 + 0) { /* need bigger buffers: allocate once */ }
+        static f4 *bin = nullptr, *bout = nullptr;
+        if (!bin) { CHECK(hipMalloc(&bin, 8 * (px * 4 + 2 * 1048576))); CHECK(hipMalloc(&bout, 3 * (px * 4 + 2 * 1048576))); CHECK(hipMemset(bin, 0x3c, 8 * (px * 4 + 2 * 1048576))); }
+        report(nm, time_us([&](int i) { hipLaunchKernelGGL((oneshot<true, 0, 256>), dim3((nv + 255) / 256), dim3(256), 0, 0, bin, bout, nv, plane + pad, plane + pad); }, iters), bytes_rw);
+    }
+#define PERSIST(NT, F, B, G) report("persistent nt=" #NT " valu/px=" #F " block=" #B " grid=" #G, time_us([&](int i) { hipLaunchKernelGGL((persistent<NT, F, B>), dim3(G), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
+    PERSIST(true, 0, 256, 1024); PERSIST(true, 0, 256, 2048);
+    PERSIST(true, 60, 256, 2048);
+    return 0;
+}

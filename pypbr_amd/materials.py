@@ -59,7 +59,7 @@ def _image_to_tensor(image) -> torch.Tensor:
         return torch.from_numpy(np.array(image, dtype=np.float32)).unsqueeze(0)
     if image.mode == "RGBA":
         image = image.convert("RGB")
-    arr = np.asarray(image)
+    arr = np.array(image)
     if arr.ndim == 2:
         arr = arr[:, :, None]
     t = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))

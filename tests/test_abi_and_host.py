@@ -1,0 +1,230 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/pbr_hip.h declares, the ctypes struct layout matches, descriptor validation returns the
+documented codes (no launch, no GPU), and the Python mirror of the reference surface behaves like
+the reference for everything that does not compute."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from pypbr_amd import _native as N
+from pypbr_amd import functional as F
+from pypbr_amd.materials import BasecolorMetallicMaterial, DiffuseSpecularMaterial, MaterialBase
+from pypbr_amd.models import BRDFModel, CookTorranceBRDF
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HAS_GPU = torch.cuda.is_available()
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "pbr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pbr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    declared = _header_functions()
+    assert declared and set(declared) == set(N.EXPORTS)
+    lib = N.lib()
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    dyn = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True).stdout
+    for sym in declared:
+        assert re.search(r"\bT %s$" % sym, dyn, flags=re.M), sym
+    assert lib.pbr_abi_version() == N.ABI_VERSION
+    assert lib.pbr_render_desc_size() == ctypes.sizeof(N.RenderDesc)
+
+
+def test_no_torch_types_in_the_abi():
+    text = open(os.path.join(ROOT, "include", "pbr_hip.h")).read()
+    assert "torch" not in re.sub(r"/\*.*?\*/", "", text, flags=re.S).lower() and "at::" not in text
+
+
+def _desc(**over):
+    B, H, W = 2, 8, 16
+    a, n, r, m = torch.rand(B, 3, H, W), torch.rand(B, 3, H, W), torch.rand(B, 1, H, W), torch.rand(B, 1, H, W)
+    o = torch.empty(B, 3, H, W)
+    kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=None,
+              albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True, convert_to_diffuse_specular=False,
+              y_offset=0, height_total=None)
+    kw.update(over)
+    d = F.build_descriptor(a, n, r, m, None, o, **kw)
+    d._keep = (a, n, r, m, o)
+    return d
+
+
+def test_descriptor_contents_and_kernel_selection():
+    lib = N.lib()
+    d = _desc()
+    assert (d.batch, d.height, d.width, d.height_total, d.y_offset) == (2, 8, 16, 8, 0)
+    assert d.workflow == N.WORKFLOW_METALLIC and d.light_type == N.LIGHT_POINT and d.n_lights == 1
+    assert d.albedo.batch_stride == 3 * 8 * 16 and d.albedo.channel_stride == 8 * 16 and d.roughness.batch_stride == 8 * 16
+    assert d.light_size == 0.0                                   # falsy -> 1.0 inside the library (cooktorrance.py:130)
+    assert lib.pbr_kernel_name(ctypes.byref(d)) == b"ct_point_metallic_f32_f32_v4"
+    assert lib.pbr_bytes_per_pixel(ctypes.byref(d)) == 44
+    d2 = _desc(light_type="Directional", light=[[0, 0, 1], [1, 0, 1]], light_intensity=[[1, 1, 1], [0.5, 0.5, 0.5]],
+               convert_to_diffuse_specular=True)
+    assert d2.light_type == N.LIGHT_DIRECTIONAL and d2.n_lights == 2 and d2.workflow == N.WORKFLOW_CONVERTED
+    assert lib.pbr_kernel_name(ctypes.byref(d2)) == b"ct_directional_converted_f32_f32_v4_multi"
+    assert [d2.lights[1][c] for c in range(3)] == [1.0, 0.0, 1.0] and d2.intensities[1][0] == 0.5
+    # one intensity for several lights is broadcast; mismatched counts are rejected
+    assert _desc(light=[[0, 0, 1], [1, 0, 1]], light_intensity=[1, 1, 1]).n_lights == 2
+    with pytest.raises(ValueError):
+        _desc(light=[[0, 0, 1]] * 3, light_intensity=[[1, 1, 1]] * 2)
+    with pytest.raises(ValueError):
+        _desc(light=[[0, 0, 1]] * (N.MAX_LIGHTS + 1), light_intensity=[1, 1, 1])
+    with pytest.raises(ValueError, match="Unsupported light_type"):
+        _desc(light_type="spot")
+
+
+def test_specular_workflow_bytes_and_batch_broadcast():
+    lib = N.lib()
+    B, H, W = 3, 4, 8
+    a, s, r = torch.rand(B, 3, H, W), torch.rand(B, 3, H, W), torch.rand(1, 1, H, W)     # roughness shared by the batch
+    o = torch.empty(B, 3, H, W)
+    d = F.build_descriptor(a, None, r, None, s, o, view_dir=[0, 0, 1], light=[0, 0, 1], light_intensity=[1, 1, 1],
+                           light_type="directional", light_size=None, albedo_is_srgb=True, specular_is_srgb=False,
+                           return_srgb=False, convert_to_diffuse_specular=False, y_offset=0, height_total=None)
+    assert d.workflow == N.WORKFLOW_SPECULAR and d.roughness.batch_stride == 0 and not d.normal.data
+    assert lib.pbr_bytes_per_pixel(ctypes.byref(d)) == 40        # 52 B minus the absent normal map
+    assert lib.pbr_kernel_name(ctypes.byref(d)) == b"ct_directional_specular_f32_f32_v4"
+    with pytest.raises(ValueError, match="either 'metallic' or 'specular'"):
+        F.build_descriptor(a, None, r, None, None, o, view_dir=[0, 0, 1], light=[0, 0, 1], light_intensity=[1, 1, 1],
+                           light_type="point", light_size=None, albedo_is_srgb=True, specular_is_srgb=True,
+                           return_srgb=True, convert_to_diffuse_specular=False, y_offset=0, height_total=None)
+
+
+def test_validation_codes_without_a_device():
+    """pbr_cook_torrance validates before it launches, so bad descriptors are testable on CPU."""
+    lib = N.lib()
+    d = _desc(); d.workflow = 7
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_WORKFLOW
+    d = _desc(); d.metallic.data = None
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_WORKFLOW
+    d = _desc(); d.light_type = 2
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_LIGHT_TYPE
+    d = _desc(); d.n_lights = 0
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_SHAPE
+    d = _desc(); d.y_offset, d.height_total = 4, 8               # band sticks out of the map
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_SHAPE
+    d = _desc(); d.albedo.data = None
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_NULL_MAP
+    d = _desc(); d.map_dtype = 5
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_DTYPE
+    d = _desc(); d.abi_version = 99
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_SHAPE
+    assert lib.pbr_decode_normal(ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 10, N.F32, ctypes.c_void_p(16), None) == N.ERR_CHANNELS
+    assert lib.pbr_srgb_to_linear(None, None, 10, N.F32, None) == N.ERR_NULL_MAP
+    assert b"metallic" in lib.pbr_error_string(N.ERR_WORKFLOW) and b"2 or 3 channels" in lib.pbr_error_string(N.ERR_CHANNELS)
+    with pytest.raises(ValueError, match="either 'metallic' or 'specular'"):
+        N.check(N.ERR_WORKFLOW)
+    with pytest.raises(TypeError):
+        N.check(N.ERR_DTYPE)
+
+
+def test_ragged_and_unaligned_maps_select_the_scalar_kernel():
+    lib = N.lib()
+    a, n, r, m = torch.rand(1, 3, 5, 13), torch.rand(1, 3, 5, 13), torch.rand(1, 1, 5, 13), torch.rand(1, 1, 5, 13)
+    kw = dict(view_dir=[0, 0, 1], light=[0, 0, 1], light_intensity=[1, 1, 1], light_type="point", light_size=1.0,
+              albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True, convert_to_diffuse_specular=False,
+              y_offset=0, height_total=None)
+    d = F.build_descriptor(a, n, r, m, None, torch.empty(1, 3, 5, 13), **kw)
+    assert lib.pbr_kernel_name(ctypes.byref(d)).endswith(b"_v1")
+    big = torch.rand(1, 3, 5, 20)
+    view = big[:, :, :, 2:18]                                     # width 16 but rows start 8 bytes off alignment
+    view_c = F._as_batched(view, (3,), "albedo")
+    assert view_c.is_contiguous()                                 # non-contiguous rows are repacked host-side
+
+
+def test_fp16_descriptor():
+    lib = N.lib()
+    a, n, r, m = (torch.rand(1, c, 4, 8).half() for c in (3, 3, 1, 1))
+    kw = dict(view_dir=[0, 0, 1], light=[0, 0, 1], light_intensity=[1, 1, 1], light_type="point", light_size=1.0,
+              albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True, convert_to_diffuse_specular=False,
+              y_offset=0, height_total=None)
+    d = F.build_descriptor(a, n, r, m, None, torch.empty(1, 3, 4, 8), **kw)
+    assert d.map_dtype == N.F16 and d.out_dtype == N.F32 and lib.pbr_bytes_per_pixel(ctypes.byref(d)) == 28
+    assert lib.pbr_kernel_name(ctypes.byref(d)) == b"ct_point_metallic_f16_f32_v4"
+    with pytest.raises(TypeError):
+        F.build_descriptor(a.double(), n.double(), r.double(), m.double(), None, torch.empty(1, 3, 4, 8), **kw)
+    with pytest.raises(TypeError):
+        F.build_descriptor(a, n.float(), r, m, None, torch.empty(1, 3, 4, 8), **kw)
+
+
+# ---------------------------------------------------------------- reference-shaped Python surface
+def test_brdf_constructor_mirrors_reference():
+    assert issubclass(CookTorranceBRDF, BRDFModel) and issubclass(BRDFModel, torch.nn.Module)
+    b = CookTorranceBRDF(light_type="POINT")
+    assert b.light_type == "point" and b.override_device is None
+    assert list(b.parameters()) == [] and list(b.buffers()) == []
+    assert CookTorranceBRDF().light_type == "point"
+    with pytest.raises(ValueError, match="Unsupported light_type: spot"):
+        CookTorranceBRDF(light_type="spot")
+
+
+def test_material_container_semantics_without_compute():
+    a, r, m = torch.rand(3, 6, 9), torch.rand(1, 6, 9), torch.rand(1, 6, 9)
+    signed = torch.rand(3, 6, 9) * 2 - 1
+    mat = BasecolorMetallicMaterial(albedo=a, roughness=r, metallic=m, height=np.zeros((1, 6, 9), np.float32))
+    assert list(mat._maps) == ["albedo", "roughness", "height", "metallic"]        # insertion order (base.py:71-84)
+    assert mat.albedo is mat.basecolor and mat.size == (6, 9) and mat.albedo_is_srgb is True
+    assert mat.height.dtype == torch.float32 and isinstance(mat.as_dict(), dict)
+    with pytest.raises(AttributeError):
+        mat.normal
+    mat.normal = None
+    assert "normal" in mat._maps and mat.normal is None
+    mat.tag = "plain attribute"                                                     # non-map values are not filed in _maps
+    assert "tag" not in mat._maps and mat.tag == "plain attribute"
+    ds = DiffuseSpecularMaterial(albedo=a, roughness=r, specular=a, specular_is_srgb=False, albedo_is_srgb=False)
+    assert ds.diffuse is ds.albedo and ds.specular_is_srgb is False
+    assert ds.linear_albedo is ds.albedo and ds.linear_specular is ds.specular      # already linear: no compute, same tensor
+    assert MaterialBase().size is None and MaterialBase().linear_albedo is None
+    t = mat.clone()
+    assert t.albedo is not mat.albedo and torch.equal(t.albedo, mat.albedo) and t.albedo_is_srgb == mat.albedo_is_srgb
+    mat.tile(2)
+    assert mat.size == (12, 18) and torch.equal(mat.albedo[:, 6:, 9:], a)
+    with pytest.raises(ValueError, match="2 or 3 channels"):
+        MaterialBase(normal=torch.rand(4, 6, 9))
+    with pytest.raises(ValueError, match="albedo and metallic"):
+        BasecolorMetallicMaterial(albedo=a).to_diffuse_specular_material()
+    with pytest.raises(ValueError, match="specular maps are required"):
+        DiffuseSpecularMaterial(albedo=a).to_basecolor_metallic_material()
+    if not HAS_GPU:                # everything that computes needs the device: loud failure, no CPU fallback
+        with pytest.raises(RuntimeError, match="no CPU"):
+            MaterialBase(normal=signed)
+        with pytest.raises(RuntimeError, match="no CPU"):
+            BasecolorMetallicMaterial(albedo=a, roughness=r, metallic=m).linear_albedo
+        full = BasecolorMetallicMaterial(albedo=a, roughness=r, metallic=m)
+        full.normal = None
+        with pytest.raises(RuntimeError, match="no CPU"):
+            CookTorranceBRDF()(full, torch.tensor([0, 0, 1.0]), torch.tensor([0, 0, 1.0]), torch.tensor([1, 1, 1.0]))
+        with pytest.raises(RuntimeError, match="no CPU"):
+            F.cook_torrance(a, None, r, m, view_dir=[0, 0, 1], light=[0, 0, 1], light_intensity=[1, 1, 1])
+
+
+def test_pil_and_numpy_ingest():
+    from PIL import Image
+    rgb = (np.random.default_rng(0).random((5, 7, 3)) * 255).astype(np.uint8)
+    mat = MaterialBase(albedo=Image.fromarray(rgb, "RGB"), roughness=Image.fromarray(rgb[:, :, 0], "L"))
+    assert mat.albedo.shape == (3, 5, 7) and mat.roughness.shape == (1, 5, 7)
+    assert torch.equal(mat.albedo, torch.from_numpy(rgb.transpose(2, 0, 1).astype(np.float32) / 255))
+    h16 = Image.fromarray((np.arange(35, dtype=np.uint16) * 1000).reshape(5, 7))
+    mat.height = h16
+    assert mat.height.shape == (1, 5, 7) and abs(float(mat.height.max()) - 34000 / 65535) < 1e-6
+    mat.metallic = np.ones((1, 5, 7))
+    assert mat.metallic.dtype == torch.float32
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "pypbr_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "torch_oracle" not in text and "c_oracle" not in text and "ct_oracle" not in text, f
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f

@@ -3,14 +3,16 @@
 
 Tolerances (DESIGN.md "Parity criterion"):
   TOL = 1e-5 absolute on fp32 outputs -- the tolerance BASELINE.json's north_star states.
-  (i)  wherever roughness >= 0.12 (every pixel of the reference's own PNG fixtures, and the
-       bench workload) |hip - ref32| <= TOL, no exceptions;
-  (ii) below that the reference's OWN fp32 output is not reproducible to 1e-5 (it is up to
-       5e-5 from the same code run in float64: GGX denominator cancellation).  There the HIP
-       result must be (a) within TOL of the float64 evaluation of the reference, i.e. closer
-       to the exact value of the reference's formula than the reference's fp32 run is, and
-       (b) within the reference's own fp32 rounding envelope of ref32:
-       |hip - ref32| <= |ref32 - ref64| + TOL.
+  (i)  |hip - ref32| <= TOL on every pixel of the crops of the reference's own PNG fixtures
+       (tiles, rocks), and on synthetic maps wherever roughness >= 0.2;
+  (ii) at lower roughness the reference's OWN fp32 output is not reproducible to 1e-5: its GGX
+       denominator NdotH^2 (a^2-1) + 1 cancels, and the fixtures show it up to 1.1e-5 (a >= 0.15)
+       and 5e-5 (a >= 0.05) away from the same code run in float64.  There the HIP result must be
+       (a) within TOL of the float64 evaluation of the reference -- i.e. at least as close to the
+       exact value of the reference's formula as the reference's fp32 run is -- and
+       (b) inside the reference's own fp32 rounding envelope: |hip - ref32| <= |ref32 - ref64| + TOL.
+       Variants without a float64 twin in the fixtures are bounded by 1e-4 (twice the largest
+       envelope measured on the variants that have one).
 """
 import numpy as np
 import pytest
@@ -21,7 +23,7 @@ from conftest import RANDOM_SETS, parse_case, render_keys
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
-ROUGH_OK = 0.12
+ROUGH_OK = 0.2
 
 
 def _dev(x):
@@ -269,9 +271,11 @@ def test_material_api_end_to_end(golden, manifest):
         brdf(bare, view, light, inten, 1.0)
     bare.normal = None
     assert brdf(bare, view, light, inten, 1.0).shape == (3, 8, 8)
+    from pypbr_amd.materials import MaterialBase
+    plain = MaterialBase(albedo=torch.rand(3, 8, 8), roughness=torch.rand(1, 8, 8))
+    plain.normal = None
     with pytest.raises(ValueError, match="either 'metallic' or 'specular'"):
-        from pypbr_amd.materials import MaterialBase
-        brdf(MaterialBase(albedo=torch.rand(3, 8, 8), normal=None, roughness=torch.rand(1, 8, 8)), view, light, inten)
+        brdf(plain, view, light, inten)
 
 
 def test_full_size_4k_properties_and_sampled_parity():
@@ -285,7 +289,7 @@ def test_full_size_4k_properties_and_sampled_parity():
     nxy = torch.rand(2, H, W, device="cuda", generator=g) - 0.5
     n = torch.cat([nxy, torch.ones(1, H, W, device="cuda")], 0)
     n = n / n.norm(dim=0, keepdim=True)
-    r = torch.rand(1, H, W, device="cuda", generator=g) * 0.88 + 0.12
+    r = torch.rand(1, H, W, device="cuda", generator=g) * 0.95 + 0.05        # bench.py's roughness range
     m = torch.rand(1, H, W, device="cuda", generator=g)
     kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
     out = F.cook_torrance(a, n, r, m, **kw)
@@ -299,8 +303,15 @@ def test_full_size_4k_properties_and_sampled_parity():
     # linear output then stand-alone encode == fused encode
     lin = F.cook_torrance(a, n, r, m, return_srgb=False, **kw)
     assert torch.equal(F.linear_to_srgb(lin), out)
-    ref = C.render(a.cpu().numpy(), n.cpu().numpy(), r.cpu().numpy(), m.cpu().numpy(), None, view=[0, 0, 1],
-                   lights=[0.1, 0.1, 1.0], intensities=[1, 1, 1], light_type="point", light_size=1.0)
-    err = np.abs(out.cpu().numpy() - ref)
-    print(f"\n[4096x4096] max|hip - C oracle| = {err.max():.2e}, values > 1e-5: {(err > TOL).sum()} of {err.size}")
-    assert err.max() <= TOL
+    host = [t.cpu().numpy() for t in (a, n, r, m)]
+    ckw = dict(view=[0, 0, 1], lights=[0.1, 0.1, 1.0], intensities=[1, 1, 1], light_type="point", light_size=1.0)
+    ref32 = C.render(*host, None, **ckw)
+    ref64 = C.render(*host, None, dtype=np.float64, **ckw)
+    got = out.cpu().numpy()
+    err32, err64 = np.abs(got - ref32), np.abs(got.astype(np.float64) - ref64)
+    env = np.abs(ref32.astype(np.float64) - ref64)
+    print(f"\n[4096x4096] max|hip - C oracle fp32| = {err32.max():.2e} ({(err32 > TOL).sum()} of {err32.size} values > 1e-5); "
+          f"max|hip - C oracle fp64| = {err64.max():.2e}; max|C fp32 - C fp64| = {env.max():.2e}")
+    assert err64.max() <= TOL                      # criterion (ii a) at full size
+    assert (err32 <= env + TOL).all()              # criterion (ii b)
+    assert (err32 > TOL).sum() <= 2e-5 * err32.size

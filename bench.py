@@ -108,7 +108,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # PBR_BENCH_FORCE_DIST=1 exercises the RCCL path (init, broadcast, barrier, all-reduce) with one rank
+    distributed = world > 1 or (os.environ.get("PBR_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and not distributed:

@@ -313,5 +313,6 @@ def test_full_size_4k_properties_and_sampled_parity():
     print(f"\n[4096x4096] max|hip - C oracle fp32| = {err32.max():.2e} ({(err32 > TOL).sum()} of {err32.size} values > 1e-5); "
           f"max|hip - C oracle fp64| = {err64.max():.2e}; max|C fp32 - C fp64| = {env.max():.2e}")
     assert err64.max() <= TOL                      # criterion (ii a) at full size
-    assert (err32 <= env + TOL).all()              # criterion (ii b)
-    assert (err32 > TOL).sum() <= 2e-5 * err32.size
+    assert (err32 <= env + TOL).all()              # criterion (ii b): every > TOL difference is the fp32 oracle's own error
+    assert np.abs(got[np.broadcast_to(host[2] >= ROUGH_OK, got.shape)] -
+                  ref32[np.broadcast_to(host[2] >= ROUGH_OK, got.shape)]).max() <= TOL      # criterion (i)

@@ -158,8 +158,8 @@ def main():
         plans[i % N_BUFFER_SETS].launch(stream)
     ev1.record()
     torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0             # this rank's K steps; MAX over ranks below
     barrier()
-    elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps
 
     if distributed:

@@ -80,36 +80,58 @@ __device__ __forceinline__ LightGeom point_light_geom(const Vec3 &V, const Vec3 
     return g;
 }
 
-// One light's linear RGB contribution, clamped to [0,1] (:160-177).
-//   n: stored normal (un-normalised), nn = |n|^2, rn = 1/max(|n|,1e-12)
-//   base: linear albedo; f0: reflectance at normal incidence; kd_scale: (1-metallic) or 1
-__device__ __forceinline__ void shade(const Vec3 &n, float nn, float rn, const Vec3 &V, const LightGeom &g,
-                                      float rough, const float base[3], const float f0[3], float kd_scale,
-                                      const float inten[3], float out[3]) {
-    const float ndv = clamp01(dot(n, V) * rn);                     // :163
-    const float ndl = clamp01(dot(n, g.L) * rn);                   // :164
-    // GGX (:213-217), cancellation-free: den = a2 + (1-a2) sin^2 when N.H > 0, else 1.
-    const float a2 = rough * rough;
-    const float nh = dot(n, g.h);
-    const Vec3 c = {fmaf(n.y, g.h.z, -(n.z * g.h.y)), fmaf(n.z, g.h.x, -(n.x * g.h.z)), fmaf(n.x, g.h.y, -(n.y * g.h.x))};
-    const float s2 = fminf(dot(c, c) * rcp(fmaxf(nn * g.hh, 1e-36f)), 1.0f);
-    const float den = nh > 0.0f ? fmaf(s2, 1.0f - a2, a2) : 1.0f;
-    // D * G / (4 NdotV NdotL + 1e-7) with one reciprocal (:217, :232-235, :165-166).
+// Light-independent terms of one pixel, computed once and reused by every light.
+struct PixelTerms {
+    Vec3 n;            // stored normal, un-normalised
+    float nn, rn;      // |n|^2, 1/max(|n|, 1e-12)   (F.normalize :154)
+    float ndv;         // clamp(N.V)                  (:163)
+    float a2, oma2;    // roughness^2, 1 - roughness^2 (alpha = roughness, :213-214)
+    float k, omk;      // (r+1)^2/8, 1-k              (:232-233)
+    float dv;          // NdotV (1-k) + k + 1e-7      (:234)
+    float a2ndv;       // a2 * NdotV
+    float base[3];     // linear albedo / diffuse colour, pre-multiplied by 1/pi (:174)
+    float f0[3];       // reflectance at normal incidence
+    float kd_scale;    // (1 - metallic) or 1          (:169-172)
+};
+
+__device__ __forceinline__ void pixel_terms(const Vec3 &n, const Vec3 &V, float rough, const float base[3],
+                                            const float f0[3], float kd_scale, PixelTerms &t) {
+    t.n = n;
+    t.nn = dot(n, n);
+    t.rn = rsq(fmaxf(t.nn, 1e-24f));
+    t.ndv = clamp01(dot(n, V) * t.rn);
+    t.a2 = rough * rough;
+    t.oma2 = 1.0f - t.a2;
     const float r1 = rough + 1.0f;
-    const float k = r1 * r1 * 0.125f;
-    const float omk = 1.0f - k;
-    const float dv = fmaf(ndv, omk, k) + 1e-7f;
-    const float dl = fmaf(ndl, omk, k) + 1e-7f;
+    t.k = r1 * r1 * 0.125f;
+    t.omk = 1.0f - t.k;
+    t.dv = fmaf(t.ndv, t.omk, t.k) + 1e-7f;
+    t.a2ndv = t.a2 * t.ndv;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { t.base[c] = base[c] * kInvPi; t.f0[c] = f0[c]; }
+    t.kd_scale = kd_scale;
+}
+
+// One light's linear RGB contribution, clamped to [0,1] (:160-177).
+__device__ __forceinline__ void shade_light(const PixelTerms &t, const LightGeom &g, const float inten[3], float out[3]) {
+    const float ndl = clamp01(dot(t.n, g.L) * t.rn);               // :164
+    // GGX (:213-217), cancellation-free: den = a2 + (1-a2) sin^2 when N.H > 0, else 1.
+    const float nh = dot(t.n, g.h);
+    const Vec3 c = {fmaf(t.n.y, g.h.z, -(t.n.z * g.h.y)), fmaf(t.n.z, g.h.x, -(t.n.x * g.h.z)),
+                    fmaf(t.n.x, g.h.y, -(t.n.y * g.h.x))};
+    const float s2 = fminf(dot(c, c) * rcp(fmaxf(t.nn * g.hh, 1e-36f)), 1.0f);
+    const float den = nh > 0.0f ? fmaf(s2, t.oma2, t.a2) : 1.0f;
+    // D * G / (4 NdotV NdotL + 1e-7) with one reciprocal (:217, :232-235, :165-166).
+    const float dl = fmaf(ndl, t.omk, t.k) + 1e-7f;
     const float dD = fmaf(kPi, den * den, 1e-7f);
-    const float ds = fmaf(4.0f * ndv, ndl, 1e-7f);
-    const float dg = (a2 * ndv) * ndl * rcp((dD * dv) * (dl * ds));
+    const float ds = fmaf(4.0f * t.ndv, ndl, 1e-7f);
+    const float dg = t.a2ndv * ndl * rcp((dD * t.dv) * (dl * ds));
     const float rad = ndl * g.att;                                 // :175
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const float F = fmaf(1.0f - f0[ch], g.p5, f0[ch]);         // :196
-        const float kd = (1.0f - F) * kd_scale;                    // :169-172
-        const float diff = kd * base[ch] * kInvPi;                 // :174
-        out[ch] = clamp01(fmaf(F, dg, diff) * (inten[ch] * rad));  // :176-177
+        const float F = fmaf(1.0f - t.f0[ch], g.p5, t.f0[ch]);     // :196
+        const float kd = (1.0f - F) * t.kd_scale;                  // :169-172
+        out[ch] = clamp01(fmaf(F, dg, kd * t.base[ch]) * (inten[ch] * rad));   // :174-177
     }
 }
 

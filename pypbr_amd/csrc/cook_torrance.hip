@@ -36,6 +36,7 @@ namespace pbr {
 // nt hint on: -5 % time; one-wave workgroups: -2 % vs 256 lanes (no LDS/barrier, so nothing is lost).
 static int g_nontemporal = 1;
 static int g_block_log2 = 6;       // workgroup size: 64 (6), 128 (7) or 256 (8) lanes
+static int g_f16_vec = 8;          // pixels per lane for fp16 maps with one light: 8 (16-byte loads) or 4
 
 static inline void normalize_host(const float v[3], float o[3]) {   // F.normalize(v, dim=0), fp32
     const float nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
@@ -76,6 +77,17 @@ static int pick_vec(const pbr_render_desc *d) {
         !ok(d->metallic, esz_in, false) || !ok(d->specular, esz_in, true))
         return 1;
     if (reinterpret_cast<uintptr_t>(d->out) & (esz_out == 4 ? 15u : 7u)) return 1;
+    // fp16 maps, ONE light (HBM-bound): 8 pixels per lane keep the loads 16 bytes wide.  With several
+    // lights the kernel is VALU-bound and the 4-pixel body's lower register count wins.
+    if (esz_in == 2 && d->width % 8 == 0 && d->n_lights == 1 && g_f16_vec == 8) {
+        auto ok16 = [&](const pbr_map &m, bool three) {
+            return !m.data || ((reinterpret_cast<uintptr_t>(m.data) & 15u) == 0 && m.batch_stride % 8 == 0 &&
+                               (!three || m.channel_stride % 8 == 0));
+        };
+        if (ok16(d->albedo, true) && ok16(d->normal, true) && ok16(d->roughness, false) && ok16(d->metallic, false) &&
+            ok16(d->specular, true) && (reinterpret_cast<uintptr_t>(d->out) & 15u) == 0)
+            return 8;
+    }
     return 4;
 }
 
@@ -137,6 +149,14 @@ struct KernelEntry { KernelFn fn; const char *name; };
 // Storage-type pairs built: (f32 -> f32), (f16 -> f32), (f16 -> f16).
 template <int LIGHT, int WF, typename TI, typename TO>
 static KernelFn pick_variant(int vec, bool multi, bool nt) {
+    if constexpr (sizeof(TI) == 2) {
+        if (vec == 8) {
+            if (multi) return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 8, true, true>
+                                 : cook_torrance_kernel<LIGHT, WF, TI, TO, 8, true, false>;
+            return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 8, false, true>
+                      : cook_torrance_kernel<LIGHT, WF, TI, TO, 8, false, false>;
+        }
+    }
     if (vec == 1) return multi ? cook_torrance_kernel<LIGHT, WF, TI, TO, 1, true, false>
                                : cook_torrance_kernel<LIGHT, WF, TI, TO, 1, false, false>;
     if (multi) return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 4, true, true>
@@ -209,6 +229,7 @@ int pbr_set_tuning(int knob, int value) {
     switch (knob) {
         case PBR_TUNE_NONTEMPORAL: slot = &pbr::g_nontemporal; break;
         case PBR_TUNE_BLOCK_LOG2: slot = &pbr::g_block_log2; break;
+        case PBR_TUNE_F16_VEC: slot = &pbr::g_f16_vec; break;
         default: return -1;
     }
     const int old = *slot;

@@ -115,6 +115,32 @@ template <> struct Ld<__half, 1> {
     }
 };
 
+// 8 pixels per lane: fp16 maps read as one 16-byte load per plane; fp32 results leave as two 16-byte stores.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <> struct Ld<__half, 8> {
+    template <bool NT> static __device__ __forceinline__ void load(const void *p, int64_t i, float v[8]) {
+        const f16x8 *q = reinterpret_cast<const f16x8 *>(static_cast<const _Float16 *>(p) + i);
+        const f16x8 t = NT ? __builtin_nontemporal_load(q) : *q;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+    }
+    template <bool NT> static __device__ __forceinline__ void store(void *p, int64_t i, const float v[8]) {
+        f16x8 t;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = (_Float16)v[j];
+        f16x8 *q = reinterpret_cast<f16x8 *>(static_cast<_Float16 *>(p) + i);
+        if (NT) __builtin_nontemporal_store(t, q); else *q = t;
+    }
+};
+template <> struct Ld<float, 8> {
+    template <bool NT> static __device__ __forceinline__ void load(const void *p, int64_t i, float v[8]) {
+        Ld<float, 4>::load<NT>(p, i, v); Ld<float, 4>::load<NT>(p, i + 4, v + 4);
+    }
+    template <bool NT> static __device__ __forceinline__ void store(void *p, int64_t i, const float v[8]) {
+        Ld<float, 4>::store<NT>(p, i, v); Ld<float, 4>::store<NT>(p, i + 4, v + 4);
+    }
+};
+
 // torch.linspace two-ended evaluation (what ATen's device kernel computes), branch-free:
 // i < n/2 ? a + step*i : b - step*(n-1-i).
 __device__ __forceinline__ float linspace_at(float a, float b, float step, int n, int i) {
@@ -162,6 +188,24 @@ __device__ __forceinline__ void load_texels(const KArgs &a, const LanePos &p, Te
     }
 }
 
+// Material terms of pixel j of the lane (:99-118): base colour, F0, kD scale, normal, roughness.
+template <int WF, int VEC>
+__device__ __forceinline__ void material_terms(const Texels<VEC> &t, int j, const Vec3 &V, PixelTerms &pt) {
+    float base[3], f0[3], kd_scale = 1.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) base[c] = t.al[c][j];
+    if (WF == PBR_WORKFLOW_METALLIC) {
+        const float m = t.me[j];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f0[c] = fmaf(m, base[c] - kDielectricF0, kDielectricF0);   // lerp :107
+        kd_scale = 1.0f - m;                                                            // :170
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f0[c] = t.sp[c][j];                                 // :112-113
+    }
+    pixel_terms(Vec3{t.nm[0][j], t.nm[1][j], t.nm[2][j]}, V, t.ro[j], base, f0, kd_scale, pt);
+}
+
 // Everything between the loads and the stores (cooktorrance.py:99-180 and the conversions it calls).
 // Run-time flags (sRGB decode/encode, normal present) are wave-uniform and each guards ONE hoisted
 // block over all VEC pixels, so the shading code stays one basic block and the scheduler can
@@ -202,48 +246,62 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
     if (LIGHT == PBR_LIGHT_POINT) ys = linspace_at(a.y0, a.y1, a.ystep, a.H_total, p.y + a.y_offset);
 
     float res[3][VEC];
+    if constexpr (!MULTI) {
+        // ---- one light: pixel by pixel, terms and shading back to back (shortest live ranges: 87 VGPRs)
+        const LightU &lu = a.lights[0];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-        // ---- material terms (:99-118)
-        float base[3], f0[3], kd_scale = 1.0f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) base[c] = t.al[c][j];
-        if (WF == PBR_WORKFLOW_METALLIC) {
-            const float m = t.me[j];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) f0[c] = fmaf(m, base[c] - kDielectricF0, kDielectricF0);   // lerp :107
-            kd_scale = 1.0f - m;                                                            // :170
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) f0[c] = t.sp[c][j];                                 // :112-113
-        }
-        const Vec3 n = {t.nm[0][j], t.nm[1][j], t.nm[2][j]};
-        const float nn = dot(n, n);
-        const float rn = rsq(fmaxf(nn, 1e-24f));                            // F.normalize :154
-        const float rough = t.ro[j];
-
-        float xs = 0.0f;
-        if (LIGHT == PBR_LIGHT_POINT) xs = linspace_at(a.x0, a.x1, a.xstep, a.W, p.x + j);
-
-        float acc[3] = {0.0f, 0.0f, 0.0f};
-        const int nl = MULTI ? a.n_lights : 1;
-        for (int l = 0; l < nl; ++l) {
-            const LightU &lu = a.lights[l];
+        for (int j = 0; j < VEC; ++j) {
+            PixelTerms pt;
+            material_terms<WF, VEC>(t, j, V, pt);
             LightGeom g;
             if (LIGHT == PBR_LIGHT_POINT) {
-                g = point_light_geom(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, xs, ys);
+                g = point_light_geom(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, linspace_at(a.x0, a.x1, a.xstep, a.W, p.x + j), ys);
             } else {
                 g.L = {lu.l[0], lu.l[1], lu.l[2]};
                 g.h = {lu.h[0], lu.h[1], lu.h[2]};
                 g.hh = lu.hh; g.p5 = lu.p5; g.att = 1.0f;
             }
             float col[3];
-            shade(n, nn, rn, V, g, rough, base, f0, kd_scale, lu.inten, col);
+            shade_light(pt, g, lu.inten, col);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] += col[c];
+            for (int c = 0; c < 3; ++c) res[c][j] = col[c];
+        }
+    } else {
+        // ---- several lights (H12): light-independent terms of every pixel first, then lights in the
+        // OUTER (uniform) loop and the lane's pixels inside it, so each light's scalar loads and loop
+        // overhead are paid once per VEC pixels and the pixels' transcendental latencies interleave
+        PixelTerms pt[VEC];
+        float xs[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            material_terms<WF, VEC>(t, j, V, pt[j]);
+            xs[j] = LIGHT == PBR_LIGHT_POINT ? linspace_at(a.x0, a.x1, a.xstep, a.W, p.x + j) : 0.0f;
         }
 #pragma unroll
-        for (int c = 0; c < 3; ++c) res[c][j] = MULTI ? clamp01(acc[c]) : acc[c];   // H12 (shade() clamps per light)
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) res[c][j] = 0.0f;
+        for (int l = 0; l < a.n_lights; ++l) {
+            const LightU &lu = a.lights[l];
+            LightGeom g;
+            if (LIGHT == PBR_LIGHT_DIRECTIONAL) {
+                g.L = {lu.l[0], lu.l[1], lu.l[2]};
+                g.h = {lu.h[0], lu.h[1], lu.h[2]};
+                g.hh = lu.hh; g.p5 = lu.p5; g.att = 1.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                if (LIGHT == PBR_LIGHT_POINT) g = point_light_geom(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, xs[j], ys);
+                float col[3];
+                shade_light(pt[j], g, lu.inten, col);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) res[c][j] += col[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)                                         // sum of per-light clamped terms, clamped
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) res[c][j] = clamp01(res[c][j]);
     }
     if (a.out_srgb) {                                                       // :179-180
 #pragma unroll
@@ -257,7 +315,8 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
 
 // ------------------------------------------------------------------ kernel
 //   LIGHT: PBR_LIGHT_*     WF: PBR_WORKFLOW_*     TI/TO: map / output storage types
-//   VEC: pixels per lane (4 = 16-byte accesses, 1 = ragged widths / unaligned views)
+//   VEC: pixels per lane (4 = 16-byte fp32 accesses, 8 = 16-byte fp16 accesses, 1 = ragged widths /
+//        unaligned views)
 //   MULTI: more than one light (uniform loop) -- the single-light body is straight-line
 // 1-D grid, one tile per workgroup, tiles ordered x fastest.
 template <int LIGHT, int WF, typename TI, typename TO, int VEC, bool MULTI, bool NT>

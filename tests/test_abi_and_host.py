@@ -148,7 +148,10 @@ def test_fp16_descriptor():
               y_offset=0, height_total=None)
     d = F.build_descriptor(a, n, r, m, None, torch.empty(1, 3, 4, 8), **kw)
     assert d.map_dtype == N.F16 and d.out_dtype == N.F32 and lib.pbr_bytes_per_pixel(ctypes.byref(d)) == 28
-    assert lib.pbr_kernel_name(ctypes.byref(d)) == b"ct_point_metallic_f16_f32_v4"
+    assert lib.pbr_kernel_name(ctypes.byref(d)) == b"ct_point_metallic_f16_f32_v8"        # W % 8 == 0: 16-byte fp16 loads
+    a6, n6, r6, m6 = (torch.rand(1, c, 4, 12).half() for c in (3, 3, 1, 1))
+    d6 = F.build_descriptor(a6, n6, r6, m6, None, torch.empty(1, 3, 4, 12), **kw)
+    assert lib.pbr_kernel_name(ctypes.byref(d6)) == b"ct_point_metallic_f16_f32_v4"       # W % 8 != 0
     with pytest.raises(TypeError):
         F.build_descriptor(a.double(), n.double(), r.double(), m.double(), None, torch.empty(1, 3, 4, 8), **kw)
     with pytest.raises(TypeError):

@@ -132,6 +132,16 @@ int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *ba
 int pbr_decode_normal(const void *src, void *dst, int32_t channels, int64_t pixels, int dtype,
                       void *workspace, void *stream);
 
+/*
+ * MaterialBase.resize, base.py:490-504 (torchvision resize of a float (C,H,W) map ==
+ * F.interpolate(mode="bilinear", align_corners=False, antialias=...)).  fp32 planar
+ * [planes][h_in][w_in] -> [planes][h_out][w_out]; `workspace` holds the width-pass
+ * intermediate, pbr_resize_workspace_bytes(planes, h_in, w_out) bytes of device memory.
+ */
+size_t pbr_resize_workspace_bytes(int64_t planes, int32_t h_in, int32_t w_out);
+int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in, int32_t w_in,
+                        int32_t h_out, int32_t w_out, int antialias, void *workspace, void *stream);
+
 /* ---- introspection / tuning (bench and tests only) --------------------------------- */
 int pbr_abi_version(void);
 /* sizeof(pbr_render_desc) as compiled: bindings check their struct layout against it. */

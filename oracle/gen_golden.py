@@ -231,6 +231,55 @@ def misc_set(manifest):
             "shape": list(v.shape), "dtype": str(v.dtype)} for k, v in d.items()}
 
 
+def _entry(v):
+    return {"sha1_12": sha12(v), "mean": float(np.asarray(v, dtype=np.float64).mean()),
+            "shape": list(v.shape), "dtype": str(v.dtype)}
+
+
+def example_set(manifest):
+    """examples/example_brdf.py, literally: load the `tiles` folder (the PNGs are committed as data
+    fixtures under tests/golden/tiles/), resize((512,512)), tile(2), point-light render.  Also
+    resize-only vectors (antialiased down / up-scaling, tuple and int sizes) on small maps."""
+    import shutil
+    import warnings
+    src = os.path.join(REFERENCE_ROOT, "tests", "data", "tiles")
+    dst = os.path.join(GOLDEN, "tiles")
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(os.listdir(src)):
+        if f.endswith(".png"):
+            shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+    d = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        mat = load_material_from_folder(dst, preferred_workflow="metallic")
+    d["meta_map_order"] = np.array(list(mat._maps.keys()))
+    for k, v in mat._maps.items():
+        d[f"loaded_mean_{k}"] = np.array(float(v.double().mean()))
+        d[f"loaded_crop_{k}"] = v[:, 500:532, 700:732].numpy()
+    mat.resize((512, 512)).tile(2)
+    assert mat.size == (1024, 1024)
+    for k, v in mat._maps.items():
+        d[f"resized_crop_{k}"] = v[:, 480:544, 480:544].numpy()          # straddles the tile seam at 512
+        d[f"resized_mean_{k}"] = np.array(float(v.double().mean()))
+    out = CookTorranceBRDF(light_type="point")(mat, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]),
+                                               torch.tensor([1.0, 1.0, 1.0]), 1.0)
+    d["example_mean"] = np.array(float(out.double().mean()))
+    d["example_crop"] = out[:, 448:576, 448:576].numpy()
+    d["example_rowsum"] = out.double().sum(dim=(0, 2)).numpy()           # 1024 row sums: a checksum of the whole image
+    # resize-only vectors on a small seeded map
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(3, 37, 53, generator=g)
+    d["in_resize"] = x.numpy()
+    for name, size, aa in (("down", (20, 31), True), ("up", (80, 97), True), ("down_noaa", (20, 31), False),
+                           ("int", 24, True), ("same", (37, 53), True), ("half", (18, 26), True)):
+        m = MaterialBase(albedo=x.clone(), normal=None)
+        m.resize(size, antialias=aa)
+        d[f"out_resize_{name}"] = m.albedo.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "example.npz"), **d)
+    manifest["sets"]["example"] = {k: _entry(v) for k, v in d.items() if v.dtype.kind == "f"}
+    print("example path mean", float(d["example_mean"]))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -251,6 +300,7 @@ def main():
     fixture_set("tiles96", "tiles", (300, 420, 96, 96), manifest)
     fixture_set("rocks96", "rocks", (512, 100, 96, 96), manifest)
     misc_set(manifest)
+    example_set(manifest)
     with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))

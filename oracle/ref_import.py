@@ -64,10 +64,17 @@ def _install_torchvision_stub():
         return t.to(torch.float32)
 
     def resize(img, size, interpolation=None, max_size=None, antialias=True):
+        # torchvision semantics for float tensors: an int (or 1-tuple) size fixes the SMALLER edge and
+        # keeps the aspect ratio; bilinear, align_corners=False, antialias as given
+        if isinstance(size, (list, tuple)) and len(size) == 1:
+            size = size[0]
         if isinstance(size, int):
-            size = (size, size)
+            h, w = img.shape[-2:]
+            short, long = (w, h) if w <= h else (h, w)
+            new_short, new_long = size, int(size * long / short)
+            size = (new_long, new_short) if w <= h else (new_short, new_long)
         return F.interpolate(img[None], size=tuple(size), mode="bilinear",
-                             align_corners=False, antialias=True)[0]
+                             align_corners=False, antialias=bool(antialias))[0]
 
     fn.to_tensor = to_tensor
     fn.resize = resize

@@ -25,6 +25,7 @@ EXPORTS = (
     "pbr_cook_torrance", "pbr_srgb_to_linear", "pbr_linear_to_srgb", "pbr_metallic_to_specular",
     "pbr_specular_to_metallic", "pbr_decode_normal", "pbr_abi_version", "pbr_error_string",
     "pbr_kernel_name", "pbr_bytes_per_pixel", "pbr_set_tuning", "pbr_render_desc_size",
+    "pbr_resize_workspace_bytes", "pbr_resize_bilinear",
 )
 
 
@@ -86,6 +87,10 @@ def lib():
     L.pbr_kernel_name.restype = ctypes.c_char_p
     L.pbr_bytes_per_pixel.argtypes = [ctypes.POINTER(RenderDesc)]
     L.pbr_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
+    L.pbr_resize_workspace_bytes.argtypes = [i64, i32, i32]
+    L.pbr_resize_workspace_bytes.restype = ctypes.c_size_t
+    L.pbr_resize_bilinear.argtypes = [vp, vp, i64, i32, i32, i32, i32, ctypes.c_int, vp, vp]
+    L.pbr_resize_bilinear.restype = ctypes.c_int
     L.pbr_render_desc_size.restype = ctypes.c_size_t
     if L.pbr_render_desc_size() != ctypes.sizeof(RenderDesc):
         raise NativeLibraryError("pbr_render_desc layout mismatch: library %d bytes, binding %d"

@@ -263,6 +263,33 @@ def diffuse_specular_to_basecolor_metallic(diffuse: torch.Tensor, specular: torc
     return base, met
 
 
+def resize(texture: torch.Tensor, size, antialias: bool = True) -> torch.Tensor:
+    """MaterialBase.resize for one map (base.py:490-504 -> torchvision resize of a float tensor):
+    bilinear, align_corners=False, optional antialiasing.  `size` = (h, w), or an int that fixes the
+    SMALLER edge and keeps the aspect ratio (torchvision semantics).  [..., H, W] float32 on device."""
+    if not texture.is_cuda:
+        raise RuntimeError("resize needs a tensor on a ROCm device; there is no CPU path")
+    if texture.dtype != torch.float32:
+        raise TypeError("resize supports float32 maps, got %s" % texture.dtype)
+    h, w = texture.shape[-2:]
+    if isinstance(size, (list, tuple)) and len(size) == 1:
+        size = size[0]
+    if isinstance(size, int):
+        short, long = (w, h) if w <= h else (h, w)
+        new_short, new_long = size, int(size * long / short)
+        size = (new_long, new_short) if w <= h else (new_short, new_long)
+    ho, wo = int(size[0]), int(size[1])
+    t = texture.contiguous()
+    planes = t.numel() // (h * w)
+    out = torch.empty(t.shape[:-2] + (ho, wo), dtype=t.dtype, device=t.device)
+    lib = N.lib()
+    ws = torch.empty(lib.pbr_resize_workspace_bytes(planes, h, wo) // 4, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        N.check(lib.pbr_resize_bilinear(t.data_ptr(), out.data_ptr(), planes, h, w, ho, wo, int(bool(antialias)),
+                                        ws.data_ptr(), _stream_ptr(t.device)))
+    return out
+
+
 def decode_normal(normal_map: torch.Tensor) -> torch.Tensor:
     """MaterialBase._process_normal_map (base.py:191-242) on the device: (2|3,H,W) -> (3,H,W)."""
     if normal_map.dim() != 3 or normal_map.shape[0] not in (2, 3):

@@ -184,6 +184,14 @@ class MaterialBase:
             self.albedo_is_srgb = True
         return self
 
+    # -- the two calls around the BRDF in examples/example_brdf.py:11
+    def resize(self, size, antialias: bool = True):
+        """Resize every map (base.py:490-504): bilinear, antialiased by default; in place, returns self."""
+        for name, t in self._maps.items():
+            if t is not None:
+                self._maps[name] = _through_device(t, lambda x: F_.resize(x, size, antialias=antialias))
+        return self
+
     # -- pure indexing (base.py:524-537); no arithmetic involved
     def tile(self, num_tiles: int):
         for name, t in self._maps.items():

@@ -231,3 +231,55 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "torch_oracle" not in text and "c_oracle" not in text and "ct_oracle" not in text, f
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+
+
+# ---------------------------------------------------------------- N1: loader + alias (host side)
+def _write_png(path, arr, mode):
+    from PIL import Image
+    Image.fromarray(arr, mode).save(path)
+
+
+def test_loader_workflow_selection_and_alias(tmp_path):
+    import warnings
+    from pypbr_amd import compat
+    from pypbr_amd.io import load_material_from_folder, select_material_class
+    rng = np.random.default_rng(3)
+    rgb = (rng.random((6, 8, 3)) * 255).astype(np.uint8)
+    gray = (rng.random((6, 8)) * 255).astype(np.uint8)
+    _write_png(tmp_path / "albedo.png", rgb, "RGB")                  # "albedo" is an accepted stem for basecolor
+    _write_png(tmp_path / "diffuse.png", rgb, "RGB")
+    _write_png(tmp_path / "roughness.png", gray, "L")
+    _write_png(tmp_path / "metalness.png", gray, "L")
+    _write_png(tmp_path / "specular.png", rgb, "RGB")
+    _write_png(tmp_path / "height.png", (rng.random((6, 8)) * 65535).astype(np.uint16), "I;16")
+    with pytest.warns(UserWarning, match="Using metallic workflow as preferred"):
+        mat = load_material_from_folder(str(tmp_path), preferred_workflow="metallic")
+    assert isinstance(mat, BasecolorMetallicMaterial)
+    assert list(mat._maps) == ["albedo", "roughness", "height", "metallic"]      # no normal file -> no entry (F7)
+    assert torch.equal(mat.albedo, torch.from_numpy(rgb.transpose(2, 0, 1).astype(np.float32) / 255))
+    assert mat.height.shape == (1, 6, 8) and float(mat.height.max()) <= 1.0 and mat.albedo_is_srgb is True
+    with pytest.warns(UserWarning, match="Using specular workflow as preferred"):
+        ds = load_material_from_folder(str(tmp_path), preferred_workflow="specular", is_srgb=False)
+    assert isinstance(ds, DiffuseSpecularMaterial) and "metallic" not in ds._maps and ds.specular_is_srgb is False
+    with pytest.warns(UserWarning, match="Defaulting to metallic workflow"):
+        assert select_material_class({"metallic": 1, "specular": 2}) is BasecolorMetallicMaterial
+    assert select_material_class({"specular": 1}) is DiffuseSpecularMaterial
+    assert select_material_class({"diffuse": 1}) is DiffuseSpecularMaterial
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert select_material_class({}) is BasecolorMetallicMaterial
+    # alias: the reference's import lines resolve to this package
+    import sys
+    saved = {k: v for k, v in sys.modules.items() if k == "pypbr" or k.startswith("pypbr.")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        compat.install()
+        from pypbr.io import load_material_from_folder as aliased_loader
+        from pypbr.models import CookTorranceBRDF as AliasedBRDF
+        assert AliasedBRDF is CookTorranceBRDF and aliased_loader is load_material_from_folder
+        import pypbr
+        assert pypbr.materials.MaterialBase is MaterialBase
+    finally:
+        compat.uninstall()
+        sys.modules.update(saved)

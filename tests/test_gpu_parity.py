@@ -316,3 +316,58 @@ def test_full_size_4k_properties_and_sampled_parity():
     assert (err32 <= env + TOL).all()              # criterion (ii b): every > TOL difference is the fp32 oracle's own error
     assert np.abs(got[np.broadcast_to(host[2] >= ROUGH_OK, got.shape)] -
                   ref32[np.broadcast_to(host[2] >= ROUGH_OK, got.shape)]).max() <= TOL      # criterion (i)
+
+
+def test_resize_matches_reference_vectors(golden):
+    """MaterialBase.resize (N1): antialiased bilinear, tuple and int sizes, up and down."""
+    from pypbr_amd import functional as F
+    z = golden("example")
+    x = _dev(z["in_resize"])
+    for name, size, aa in (("down", (20, 31), True), ("up", (80, 97), True), ("down_noaa", (20, 31), False),
+                           ("int", 24, True), ("same", (37, 53), True), ("half", (18, 26), True)):
+        got = F.resize(x, size, antialias=aa).cpu().numpy()
+        assert got.shape == z[f"out_resize_{name}"].shape, name
+        assert np.abs(got - z[f"out_resize_{name}"]).max() <= 2e-6, (name, float(np.abs(got - z[f"out_resize_{name}"]).max()))
+
+
+def test_example_brdf_script_path(golden):
+    """examples/example_brdf.py statement by statement, through the `pypbr` alias: load the tiles folder,
+    resize((512, 512)).tile(2), point-light render -- against the output of the real reference."""
+    import os
+    import sys
+    import warnings
+    from pypbr_amd import compat
+    saved = {k: v for k, v in sys.modules.items() if k == "pypbr" or k.startswith("pypbr.")}
+    for k in saved:
+        del sys.modules[k]
+    compat.install()
+    try:
+        from pypbr.io import load_material_from_folder
+        from pypbr.models import CookTorranceBRDF
+        z = golden("example")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            material = load_material_from_folder(os.path.join(os.path.dirname(__file__), "golden", "tiles"),
+                                                 preferred_workflow="metallic")
+        assert list(material._maps) == list(z["meta_map_order"])
+        for k, v in material._maps.items():
+            assert np.abs(v[:, 500:532, 700:732].numpy() - z[f"loaded_crop_{k}"]).max() <= 2e-6, k
+        H, W = 512, 512
+        material.resize((H, W)).tile(2)
+        assert material.size == (1024, 1024)
+        for k, v in material._maps.items():
+            assert np.abs(v[:, 480:544, 480:544].numpy() - z[f"resized_crop_{k}"]).max() <= 1e-5, k
+            assert abs(float(v.double().mean()) - float(z[f"resized_mean_{k}"])) <= 1e-6, k
+        brdf = CookTorranceBRDF(light_type="point")
+        view_dir = torch.tensor([0.0, 0.0, 1.0])
+        light_dir = torch.tensor([0.1, 0.1, 1.0])
+        light_intensity = torch.tensor([1.0, 1.0, 1.0])
+        light_size = 1.0
+        reflected_color = brdf(material, view_dir, light_dir, light_intensity, light_size)
+        assert reflected_color.shape == (3, 1024, 1024) and reflected_color.device.type == "cpu"
+        assert np.abs(reflected_color[:, 448:576, 448:576].numpy() - z["example_crop"]).max() <= TOL
+        assert abs(float(reflected_color.double().mean()) - float(z["example_mean"])) <= 1e-6     # 0.493188 (SURVEY.md 8c)
+        assert np.abs(reflected_color.double().sum(dim=(0, 2)).numpy() - z["example_rowsum"]).max() <= 3e-3   # 3072 values per row
+    finally:
+        compat.uninstall()
+        sys.modules.update(saved)

@@ -82,11 +82,10 @@ __device__ __forceinline__ LightGeom point_light_geom(const Vec3 &V, const Vec3 
 
 // Light-independent terms of one pixel, computed once and reused by every light.
 struct PixelTerms {
-    Vec3 n;            // stored normal, un-normalised
-    float nn, rn;      // |n|^2, 1/max(|n|, 1e-12)   (F.normalize :154)
+    Vec3 n;            // unit normal: stored normal * 1/max(|n|, 1e-12)   (F.normalize :154)
     float ndv;         // clamp(N.V)                  (:163)
-    float a2, oma2;    // roughness^2, 1 - roughness^2 (alpha = roughness, :213-214)
-    float k, omk;      // (r+1)^2/8, 1-k              (:232-233)
+    float a2;          // roughness^2                 (alpha = roughness, :213-214)
+    float k;           // (r+1)^2/8                   (:232-233)
     float dv;          // NdotV (1-k) + k + 1e-7      (:234)
     float a2ndv;       // a2 * NdotV
     float base[3];     // linear albedo / diffuse colour, pre-multiplied by 1/pi (:174)
@@ -96,16 +95,13 @@ struct PixelTerms {
 
 __device__ __forceinline__ void pixel_terms(const Vec3 &n, const Vec3 &V, float rough, const float base[3],
                                             const float f0[3], float kd_scale, PixelTerms &t) {
-    t.n = n;
-    t.nn = dot(n, n);
-    t.rn = rsq(fmaxf(t.nn, 1e-24f));
-    t.ndv = clamp01(dot(n, V) * t.rn);
+    const float rn = rsq(fmaxf(dot(n, n), 1e-24f));
+    t.n = {n.x * rn, n.y * rn, n.z * rn};
+    t.ndv = clamp01(dot(t.n, V));
     t.a2 = rough * rough;
-    t.oma2 = 1.0f - t.a2;
     const float r1 = rough + 1.0f;
     t.k = r1 * r1 * 0.125f;
-    t.omk = 1.0f - t.k;
-    t.dv = fmaf(t.ndv, t.omk, t.k) + 1e-7f;
+    t.dv = fmaf(t.ndv, 1.0f - t.k, t.k) + 1e-7f;
     t.a2ndv = t.a2 * t.ndv;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { t.base[c] = base[c] * kInvPi; t.f0[c] = f0[c]; }
@@ -114,15 +110,16 @@ __device__ __forceinline__ void pixel_terms(const Vec3 &n, const Vec3 &V, float 
 
 // One light's linear RGB contribution, clamped to [0,1] (:160-177).
 __device__ __forceinline__ void shade_light(const PixelTerms &t, const LightGeom &g, const float inten[3], float out[3]) {
-    const float ndl = clamp01(dot(t.n, g.L) * t.rn);               // :164
-    // GGX (:213-217), cancellation-free: den = a2 + (1-a2) sin^2 when N.H > 0, else 1.
+    const float ndl = clamp01(dot(t.n, g.L));                      // :164
+    // GGX (:213-217), cancellation-free: den = a2 + (1-a2) sin^2(N,H) when N.H > 0, else 1;
+    // sin^2 = |N x h|^2 / |h|^2 with N unit.
     const float nh = dot(t.n, g.h);
     const Vec3 c = {fmaf(t.n.y, g.h.z, -(t.n.z * g.h.y)), fmaf(t.n.z, g.h.x, -(t.n.x * g.h.z)),
                     fmaf(t.n.x, g.h.y, -(t.n.y * g.h.x))};
-    const float s2 = fminf(dot(c, c) * rcp(fmaxf(t.nn * g.hh, 1e-36f)), 1.0f);
-    const float den = nh > 0.0f ? fmaf(s2, t.oma2, t.a2) : 1.0f;
+    const float s2 = fminf(dot(c, c) * rcp(fmaxf(g.hh, 1e-36f)), 1.0f);
+    const float den = nh > 0.0f ? fmaf(s2, 1.0f - t.a2, t.a2) : 1.0f;
     // D * G / (4 NdotV NdotL + 1e-7) with one reciprocal (:217, :232-235, :165-166).
-    const float dl = fmaf(ndl, t.omk, t.k) + 1e-7f;
+    const float dl = fmaf(ndl, 1.0f - t.k, t.k) + 1e-7f;
     const float dD = fmaf(kPi, den * den, 1e-7f);
     const float ds = fmaf(4.0f * t.ndv, ndl, 1e-7f);
     const float dg = t.a2ndv * ndl * rcp((dD * t.dv) * (dl * ds));

@@ -320,7 +320,7 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
 //   MULTI: more than one light (uniform loop) -- the single-light body is straight-line
 // 1-D grid, one tile per workgroup, tiles ordered x fastest.
 template <int LIGHT, int WF, typename TI, typename TO, int VEC, bool MULTI, bool NT>
-__global__ __launch_bounds__(256) void cook_torrance_kernel(const KArgs a) {
+__global__ __launch_bounds__(256, MULTI ? 4 : 1) void cook_torrance_kernel(const KArgs a) {
     const int ty = (int)a.div_tx.div(blockIdx.x);
     const LanePos p = lane_pos<VEC>(a, (int)blockIdx.x - ty * a.tiles_x, ty);
     if (!p.valid) return;

@@ -43,7 +43,8 @@ enum {
     PBR_ERR_SHAPE = -4,           /* non-positive extent, band outside the map, > PBR_MAX_LIGHTS */
     PBR_ERR_DTYPE = -5,
     PBR_ERR_CHANNELS = -6,        /* base.py:219 "Normal map must have 2 or 3 channels." */
-    PBR_ERR_NO_DEVICE = -7
+    PBR_ERR_NO_DEVICE = -7,
+    PBR_ERR_UNSUPPORTED = -8      /* valid request this build does not implement (e.g. backward of CONVERTED) */
 };
 
 enum { PBR_F32 = 0, PBR_F16 = 1 };                 /* storage type of maps */
@@ -102,6 +103,19 @@ typedef struct pbr_render_desc {
 
 /* Enqueue the fused kernel.  Returns PBR_OK or an error code; never blocks. */
 int pbr_cook_torrance(const pbr_render_desc *desc, void *stream);
+
+/*
+ * Gradient of pbr_cook_torrance w.r.t. the maps (what torch.autograd computes through
+ * cooktorrance.py:92-182 in the reference's rendering-loss use,
+ * docs/source/tutorials/06_advanced.rst:73-107).  `desc` is the forward descriptor (its `out` is
+ * ignored), fp32 maps, METALLIC or SPECULAR workflow; `grad_out` is [B][3][H][W] contiguous.
+ * Each non-NULL g_* receives a contiguous fp32 gradient shaped like its map
+ * ([B][3|1][H][W]); NULL skips it.  Same sub-gradient conventions as torch (clamp passes on the
+ * closed interval).
+ */
+int pbr_cook_torrance_backward(const pbr_render_desc *desc, const void *grad_out, void *g_albedo,
+                               void *g_normal, void *g_roughness, void *g_metallic, void *g_specular,
+                               void *stream);
 
 /* ---- stand-alone map conversions (same arithmetic as the fused kernel) ------------- */
 

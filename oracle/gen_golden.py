@@ -280,6 +280,49 @@ def example_set(manifest):
     print("example path mean", float(d["example_mean"]))
 
 
+def grad_set(manifest):
+    """Gradients of the reference (torch.autograd through CookTorranceBRDF.forward) of
+    loss = sum(out * W) w.r.t. the maps: the rendering-loss use of docs/.../06_advanced.rst:73-107."""
+    H, W = 24, 40
+    g = torch.Generator().manual_seed(515)
+    a = torch.rand(3, H, W, generator=g)
+    nxy = (torch.rand(2, H, W, generator=g) - 0.5) * 1.6
+    n = torch.cat([nxy, torch.ones(1, H, W)], 0)                      # un-normalised on purpose (F.normalize backward)
+    r = torch.rand(1, H, W, generator=g) * 0.8 + 0.2
+    m = torch.rand(1, H, W, generator=g)
+    s = torch.rand(3, H, W, generator=g) * 0.5
+    wt = torch.rand(3, H, W, generator=g) - 0.3
+    d = {"in_albedo": a, "in_normal": n, "in_roughness": r, "in_metallic": m, "in_specular": s, "in_weight": wt}
+
+    def run(kind, lk, srgb, dtype):
+        leaves = {k: v.clone().to(dtype).requires_grad_(True) for k, v in (("albedo", a), ("normal", n), ("roughness", r),
+                                                                             ("metallic", m), ("specular", s))}
+        if kind == "metallic":
+            mat = BasecolorMetallicMaterial()
+            mat._maps["metallic"] = leaves["metallic"]
+        else:
+            mat = DiffuseSpecularMaterial()
+            mat._maps["specular"] = leaves["specular"]
+        for k in ("albedo", "normal", "roughness"):
+            mat._maps[k] = leaves[k]
+        out = render(mat, lk, return_srgb=srgb, dtype=dtype)
+        (out * wt.to(dtype)).sum().backward()
+        names = ("albedo", "normal", "roughness", "metallic" if kind == "metallic" else "specular")
+        return {k: leaves[k].grad.numpy() for k in names}
+
+    for kind in ("metallic", "specular"):
+        for lk in ("pt1", "dir"):
+            for srgb in (True, False):
+                tag = f"{kind}_{lk}_{'srgb' if srgb else 'lin'}"
+                for k, v in run(kind, lk, srgb, torch.float32).items():
+                    d[f"grad_{tag}_{k}"] = v
+                for k, v in run(kind, lk, srgb, torch.float64).items():
+                    d[f"g64_{tag}_{k}"] = v
+    d = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+    np.savez(os.path.join(GOLDEN, "grad.npz"), **d)
+    manifest["sets"]["grad"] = {k: _entry(v) for k, v in d.items()}
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -301,6 +344,7 @@ def main():
     fixture_set("rocks96", "rocks", (512, 100, 96, 96), manifest)
     misc_set(manifest)
     example_set(manifest)
+    grad_set(manifest)
     with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))

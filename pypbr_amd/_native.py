@@ -19,13 +19,14 @@ TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC = 0, 1, 2
 
 OK = 0
 ERR_NULL_MAP, ERR_WORKFLOW, ERR_LIGHT_TYPE, ERR_SHAPE, ERR_DTYPE, ERR_CHANNELS, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
+ERR_UNSUPPORTED = -8
 
 # every symbol include/pbr_hip.h declares (tests/test_abi.py checks the export table against the header)
 EXPORTS = (
     "pbr_cook_torrance", "pbr_srgb_to_linear", "pbr_linear_to_srgb", "pbr_metallic_to_specular",
     "pbr_specular_to_metallic", "pbr_decode_normal", "pbr_abi_version", "pbr_error_string",
     "pbr_kernel_name", "pbr_bytes_per_pixel", "pbr_set_tuning", "pbr_render_desc_size",
-    "pbr_resize_workspace_bytes", "pbr_resize_bilinear",
+    "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
 )
 
 
@@ -72,6 +73,8 @@ def lib():
     vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
     L.pbr_cook_torrance.argtypes = [ctypes.POINTER(RenderDesc), vp]
     L.pbr_cook_torrance.restype = ctypes.c_int
+    L.pbr_cook_torrance_backward.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp]
+    L.pbr_cook_torrance_backward.restype = ctypes.c_int
     L.pbr_srgb_to_linear.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     L.pbr_linear_to_srgb.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     L.pbr_metallic_to_specular.argtypes = [vp, vp, vp, vp, i32, i64, ctypes.c_int, ctypes.c_int, vp]
@@ -115,6 +118,8 @@ def check(code: int):
         raise ValueError(msg)
     if code == ERR_DTYPE:
         raise TypeError(msg)
+    if code == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
     raise RuntimeError("HIP error %d: %s" % (code, msg))
 
 

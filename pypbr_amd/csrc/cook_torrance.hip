@@ -28,6 +28,7 @@
 #include <cstring>
 
 #include "../../include/pbr_hip.h"
+#include "ct_backward.hpp"
 #include "ct_kernel.hpp"
 
 namespace pbr {
@@ -206,6 +207,35 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane
     hipLaunchKernelGGL(e.fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0,
                        static_cast<hipStream_t>(stream), k);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
+
+int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal,
+                               void *g_roughness, void *g_metallic, void *g_specular, void *stream) {
+    using namespace pbr;
+    const int rc = validate(d);
+    if (rc != PBR_OK) return rc;
+    if (!grad_out) return PBR_ERR_NULL_MAP;
+    if (d->map_dtype != PBR_F32 || d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;
+    if (d->workflow == PBR_WORKFLOW_CONVERTED) return PBR_ERR_UNSUPPORTED;
+    int vec = pick_vec(d);
+    for (const void *g : {grad_out, (const void *)g_albedo, (const void *)g_normal, (const void *)g_roughness,
+                          (const void *)g_metallic, (const void *)g_specular})
+        if (g && (reinterpret_cast<uintptr_t>(g) & 15u)) vec = 1;
+    if (vec == 8) vec = 4;
+    KArgs k;
+    fill_args(d, vec, k);
+    const BArgs b = {grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular};
+    const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT, spec = d->workflow == PBR_WORKFLOW_SPECULAR;
+    void (*fn)(const KArgs, const BArgs) = nullptr;
+#define PBR_BWD(L, W)                                                                                           \
+    fn = vec == 4 ? (multi ? cook_torrance_backward_kernel<L, W, 4, true> : cook_torrance_backward_kernel<L, W, 4, false>) \
+                  : (multi ? cook_torrance_backward_kernel<L, W, 1, true> : cook_torrance_backward_kernel<L, W, 1, false>)
+    if (point) { if (spec) { PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR); } else { PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC); } }
+    else       { if (spec) { PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR); } else { PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC); } }
+#undef PBR_BWD
+    hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0, static_cast<hipStream_t>(stream), k, b);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? PBR_OK : 1000 + (int)err;
 }

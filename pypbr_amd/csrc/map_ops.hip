@@ -273,6 +273,7 @@ const char *pbr_error_string(int code) {
         case PBR_ERR_DTYPE: return "unsupported map dtype";
         case PBR_ERR_CHANNELS: return "Normal map must have 2 or 3 channels.";
         case PBR_ERR_NO_DEVICE: return "no HIP device";
+        case PBR_ERR_UNSUPPORTED: return "not implemented for this configuration";
         default: break;
     }
     if (code >= 1000) return hipGetErrorString(static_cast<hipError_t>(code - 1000));

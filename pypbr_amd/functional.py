@@ -201,9 +201,58 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
     Returns [3,H,W] or [B,3,H,W] (float32 unless `out_dtype`), on the same device,
     enqueued on the current stream without synchronising.
     """
+    maps = (albedo, normal, roughness, metallic, specular)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in maps):
+        return _CookTorranceFn.apply(albedo, normal, roughness, metallic, specular, kwargs)
     plan = plan_cook_torrance(albedo, normal, roughness, metallic, specular, **kwargs)
     with torch.cuda.device(plan.device):
         return plan.launch()
+
+
+class _CookTorranceFn(torch.autograd.Function):
+    """Autograd bridge: forward = the fused kernel, backward = pbr_cook_torrance_backward (one
+    more streaming kernel that recomputes the forward terms).  Gradients flow to the maps only;
+    view/light parameters are host scalars (as in the reference's rendering-loss use)."""
+
+    @staticmethod
+    def forward(ctx, albedo, normal, roughness, metallic, specular, kwargs):
+        if kwargs.get("convert_to_diffuse_specular") or kwargs.get("out") is not None:
+            raise NotImplementedError("gradients are implemented for the metallic and specular workflows, out=None")
+        maps = (albedo, normal, roughness, metallic, specular)
+        plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **kwargs)
+        if plan.desc.map_dtype != N.F32 or plan.desc.out_dtype != N.F32:
+            raise NotImplementedError("gradients need float32 maps and output")
+        ctx.plan = plan
+        ctx.in_shapes = [None if t is None else tuple(t.shape) for t in maps]
+        with torch.cuda.device(plan.device):
+            return plan.launch()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        plan = ctx.plan
+        d = plan.desc
+        B, H, W = d.batch, d.height, d.width
+        g = grad_out.reshape(B, 3, H, W).to(torch.float32).contiguous()
+        channels = (3, 3, 1, 1, 3)
+        present = (True, bool(d.normal.data), True, bool(d.metallic.data), bool(d.specular.data))
+        bufs = []
+        for i in range(5):
+            want = ctx.needs_input_grad[i] and present[i] and ctx.in_shapes[i] is not None
+            bufs.append(torch.empty((B, channels[i], H, W), dtype=torch.float32, device=g.device) if want else None)
+        with torch.cuda.device(g.device):
+            N.check(N.lib().pbr_cook_torrance_backward(
+                ctypes.byref(d), g.data_ptr(), *[None if b is None else b.data_ptr() for b in bufs], _stream_ptr(g.device)))
+        grads = []
+        for b, shape in zip(bufs, ctx.in_shapes):
+            if b is None:
+                grads.append(None)
+                continue
+            if len(shape) == 3:                      # unbatched map
+                b = b[0] if B == 1 else b.sum(0)
+            elif shape[0] == 1 and B > 1:            # one map shared by the whole batch
+                b = b.sum(0, keepdim=True)
+            grads.append(b.reshape(shape))
+        return (*grads, None)
 
 
 # ------------------------------------------------------------------ stand-alone conversions

@@ -1,0 +1,99 @@
+"""GPU parity of the backward kernel: gradients of sum(out * W) w.r.t. the maps
+against the REAL reference's autograd gradients (tests/golden/grad.npz, fp32 and float64 runs) and
+against autograd through the ATen oracle for the build extensions (batch, several lights).
+
+Tolerance: gradients are not bounded by 1 like the colours, so the bound is relative to the
+gradient scale: |g - g64| <= 2e-5 * (1 + |g64|) against the float64 reference, and the fp32
+reference must lie in the same band (it does, by construction of the fixture: roughness >= 0.2)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LIGHTS = {"pt1": ("point", [0.1, 0.1, 1.0], 1.0), "dir": ("directional", [0.3, -0.2, 1.0], None)}
+
+
+def _leaf(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).cuda().requires_grad_(True)
+
+
+@pytest.mark.parametrize("kind", ["metallic", "specular"])
+@pytest.mark.parametrize("lk", ["pt1", "dir"])
+@pytest.mark.parametrize("srgb", [True, False])
+def test_gradients_match_reference_autograd(kind, lk, srgb, golden):
+    from pypbr_amd import functional as F
+    z = golden("grad")
+    a, n, r = _leaf(z["in_albedo"]), _leaf(z["in_normal"]), _leaf(z["in_roughness"])
+    m = _leaf(z["in_metallic"]) if kind == "metallic" else None
+    s = _leaf(z["in_specular"]) if kind == "specular" else None
+    w = torch.from_numpy(z["in_weight"]).cuda()
+    ltype, lvec, lsize = LIGHTS[lk]
+    out = F.cook_torrance(a, n, r, m, s, view_dir=[0, 0, 1], light=lvec, light_intensity=[1, 1, 1], light_type=ltype,
+                          light_size=lsize, return_srgb=srgb)
+    assert out.requires_grad
+    (out * w).sum().backward()
+    tag = f"{kind}_{lk}_{'srgb' if srgb else 'lin'}"
+    got = {"albedo": a.grad, "normal": n.grad, "roughness": r.grad, "metallic" if m is not None else "specular": (m if m is not None else s).grad}
+    for name, g in got.items():
+        g = g.cpu().numpy()
+        ref32, ref64 = z[f"grad_{tag}_{name}"], z[f"g64_{tag}_{name}"]
+        assert g.shape == ref32.shape and np.isfinite(g).all()
+        band = 2e-5 * (1.0 + np.abs(ref64))
+        assert (np.abs(g.astype(np.float64) - ref64) <= band).all(), (tag, name, float(np.abs(g - ref64).max()))
+        # and against the reference's own fp32 gradient, allowing its own rounding envelope
+        env = np.abs(ref32.astype(np.float64) - ref64)
+        assert (np.abs(g - ref32) <= env + band).all(), (tag, name, float((np.abs(g - ref32) - env).max()))
+
+
+def test_backward_of_batched_multilight_against_oracle_autograd():
+    import torch_oracle as O
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(99)
+    B, H, W = 2, 20, 36
+    a = torch.rand(B, 3, H, W, generator=g)
+    n = torch.cat([(torch.rand(B, 2, H, W, generator=g) - 0.5), torch.ones(B, 1, H, W)], 1)
+    r = torch.rand(1, 1, H, W, generator=g) * 0.7 + 0.3                 # ONE roughness map shared by the batch
+    m = torch.rand(B, 1, H, W, generator=g)
+    wt = torch.rand(B, 3, H, W, generator=g) - 0.4
+    lights = torch.tensor([[0.3, 0.2, 0.8], [-0.4, 0.1, 0.6], [0.0, -0.5, 1.0]])
+    inten = torch.tensor([[0.6, 0.5, 0.4], [0.3, 0.3, 0.5], [0.4, 0.4, 0.4]])
+    # float64 oracle autograd = ground truth for the build extension
+    leaves = [t.double().requires_grad_(True) for t in (a, n, r, m)]
+    ref = O.cook_torrance_batched(leaves[0], leaves[1], leaves[2].expand(B, 1, H, W), leaves[3], None, lights=lights.double(),
+                                  intensities=inten.double(), view=torch.tensor([0.0, 0.1, 1.0], dtype=torch.float64),
+                                  light_type="point", light_size=1.5)
+    (ref * wt.double()).sum().backward()
+    dev = [t.clone().cuda().requires_grad_(True) for t in (a, n, r, m)]
+    out = F.cook_torrance(dev[0], dev[1], dev[2], dev[3], view_dir=[0.0, 0.1, 1.0], light=lights, light_intensity=inten,
+                          light_type="point", light_size=1.5)
+    assert (out.detach().cpu() - ref.detach().float()).abs().max().item() <= 1e-5
+    (out * wt.cuda()).sum().backward()
+    for name, d, l in zip(("albedo", "normal", "roughness", "metallic"), dev, leaves):
+        assert d.grad.shape == d.shape
+        err = (d.grad.cpu().double() - l.grad).abs()
+        assert (err <= 2e-5 * (1 + l.grad.abs())).all(), (name, float(err.max()))
+
+
+def test_rendering_loss_step_through_the_module():
+    """docs/source/tutorials/06_advanced.rst:73-107: MSE between two renders, gradient reaches the maps."""
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    from pypbr_amd.models import CookTorranceBRDF
+    g = torch.Generator().manual_seed(3)
+    H = W = 32
+    pred = {k: torch.rand(c, H, W, generator=g).cuda().requires_grad_(True) for k, c in (("albedo", 3), ("roughness", 1), ("metallic", 1))}
+    normal = torch.cat([torch.zeros(2, H, W), torch.ones(1, H, W)], 0).cuda()
+    mat = BasecolorMetallicMaterial(albedo=pred["albedo"], normal=None, roughness=pred["roughness"], metallic=pred["metallic"],
+                                    device=torch.device("cuda"))
+    mat._maps["normal"] = normal
+    target = torch.rand(3, H, W, generator=g).cuda()
+    brdf = CookTorranceBRDF("point")
+    out = brdf(mat, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0]), 1.0)
+    loss = torch.nn.functional.mse_loss(out, target)
+    loss.backward()
+    for k, t in pred.items():
+        assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().sum()) > 0, k
+    with pytest.raises(NotImplementedError):
+        from pypbr_amd import functional as F
+        F.cook_torrance(pred["albedo"], normal, pred["roughness"], pred["metallic"], view_dir=[0, 0, 1], light=[0, 0, 1],
+                        light_intensity=[1, 1, 1], convert_to_diffuse_specular=True)

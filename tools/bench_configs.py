@@ -86,6 +86,32 @@ def main():
     p1 = F.plan_cook_torrance(*s5, view_dir=[0, 0, 1], light=lights[0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
     report("cfg5' same maps, ONE point light fp16 -> fp32", [p1], 4 * 4096 * 4096, 10)
     del s5, p, p1
+    # backward (N3): gradients w.r.t. all four maps of one 4096^2 material, point light
+    import ctypes
+    from pypbr_amd import _native as N
+    a, n, r, m = maps(1, 4096, 4096, seed=7)
+    plan = F.plan_cook_torrance(a, n, r, m, **pt)
+    gout = torch.rand(1, 3, 4096, 4096, device=DEV)
+    grads = [torch.empty_like(t) for t in (a, n, r, m)]
+    lib, stream = N.lib(), torch.cuda.current_stream(DEV).cuda_stream
+
+    def bwd():
+        N.check(lib.pbr_cook_torrance_backward(ctypes.byref(plan.desc), gout.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
+                                               grads[2].data_ptr(), grads[3].data_ptr(), None, stream))
+    for _ in range(3):
+        bwd()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        bwd()
+    e1.record()
+    torch.cuda.synchronize()
+    dt = e0.elapsed_time(e1) / 20 * 1e-3
+    px = 4096 * 4096
+    print(json.dumps({"config": "backward B=1 4096^2 point fp32 (grads of albedo, normal, roughness, metallic)",
+                      "bytes_per_pixel": 76, "us_per_launch": round(dt * 1e6, 1), "Mpixels_per_s": round(px / dt / 1e6, 1),
+                      "hbm_GBps_algorithmic": round(76 * px / dt / 1e9, 1), "frac_of_8TBps": round(76 * px / dt / 1e9 / PEAK, 4)}), flush=True)
+    del a, n, r, m, plan, gout, grads
     # PCIe-inclusive: CPU-resident 4096^2 material through the reference-shaped callable
     from pypbr_amd.materials import BasecolorMetallicMaterial
     from pypbr_amd.models import CookTorranceBRDF

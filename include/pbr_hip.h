@@ -156,6 +156,22 @@ size_t pbr_resize_workspace_bytes(int64_t planes, int32_t h_in, int32_t w_out);
 int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in, int32_t w_in,
                         int32_t h_out, int32_t w_out, int antialias, void *workspace, void *stream);
 
+/*
+ * Material blending in front of the BRDF (examples/example_blend.py:14-16), fp32 planar maps.
+ * pbr_blend_maps: blend_with_mask blending/functional.py:64-116 for ONE map, out = mask * map1 +
+ * (1 - mask) * map2 over [channels][pixels] with a [pixels] mask; is_normal selects _blend_normals
+ * (:119-145: normalise both, blend, re-normalise; 3 channels).
+ * pbr_blend_sigmoid_mask: the mask of blend_on_height / blend_on_properties (:148-239),
+ * sigmoid((prop1 + shift - prop2) / (blend_width + 1e-6)).
+ * pbr_blend_gradient_mask: the mask of blend_with_gradient (:242-286), linspace(0,1) along x
+ * (vertical = 0) or y (vertical = 1), shape [height][width].
+ */
+int pbr_blend_maps(const void *map1, const void *map2, const void *mask, void *out, int32_t channels,
+                   int64_t pixels, int is_normal, void *stream);
+int pbr_blend_sigmoid_mask(const void *prop1, const void *prop2, void *mask, int64_t n, float shift,
+                           float blend_width, void *stream);
+int pbr_blend_gradient_mask(void *mask, int32_t height, int32_t width, int vertical, void *stream);
+
 /* ---- introspection / tuning (bench and tests only) --------------------------------- */
 int pbr_abi_version(void);
 /* sizeof(pbr_render_desc) as compiled: bindings check their struct layout against it. */

@@ -323,6 +323,40 @@ def grad_set(manifest):
     manifest["sets"]["grad"] = {k: _entry(v) for k, v in d.items()}
 
 
+def blend_set(manifest):
+    """pypbr.blending on 96x96 crops of the reference's two PNG materials (examples/example_blend.py uses
+    HeightBlend(blend_width=0.1, shift=-0.5) on the full maps): every blend kind, blended maps + masks."""
+    import warnings
+    import pypbr.blending as B
+    crop = (slice(None), slice(300, 396), slice(420, 516))
+    mats = []
+    for folder in ("tiles", "rocks"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            full = load_material_from_folder(os.path.join(REFERENCE_ROOT, "tests", "data", folder), preferred_workflow="metallic")
+        m = BasecolorMetallicMaterial()
+        for k, v in full._maps.items():
+            m._maps[k] = v[crop].contiguous()
+        mats.append(m)
+    d = {}
+    for i, m in enumerate(mats, 1):
+        for k, v in m._maps.items():
+            d[f"in_m{i}_{k}"] = v.numpy()
+    g = torch.Generator().manual_seed(77)
+    rnd_mask = torch.rand(96, 96, generator=g)
+    d["in_mask"] = rnd_mask.numpy()
+    blends = {"height": B.HeightBlend(blend_width=0.1, shift=-0.5), "mask": B.MaskBlend(rnd_mask),
+              "prop": B.PropertyBlend(property_name="roughness", blend_width=0.1),
+              "gradh": B.GradientBlend("horizontal"), "gradv": B.GradientBlend("vertical")}
+    for name, blender in blends.items():
+        out, mask = blender(mats[0], mats[1])
+        d[f"out_{name}_mask"] = mask.numpy()
+        for k, v in out._maps.items():
+            d[f"out_{name}_{k}"] = v.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "blend.npz"), **d)
+    manifest["sets"]["blend"] = {k: _entry(v) for k, v in d.items()}
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -345,6 +379,7 @@ def main():
     misc_set(manifest)
     example_set(manifest)
     grad_set(manifest)
+    blend_set(manifest)
     with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))

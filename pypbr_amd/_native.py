@@ -27,6 +27,7 @@ EXPORTS = (
     "pbr_specular_to_metallic", "pbr_decode_normal", "pbr_abi_version", "pbr_error_string",
     "pbr_kernel_name", "pbr_bytes_per_pixel", "pbr_set_tuning", "pbr_render_desc_size",
     "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
+    "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask",
 )
 
 
@@ -94,6 +95,11 @@ def lib():
     L.pbr_resize_workspace_bytes.restype = ctypes.c_size_t
     L.pbr_resize_bilinear.argtypes = [vp, vp, i64, i32, i32, i32, i32, ctypes.c_int, vp, vp]
     L.pbr_resize_bilinear.restype = ctypes.c_int
+    L.pbr_blend_maps.argtypes = [vp, vp, vp, vp, i32, i64, ctypes.c_int, vp]
+    L.pbr_blend_sigmoid_mask.argtypes = [vp, vp, vp, i64, ctypes.c_float, ctypes.c_float, vp]
+    L.pbr_blend_gradient_mask.argtypes = [vp, i32, i32, ctypes.c_int, vp]
+    for name in ("pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask"):
+        getattr(L, name).restype = ctypes.c_int
     L.pbr_render_desc_size.restype = ctypes.c_size_t
     if L.pbr_render_desc_size() != ctypes.sizeof(RenderDesc):
         raise NativeLibraryError("pbr_render_desc layout mismatch: library %d bytes, binding %d"

@@ -1,0 +1,198 @@
+"""Material blending in front of the BRDF: mirrors the surface of
+pypbr.blending that examples/example_blend.py uses -- the functional API
+(/root/reference/pypbr/blending/functional.py:25-286) and the callable classes
+(/root/reference/pypbr/blending/blending.py:28-214).  Every blend returns `(material, mask)`
+exactly like the reference.  All arithmetic (mask generation, per-map lerp, normal blend)
+runs in libpbr_hip.so; CPU-resident materials are staged through the device."""
+from abc import ABC, abstractmethod
+from typing import Optional
+
+import torch
+
+from . import _native
+from . import functional as F_
+from .materials import MaterialBase, _through_device
+
+
+# ---------------------------------------------------------------- device ops (fp32 planar maps)
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _check_f32(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s needs tensors on a ROCm device; there is no CPU path" % what)
+    if t.dtype != torch.float32:
+        raise TypeError("%s supports float32 maps, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
+def blend_maps(map1: torch.Tensor, map2: torch.Tensor, mask: torch.Tensor, is_normal: bool = False) -> torch.Tensor:
+    """mask * map1 + (1 - mask) * map2 for one (C,H,W) map and a (1,H,W) mask; `is_normal`:
+    normalise both, blend, re-normalise (functional.py:119-145)."""
+    a, b, m = _check_f32(map1, "blend_maps"), _check_f32(map2, "blend_maps"), _check_f32(mask, "blend_maps")
+    if a.shape != b.shape or a.dim() != 3 or m.numel() != a.shape[1] * a.shape[2]:
+        raise ValueError("maps %s / %s and mask %s do not match" % (tuple(a.shape), tuple(b.shape), tuple(m.shape)))
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _native.check(_native.lib().pbr_blend_maps(a.data_ptr(), b.data_ptr(), m.data_ptr(), out.data_ptr(), a.shape[0],
+                                                   a.shape[1] * a.shape[2], int(bool(is_normal)), _stream(a)))
+    return out
+
+
+def sigmoid_mask(prop1: torch.Tensor, prop2: torch.Tensor, blend_width: float, shift: float = 0.0) -> torch.Tensor:
+    """sigmoid((prop1 + shift - prop2) / (blend_width + 1e-6)) (functional.py:184-193, :227-236)."""
+    a, b = _check_f32(prop1, "sigmoid_mask"), _check_f32(prop2, "sigmoid_mask")
+    if a.shape != b.shape:
+        raise ValueError("property maps %s / %s differ in shape" % (tuple(a.shape), tuple(b.shape)))
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _native.check(_native.lib().pbr_blend_sigmoid_mask(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(),
+                                                           float(shift), float(blend_width), _stream(a)))
+    return out
+
+
+def gradient_mask(height: int, width: int, direction: str, device) -> torch.Tensor:
+    """linspace(0, 1) along x ('horizontal') or y ('vertical'), shape (1,H,W) (functional.py:262-281)."""
+    if direction not in ("horizontal", "vertical"):
+        raise ValueError("Direction must be 'horizontal' or 'vertical'.")
+    out = torch.empty((1, height, width), dtype=torch.float32, device=device)
+    with torch.cuda.device(out.device):
+        _native.check(_native.lib().pbr_blend_gradient_mask(out.data_ptr(), height, width, int(direction == "vertical"),
+                                                            _stream(out)))
+    return out
+
+
+# ---------------------------------------------------------------- functional API (functional.py)
+def blend_with_mask(material1: MaterialBase, material2: MaterialBase, mask: torch.Tensor):
+    """functional.py:64-116.  Returns (blended material of material1's class, mask as (1,H,W))."""
+    if mask.dim() == 2:
+        mask = mask.unsqueeze(0)
+    elif mask.dim() != 3 or mask.size(0) != 1:
+        raise ValueError("Mask must have shape [1, H, W] or [H, W].")
+    blended = material1.__class__()
+    blended.device = material1.device
+    names = list(material1._maps.keys()) + [k for k in material2._maps.keys() if k not in material1._maps]
+    for name in names:
+        m1, m2 = material1._maps.get(name), material2._maps.get(name)
+        if m1 is None or m2 is None:
+            result = m2 if m1 is None else m1
+        else:
+            normal = name == "normal"
+            result = _through_device(m1, lambda a: blend_maps(a, m2.to(a.device), mask.to(a.device), is_normal=normal))
+        setattr(blended, name, result)              # normals pass through _process_normal_map again, as upstream
+    blended.albedo_is_srgb = material1.albedo_is_srgb
+    return blended, mask
+
+
+def _resized_like(prop2: torch.Tensor, prop1: torch.Tensor) -> torch.Tensor:
+    if prop1.shape == prop2.shape:
+        return prop2
+    return _through_device(prop2, lambda t: F_.resize(t, tuple(prop1.shape[1:]), antialias=True))
+
+
+def blend_on_height(material1: MaterialBase, material2: MaterialBase, blend_width: float = 0.1, shift: float = 0.0):
+    """functional.py:148-196."""
+    h1, h2 = material1._maps.get("height"), material2._maps.get("height")
+    if h1 is None or h2 is None:
+        raise ValueError("Both materials must have height maps for height-based blending.")
+    h2 = _resized_like(h2, h1)
+    mask = _through_device(h1, lambda a: sigmoid_mask(a, h2.to(a.device), blend_width, shift))
+    return blend_with_mask(material1, material2, mask)
+
+
+def blend_on_properties(material1: MaterialBase, material2: MaterialBase, property_name: str = "metallic",
+                        blend_width: float = 0.1):
+    """functional.py:199-239."""
+    p1, p2 = material1._maps.get(property_name), material2._maps.get(property_name)
+    if p1 is None or p2 is None:
+        raise ValueError(f"Both materials must have '{property_name}' maps for property-based blending.")
+    p2 = _resized_like(p2, p1)
+    mask = _through_device(p1, lambda a: sigmoid_mask(a, p2.to(a.device), blend_width, 0.0))
+    return blend_with_mask(material1, material2, mask)
+
+
+def blend_with_gradient(material1: MaterialBase, material2: MaterialBase, direction: str = "horizontal"):
+    """functional.py:242-286."""
+    size = material1.size
+    if size is None:
+        raise ValueError("Materials must have at least one map to determine size.")
+    if direction not in ("horizontal", "vertical"):
+        raise ValueError("Direction must be 'horizontal' or 'vertical'.")
+    dev = torch.device(material1.device)
+    if dev.type == "cuda":
+        mask = gradient_mask(size[0], size[1], direction, dev)
+    else:
+        _native.require_device()
+        mask = gradient_mask(size[0], size[1], direction, torch.device("cuda", torch.cuda.current_device())).to(dev)
+    return blend_with_mask(material1, material2, mask)
+
+
+def blend_materials(material1: MaterialBase, material2: MaterialBase, method: str = "mask", **kwargs):
+    """functional.py:25-61."""
+    if method == "mask":
+        mask = kwargs.get("mask")
+        if mask is None:
+            raise ValueError("Mask must be provided for 'mask' blending method.")
+        return blend_with_mask(material1, material2, mask)
+    if method == "height":
+        return blend_on_height(material1, material2, kwargs.get("blend_width", 0.1))
+    if method == "properties":
+        return blend_on_properties(material1, material2, kwargs.get("property_name", "metallic"), kwargs.get("blend_width", 0.1))
+    if method == "gradient":
+        return blend_with_gradient(material1, material2, kwargs.get("direction", "horizontal"))
+    raise ValueError(f"Unknown blending method: {method}")
+
+
+import sys as _sys
+functional = _sys.modules[__name__]      # `pypbr.blending.functional` is this module's function set
+
+
+# ---------------------------------------------------------------- class API (blending.py)
+class BlendMethod(ABC):
+    @abstractmethod
+    def __call__(self, material1: MaterialBase, material2: MaterialBase):
+        ...
+
+
+class MaskBlend(BlendMethod):
+    def __init__(self, mask: torch.Tensor):
+        self.mask = mask
+
+    def __call__(self, material1, material2):
+        return blend_with_mask(material1, material2, self.mask)
+
+
+class HeightBlend(BlendMethod):
+    def __init__(self, blend_width: float = 0.1, shift: float = 0.0):
+        self.blend_width, self.shift = blend_width, shift
+
+    def __call__(self, material1, material2):
+        return blend_on_height(material1, material2, self.blend_width, self.shift)
+
+
+class PropertyBlend(BlendMethod):
+    def __init__(self, property_name: str = "metallic", blend_width: float = 0.1):
+        self.property_name, self.blend_width = property_name, blend_width
+
+    def __call__(self, material1, material2):
+        return blend_on_properties(material1, material2, self.property_name, self.blend_width)
+
+
+class GradientBlend(BlendMethod):
+    def __init__(self, direction: str = "horizontal"):
+        self.direction = direction
+
+    def __call__(self, material1, material2):
+        return blend_with_gradient(material1, material2, self.direction)
+
+
+class BlendFactory:
+    _methods = {"mask": MaskBlend, "height": HeightBlend, "properties": PropertyBlend, "gradient": GradientBlend}
+
+    @staticmethod
+    def get_blend_method(method_name: str, **kwargs) -> BlendMethod:
+        cls = BlendFactory._methods.get(method_name.lower())
+        if cls is None:
+            raise ValueError(f"Unknown blending method: {method_name}")
+        return cls(**kwargs)

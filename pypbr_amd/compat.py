@@ -1,13 +1,13 @@
 """Run reference scripts unchanged: `import pypbr_amd.compat; pypbr_amd.compat.install()` registers
-`pypbr`, `pypbr.models`, `pypbr.materials`, `pypbr.utils` and `pypbr.io` as aliases of the
+`pypbr`, `pypbr.models`, `pypbr.materials`, `pypbr.utils`, `pypbr.io` and `pypbr.blending` as aliases of the
 pypbr_amd modules, so that e.g. examples/example_brdf.py's
 
     from pypbr.models import CookTorranceBRDF
     from pypbr.io import load_material_from_folder
 
 resolve to the MI355X implementation.  Only the Cook-Torrance path and the calls either side of it
-(load, resize, tile) exist here; everything else of PyPBR (transforms, blending, ...) is out of
-scope and raises ImportError/AttributeError as an absent module would."""
+(load, blend, resize, tile) exist here; everything else of PyPBR (transforms, authoring utilities,
+...) is out of scope and raises ImportError/AttributeError as an absent module would."""
 import sys
 import types
 
@@ -15,7 +15,7 @@ import types
 def install(force: bool = False) -> types.ModuleType:
     """Registers the aliases.  Refuses to shadow an already-imported real `pypbr` unless `force`."""
     import pypbr_amd
-    from pypbr_amd import io, materials, models, utils
+    from pypbr_amd import blending, io, materials, models, utils
 
     existing = sys.modules.get("pypbr")
     if existing is not None and not getattr(existing, "__pypbr_amd_alias__", False) and not force:
@@ -26,7 +26,8 @@ def install(force: bool = False) -> types.ModuleType:
     pkg.__path__ = []                      # a package, with no files of its own
     pkg.__pypbr_amd_alias__ = True
     pkg.__version__ = pypbr_amd.__version__
-    for name, mod in (("models", models), ("materials", materials), ("utils", utils), ("io", io)):
+    sys.modules["pypbr.blending.functional"] = blending
+    for name, mod in (("models", models), ("materials", materials), ("utils", utils), ("io", io), ("blending", blending)):
         setattr(pkg, name, mod)
         sys.modules["pypbr." + name] = mod
     sys.modules["pypbr"] = pkg

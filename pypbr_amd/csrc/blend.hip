@@ -1,0 +1,108 @@
+// blend.hip -- material blending pre-stage: the per-pixel pass in
+// front of the BRDF in /root/reference/examples/example_blend.py:14-16.
+//
+// Replaces, from /root/reference/pypbr/blending/functional.py:
+//   blend_with_mask   :64-116   out = mask * map1 + (1 - mask) * map2 for every map,
+//   _blend_normals    :119-145  normals: normalise both, blend, re-normalise,
+//   blend_on_height / blend_on_properties :148-239  mask = sigmoid((p1 + shift - p2) / (width + 1e-6)),
+//   blend_with_gradient :242-286  mask = linspace(0, 1) along x or y.
+// All HBM streams: one lane per pixel walks the map's channels (planar (C,H,W) fp32).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/pbr_hip.h"
+#include "brdf_math.hpp"
+
+namespace pbr {
+
+// map1, map2: [C][P]; mask: [P]; out: [C][P].  NORMAL: F.normalize both, blend, F.normalize.
+template <bool NORMAL>
+__global__ __launch_bounds__(256) void blend_kernel(const float *__restrict__ m1, const float *__restrict__ m2,
+                                                    const float *__restrict__ mask, float *__restrict__ out,
+                                                    int channels, int64_t P) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const float w = mask[p], iw = 1.0f - w;
+        if (NORMAL) {
+            Vec3 a = {m1[p], m1[P + p], m1[2 * P + p]}, b = {m2[p], m2[P + p], m2[2 * P + p]};
+            const float ra = rsq(fmaxf(dot(a, a), 1e-24f)), rb = rsq(fmaxf(dot(b, b), 1e-24f));
+            Vec3 c = {fmaf(w, a.x * ra, iw * (b.x * rb)), fmaf(w, a.y * ra, iw * (b.y * rb)), fmaf(w, a.z * ra, iw * (b.z * rb))};
+            const float rc = rsq(fmaxf(dot(c, c), 1e-24f));
+            out[p] = c.x * rc; out[P + p] = c.y * rc; out[2 * P + p] = c.z * rc;
+        } else {
+            for (int ch = 0; ch < channels; ++ch) out[ch * P + p] = fmaf(w, m1[ch * P + p], iw * m2[ch * P + p]);
+        }
+    }
+}
+
+// torch.sigmoid((p1 + shift - p2) / (width + 1e-6))
+__global__ __launch_bounds__(256) void sigmoid_mask_kernel(const float *__restrict__ p1, const float *__restrict__ p2,
+                                                           float *__restrict__ mask, int64_t n, float shift, float inv_width) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float x = ((p1[i] + shift) - p2[i]) * inv_width;
+        mask[i] = rcp(1.0f + exp2_hw(-1.44269504f * x));           // 1 / (1 + e^-x)
+    }
+}
+
+// torch.linspace(0, 1, n) along x (horizontal) or y (vertical), two-ended evaluation
+__global__ __launch_bounds__(256) void gradient_mask_kernel(float *__restrict__ mask, int H, int W, int vertical) {
+    const int64_t total = (int64_t)H * W, stride = (int64_t)gridDim.x * blockDim.x;
+    const int n = vertical ? H : W;
+    const float step = n > 1 ? 1.0f / (float)(n - 1) : 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        const int k = vertical ? y : x;
+        mask[i] = n == 1 ? 0.0f : (k < n / 2 ? step * (float)k : 1.0f - step * (float)(n - 1 - k));
+    }
+}
+
+static inline unsigned blend_grid(int64_t items) {
+    const int64_t blocks = (items + 255) / 256, cap = 256 * 16;
+    return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
+static inline int blend_status() {
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+}
+
+}  // namespace pbr
+
+extern "C" {
+
+int pbr_blend_maps(const void *map1, const void *map2, const void *mask, void *out, int32_t channels, int64_t pixels,
+                   int is_normal, void *stream) {
+    using namespace pbr;
+    if (!map1 || !map2 || !mask || !out) return PBR_ERR_NULL_MAP;
+    if (channels < 1 || pixels < 1) return PBR_ERR_SHAPE;
+    if (is_normal && channels != 3) return PBR_ERR_CHANNELS;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    auto a = static_cast<const float *>(map1), b = static_cast<const float *>(map2), m = static_cast<const float *>(mask);
+    if (is_normal) hipLaunchKernelGGL(blend_kernel<true>, dim3(blend_grid(pixels)), dim3(256), 0, s, a, b, m, static_cast<float *>(out), 3, pixels);
+    else hipLaunchKernelGGL(blend_kernel<false>, dim3(blend_grid(pixels)), dim3(256), 0, s, a, b, m, static_cast<float *>(out), (int)channels, pixels);
+    return blend_status();
+}
+
+int pbr_blend_sigmoid_mask(const void *prop1, const void *prop2, void *mask, int64_t n, float shift, float blend_width,
+                           void *stream) {
+    using namespace pbr;
+    if (!prop1 || !prop2 || !mask) return PBR_ERR_NULL_MAP;
+    if (n < 1) return PBR_ERR_SHAPE;
+    hipLaunchKernelGGL(sigmoid_mask_kernel, dim3(blend_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(prop1), static_cast<const float *>(prop2), static_cast<float *>(mask), n,
+                       shift, 1.0f / (blend_width + 1e-6f));
+    return blend_status();
+}
+
+int pbr_blend_gradient_mask(void *mask, int32_t height, int32_t width, int vertical, void *stream) {
+    using namespace pbr;
+    if (!mask) return PBR_ERR_NULL_MAP;
+    if (height < 1 || width < 1) return PBR_ERR_SHAPE;
+    hipLaunchKernelGGL(gradient_mask_kernel, dim3(blend_grid((int64_t)height * width)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), static_cast<float *>(mask), (int)height, (int)width, vertical);
+    return blend_status();
+}
+
+}  // extern "C"

@@ -2,31 +2,45 @@
 //
 // What is computed follows the reference line by line (citations are to
 // /root/reference/pypbr/models/cooktorrance.py unless another file is named).  HOW it
-// is computed is chosen for the MI355X VALU budget (about 430
-// lane-instructions per pixel at the 44 B/pixel HBM roofline):
+// is computed is chosen for the MI355X VALU: rocprofv3 SQ counters on this kernel show a plain
+// fp32 VALU wave-instruction holding its SIMD for ~4.25 cycles (SQ_ACTIVE_INST_VALU x 4 /
+// SQ_INSTS_VALU), i.e. 16 lanes per clock; only the PACKED forms (v_pk_fma_f32, v_pk_mul_f32,
+// v_pk_add_f32: two fp32 values per lane per instruction, same 4 cycles) reach the chip's fp32 peak.
+// At ~190 scalar instructions per pixel the one-light kernel had its VALUs 73 % busy next to a
+// 76 %-busy HBM, and the 16-light configuration is VALU-bound outright.  Hence:
 //
-//  * every division / sqrt / pow goes to the quarter-rate transcendental unit
-//    (v_rcp_f32, v_rsq_f32, v_sqrt_f32, v_log_f32, v_exp_f32: 1 ulp each) -- no IEEE
-//    division sequences, no ocml powf;
+//  * every function here is a template over the real type R: float (one pixel) or f32x2 (TWO pixels
+//    of the lane at once).  The kernels use f32x2, so that nearly all adds / multiplies / fmas are
+//    packed instructions; transcendental and min/max/select instructions have no packed form and
+//    are issued per component;
+//  * every division / sqrt / pow goes to the transcendental unit (v_rcp_f32, v_rsq_f32,
+//    v_log_f32, v_exp_f32: 1 ulp each) -- no IEEE division sequences, no ocml powf; one light
+//    evaluation costs 4 of them (point light) or 1 (directional);
 //  * the four denominators of D, G(V), G(L) and the specular term share ONE v_rcp_f32;
 //  * x^5 is three multiplies; x^2.4 and x^(1/2.4) are exp2(c*log2(x)) on the restricted
 //    domains the sRGB transfer functions reach;
+//  * F dg + (1-F) kd base/pi is evaluated as kb + F (dg - kb) with kb = kd_scale base/pi hoisted
+//    out of the light loop;
 //  * the GGX denominator NdotH^2 (a^2-1) + 1 is evaluated as a^2 + (1-a^2) sin^2(N,H) with
-//    sin^2 = |n x h|^2 / (|n|^2 |h|^2).  The reference's form cancels catastrophically
-//    for small roughness near the highlight: its own fp32 result is only ~2e-5..5e-5 from
-//    the same code run in fp64 there (measured again in DESIGN.md).  The
-//    cross-product form has no cancellation, so this kernel tracks the fp64 evaluation
-//    of the reference to ~1e-6 and its distance to the reference's fp32 output is the
+//    sin^2 = |N x h|^2 / |h|^2, N the unit normal.  The reference's form cancels
+//    catastrophically for small roughness near the highlight: its own fp32 result is only
+//    ~2e-5..5e-5 from the same code run in fp64 there.  The
+//    cross-product form has no cancellation, so this kernel tracks the fp64 evaluation of
+//    the reference to ~1e-6 and its distance to the reference's fp32 output is the
 //    reference's own rounding error, not the sum of two.
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace pbr {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
 constexpr float kPi = 3.14159265358979323846f;      // torch.pi / math.pi rounded to fp32
 constexpr float kInvPi = 0.31830988618379067154f;
 constexpr float kDielectricF0 = 0.04f;              // :107
 
+// ---- scalar primitives
 __device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float sqrt_hw(float x) { return __builtin_amdgcn_sqrtf(x); }
@@ -34,101 +48,151 @@ __device__ __forceinline__ float log2_hw(float x) { return __builtin_amdgcn_logf
 __device__ __forceinline__ float exp2_hw(float x) { return __builtin_amdgcn_exp2f(x); }
 // med3(x,0,1): one VALU op, folded into the producer's clamp modifier where possible.
 __device__ __forceinline__ float clamp01(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ float max_(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float min_(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float select_(bool m, float a, float b) { return m ? a : b; }
+__device__ __forceinline__ bool gt_(float a, float b) { return a > b; }
+__device__ __forceinline__ bool le_(float a, float b) { return a <= b; }
+
+// ---- two pixels per lane: +, -, * on f32x2 compile to v_pk_add/mul_f32, fma to v_pk_fma_f32
+__device__ __forceinline__ f32x2 rcp(f32x2 x) { return f32x2{rcp(x.x), rcp(x.y)}; }
+__device__ __forceinline__ f32x2 rsq(f32x2 x) { return f32x2{rsq(x.x), rsq(x.y)}; }
+__device__ __forceinline__ f32x2 sqrt_hw(f32x2 x) { return f32x2{sqrt_hw(x.x), sqrt_hw(x.y)}; }
+__device__ __forceinline__ f32x2 log2_hw(f32x2 x) { return f32x2{log2_hw(x.x), log2_hw(x.y)}; }
+__device__ __forceinline__ f32x2 exp2_hw(f32x2 x) { return f32x2{exp2_hw(x.x), exp2_hw(x.y)}; }
+__device__ __forceinline__ f32x2 clamp01(f32x2 x) { return f32x2{clamp01(x.x), clamp01(x.y)}; }
+__device__ __forceinline__ f32x2 fma_(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 max_(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
+__device__ __forceinline__ f32x2 min_(f32x2 a, f32x2 b) { return f32x2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+__device__ __forceinline__ f32x2 select_(i32x2 m, f32x2 a, f32x2 b) { return m ? a : b; }
+__device__ __forceinline__ i32x2 gt_(f32x2 a, f32x2 b) { return a > b; }
+__device__ __forceinline__ i32x2 le_(f32x2 a, f32x2 b) { return a <= b; }
+
+template <class R> __device__ __forceinline__ R splat(float v);
+template <> __device__ __forceinline__ float splat<float>(float v) { return v; }
+template <> __device__ __forceinline__ f32x2 splat<f32x2>(float v) { return f32x2{v, v}; }
 
 // utils/functions.py:31-47.  ((t+0.055)/1.055)^2.4 = exp2(2.4 log2(t+0.055) - 2.4 log2(1.055)).
-__device__ __forceinline__ float srgb_to_linear(float x) {
-    const float t = clamp01(x);
-    const float lo = t * (1.0f / 12.92f);
-    const float hi = exp2_hw(fmaf(2.4f, log2_hw(t + 0.055f), -0.18538320f /* 2.4*log2(1.055) = 0.185383197... */));
-    return fminf(t <= 0.04045f ? lo : hi, 1.0f);
+template <class R> __device__ __forceinline__ R srgb_to_linear(R x) {
+    const R t = clamp01(x);
+    const R lo = t * (1.0f / 12.92f);
+    const R hi = exp2_hw(fma_(splat<R>(2.4f), log2_hw(t + 0.055f), splat<R>(-0.18538320f) /* 2.4*log2(1.055) */));
+    return min_(select_(le_(t, splat<R>(0.04045f)), lo, hi), splat<R>(1.0f));
 }
 
 // utils/functions.py:50-66; `c` must already be in [0,1] (callers clamp).
-__device__ __forceinline__ float linear_to_srgb_unit(float c) {
-    const float lo = c * 12.92f;
-    const float hi = fmaf(1.055f, exp2_hw(log2_hw(c) * (1.0f / 2.4f)), -0.055f);
-    return clamp01(c <= 0.0031308f ? lo : hi);
+template <class R> __device__ __forceinline__ R linear_to_srgb_unit(R c) {
+    const R lo = c * 12.92f;
+    const R hi = fma_(splat<R>(1.055f), exp2_hw(log2_hw(c) * (1.0f / 2.4f)), splat<R>(-0.055f));
+    return clamp01(select_(le_(c, splat<R>(0.0031308f)), lo, hi));
 }
-__device__ __forceinline__ float linear_to_srgb(float x) { return linear_to_srgb_unit(clamp01(x)); }
+template <class R> __device__ __forceinline__ R linear_to_srgb(R x) { return linear_to_srgb_unit(clamp01(x)); }
 
-struct Vec3 { float x, y, z; };
-__device__ __forceinline__ float dot(const Vec3 &a, const Vec3 &b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+template <class R> struct Vec3T { R x, y, z; };
+using Vec3 = Vec3T<float>;
+template <class R> __device__ __forceinline__ R dot(const Vec3T<R> &a, const Vec3T<R> &b) {
+    return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x));
+}
+template <class R> __device__ __forceinline__ R dotu(const Vec3T<R> &a, const Vec3 &b) {   // b wave-uniform
+    return fma_(a.z, splat<R>(b.z), fma_(a.y, splat<R>(b.y), a.x * b.x));
+}
 
 // Light-dependent, material-independent terms of one pixel (:122-140, :155-159).
-struct LightGeom {
-    Vec3 L;        // light direction as the reference uses it (point: d/(dist+1e-7))
-    Vec3 h;        // V + L, un-normalised
-    float hh;      // |h|^2
-    float att;     // 1/(dist^2+1e-7), 1 for directional
-    float p5;      // (1 - clamp(Hv.V))^5
+template <class R> struct LightGeomT {
+    Vec3T<R> L;    // light direction as the reference uses it (point: d/(dist+1e-7))
+    Vec3T<R> h;    // V + L, un-normalised
+    R rhh;         // 1/|h|^2  (|h|^2 clamped at 1e-24: F.normalize's 1e-12 on the norm)
+    R att;         // 1/(dist^2+1e-7), 1 for directional
+    R p5;          // (1 - clamp(Hv.V))^5
 };
+using LightGeom = LightGeomT<float>;
 
-__device__ __forceinline__ float pow5(float x) { const float x2 = x * x; return x2 * x2 * x; }
+template <class R> __device__ __forceinline__ R pow5(R x) { const R x2 = x * x; return x2 * x2 * x; }
 
-// Point light (:129-140): surface point (xs, -ys, 0).
-__device__ __forceinline__ LightGeom point_light_geom(const Vec3 &V, const Vec3 &Lpos, float xs, float ys) {
-    LightGeom g;
-    const Vec3 d = {Lpos.x - xs, Lpos.y + ys, Lpos.z};
-    const float dist = sqrt_hw(dot(d, d));                         // torch.norm :138
-    const float rinv = rcp(dist + 1e-7f);                          // :139
+// Point light (:129-140): surface point (xs, -ys, 0); ys is the lane's row, shared by its pixels.
+//   dist = sqrt(dd) and 1/(dist + 1e-7) come from ONE v_rsq: r = rsq(dd), dist = dd r,
+//   1/(dist + 1e-7) = r / (1 + 1e-7 r) = r (1 - 1e-7 r) + O((1e-7 r)^2) -- exact to 1e-8 relative for any
+//   light further than 1e-3 from the surface point (dd is clamped at 1e-12 so that a light sitting
+//   exactly on a pixel gives L = 0 like the reference instead of NaN).
+template <class R>
+__device__ __forceinline__ LightGeomT<R> point_light_geom(const Vec3 &V, const Vec3 &Lpos, R xs, float ys) {
+    LightGeomT<R> g;
+    const Vec3T<R> d = {splat<R>(Lpos.x) - xs, splat<R>(Lpos.y + ys), splat<R>(Lpos.z)};
+    const R dd = max_(dot(d, d), splat<R>(1e-12f));                 // dist^2, torch.norm :138
+    const R r = rsq(dd);
+    const R rinv = r * fma_(splat<R>(-1e-7f), r, splat<R>(1.0f));   // 1/(dist + 1e-7)  :139
     g.L = {d.x * rinv, d.y * rinv, d.z * rinv};
-    g.att = rcp(fmaf(dist, dist, 1e-7f));                          // :140 (distances**2, re-squared)
-    g.h = {V.x + g.L.x, V.y + g.L.y, V.z + g.L.z};                 // :155
-    g.hh = dot(g.h, g.h);
-    const float rh = rsq(fmaxf(g.hh, 1e-24f));                     // F.normalize eps 1e-12 on the norm
-    g.p5 = pow5(1.0f - clamp01(dot(g.h, V) * rh));                 // :156-158, :196
+    g.att = rcp(dd + 1e-7f);                                        // :140
+    g.h = {g.L.x + V.x, g.L.y + V.y, g.L.z + V.z};                  // :155
+    const R rh = rsq(max_(dot(g.h, g.h), splat<R>(1e-24f)));
+    g.rhh = rh * rh;
+    g.p5 = pow5(splat<R>(1.0f) - clamp01(dotu(g.h, V) * rh));        // :156-158, :196
     return g;
 }
 
 // Light-independent terms of one pixel, computed once and reused by every light.
-struct PixelTerms {
-    Vec3 n;            // unit normal: stored normal * 1/max(|n|, 1e-12)   (F.normalize :154)
-    float ndv;         // clamp(N.V)                  (:163)
-    float a2;          // roughness^2                 (alpha = roughness, :213-214)
-    float k;           // (r+1)^2/8                   (:232-233)
-    float dv;          // NdotV (1-k) + k + 1e-7      (:234)
-    float a2ndv;       // a2 * NdotV
-    float base[3];     // linear albedo / diffuse colour, pre-multiplied by 1/pi (:174)
-    float f0[3];       // reflectance at normal incidence
-    float kd_scale;    // (1 - metallic) or 1          (:169-172)
+template <class R> struct PixelTermsT {
+    Vec3T<R> n;        // unit normal: stored normal * 1/max(|n|, 1e-12)   (F.normalize :154)
+    R ndv;             // clamp(N.V)                  (:163)
+    R a2;              // roughness^2                 (alpha = roughness, :213-214)
+    R k;               // (r+1)^2/8                   (:232-233)
+    R dv;              // NdotV (1-k) + k + 1e-7      (:234)
+    R a2ndv;           // a2 * NdotV
+    R kb[3];           // kd_scale * base / pi: the diffuse term is (1 - F) kb   (:169-174)
+    R f0[3];           // reflectance at normal incidence
 };
+using PixelTerms = PixelTermsT<float>;
 
-__device__ __forceinline__ void pixel_terms(const Vec3 &n, const Vec3 &V, float rough, const float base[3],
-                                            const float f0[3], float kd_scale, PixelTerms &t) {
-    const float rn = rsq(fmaxf(dot(n, n), 1e-24f));
+// base: linear albedo / diffuse colour; kd_scale: (1 - metallic) or 1.
+template <class R>
+__device__ __forceinline__ void pixel_terms(const Vec3T<R> &n, const Vec3 &V, R rough, const R base[3], const R f0[3],
+                                            R kd_scale, PixelTermsT<R> &t) {
+    const R rn = rsq(max_(dot(n, n), splat<R>(1e-24f)));
     t.n = {n.x * rn, n.y * rn, n.z * rn};
-    t.ndv = clamp01(dot(t.n, V));
+    t.ndv = clamp01(dotu(t.n, V));
     t.a2 = rough * rough;
-    const float r1 = rough + 1.0f;
+    const R r1 = rough + 1.0f;
     t.k = r1 * r1 * 0.125f;
-    t.dv = fmaf(t.ndv, 1.0f - t.k, t.k) + 1e-7f;
+    t.dv = fma_(t.ndv, splat<R>(1.0f) - t.k, t.k) + 1e-7f;
     t.a2ndv = t.a2 * t.ndv;
+    const R s = kd_scale * kInvPi;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { t.base[c] = base[c] * kInvPi; t.f0[c] = f0[c]; }
-    t.kd_scale = kd_scale;
+    for (int c = 0; c < 3; ++c) { t.kb[c] = base[c] * s; t.f0[c] = f0[c]; }
 }
 
-// One light's linear RGB contribution, clamped to [0,1] (:160-177).
-__device__ __forceinline__ void shade_light(const PixelTerms &t, const LightGeom &g, const float inten[3], float out[3]) {
-    const float ndl = clamp01(dot(t.n, g.L));                      // :164
-    // GGX (:213-217), cancellation-free: den = a2 + (1-a2) sin^2(N,H) when N.H > 0, else 1;
-    // sin^2 = |N x h|^2 / |h|^2 with N unit.
-    const float nh = dot(t.n, g.h);
-    const Vec3 c = {fmaf(t.n.y, g.h.z, -(t.n.z * g.h.y)), fmaf(t.n.z, g.h.x, -(t.n.x * g.h.z)),
-                    fmaf(t.n.x, g.h.y, -(t.n.y * g.h.x))};
-    const float s2 = fminf(dot(c, c) * rcp(fmaxf(g.hh, 1e-36f)), 1.0f);
-    const float den = nh > 0.0f ? fmaf(s2, 1.0f - t.a2, t.a2) : 1.0f;
+// GGX denominator (:213-217), cancellation-free: a2 + (1-a2) sin^2(N,H) when N.H > 0, else 1.
+template <class R, class M>
+__device__ __forceinline__ R ggx_den(const PixelTermsT<R> &t, const LightGeomT<R> &g, R &s2, M &nh_pos) {
+    const R nh = dot(t.n, g.h);
+    const Vec3T<R> c = {fma_(t.n.y, g.h.z, -(t.n.z * g.h.y)), fma_(t.n.z, g.h.x, -(t.n.x * g.h.z)),
+                        fma_(t.n.x, g.h.y, -(t.n.y * g.h.x))};
+    s2 = min_(dot(c, c) * g.rhh, splat<R>(1.0f));
+    nh_pos = gt_(nh, splat<R>(0.0f));
+    return select_(nh_pos, fma_(s2, splat<R>(1.0f) - t.a2, t.a2), splat<R>(1.0f));
+}
+
+template <class R> struct MaskOf { using type = bool; };
+template <> struct MaskOf<f32x2> { using type = i32x2; };
+
+// One light's linear RGB contribution, clamped to [0,1] (:160-177).  `inten` is wave-uniform.
+template <class R>
+__device__ __forceinline__ void shade_light(const PixelTermsT<R> &t, const LightGeomT<R> &g, const float inten[3], R out[3]) {
+    const R ndl = clamp01(dot(t.n, g.L));                          // :164
+    R s2;
+    typename MaskOf<R>::type nh_pos;
+    const R den = ggx_den(t, g, s2, nh_pos);
     // D * G / (4 NdotV NdotL + 1e-7) with one reciprocal (:217, :232-235, :165-166).
-    const float dl = fmaf(ndl, 1.0f - t.k, t.k) + 1e-7f;
-    const float dD = fmaf(kPi, den * den, 1e-7f);
-    const float ds = fmaf(4.0f * t.ndv, ndl, 1e-7f);
-    const float dg = t.a2ndv * ndl * rcp((dD * t.dv) * (dl * ds));
-    const float rad = ndl * g.att;                                 // :175
+    const R dl = fma_(ndl, splat<R>(1.0f) - t.k, t.k) + 1e-7f;
+    const R dD = fma_(splat<R>(kPi), den * den, splat<R>(1e-7f));
+    const R ds = fma_(t.ndv * 4.0f, ndl, splat<R>(1e-7f));
+    const R dg = t.a2ndv * ndl * rcp((dD * t.dv) * (dl * ds));
+    const R rad = ndl * g.att;                                     // :175
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const float F = fmaf(1.0f - t.f0[ch], g.p5, t.f0[ch]);     // :196
-        const float kd = (1.0f - F) * t.kd_scale;                  // :169-172
-        out[ch] = clamp01(fmaf(F, dg, kd * t.base[ch]) * (inten[ch] * rad));   // :174-177
+        const R F = fma_(splat<R>(1.0f) - t.f0[ch], g.p5, t.f0[ch]);   // :196
+        // F dg + (1 - F) kb  ==  kb + F (dg - kb)                    (:166, :169-174)
+        out[ch] = clamp01(fma_(F, dg - t.kb[ch], t.kb[ch]) * (rad * inten[ch]));   // :175-177
     }
 }
 

@@ -143,7 +143,8 @@ static void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
             normalize_host(d->lights[i], u.l);                                   // :126
             float hn[3];
             for (int c = 0; c < 3; ++c) u.h[c] = k.V[c] + u.l[c];                // :155
-            u.hh = u.h[0] * u.h[0] + u.h[1] * u.h[1] + u.h[2] * u.h[2];
+            const float hh = u.h[0] * u.h[0] + u.h[1] * u.h[1] + u.h[2] * u.h[2];
+            u.rhh = 1.0f / (hh > 1e-24f ? hh : 1e-24f);
             normalize_host(u.h, hn);
             float ct = hn[0] * k.V[0] + hn[1] * k.V[1] + hn[2] * k.V[2];          // :156-158
             ct = ct < 0.0f ? 0.0f : (ct > 1.0f ? 1.0f : ct);

@@ -40,20 +40,14 @@ __device__ __forceinline__ bool in_unit(float x) { return x >= 0.0f && x <= 1.0f
 struct LightEval {
     float ndl_raw, ndl, c, s2, den, dl, dD, ds, q, dg, rad;
     bool nh_pos;
-    float F[3], kd[3], u[3];
+    float F[3], u[3];
 };
 
 __device__ __forceinline__ void eval_light(const PixelTerms &t, const LightGeom &g, const float inten[3], LightEval &e) {
     e.ndl_raw = dot(t.n, g.L);
     e.ndl = clamp01(e.ndl_raw);
-    const float nh = dot(t.n, g.h);
-    const Vec3 cr = {fmaf(t.n.y, g.h.z, -(t.n.z * g.h.y)), fmaf(t.n.z, g.h.x, -(t.n.x * g.h.z)),
-                     fmaf(t.n.x, g.h.y, -(t.n.y * g.h.x))};
-    const float rhh = rcp(fmaxf(g.hh, 1e-36f));
-    e.s2 = fminf(dot(cr, cr) * rhh, 1.0f);
-    e.nh_pos = nh > 0.0f;
-    e.c = e.nh_pos ? nh * rsq(fmaxf(g.hh, 1e-36f)) : 0.0f;          // clamp(N.H), :215
-    e.den = e.nh_pos ? fmaf(e.s2, 1.0f - t.a2, t.a2) : 1.0f;
+    e.den = ggx_den(t, g, e.s2, e.nh_pos);
+    e.c = e.nh_pos ? dot(t.n, g.h) * sqrt_hw(g.rhh) : 0.0f;         // clamp(N.H), :215
     e.dl = fmaf(e.ndl, 1.0f - t.k, t.k) + 1e-7f;
     e.dD = fmaf(kPi, e.den * e.den, 1e-7f);
     e.ds = fmaf(4.0f * t.ndv, e.ndl, 1e-7f);
@@ -63,16 +57,14 @@ __device__ __forceinline__ void eval_light(const PixelTerms &t, const LightGeom 
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         e.F[ch] = fmaf(1.0f - t.f0[ch], g.p5, t.f0[ch]);
-        e.kd[ch] = (1.0f - e.F[ch]) * t.kd_scale;
-        e.u[ch] = fmaf(e.F[ch], e.dg, e.kd[ch] * t.base[ch]) * (inten[ch] * e.rad);
+        e.u[ch] = fmaf(e.F[ch], e.dg - t.kb[ch], t.kb[ch]) * (inten[ch] * e.rad);
     }
 }
 
 // Accumulators that do not depend on the light.
 struct PixelAdjoint {
-    float g_baseq[3];     // adjoint of base/pi
+    float g_kb[3];        // adjoint of kb = kd_scale * base / pi
     float g_f0[3];
-    float g_kdscale;      // adjoint of (1 - metallic)
     float g_a2, g_k, g_ndv;
     Vec3 g_n;             // adjoint of the unit normal
 };
@@ -84,15 +76,12 @@ __device__ __forceinline__ void backprop_light(const PixelTerms &t, const LightG
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const float gu = in_unit(e.u[ch]) ? g_col[ch] : 0.0f;               // clamp :177
-        const float R = inten[ch] * e.rad;
-        const float S = fmaf(e.F[ch], e.dg, e.kd[ch] * t.base[ch]);
-        const float gS = gu * R;
+        const float S = fmaf(e.F[ch], e.dg - t.kb[ch], t.kb[ch]);           // F dg + (1 - F) kb
+        const float gS = gu * (inten[ch] * e.rad);
         g_rad = fmaf(gu * S, inten[ch], g_rad);
-        const float g_kd = gS * t.base[ch];
-        adj.g_baseq[ch] = fmaf(gS, e.kd[ch], adj.g_baseq[ch]);
-        adj.g_kdscale = fmaf(g_kd, 1.0f - e.F[ch], adj.g_kdscale);
-        const float gF = fmaf(gS, e.dg, -g_kd * t.kd_scale);
+        adj.g_kb[ch] = fmaf(gS, 1.0f - e.F[ch], adj.g_kb[ch]);
         g_dg = fmaf(gS, e.F[ch], g_dg);
+        const float gF = gS * (e.dg - t.kb[ch]);
         adj.g_f0[ch] = fmaf(gF, 1.0f - g.p5, adj.g_f0[ch]);                  // F = f0 + (1-f0) p5, :196
     }
     float g_ndl = g_rad * g.att;                                             // :175
@@ -122,25 +111,12 @@ __device__ __forceinline__ void backprop_light(const PixelTerms &t, const LightG
     g_ndv = fmaf(g_ds, 4.0f * e.ndl, g_ndv);
     g_ndl = fmaf(g_ds, 4.0f * t.ndv, g_ndl);
     adj.g_ndv += g_ndv;                                                      // N.V does not depend on the light
-    // dots -> unit normal (clamps pass on the closed interval)
+    // dots -> unit normal (clamps pass on the closed interval); c = N . h / |h|
     const float gl = in_unit(e.ndl_raw) ? g_ndl : 0.0f;
-    const float rh = rsq(fmaxf(g.hh, 1e-36f));
-    adj.g_n.x = fmaf(gl, g.L.x, fmaf(g_c * rh, g.h.x, adj.g_n.x));
-    adj.g_n.y = fmaf(gl, g.L.y, fmaf(g_c * rh, g.h.y, adj.g_n.y));
-    adj.g_n.z = fmaf(gl, g.L.z, fmaf(g_c * rh, g.h.z, adj.g_n.z));
-}
-
-template <int LIGHT>
-__device__ __forceinline__ LightGeom light_geom(const KArgs &a, const LightU &lu, const Vec3 &V, float xs, float ys) {
-    LightGeom g;
-    if (LIGHT == PBR_LIGHT_POINT) {
-        g = point_light_geom(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, xs, ys);
-    } else {
-        g.L = {lu.l[0], lu.l[1], lu.l[2]};
-        g.h = {lu.h[0], lu.h[1], lu.h[2]};
-        g.hh = lu.hh; g.p5 = lu.p5; g.att = 1.0f;
-    }
-    return g;
+    const float gch = g_c * sqrt_hw(g.rhh);
+    adj.g_n.x = fmaf(gl, g.L.x, fmaf(gch, g.h.x, adj.g_n.x));
+    adj.g_n.y = fmaf(gl, g.L.y, fmaf(gch, g.h.y, adj.g_n.y));
+    adj.g_n.z = fmaf(gl, g.L.z, fmaf(gch, g.h.z, adj.g_n.z));
 }
 
 //   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_METALLIC | PBR_WORKFLOW_SPECULAR    VEC: 4 | 1    fp32 maps
@@ -185,7 +161,7 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
         const Vec3 nraw = {t.nm[0][j], t.nm[1][j], t.nm[2][j]};
         PixelTerms pt;
         pixel_terms(nraw, V, t.ro[j], base, f0, kd_scale, pt);
-        const float ndv_raw = dot(pt.n, V);
+        const float ndv_raw = dotu(pt.n, V);
         const float xs = LIGHT == PBR_LIGHT_POINT ? linspace_at(a.x0, a.x1, a.xstep, a.W, p.x + j) : 0.0f;
 
         // ---- adjoint of the linear colour before per-light clamps
@@ -196,7 +172,7 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
             for (int l = 0; l < nl; ++l) {
                 const LightU &lu = a.lights[l];
                 LightEval e;
-                eval_light(pt, light_geom<LIGHT>(a, lu, V, xs, ys), lu.inten, e);
+                eval_light(pt, light_geom<LIGHT, float>(lu, V, xs, ys), lu.inten, e);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) sum[c] += clamp01(e.u[c]);
             }
@@ -210,7 +186,7 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
         PixelAdjoint adj = {};
         for (int l = 0; l < nl; ++l) {
             const LightU &lu = a.lights[l];
-            const LightGeom g = light_geom<LIGHT>(a, lu, V, xs, ys);
+            const LightGeom g = light_geom<LIGHT, float>(lu, V, xs, ys);
             LightEval e;
             eval_light(pt, g, lu.inten, e);
             if (!MULTI) {
@@ -223,10 +199,12 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
             backprop_light(pt, g, lu.inten, e, g_col, adj);
         }
         // ---- light-independent tail
-        float g_m = -adj.g_kdscale;                                          // kd_scale = 1 - m  (:170)
+        // kb = kd_scale * base / pi ; kd_scale = 1 - m  (:169-174)
+        float g_m = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float g_base = adj.g_baseq[c] * kInvPi;
+            float g_base = adj.g_kb[c] * (kd_scale * kInvPi);
+            g_m = fmaf(adj.g_kb[c], -base[c] * kInvPi, g_m);
             if (WF == PBR_WORKFLOW_METALLIC) {                               // lerp(0.04, base, m)  (:107)
                 g_base = fmaf(adj.g_f0[c], m, g_base);
                 g_m = fmaf(adj.g_f0[c], base[c] - kDielectricF0, g_m);

@@ -25,7 +25,7 @@ namespace pbr {
 struct LightU {
     float l[3];       // directional: normalised L (:126); point: position (:129)
     float h[3];       // directional: V + L
-    float hh;         // directional: |V+L|^2
+    float rhh;        // directional: 1/|V+L|^2
     float p5;         // directional: (1 - clamp(Hv.V))^5
     float inten[3];   // :96
 };
@@ -188,30 +188,68 @@ __device__ __forceinline__ void load_texels(const KArgs &a, const LanePos &p, Te
     }
 }
 
-// Material terms of pixel j of the lane (:99-118): base colour, F0, kD scale, normal, roughness.
-template <int WF, int VEC>
-__device__ __forceinline__ void material_terms(const Texels<VEC> &t, int j, const Vec3 &V, PixelTerms &pt) {
-    float base[3], f0[3], kd_scale = 1.0f;
+// The real type of the shading code.  PACKED: two pixels per instruction (v_pk_* fp32).  Measured
+// in-process A/B on MI355X (tools/tune.py --altlib): packed math makes the VALU-bound 16-light
+// kernel 22 % faster (940 vs 1199 us on 2 x 4096^2 fp16 maps) but the HBM-bound one-light fp32
+// kernel 15 % SLOWER (137 vs 119 us) although it halves its VALU-busy time; with fp16 maps and
+// one light (neither unit saturated) it is 5 % faster -- so it is used for several lights and
+// for fp16 maps, not for the fp32 one-light kernels.
+template <int VEC, bool PACKED> struct RealOf { using type = float; static constexpr int N = VEC; };
+template <int VEC> struct RealOf<VEC, true> { using type = f32x2; static constexpr int N = VEC / 2; };
+template <> struct RealOf<1, true> { using type = float; static constexpr int N = 1; };
+
+template <class R> __device__ __forceinline__ R gather(const float *v, int g);
+template <> __device__ __forceinline__ float gather<float>(const float *v, int g) { return v[g]; }
+template <> __device__ __forceinline__ f32x2 gather<f32x2>(const float *v, int g) { return f32x2{v[2 * g], v[2 * g + 1]}; }
+__device__ __forceinline__ void scatter(float *v, int g, float r) { v[g] = r; }
+__device__ __forceinline__ void scatter(float *v, int g, f32x2 r) { v[2 * g] = r.x; v[2 * g + 1] = r.y; }
+
+// Material terms of pixel group g of the lane (:99-118): base colour, F0, kD scale, normal, roughness.
+template <int WF, int VEC, class R>
+__device__ __forceinline__ void material_terms(const Texels<VEC> &t, int g, const Vec3 &V, PixelTermsT<R> &pt) {
+    R base[3], f0[3], kd_scale = splat<R>(1.0f);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) base[c] = t.al[c][j];
+    for (int c = 0; c < 3; ++c) base[c] = gather<R>(t.al[c], g);
     if (WF == PBR_WORKFLOW_METALLIC) {
-        const float m = t.me[j];
+        const R m = gather<R>(t.me, g);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) f0[c] = fmaf(m, base[c] - kDielectricF0, kDielectricF0);   // lerp :107
-        kd_scale = 1.0f - m;                                                            // :170
+        for (int c = 0; c < 3; ++c) f0[c] = fma_(m, base[c] - kDielectricF0, splat<R>(kDielectricF0));   // lerp :107
+        kd_scale = splat<R>(1.0f) - m;                                                            // :170
     } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) f0[c] = t.sp[c][j];                                 // :112-113
+        for (int c = 0; c < 3; ++c) f0[c] = gather<R>(t.sp[c], g);                                // :112-113
     }
-    pixel_terms(Vec3{t.nm[0][j], t.nm[1][j], t.nm[2][j]}, V, t.ro[j], base, f0, kd_scale, pt);
+    const Vec3T<R> n = {gather<R>(t.nm[0], g), gather<R>(t.nm[1], g), gather<R>(t.nm[2], g)};
+    pixel_terms(n, V, gather<R>(t.ro, g), base, f0, kd_scale, pt);
+}
+
+// x grid values of pixel group g (torch.linspace over W, :132)
+template <class R> __device__ __forceinline__ R xs_of(const KArgs &a, int x0, int g);
+template <> __device__ __forceinline__ float xs_of<float>(const KArgs &a, int x0, int g) {
+    return linspace_at(a.x0, a.x1, a.xstep, a.W, x0 + g);
+}
+template <> __device__ __forceinline__ f32x2 xs_of<f32x2>(const KArgs &a, int x0, int g) {
+    return f32x2{linspace_at(a.x0, a.x1, a.xstep, a.W, x0 + 2 * g), linspace_at(a.x0, a.x1, a.xstep, a.W, x0 + 2 * g + 1)};
+}
+
+template <int LIGHT, class R>
+__device__ __forceinline__ LightGeomT<R> light_geom(const LightU &lu, const Vec3 &V, R xs, float ys) {
+    if (LIGHT == PBR_LIGHT_POINT) return point_light_geom<R>(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, xs, ys);
+    LightGeomT<R> g;                       // directional: everything folded on the host, wave-uniform
+    g.L = {splat<R>(lu.l[0]), splat<R>(lu.l[1]), splat<R>(lu.l[2])};
+    g.h = {splat<R>(lu.h[0]), splat<R>(lu.h[1]), splat<R>(lu.h[2])};
+    g.rhh = splat<R>(lu.rhh); g.p5 = splat<R>(lu.p5); g.att = splat<R>(1.0f);
+    return g;
 }
 
 // Everything between the loads and the stores (cooktorrance.py:99-180 and the conversions it calls).
 // Run-time flags (sRGB decode/encode, normal present) are wave-uniform and each guards ONE hoisted
 // block over all VEC pixels, so the shading code stays one basic block and the scheduler can
-// interleave the pixels' transcendental latencies.
-template <int LIGHT, int WF, typename TO, int VEC, bool MULTI, bool NT>
+// interleave the pixel groups' transcendental latencies.
+template <int LIGHT, int WF, typename TO, int VEC, bool MULTI, bool NT, bool PACKED>
 __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p, Texels<VEC> &t) {
+    using R = typename RealOf<VEC, PACKED>::type;
+    constexpr int NG = RealOf<VEC, PACKED>::N;                             // pixel groups per lane
     if (!a.has_normal) {                                                    // +Z, :147-152
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { t.nm[0][j] = 0.0f; t.nm[1][j] = 0.0f; t.nm[2][j] = 1.0f; }
@@ -221,16 +259,17 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) t.al[c][j] = srgb_to_linear(t.al[c][j]);
+            for (int g = 0; g < NG; ++g) scatter(t.al[c], g, srgb_to_linear(gather<R>(t.al[c], g)));
     }
     if (WF == PBR_WORKFLOW_CONVERTED) {   // to_diffuse_specular_material, then the specular workflow
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const float m = t.me[j], om = 1.0f - m;
+        for (int g = 0; g < NG; ++g) {
+            const R m = gather<R>(t.me, g), om = splat<R>(1.0f) - m;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                t.sp[c][j] = fmaf(t.al[c][j], m, kDielectricF0 * om);       // metallic.py:108
-                t.al[c][j] = t.al[c][j] * om;                               // metallic.py:105
+                const R al = gather<R>(t.al[c], g);
+                scatter(t.sp[c], g, fma_(al, m, om * kDielectricF0));       // metallic.py:108
+                scatter(t.al[c], g, al * om);                               // metallic.py:105
             }
         }
     }
@@ -238,79 +277,71 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) t.sp[c][j] = srgb_to_linear(t.sp[c][j]);
+            for (int g = 0; g < NG; ++g) scatter(t.sp[c], g, srgb_to_linear(gather<R>(t.sp[c], g)));
     }
 
     const Vec3 V = {a.V[0], a.V[1], a.V[2]};
     float ys = 0.0f;
     if (LIGHT == PBR_LIGHT_POINT) ys = linspace_at(a.y0, a.y1, a.ystep, a.H_total, p.y + a.y_offset);
 
-    float res[3][VEC];
+    R res[3][NG];
     if constexpr (!MULTI) {
-        // ---- one light: pixel by pixel, terms and shading back to back (shortest live ranges: 87 VGPRs)
+        // ---- one light: group by group, terms and shading back to back (shortest live ranges)
         const LightU &lu = a.lights[0];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            PixelTerms pt;
-            material_terms<WF, VEC>(t, j, V, pt);
-            LightGeom g;
-            if (LIGHT == PBR_LIGHT_POINT) {
-                g = point_light_geom(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, linspace_at(a.x0, a.x1, a.xstep, a.W, p.x + j), ys);
-            } else {
-                g.L = {lu.l[0], lu.l[1], lu.l[2]};
-                g.h = {lu.h[0], lu.h[1], lu.h[2]};
-                g.hh = lu.hh; g.p5 = lu.p5; g.att = 1.0f;
-            }
-            float col[3];
-            shade_light(pt, g, lu.inten, col);
+        for (int g = 0; g < NG; ++g) {
+            PixelTermsT<R> pt;
+            material_terms<WF, VEC, R>(t, g, V, pt);
+            const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs_of<R>(a, p.x, g), ys);
+            R col[3];
+            shade_light(pt, lg, lu.inten, col);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) res[c][j] = col[c];
+            for (int c = 0; c < 3; ++c) res[c][g] = col[c];
         }
     } else {
         // ---- several lights (H12): light-independent terms of every pixel first, then lights in the
-        // OUTER (uniform) loop and the lane's pixels inside it, so each light's scalar loads and loop
-        // overhead are paid once per VEC pixels and the pixels' transcendental latencies interleave
-        PixelTerms pt[VEC];
-        float xs[VEC];
+        // OUTER (uniform) loop and the lane's pixel groups inside it, so each light's scalar loads and
+        // loop overhead are paid once per VEC pixels and the groups' transcendental latencies interleave
+        PixelTermsT<R> pt[NG];
+        R xs[NG];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            material_terms<WF, VEC>(t, j, V, pt[j]);
-            xs[j] = LIGHT == PBR_LIGHT_POINT ? linspace_at(a.x0, a.x1, a.xstep, a.W, p.x + j) : 0.0f;
+        for (int g = 0; g < NG; ++g) {
+            material_terms<WF, VEC, R>(t, g, V, pt[g]);
+            xs[g] = LIGHT == PBR_LIGHT_POINT ? xs_of<R>(a, p.x, g) : splat<R>(0.0f);
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) res[c][j] = 0.0f;
+            for (int g = 0; g < NG; ++g) res[c][g] = splat<R>(0.0f);
         for (int l = 0; l < a.n_lights; ++l) {
             const LightU &lu = a.lights[l];
-            LightGeom g;
-            if (LIGHT == PBR_LIGHT_DIRECTIONAL) {
-                g.L = {lu.l[0], lu.l[1], lu.l[2]};
-                g.h = {lu.h[0], lu.h[1], lu.h[2]};
-                g.hh = lu.hh; g.p5 = lu.p5; g.att = 1.0f;
-            }
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                if (LIGHT == PBR_LIGHT_POINT) g = point_light_geom(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, xs[j], ys);
-                float col[3];
-                shade_light(pt[j], g, lu.inten, col);
+            for (int g = 0; g < NG; ++g) {
+                const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[g], ys);
+                R col[3];
+                shade_light(pt[g], lg, lu.inten, col);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) res[c][j] += col[c];
+                for (int c = 0; c < 3; ++c) res[c][g] += col[c];
             }
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c)                                         // sum of per-light clamped terms, clamped
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) res[c][j] = clamp01(res[c][j]);
+            for (int g = 0; g < NG; ++g) res[c][g] = clamp01(res[c][g]);
     }
     if (a.out_srgb) {                                                       // :179-180
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) res[c][j] = linear_to_srgb_unit(res[c][j]);
+            for (int g = 0; g < NG; ++g) res[c][g] = linear_to_srgb_unit(res[c][g]);
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Ld<TO, VEC>::template store<NT>(a.out, p.b * a.o_bs + c * a.o_cs + p.pix, res[c]);
+    for (int c = 0; c < 3; ++c) {
+        float o[VEC];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) scatter(o, g, res[c][g]);
+        Ld<TO, VEC>::template store<NT>(a.out, p.b * a.o_bs + c * a.o_cs + p.pix, o);
+    }
 }
 
 // ------------------------------------------------------------------ kernel
@@ -326,7 +357,7 @@ __global__ __launch_bounds__(256, MULTI ? 4 : 1) void cook_torrance_kernel(const
     if (!p.valid) return;
     Texels<VEC> t;
     load_texels<WF, TI, VEC, NT>(a, p, t);
-    shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT>(a, p, t);
+    shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, (MULTI || sizeof(TI) == 2)>(a, p, t);
 }
 
 }  // namespace pbr

@@ -318,6 +318,47 @@ def test_full_size_4k_properties_and_sampled_parity():
                   ref32[np.broadcast_to(host[2] >= ROUGH_OK, got.shape)]).max() <= TOL      # criterion (i)
 
 
+def test_shape_fuzz_against_c_oracle():
+    """Ragged shapes, tile edges and batch/row arithmetic: 60 seeded (B, H, W) draws x workflows x
+    light types, fp32 and fp16 maps, against the plain-C oracle (float64 build = truth)."""
+    import c_oracle as C
+    from pypbr_amd import functional as F
+    rng = np.random.default_rng(2025)
+    shapes = [(1, 1, 1), (1, 1, 4), (2, 3, 8), (1, 2, 256), (1, 1, 260), (3, 5, 12), (1, 64, 4), (2, 65, 20), (1, 7, 1028)]
+    while len(shapes) < 60:
+        shapes.append((int(rng.integers(1, 4)), int(rng.integers(1, 40)), int(rng.integers(1, 300))))
+    worst = 0.0
+    for i, (B, H, W) in enumerate(shapes):
+        a = rng.random((B, 3, H, W), dtype=np.float32)
+        n = np.concatenate([rng.random((B, 2, H, W), dtype=np.float32) - 0.5, np.ones((B, 1, H, W), np.float32)], 1)
+        r = rng.random((B, 1, H, W), dtype=np.float32) * 0.7 + 0.3
+        m = rng.random((B, 1, H, W), dtype=np.float32)
+        s = rng.random((B, 3, H, W), dtype=np.float32) * 0.3
+        workflow = ("metallic", "specular", "converted")[i % 3]
+        ltype = ("point", "directional")[(i // 3) % 2]
+        nl = (1, 3)[(i // 6) % 2]
+        half = (i // 12) % 2 == 1
+        if half:
+            a, n, r, m, s = [x.astype(np.float16).astype(np.float32) for x in (a, n, r, m, s)]
+        lights = rng.random((nl, 3)) * [0.8, 0.8, 0.5] + [-0.4, -0.4, 0.6]
+        inten = rng.random((nl, 3)) * 0.8 + 0.2
+        view = [0.1, -0.05, 1.0]
+        kw = dict(view=view, lights=lights, intensities=inten, light_type=ltype, light_size=1.3, workflow=workflow,
+                  specular_is_srgb=True)
+        ref = C.render(a, n, r, None if workflow == "specular" else m, s if workflow == "specular" else None,
+                       dtype=np.float64, **kw)
+        dt = torch.float16 if half else torch.float32
+        dev = [None if x is None else torch.from_numpy(x).to(dt).cuda() for x in
+               (a, n, r, None if workflow == "specular" else m, s if workflow == "specular" else None)]
+        out = F.cook_torrance(*dev, view_dir=view, light=lights, light_intensity=inten, light_type=ltype, light_size=1.3,
+                              convert_to_diffuse_specular=(workflow == "converted"))
+        assert out.shape == (B, 3, H, W) and out.dtype == torch.float32
+        err = float(np.abs(out.cpu().numpy().astype(np.float64) - ref).max())
+        worst = max(worst, err)
+        assert err <= TOL, ((B, H, W), workflow, ltype, nl, half, err)
+    print(f"\n[shape fuzz] worst |hip - C oracle fp64| over {len(shapes)} cases: {worst:.2e}")
+
+
 def test_resize_matches_reference_vectors(golden):
     """MaterialBase.resize (N1): antialiased bilinear, tuple and int sizes, up and down."""
     from pypbr_amd import functional as F

@@ -29,11 +29,12 @@ ap.add_argument("--light", type=str, default="point")
 ap.add_argument("--lights", type=int, default=1)
 ap.add_argument("--dtype", type=str, default="float32")
 ap.add_argument("--altlib", type=str, default="")
+ap.add_argument("--linear", action="store_true", help="maps already linear, linear output: no sRGB transcendental work")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 libs = [N.lib()]
-if args.altlib:
-    alt = ctypes.CDLL(os.path.abspath(args.altlib))
+for path in filter(None, args.altlib.split(",")):       # alt=1 -> first path, alt=2 -> second, ...
+    alt = ctypes.CDLL(os.path.abspath(path))
     alt.pbr_cook_torrance.argtypes = [ctypes.POINTER(N.RenderDesc), ctypes.c_void_p]
     alt.pbr_cook_torrance.restype = ctypes.c_int
     alt.pbr_set_tuning.argtypes = [ctypes.c_int, ctypes.c_int]
@@ -50,6 +51,8 @@ if args.lights > 1:
 else:
     light, inten = ([0.1, 0.1, 1.0] if args.light == "point" else [0.3, -0.2, 1.0]), [1, 1, 1]
 kw = dict(view_dir=[0, 0, 1], light=light, light_intensity=inten, light_type=args.light, light_size=1.0)
+if args.linear:
+    kw.update(albedo_is_srgb=False, return_srgb=False)
 plans = [F.plan_cook_torrance(*s, **kw) for s in sets]
 stream = torch.cuda.current_stream(dev).cuda_stream
 configs = [dict(kv.split("=") for kv in c.split(",")) for c in args.configs.split(";")]

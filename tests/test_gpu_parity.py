@@ -318,6 +318,37 @@ def test_full_size_4k_properties_and_sampled_parity():
                   ref32[np.broadcast_to(host[2] >= ROUGH_OK, got.shape)]).max() <= TOL      # criterion (i)
 
 
+def test_launch_is_stream_ordered_and_graph_capturable():
+    """The C-ABI contract: a call only enqueues on the given stream -- no host sync, no allocation, no
+    state.  So it can run on a side stream and be captured into a HIP graph and replayed."""
+    from pypbr_amd import functional as F
+    a, n, r, m, _ = [t[0].cuda() for t in _seeded(8, 1, 64, 128)]
+    kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
+    ref = F.cook_torrance(a, n, r, m, **kw).clone()
+    plan = F.plan_cook_torrance(a, n, r, m, **kw)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.out.zero_()
+        plan.launch()                                   # picks up torch's current (side) stream
+    side.synchronize()
+    assert torch.equal(plan.result, ref)
+    graph = torch.cuda.CUDAGraph()
+    plan.out.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        plan.launch()
+    plan.out.zero_()
+    a.mul_(0.5)                                         # the graph reads the maps at replay time
+    graph.replay()
+    torch.cuda.synchronize()
+    a.mul_(2.0)
+    half = plan.result.clone()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(plan.result, ref) and not torch.equal(half, ref)
+
+
 def test_shape_fuzz_against_c_oracle():
     """Ragged shapes, tile edges and batch/row arithmetic: 60 seeded (B, H, W) draws x workflows x
     light types, fp32 and fp16 maps, against the plain-C oracle (float64 build = truth)."""

@@ -106,6 +106,10 @@ def lib():
                                  % (L.pbr_render_desc_size(), ctypes.sizeof(RenderDesc)))
     if L.pbr_abi_version() != ABI_VERSION:
         raise NativeLibraryError("libpbr_hip.so ABI %d, binding expects %d" % (L.pbr_abi_version(), ABI_VERSION))
+    for env, knob in (("PBR_TUNE_LDS_BYTES", TUNE_LDS_BYTES), ("PBR_TUNE_NONTEMPORAL", TUNE_NONTEMPORAL),
+                      ("PBR_TUNE_BLOCK_LOG2", TUNE_BLOCK_LOG2)):      # profiling runs: knobs from the environment
+        if os.environ.get(env, "") != "":
+            L.pbr_set_tuning(knob, int(os.environ[env]))
     _lib = L
     return L
 

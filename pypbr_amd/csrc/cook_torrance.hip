@@ -38,17 +38,11 @@ namespace pbr {
 static int g_nontemporal = 1;
 static int g_block_log2 = 6;       // workgroup size: 64 (6), 128 (7) or 256 (8) lanes
 static int g_f16_vec = 8;          // pixels per lane for fp16 maps with one light: 8 (16-byte loads) or 4
-// Occupancy governor.  The one-light fp32 kernel needs 69 VGPRs, so 28 one-wave workgroups fit on a
-// CU -- far more than the ~12 that already saturate HBM (12 waves x 8 KiB x 256 CUs = 25 MB in
-// flight).  Every extra resident wave is 11 more concurrent plane streams competing for DRAM pages:
-// measured on MI355X (tools/tune.py, interleaved A/B), capping residency at 12-13 waves per CU is
-// 3-7 % FASTER on every large fp32 workload (4096^2: 127 -> 119 us; 64 x 1024^2: 480 -> 463 us;
-// 16 x 2048^2: 562 -> 524 us), neutral for fp16 maps, and slightly slower only for launches that
-// finish in a few microseconds.  The cap is applied by declaring (unused) dynamic LDS at launch:
-// 160 KiB / 12.5 KiB = 13 workgroups per CU.  -1 = automatic, >= 0 = forced value (A/B runs).
-static int g_lds_bytes = -1;
-constexpr int kGovernorLdsBytes = 12800;
-constexpr int64_t kGovernorMinPixels = 4 << 20;
+// Dynamic LDS per workgroup, unused by the kernel: an occupancy throttle for A/B runs (160 KiB / value =
+// workgroups per CU).  It was the first form of the occupancy cap (12 800 B: 3-7 % faster than uncapped on
+// large fp32 workloads); the shipped cap is amdgpu_waves_per_eu(3,3) on the kernel, which refills freed slots
+// faster (another 1-3 %).
+static int g_lds_bytes = 0;
 
 static inline void normalize_host(const float v[3], float o[3]) {   // F.normalize(v, dim=0), fp32
     const float nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
@@ -217,9 +211,7 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     fill_args(d, vec, k);
     const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0);
     // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane
-    const bool governed = d->n_lights == 1 && d->map_dtype == PBR_F32 && k.bt_log2 == 6 &&
-                          (int64_t)d->batch * d->height * d->width >= kGovernorMinPixels;
-    const size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (governed ? (size_t)kGovernorLdsBytes : 0);
+    const size_t lds = g_lds_bytes > 0 ? (size_t)g_lds_bytes : 0;
     hipLaunchKernelGGL(e.fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), lds,
                        static_cast<hipStream_t>(stream), k);
     const hipError_t err = hipGetLastError();

@@ -351,13 +351,26 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
 //   MULTI: more than one light (uniform loop) -- the single-light body is straight-line
 // 1-D grid, one tile per workgroup, tiles ordered x fastest.
 template <int LIGHT, int WF, typename TI, typename TO, int VEC, bool MULTI, bool NT>
-__global__ __launch_bounds__(256, MULTI ? 4 : 1) void cook_torrance_kernel(const KArgs a) {
+// Occupancy: the one-light kernels are HBM-bound and want exactly 3 waves per SIMD (12 per CU): fewer cannot
+// cover the latency, more only add concurrent plane streams that fight for DRAM pages (measured, DESIGN.md 3.2:
+// 2 -> 126 us, 3 -> 114 us, 4 -> 123 us, uncapped (7) -> 129 us on a 4096^2 map).  amdgpu_waves_per_eu(3,3)
+// makes the register allocation enforce it.  The multi-light body is VALU-bound and wants >= 4.
+#ifndef PBR_WAVES_PER_EU
+#define PBR_WAVES_PER_EU 3
+#endif
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(MULTI ? 4 : PBR_WAVES_PER_EU, MULTI ? 8 : PBR_WAVES_PER_EU)))
+void cook_torrance_kernel(const KArgs a) {
     const int ty = (int)a.div_tx.div(blockIdx.x);
     const LanePos p = lane_pos<VEC>(a, (int)blockIdx.x - ty * a.tiles_x, ty);
     if (!p.valid) return;
     Texels<VEC> t;
     load_texels<WF, TI, VEC, NT>(a, p, t);
+#ifdef PBR_PACK_SINGLE   // build-time experiment switch: packed math for the one-light fp32 kernels too
+    shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, true>(a, p, t);
+#else
     shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, (MULTI || sizeof(TI) == 2)>(a, p, t);
+#endif
 }
 
 }  // namespace pbr

@@ -44,7 +44,7 @@ enum {
     PBR_ERR_DTYPE = -5,
     PBR_ERR_CHANNELS = -6,        /* base.py:219 "Normal map must have 2 or 3 channels." */
     PBR_ERR_NO_DEVICE = -7,
-    PBR_ERR_UNSUPPORTED = -8      /* valid request this build does not implement (e.g. backward of CONVERTED) */
+    PBR_ERR_UNSUPPORTED = -8      /* valid request this build does not implement */
 };
 
 enum { PBR_F32 = 0, PBR_F16 = 1 };                 /* storage type of maps */
@@ -108,7 +108,8 @@ int pbr_cook_torrance(const pbr_render_desc *desc, void *stream);
  * Gradient of pbr_cook_torrance w.r.t. the maps (what torch.autograd computes through
  * cooktorrance.py:92-182 in the reference's rendering-loss use,
  * docs/source/tutorials/06_advanced.rst:73-107).  `desc` is the forward descriptor (its `out` is
- * ignored), fp32 maps, METALLIC or SPECULAR workflow; `grad_out` is [B][3][H][W] contiguous.
+ * ignored), fp32 maps, any workflow (CONVERTED: gradients w.r.t. the metallic-workflow maps, through the
+ * in-kernel conversion); `grad_out` is [B][3][H][W] contiguous.
  * Each non-NULL g_* receives a contiguous fp32 gradient shaped like its map
  * ([B][3|1][H][W]); NULL skips it.  Same sub-gradient conventions as torch (clamp passes on the
  * closed interval).

@@ -225,7 +225,6 @@ int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, v
     if (rc != PBR_OK) return rc;
     if (!grad_out) return PBR_ERR_NULL_MAP;
     if (d->map_dtype != PBR_F32 || d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;
-    if (d->workflow == PBR_WORKFLOW_CONVERTED) return PBR_ERR_UNSUPPORTED;
     int vec = pick_vec(d);
     for (const void *g : {grad_out, (const void *)g_albedo, (const void *)g_normal, (const void *)g_roughness,
                           (const void *)g_metallic, (const void *)g_specular})
@@ -234,13 +233,19 @@ int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, v
     KArgs k;
     fill_args(d, vec, k);
     const BArgs b = {grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular};
-    const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT, spec = d->workflow == PBR_WORKFLOW_SPECULAR;
+    const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
     void (*fn)(const KArgs, const BArgs) = nullptr;
 #define PBR_BWD(L, W)                                                                                           \
     fn = vec == 4 ? (multi ? cook_torrance_backward_kernel<L, W, 4, true> : cook_torrance_backward_kernel<L, W, 4, false>) \
                   : (multi ? cook_torrance_backward_kernel<L, W, 1, true> : cook_torrance_backward_kernel<L, W, 1, false>)
-    if (point) { if (spec) { PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR); } else { PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC); } }
-    else       { if (spec) { PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR); } else { PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC); } }
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC); break;
+        case 1: PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR); break;
+        case 2: PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED); break;
+        case 3: PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC); break;
+        case 4: PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR); break;
+        default: PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED); break;
+    }
 #undef PBR_BWD
     hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0, static_cast<hipStream_t>(stream), k, b);
     const hipError_t err = hipGetLastError();

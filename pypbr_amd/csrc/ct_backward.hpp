@@ -119,7 +119,7 @@ __device__ __forceinline__ void backprop_light(const PixelTerms &t, const LightG
     adj.g_n.z = fmaf(gl, g.L.z, fmaf(gch, g.h.z, adj.g_n.z));
 }
 
-//   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_METALLIC | PBR_WORKFLOW_SPECULAR    VEC: 4 | 1    fp32 maps
+//   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_*    VEC: 4 | 1    fp32 maps
 template <int LIGHT, int WF, int VEC, bool MULTI>
 __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
     const int ty = (int)a.div_tx.div(blockIdx.x);
@@ -143,18 +143,23 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         // ---- forward: decoded colours and their derivatives
-        float base[3], dbase[3], f0[3], df0[3], kd_scale = 1.0f;
-        const float m = WF == PBR_WORKFLOW_METALLIC ? t.me[j] : 0.0f;
+        float base[3], dbase[3], f0[3], df0[3], alin[3], kd_scale = 1.0f;
+        const float m = WF != PBR_WORKFLOW_SPECULAR ? t.me[j] : 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            base[c] = a.albedo_srgb ? srgb_to_linear(t.al[c][j]) : t.al[c][j];
+            alin[c] = base[c] = a.albedo_srgb ? srgb_to_linear(t.al[c][j]) : t.al[c][j];
             dbase[c] = a.albedo_srgb ? srgb_to_linear_grad(t.al[c][j]) : 1.0f;
             if (WF == PBR_WORKFLOW_METALLIC) {
                 f0[c] = fmaf(m, base[c] - kDielectricF0, kDielectricF0);
                 df0[c] = 0.0f;
-            } else {
+            } else if (WF == PBR_WORKFLOW_SPECULAR) {
                 f0[c] = a.spec_srgb ? srgb_to_linear(t.sp[c][j]) : t.sp[c][j];
                 df0[c] = a.spec_srgb ? srgb_to_linear_grad(t.sp[c][j]) : 1.0f;
+            } else {   // CONVERTED: to_diffuse_specular_material (metallic.py:98-108), then the specular workflow
+                const float sp = fmaf(alin[c], m, kDielectricF0 * (1.0f - m));
+                base[c] = alin[c] * (1.0f - m);
+                f0[c] = a.spec_srgb ? srgb_to_linear(sp) : sp;
+                df0[c] = a.spec_srgb ? srgb_to_linear_grad(sp) : 1.0f;
             }
         }
         if (WF == PBR_WORKFLOW_METALLIC) kd_scale = 1.0f - m;
@@ -204,12 +209,16 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float g_base = adj.g_kb[c] * (kd_scale * kInvPi);
-            g_m = fmaf(adj.g_kb[c], -base[c] * kInvPi, g_m);
+            if (WF == PBR_WORKFLOW_METALLIC) g_m = fmaf(adj.g_kb[c], -base[c] * kInvPi, g_m);
             if (WF == PBR_WORKFLOW_METALLIC) {                               // lerp(0.04, base, m)  (:107)
                 g_base = fmaf(adj.g_f0[c], m, g_base);
                 g_m = fmaf(adj.g_f0[c], base[c] - kDielectricF0, g_m);
-            } else {
+            } else if (WF == PBR_WORKFLOW_SPECULAR) {
                 gs[c][j] = adj.g_f0[c] * df0[c];
+            } else {   // diffuse = a (1-m) ; specular = 0.04 (1-m) + a m  (kd_scale == 1 here, so g_m above is 0-weighted)
+                const float g_sp = adj.g_f0[c] * df0[c], g_diff = adj.g_kb[c] * kInvPi;
+                g_base = fmaf(g_diff, 1.0f - m, g_sp * m);
+                g_m = fmaf(g_sp, alin[c] - kDielectricF0, fmaf(-g_diff, alin[c], g_m));
             }
             ga[c][j] = g_base * dbase[c];
         }
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
         for (int c = 0; c < 3; ++c) Ld<float, VEC>::template store<true>(b.g_normal, gp3 + c * a.o_cs, gn[c]);
     }
     if (b.g_rough) Ld<float, VEC>::template store<true>(b.g_rough, gp1, gr);
-    if (WF == PBR_WORKFLOW_METALLIC) {
+    if (WF != PBR_WORKFLOW_SPECULAR) {
         if (b.g_metal) Ld<float, VEC>::template store<true>(b.g_metal, gp1, gm);
     } else if (b.g_spec) {
 #pragma unroll

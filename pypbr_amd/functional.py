@@ -216,8 +216,8 @@ class _CookTorranceFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, albedo, normal, roughness, metallic, specular, kwargs):
-        if kwargs.get("convert_to_diffuse_specular") or kwargs.get("out") is not None:
-            raise NotImplementedError("gradients are implemented for the metallic and specular workflows, out=None")
+        if kwargs.get("out") is not None:
+            raise NotImplementedError("gradients need out=None (the result must be a fresh tensor)")
         maps = (albedo, normal, roughness, metallic, specular)
         plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **kwargs)
         if plan.desc.map_dtype != N.F32 or plan.desc.out_dtype != N.F32:

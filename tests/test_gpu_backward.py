@@ -95,5 +95,35 @@ def test_rendering_loss_step_through_the_module():
         assert t.grad is not None and bool(torch.isfinite(t.grad).all()) and float(t.grad.abs().sum()) > 0, k
     with pytest.raises(NotImplementedError):
         from pypbr_amd import functional as F
-        F.cook_torrance(pred["albedo"], normal, pred["roughness"], pred["metallic"], view_dir=[0, 0, 1], light=[0, 0, 1],
-                        light_intensity=[1, 1, 1], convert_to_diffuse_specular=True)
+        F.cook_torrance(pred["albedo"].half(), normal.half(), pred["roughness"].half(), pred["metallic"].half(),
+                        view_dir=[0, 0, 1], light=[0, 0, 1], light_intensity=[1, 1, 1])      # fp16 maps: forward only
+
+
+@pytest.mark.parametrize("quirk", [True, False])
+@pytest.mark.parametrize("light_type,light,size", [("point", [0.1, 0.1, 1.0], 1.0), ("directional", [0.3, -0.2, 1.0], None)])
+def test_backward_through_the_fused_conversion(quirk, light_type, light, size):
+    """convert_to_diffuse_specular=True: gradients w.r.t. the METALLIC-workflow maps through
+    to_diffuse_specular_material (metallic.py:98-108) and the render, both settings of the F6 flag,
+    against float64 autograd through the ATen oracle."""
+    import torch_oracle as O
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(17)
+    H, W = 20, 28
+    a = torch.rand(3, H, W, generator=g)
+    n = torch.cat([(torch.rand(2, H, W, generator=g) - 0.5) * 1.2, torch.ones(1, H, W)], 0)
+    r = torch.rand(1, H, W, generator=g) * 0.7 + 0.3
+    m = torch.rand(1, H, W, generator=g)
+    wt = torch.rand(3, H, W, generator=g) - 0.3
+    leaves = [t.double().requires_grad_(True) for t in (a, n, r, m)]
+    ref = O.cook_torrance_converted(*leaves, quirk_specular_srgb=quirk, view=torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64),
+                                    light=torch.tensor(light, dtype=torch.float64), intensity=torch.tensor([1.0, 0.9, 0.8], dtype=torch.float64),
+                                    light_type=light_type, light_size=size)
+    (ref * wt.double()).sum().backward()
+    dev = [t.clone().cuda().requires_grad_(True) for t in (a, n, r, m)]
+    out = F.cook_torrance(*dev, view_dir=[0, 0, 1], light=light, light_intensity=[1.0, 0.9, 0.8], light_type=light_type,
+                          light_size=size, convert_to_diffuse_specular=True, specular_is_srgb=quirk)
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 1e-5
+    (out * wt.cuda()).sum().backward()
+    for name, d, l in zip(("albedo", "normal", "roughness", "metallic"), dev, leaves):
+        err = (d.grad.cpu().double() - l.grad).abs()
+        assert (err <= 2e-5 * (1 + l.grad.abs())).all(), (name, float(err.max()))

@@ -115,7 +115,7 @@ static void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     const int bx = 1 << lg, by = (1 << k.bt_log2) >> lg;
     k.tiles_x = (k.wv + bx - 1) / bx;
     const int64_t tiles = (int64_t)k.tiles_x * ((k.rows + by - 1) / by);
-    k.n_tiles = tiles > INT32_MAX ? INT32_MAX : (int32_t)tiles;
+    k.n_tiles = tiles > INT32_MAX ? -1 : (int32_t)tiles;      // -1: more tiles than a 1-D grid holds, rejected by the callers
     k.div_h.init((uint32_t)d->height);
     k.div_tx.init((uint32_t)k.tiles_x);
     k.y_offset = d->y_offset; k.H_total = d->height_total;
@@ -209,6 +209,7 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     const int vec = pick_vec(d);
     KArgs k;
     fill_args(d, vec, k);
+    if (k.n_tiles < 0) return PBR_ERR_SHAPE;
     const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0);
     // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane
     const size_t lds = g_lds_bytes > 0 ? (size_t)g_lds_bytes : 0;
@@ -232,6 +233,7 @@ int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, v
     if (vec == 8) vec = 4;
     KArgs k;
     fill_args(d, vec, k);
+    if (k.n_tiles < 0) return PBR_ERR_SHAPE;
     const BArgs b = {grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular};
     const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
     void (*fn)(const KArgs, const BArgs) = nullptr;

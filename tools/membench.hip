@@ -65,6 +65,44 @@ __global__ __launch_bounds__(BLOCK) void persistent(const f4 *__restrict__ in, f
     }
 }
 
+// LDS-DMA variant: the 8 plane loads go global -> LDS (global_load_lds_dwordx4, no VGPR destination), the lane then
+// reads its 16 bytes per plane back with ds_read_b128.  One-wave workgroups, 8 KiB of LDS each.
+template <bool NT, int FMAS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void oneshot_ldsdma(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size_t plane) {
+    __shared__ f4 buf[8][64];
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    const size_t ic = i < nv ? i : nv - 1;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(in + c * plane + ic),
+                                         (__attribute__((address_space(3))) void *)&buf[c][0], 16, 0, NT ? 2 : 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    f4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = buf[c][threadIdx.x];
+    if (i >= nv) return;
+    f4 r0 = work<FMAS>(v[0] + v[3] + v[6], v[6], v[7]);
+    f4 r1 = work<FMAS>(v[1] + v[4] + v[7], v[6], v[7]);
+    f4 r2 = work<FMAS>(v[2] + v[5], v[6], v[7]);
+    st<NT>(out + i, r0); st<NT>(out + plane + i, r1); st<NT>(out + 2 * plane + i, r2);
+}
+
+// the register path at the same geometry: one-wave workgroups, 3 waves per SIMD
+template <bool NT, int FMAS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void oneshot_w3(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size_t plane) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= nv) return;
+    f4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = ld<NT>(in + c * plane + i);
+    f4 r0 = work<FMAS>(v[0] + v[3] + v[6], v[6], v[7]);
+    f4 r1 = work<FMAS>(v[1] + v[4] + v[7], v[6], v[7]);
+    f4 r2 = work<FMAS>(v[2] + v[5], v[6], v[7]);
+    st<NT>(out + i, r0); st<NT>(out + plane + i, r1); st<NT>(out + 2 * plane + i, r2);
+}
+
 // read-only and write-only ceilings
 template <bool NT> __global__ __launch_bounds__(256) void readonly(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size_t plane) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -131,6 +169,10 @@ int main(int argc, char **argv) {
         if (!bin) { CHECK(hipMalloc(&bin, 8 * (px * 4 + 2 * 1048576))); CHECK(hipMalloc(&bout, 3 * (px * 4 + 2 * 1048576))); CHECK(hipMemset(bin, 0x3c, 8 * (px * 4 + 2 * 1048576))); }
         report(nm, time_us([&](int i) { hipLaunchKernelGGL((oneshot<true, 0, 256>), dim3((nv + 255) / 256), dim3(256), 0, 0, bin, bout, nv, plane + pad, plane + pad); }, iters), bytes_rw);
     }
+#define W3(K, NT, F) report(#K " nt=" #NT " valu/px=" #F " (1-wave groups, 3 waves/SIMD)", time_us([&](int i) { hipLaunchKernelGGL((K<NT, F>), dim3((nv + 63) / 64), dim3(64), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
+    W3(oneshot_w3, true, 0); W3(oneshot_ldsdma, true, 0); W3(oneshot_ldsdma, false, 0);
+    W3(oneshot_w3, true, 60); W3(oneshot_ldsdma, true, 60);
+    W3(oneshot_w3, true, 0); W3(oneshot_ldsdma, true, 0);
 #define PERSIST(NT, F, B, G) report("persistent nt=" #NT " valu/px=" #F " block=" #B " grid=" #G, time_us([&](int i) { hipLaunchKernelGGL((persistent<NT, F, B>), dim3(G), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
     PERSIST(true, 0, 256, 1024); PERSIST(true, 0, 256, 2048);
     PERSIST(true, 60, 256, 2048);

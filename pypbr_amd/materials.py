@@ -154,11 +154,6 @@ class MaterialBase:
         return _through_device(albedo, F_.srgb_to_linear) if self.albedo_is_srgb else albedo
 
     @property
-    def normal_rgb(self):
-        normal = self._maps.get("normal")
-        return None if normal is None else (normal + 1.0) * 0.5
-
-    @property
     def size(self) -> Optional[Tuple[int, int]]:
         """(height, width) of the first map that is present (base.py:293-307)."""
         for t in self._maps.values():

@@ -78,14 +78,14 @@ template <class R> __device__ __forceinline__ R srgb_to_linear(R x) {
     const R t = clamp01(x);
     const R lo = t * (1.0f / 12.92f);
     const R hi = exp2_hw(fma_(splat<R>(2.4f), log2_hw(t + 0.055f), splat<R>(-0.18538320f) /* 2.4*log2(1.055) */));
-    return min_(select_(le_(t, splat<R>(0.04045f)), lo, hi), splat<R>(1.0f));
+    return select_(le_(t, splat<R>(0.04045f)), lo, hi);      // hi(1) = 1 +- 1 ulp, like the reference's pow
 }
 
 // utils/functions.py:50-66; `c` must already be in [0,1] (callers clamp).
 template <class R> __device__ __forceinline__ R linear_to_srgb_unit(R c) {
     const R lo = c * 12.92f;
-    const R hi = fma_(splat<R>(1.055f), exp2_hw(log2_hw(c) * (1.0f / 2.4f)), splat<R>(-0.055f));
-    return clamp01(select_(le_(c, splat<R>(0.0031308f)), lo, hi));
+    const R hi = clamp01(fma_(splat<R>(1.055f), exp2_hw(log2_hw(c) * (1.0f / 2.4f)), splat<R>(-0.055f)));   // clamp = output modifier
+    return select_(le_(c, splat<R>(0.0031308f)), lo, hi);                            // lo <= 0.0405 needs none
 }
 template <class R> __device__ __forceinline__ R linear_to_srgb(R x) { return linear_to_srgb_unit(clamp01(x)); }
 
@@ -100,11 +100,14 @@ template <class R> __device__ __forceinline__ R dotu(const Vec3T<R> &a, const Ve
 
 // Light-dependent, material-independent terms of one pixel (:122-140, :155-159).
 template <class R> struct LightGeomT {
-    Vec3T<R> L;    // light direction as the reference uses it (point: d/(dist+1e-7))
+    Vec3T<R> d;    // point: light position - surface point, un-normalised; directional: L
+    R rinv;        // point: 1/(dist + 1e-7); directional: 1.   N.L = (N.d) rinv costs 4 ops, never forming L
+    Vec3T<R> L;    // light direction as the reference uses it (d * rinv); only the backward kernel reads it
     Vec3T<R> h;    // V + L, un-normalised
     R rhh;         // 1/|h|^2  (|h|^2 clamped at 1e-24: F.normalize's 1e-12 on the norm)
     R att;         // 1/(dist^2+1e-7), 1 for directional
     R p5;          // (1 - clamp(Hv.V))^5
+    R om5;         // 1 - p5:  F = f0 + (1 - f0) p5 = f0 om5 + p5, one fma per channel
 };
 using LightGeom = LightGeomT<float>;
 
@@ -122,23 +125,28 @@ __device__ __forceinline__ LightGeomT<R> point_light_geom(const Vec3 &V, const V
     const R dd = max_(dot(d, d), splat<R>(1e-12f));                 // dist^2, torch.norm :138
     const R r = rsq(dd);
     const R rinv = r * fma_(splat<R>(-1e-7f), r, splat<R>(1.0f));   // 1/(dist + 1e-7)  :139
+    g.d = d; g.rinv = rinv;
     g.L = {d.x * rinv, d.y * rinv, d.z * rinv};
     g.att = rcp(dd + 1e-7f);                                        // :140
-    g.h = {g.L.x + V.x, g.L.y + V.y, g.L.z + V.z};                  // :155
+    g.h = {fma_(d.x, rinv, splat<R>(V.x)), fma_(d.y, rinv, splat<R>(V.y)), fma_(d.z, rinv, splat<R>(V.z))};   // :155
     const R rh = rsq(max_(dot(g.h, g.h), splat<R>(1e-24f)));
     g.rhh = rh * rh;
     g.p5 = pow5(splat<R>(1.0f) - clamp01(dotu(g.h, V) * rh));        // :156-158, :196
+    g.om5 = splat<R>(1.0f) - g.p5;
     return g;
 }
 
 // Light-independent terms of one pixel, computed once and reused by every light.
 template <class R> struct PixelTermsT {
     Vec3T<R> n;        // unit normal: stored normal * 1/max(|n|, 1e-12)   (F.normalize :154)
+    R ndv_raw;         // N.V before the clamp: N.h = N.L + N.V, one add per light
     R ndv;             // clamp(N.V)                  (:163)
     R a2;              // roughness^2                 (alpha = roughness, :213-214)
     R k;               // (r+1)^2/8                   (:232-233)
+    R omk, kk;         // 1 - k, k + 1e-7: both G denominators are one fma, ndx omk + kk
     R dv;              // NdotV (1-k) + k + 1e-7      (:234)
     R a2ndv;           // a2 * NdotV
+    R a2ndv_pi;        // a2 * NdotV / pi: the pi of D's denominator, paid per pixel instead of per light
     R kb[3];           // kd_scale * base / pi: the diffuse term is (1 - F) kb   (:169-174)
     R f0[3];           // reflectance at normal incidence
 };
@@ -150,24 +158,29 @@ __device__ __forceinline__ void pixel_terms(const Vec3T<R> &n, const Vec3 &V, R 
                                             R kd_scale, PixelTermsT<R> &t) {
     const R rn = rsq(max_(dot(n, n), splat<R>(1e-24f)));
     t.n = {n.x * rn, n.y * rn, n.z * rn};
-    t.ndv = clamp01(dotu(t.n, V));
+    t.ndv_raw = dotu(t.n, V);
+    t.ndv = clamp01(t.ndv_raw);
     t.a2 = rough * rough;
     const R r1 = rough + 1.0f;
     t.k = r1 * r1 * 0.125f;
-    t.dv = fma_(t.ndv, splat<R>(1.0f) - t.k, t.k) + 1e-7f;
+    t.omk = splat<R>(1.0f) - t.k;
+    t.kk = t.k + 1e-7f;
+    t.dv = fma_(t.ndv, t.omk, t.kk);
     t.a2ndv = t.a2 * t.ndv;
+    t.a2ndv_pi = (t.a2 * kInvPi) * t.ndv;
     const R s = kd_scale * kInvPi;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { t.kb[c] = base[c] * s; t.f0[c] = f0[c]; }
 }
 
-// GGX denominator (:213-217), cancellation-free: a2 + (1-a2) sin^2(N,H) when N.H > 0, else 1.
+// GGX denominator (:213-217), cancellation-free: a2 + (1-a2) sin^2(N,H) when N.H > 0, else 1, with
+// sin^2 = |h - (N.h) N|^2 / |h|^2 (N unit).  Rounding errors of N.h and of |N| move the projection ALONG N, i.e.
+// orthogonally to it, so they enter sin^2 only to second order; 9 ops against 12 for the cross product.
+// `nh` = N.h, which the caller has as N.L + N.V.
 template <class R, class M>
-__device__ __forceinline__ R ggx_den(const PixelTermsT<R> &t, const LightGeomT<R> &g, R &s2, M &nh_pos) {
-    const R nh = dot(t.n, g.h);
-    const Vec3T<R> c = {fma_(t.n.y, g.h.z, -(t.n.z * g.h.y)), fma_(t.n.z, g.h.x, -(t.n.x * g.h.z)),
-                        fma_(t.n.x, g.h.y, -(t.n.y * g.h.x))};
-    s2 = min_(dot(c, c) * g.rhh, splat<R>(1.0f));
+__device__ __forceinline__ R ggx_den(const PixelTermsT<R> &t, const LightGeomT<R> &g, R nh, R &s2, M &nh_pos) {
+    const Vec3T<R> p = {fma_(-nh, t.n.x, g.h.x), fma_(-nh, t.n.y, g.h.y), fma_(-nh, t.n.z, g.h.z)};
+    s2 = min_(dot(p, p) * g.rhh, splat<R>(1.0f));
     nh_pos = gt_(nh, splat<R>(0.0f));
     return select_(nh_pos, fma_(s2, splat<R>(1.0f) - t.a2, t.a2), splat<R>(1.0f));
 }
@@ -178,19 +191,20 @@ template <> struct MaskOf<f32x2> { using type = i32x2; };
 // One light's linear RGB contribution, clamped to [0,1] (:160-177).  `inten` is wave-uniform.
 template <class R>
 __device__ __forceinline__ void shade_light(const PixelTermsT<R> &t, const LightGeomT<R> &g, const float inten[3], R out[3]) {
-    const R ndl = clamp01(dot(t.n, g.L));                          // :164
+    const R ndl_raw = dot(t.n, g.d) * g.rinv;
+    const R ndl = clamp01(ndl_raw);                                // :164
     R s2;
     typename MaskOf<R>::type nh_pos;
-    const R den = ggx_den(t, g, s2, nh_pos);
-    // D * G / (4 NdotV NdotL + 1e-7) with one reciprocal (:217, :232-235, :165-166).
-    const R dl = fma_(ndl, splat<R>(1.0f) - t.k, t.k) + 1e-7f;
-    const R dD = fma_(splat<R>(kPi), den * den, splat<R>(1e-7f));
+    const R den = ggx_den(t, g, ndl_raw + t.ndv_raw, s2, nh_pos);
+    // D * G / (4 NdotV NdotL + 1e-7) with one reciprocal (:217, :232-235, :165-166); D's pi sits in a2ndv_pi.
+    const R dl = fma_(ndl, t.omk, t.kk);
+    const R dD = fma_(den, den, splat<R>(1e-7f * kInvPi));
     const R ds = fma_(t.ndv * 4.0f, ndl, splat<R>(1e-7f));
-    const R dg = t.a2ndv * ndl * rcp((dD * t.dv) * (dl * ds));
+    const R dg = t.a2ndv_pi * ndl * rcp((dD * t.dv) * (dl * ds));
     const R rad = ndl * g.att;                                     // :175
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const R F = fma_(splat<R>(1.0f) - t.f0[ch], g.p5, t.f0[ch]);   // :196
+        const R F = fma_(t.f0[ch], g.om5, g.p5);                   // :196
         // F dg + (1 - F) kb  ==  kb + F (dg - kb)                    (:166, :169-174)
         out[ch] = clamp01(fma_(F, dg - t.kb[ch], t.kb[ch]) * (rad * inten[ch]));   // :175-177
     }

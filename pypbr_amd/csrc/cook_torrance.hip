@@ -38,11 +38,13 @@ namespace pbr {
 static int g_nontemporal = 1;
 static int g_block_log2 = 6;       // workgroup size: 64 (6), 128 (7) or 256 (8) lanes
 static int g_f16_vec = 8;          // pixels per lane for fp16 maps with one light: 8 (16-byte loads) or 4
-// Dynamic LDS per workgroup, unused by the kernel: an occupancy throttle for A/B runs (160 KiB / value =
-// workgroups per CU).  It was the first form of the occupancy cap (12 800 B: 3-7 % faster than uncapped on
-// large fp32 workloads); the shipped cap is amdgpu_waves_per_eu(3,3) on the kernel, which refills freed slots
-// faster (another 1-3 %).
-static int g_lds_bytes = 0;
+// Dynamic LDS per one-wave workgroup, unused by the kernel: an occupancy governor finer than whole waves per
+// SIMD (160 KiB / value = waves per CU).  amdgpu_waves_per_eu(3,3) on the kernel allows 12 waves per CU; the
+// fp32 one-light kernels stream fastest with 11 in flight (in-process A/B, DESIGN.md 3.2: 115.3 vs 118.5 us on
+// 4096^2, 33.3 vs 34.0 us on 2048^2, 249.8 vs 254.1 us on 8 x 2048^2 directional), the fp16 and multi-light
+// kernels with no cap.  -1 = that rule; >= 0 = this many bytes for every launch (A/B runs).
+static int g_lds_bytes = -1;
+constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
 
 static inline void normalize_host(const float v[3], float o[3]) {   // F.normalize(v, dim=0), fp32
     const float nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
@@ -212,7 +214,8 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
     const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0);
     // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane
-    const size_t lds = g_lds_bytes > 0 ? (size_t)g_lds_bytes : 0;
+    const bool fp32_one_light = d->map_dtype == PBR_F32 && d->n_lights == 1 && k.bt_log2 == 6;
+    const size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (fp32_one_light ? kLdsFor11WavesPerCu : 0);
     hipLaunchKernelGGL(e.fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), lds,
                        static_cast<hipStream_t>(stream), k);
     const hipError_t err = hipGetLastError();

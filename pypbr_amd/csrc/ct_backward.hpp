@@ -46,8 +46,9 @@ struct LightEval {
 __device__ __forceinline__ void eval_light(const PixelTerms &t, const LightGeom &g, const float inten[3], LightEval &e) {
     e.ndl_raw = dot(t.n, g.L);
     e.ndl = clamp01(e.ndl_raw);
-    e.den = ggx_den(t, g, e.s2, e.nh_pos);
-    e.c = e.nh_pos ? dot(t.n, g.h) * sqrt_hw(g.rhh) : 0.0f;         // clamp(N.H), :215
+    const float nh = e.ndl_raw + t.ndv_raw;                          // N.h = N.L + N.V
+    e.den = ggx_den(t, g, nh, e.s2, e.nh_pos);
+    e.c = e.nh_pos ? nh * sqrt_hw(g.rhh) : 0.0f;                    // clamp(N.H), :215
     e.dl = fmaf(e.ndl, 1.0f - t.k, t.k) + 1e-7f;
     e.dD = fmaf(kPi, e.den * e.den, 1e-7f);
     e.ds = fmaf(4.0f * t.ndv, e.ndl, 1e-7f);

@@ -212,9 +212,10 @@ __device__ __forceinline__ void material_terms(const Texels<VEC> &t, int g, cons
     for (int c = 0; c < 3; ++c) base[c] = gather<R>(t.al[c], g);
     if (WF == PBR_WORKFLOW_METALLIC) {
         const R m = gather<R>(t.me, g);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) f0[c] = fma_(m, base[c] - kDielectricF0, splat<R>(kDielectricF0));   // lerp :107
         kd_scale = splat<R>(1.0f) - m;                                                            // :170
+        const R d0 = kd_scale * kDielectricF0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f0[c] = fma_(m, base[c], d0);                                   // lerp(0.04, base, m) :107
     } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) f0[c] = gather<R>(t.sp[c], g);                                // :112-113
@@ -237,8 +238,9 @@ __device__ __forceinline__ LightGeomT<R> light_geom(const LightU &lu, const Vec3
     if (LIGHT == PBR_LIGHT_POINT) return point_light_geom<R>(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, xs, ys);
     LightGeomT<R> g;                       // directional: everything folded on the host, wave-uniform
     g.L = {splat<R>(lu.l[0]), splat<R>(lu.l[1]), splat<R>(lu.l[2])};
+    g.d = g.L; g.rinv = splat<R>(1.0f);
     g.h = {splat<R>(lu.h[0]), splat<R>(lu.h[1]), splat<R>(lu.h[2])};
-    g.rhh = splat<R>(lu.rhh); g.p5 = splat<R>(lu.p5); g.att = splat<R>(1.0f);
+    g.rhh = splat<R>(lu.rhh); g.p5 = splat<R>(lu.p5); g.om5 = splat<R>(1.0f - lu.p5); g.att = splat<R>(1.0f);
     return g;
 }
 

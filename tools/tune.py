@@ -17,7 +17,7 @@ from bench import synth_material  # noqa: E402
 from pypbr_amd import _native as N, functional as F  # noqa: E402
 
 KNOBS = {"nt": 0, "blk": 1, "f16vec": 2, "lds": 3}
-DEFAULTS = {"nt": 1, "blk": 6, "lds": 0}
+DEFAULTS = {"nt": 1, "blk": 6, "lds": -1}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)

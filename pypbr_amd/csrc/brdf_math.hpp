@@ -6,13 +6,13 @@
 // fp32 VALU wave-instruction holding its SIMD for ~4.25 cycles (SQ_ACTIVE_INST_VALU x 4 /
 // SQ_INSTS_VALU), i.e. 16 lanes per clock; only the PACKED forms (v_pk_fma_f32, v_pk_mul_f32,
 // v_pk_add_f32: two fp32 values per lane per instruction, same 4 cycles) reach the chip's fp32 peak.
-// At ~190 scalar instructions per pixel the one-light kernel had its VALUs 73 % busy next to a
-// 76 %-busy HBM, and the 16-light configuration is VALU-bound outright.  Hence:
+// At ~160 instructions per pixel the one-light kernel has its VALUs 62 % busy next to a
+// 77 %-busy HBM, and the 16-light configuration is VALU-bound outright.  Hence:
 //
 //  * every function here is a template over the real type R: float (one pixel) or f32x2 (TWO pixels
-//    of the lane at once).  The kernels use f32x2, so that nearly all adds / multiplies / fmas are
-//    packed instructions; transcendental and min/max/select instructions have no packed form and
-//    are issued per component;
+//    of the lane at once).  The multi-light and fp16 kernels use f32x2, so that nearly all adds /
+//    multiplies / fmas are packed instructions; transcendental and min/max/select instructions have
+//    no packed form and are issued per component;
 //  * every division / sqrt / pow goes to the transcendental unit (v_rcp_f32, v_rsq_f32,
 //    v_log_f32, v_exp_f32: 1 ulp each) -- no IEEE division sequences, no ocml powf; one light
 //    evaluation costs 4 of them (point light) or 1 (directional);
@@ -21,11 +21,12 @@
 //    domains the sRGB transfer functions reach;
 //  * F dg + (1-F) kd base/pi is evaluated as kb + F (dg - kb) with kb = kd_scale base/pi hoisted
 //    out of the light loop;
+//  * N.h is N.L + N.V (h = L + V) and N.L is (N.d) rinv: the normalised light vector is never formed;
 //  * the GGX denominator NdotH^2 (a^2-1) + 1 is evaluated as a^2 + (1-a^2) sin^2(N,H) with
-//    sin^2 = |N x h|^2 / |h|^2, N the unit normal.  The reference's form cancels
+//    sin^2 = |h - (N.h) N|^2 / |h|^2, N the unit normal.  The reference's form cancels
 //    catastrophically for small roughness near the highlight: its own fp32 result is only
 //    ~2e-5..5e-5 from the same code run in fp64 there.  The
-//    cross-product form has no cancellation, so this kernel tracks the fp64 evaluation of
+//    projection form has no cancellation, so this kernel tracks the fp64 evaluation of
 //    the reference to ~1e-6 and its distance to the reference's fp32 output is the
 //    reference's own rounding error, not the sum of two.
 #pragma once

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PBR_HIP_ABI_VERSION 1
+#define PBR_HIP_ABI_VERSION 2
 #define PBR_MAX_LIGHTS 16
 
 /* ---- status codes (negative = caller error, positive = HIP runtime error code + 1000) */
@@ -99,10 +99,28 @@ typedef struct pbr_render_desc {
     float light_size;             /* point lights; <= 0 or NaN means "falsy": 1.0 (cooktorrance.py:130) */
     float lights[PBR_MAX_LIGHTS][3];       /* direction (normalised here, :126) or position (:129) */
     float intensities[PBR_MAX_LIGHTS][3];  /* light_intensity per light (:96) */
+
+    int32_t schedule;             /* workgroup -> tile order: PBR_SCHEDULE_AUTO (built-in rule), PBR_SCHEDULE_LINEAR, or
+                                     PBR_SCHEDULE_XCD(c): every XCD takes runs of 1 << c consecutive tiles.  Results do
+                                     not depend on it (bit-identical); pbr_cook_torrance_autotune measures the best */
+    int32_t reserved;             /* 0 */
 } pbr_render_desc;
+
+#define PBR_SCHEDULE_AUTO 0
+#define PBR_SCHEDULE_LINEAR 1
+#define PBR_SCHEDULE_XCD(c) (1 + (c))     /* c in [1, 12] */
 
 /* Enqueue the fused kernel.  Returns PBR_OK or an error code; never blocks. */
 int pbr_cook_torrance(const pbr_render_desc *desc, void *stream);
+
+/*
+ * Which HBM channels the 8 + 3 plane streams of a launch land on depends on the buffers' addresses and
+ * strides, and so does the better workgroup order (measured spread between the two orders: -6 ... +14 %).
+ * Times the candidate schedules on the descriptor's own buffers (a few launches each, `out` is rewritten
+ * with the same values), BLOCKS until they are done, and stores the fastest in *schedule for the caller to put
+ * into desc->schedule.  Optional: PBR_SCHEDULE_AUTO picks by a rule derived from the same measurements.
+ */
+int pbr_cook_torrance_autotune(const pbr_render_desc *desc, void *stream, int32_t *schedule);
 
 /*
  * Gradient of pbr_cook_torrance w.r.t. the maps (what torch.autograd computes through
@@ -183,7 +201,7 @@ const char *pbr_kernel_name(const pbr_render_desc *desc);
 /* Algorithmic HBM bytes per pixel of that dispatch: reads + writes. */
 int pbr_bytes_per_pixel(const pbr_render_desc *desc);
 /* Tuning knobs for A/B runs inside one process; returns the previous value. */
-enum { PBR_TUNE_NONTEMPORAL = 0, PBR_TUNE_BLOCK_LOG2 = 1, PBR_TUNE_F16_VEC = 2, PBR_TUNE_LDS_BYTES = 3 };   /* nt hint on/off; workgroup = 1 << value lanes (6..8); fp16 pixels per lane (4|8); unused dynamic LDS per workgroup as an occupancy governor (-1 = built-in rule) */
+enum { PBR_TUNE_NONTEMPORAL = 0, PBR_TUNE_BLOCK_LOG2 = 1, PBR_TUNE_F16_VEC = 2, PBR_TUNE_LDS_BYTES = 3, PBR_TUNE_XCD_LOG2 = 4 };   /* nt hint on/off; workgroup = 1 << value lanes (6..8); fp16 pixels per lane (4|8); unused dynamic LDS per workgroup as an occupancy governor (-1 = built-in rule); consecutive tiles per XCD = 1 << value */
 int pbr_set_tuning(int knob, int value);
 
 #ifdef __cplusplus

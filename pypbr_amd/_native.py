@@ -9,13 +9,13 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBR_HIP_LIB") or os.path.join(_HERE, "libpbr_hip.so")   # env override: A/B of two builds
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_LIGHTS = 16
 
 F32, F16 = 0, 1
 LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 WORKFLOW_METALLIC, WORKFLOW_SPECULAR, WORKFLOW_CONVERTED = 0, 1, 2
-TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES = 0, 1, 2, 3
+TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, TUNE_XCD_LOG2 = 0, 1, 2, 3, 4
 
 OK = 0
 ERR_NULL_MAP, ERR_WORKFLOW, ERR_LIGHT_TYPE, ERR_SHAPE, ERR_DTYPE, ERR_CHANNELS, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
@@ -27,7 +27,7 @@ EXPORTS = (
     "pbr_specular_to_metallic", "pbr_decode_normal", "pbr_abi_version", "pbr_error_string",
     "pbr_kernel_name", "pbr_bytes_per_pixel", "pbr_set_tuning", "pbr_render_desc_size",
     "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
-    "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask",
+    "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask", "pbr_cook_torrance_autotune",
 )
 
 
@@ -46,7 +46,16 @@ class RenderDesc(ctypes.Structure):
         ("out", ctypes.c_void_p),
         ("view_dir", ctypes.c_float * 3), ("light_size", ctypes.c_float),
         ("lights", (ctypes.c_float * 3) * MAX_LIGHTS), ("intensities", (ctypes.c_float * 3) * MAX_LIGHTS),
+        ("schedule", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
+
+
+SCHEDULE_AUTO, SCHEDULE_LINEAR = 0, 1
+
+
+def schedule_xcd(c: int) -> int:
+    """PBR_SCHEDULE_XCD(c): every XCD takes runs of 1 << c consecutive tiles."""
+    return 1 + c
 
 
 class NativeLibraryError(RuntimeError):
@@ -74,6 +83,8 @@ def lib():
     vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
     L.pbr_cook_torrance.argtypes = [ctypes.POINTER(RenderDesc), vp]
     L.pbr_cook_torrance.restype = ctypes.c_int
+    L.pbr_cook_torrance_autotune.argtypes = [ctypes.POINTER(RenderDesc), vp, ctypes.POINTER(ctypes.c_int32)]
+    L.pbr_cook_torrance_autotune.restype = ctypes.c_int
     L.pbr_cook_torrance_backward.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp]
     L.pbr_cook_torrance_backward.restype = ctypes.c_int
     L.pbr_srgb_to_linear.argtypes = [vp, vp, sz, ctypes.c_int, vp]
@@ -107,7 +118,7 @@ def lib():
     if L.pbr_abi_version() != ABI_VERSION:
         raise NativeLibraryError("libpbr_hip.so ABI %d, binding expects %d" % (L.pbr_abi_version(), ABI_VERSION))
     for env, knob in (("PBR_TUNE_LDS_BYTES", TUNE_LDS_BYTES), ("PBR_TUNE_NONTEMPORAL", TUNE_NONTEMPORAL),
-                      ("PBR_TUNE_BLOCK_LOG2", TUNE_BLOCK_LOG2)):      # profiling runs: knobs from the environment
+                      ("PBR_TUNE_BLOCK_LOG2", TUNE_BLOCK_LOG2), ("PBR_TUNE_XCD_LOG2", TUNE_XCD_LOG2)):      # profiling runs: knobs from the environment
         if os.environ.get(env, "") != "":
             L.pbr_set_tuning(knob, int(os.environ[env]))
     _lib = L

@@ -44,6 +44,7 @@ static int g_f16_vec = 8;          // pixels per lane for fp16 maps with one lig
 // 4096^2, 33.3 vs 34.0 us on 2048^2, 249.8 vs 254.1 us on 8 x 2048^2 directional), the fp16 and multi-light
 // kernels with no cap.  -1 = that rule; >= 0 = this many bytes for every launch (A/B runs).
 static int g_lds_bytes = -1;
+static int g_xcd_log2 = -1;        // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
 constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
 
 static inline void normalize_host(const float v[3], float o[3]) {   // F.normalize(v, dim=0), fp32
@@ -66,6 +67,7 @@ static int validate(const pbr_render_desc *d) {
     if ((d->map_dtype != PBR_F32 && d->map_dtype != PBR_F16) || (d->out_dtype != PBR_F32 && d->out_dtype != PBR_F16))
         return PBR_ERR_DTYPE;
     if (d->map_dtype == PBR_F32 && d->out_dtype == PBR_F16) return PBR_ERR_DTYPE;   // not built
+    if (d->schedule < PBR_SCHEDULE_AUTO || d->schedule > PBR_SCHEDULE_XCD(12)) return PBR_ERR_SHAPE;
     return PBR_OK;
 }
 
@@ -99,6 +101,26 @@ static int pick_vec(const pbr_render_desc *d) {
     return 4;
 }
 
+// Workgroup -> tile order (ct_kernel.hpp: tile_of_workgroup).  Workgroups are dealt to the 8 XCDs round-robin, so
+// with the linear order XCD x touches byte offsets ~ x KiB (mod 8 KiB) of every plane, all XCDs inside one narrow
+// window; with runs of 64 tiles every XCD streams 64 KiB-contiguous pieces.  Measured on MI355X (tools/tune.py,
+// "xcd" knob): the run order gives 6.1-6.3 TB/s whatever the shape; the linear order gives
+// 6.4-6.6 TB/s when the plane streams happen to spread over the HBM channels (1024^2, 4096^2, 3072^2, ...) and
+// 5.4-5.8 TB/s when they do not: rows that are not a whole number of tiles (1000^2, 3000^2: -12..14 %) and
+// 8 / 16 MiB plane strides (2048^2, 4096x1024: -2..12 %).  AUTO encodes exactly that; pbr_cook_torrance_autotune
+// measures instead of guessing.
+static int schedule_xcd_log2(const pbr_render_desc *d, int vec) {
+    if (g_xcd_log2 >= 0) return g_xcd_log2 > 12 ? 12 : g_xcd_log2;
+    if (d->schedule >= PBR_SCHEDULE_LINEAR) return d->schedule - PBR_SCHEDULE_LINEAR;
+    const int64_t esz = d->map_dtype == PBR_F32 ? 4 : 2;
+    const int64_t row_bytes = (int64_t)d->width * esz, tile_bytes = 64 * (int64_t)vec * esz;
+    const int64_t plane_bytes = d->albedo.channel_stride * esz;
+    if (d->map_dtype == PBR_F16) return 6;           // fp16 maps: runs are 1.5-5 % ahead on every shape tried
+    if (row_bytes % tile_bytes) return 6;
+    if (plane_bytes == (8ll << 20) || plane_bytes == (16ll << 20)) return 6;
+    return 0;
+}
+
 static void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     std::memset(&k, 0, sizeof(k));
     k.albedo = d->albedo.data; k.normal = d->normal.data; k.rough = d->roughness.data;
@@ -118,6 +140,8 @@ static void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     k.tiles_x = (k.wv + bx - 1) / bx;
     const int64_t tiles = (int64_t)k.tiles_x * ((k.rows + by - 1) / by);
     k.n_tiles = tiles > INT32_MAX ? -1 : (int32_t)tiles;      // -1: more tiles than a 1-D grid holds, rejected by the callers
+    k.xcd_log2 = schedule_xcd_log2(d, vec);
+    k.xcd_tiles = k.n_tiles < 0 ? 0 : (k.n_tiles >> (k.xcd_log2 + 3)) << (k.xcd_log2 + 3);
     k.div_h.init((uint32_t)d->height);
     k.div_tx.init((uint32_t)k.tiles_x);
     k.y_offset = d->y_offset; k.H_total = d->height_total;
@@ -222,6 +246,39 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     return err == hipSuccess ? PBR_OK : 1000 + (int)err;
 }
 
+int pbr_cook_torrance_autotune(const pbr_render_desc *d, void *stream, int32_t *schedule) {
+    using namespace pbr;
+    const int rc = validate(d);
+    if (rc != PBR_OK) return rc;
+    if (!schedule) return PBR_ERR_NULL_MAP;
+    const int32_t cands[2] = {PBR_SCHEDULE_LINEAR, PBR_SCHEDULE_XCD(6)};
+    float best[2] = {3.4e38f, 3.4e38f};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 1000 + (int)hipGetLastError();
+    pbr_render_desc t = *d;
+    int err = PBR_OK;
+    const int reps = 4;
+    for (int round = 0; round < 3 && err == PBR_OK; ++round) {          // interleaved rounds, best of each candidate
+        for (int c = 0; c < 2 && err == PBR_OK; ++c) {
+            t.schedule = cands[c];
+            if ((err = pbr_cook_torrance(&t, stream)) != PBR_OK) break;   // warm
+            hipError_t he = hipEventRecord(e0, st);
+            for (int i = 0; i < reps && err == PBR_OK; ++i) err = pbr_cook_torrance(&t, stream);
+            if (he == hipSuccess) he = hipEventRecord(e1, st);
+            if (he == hipSuccess) he = hipEventSynchronize(e1);
+            float ms = 0.0f;
+            if (he == hipSuccess) he = hipEventElapsedTime(&ms, e0, e1);
+            if (he != hipSuccess) { err = 1000 + (int)he; break; }
+            if (ms < best[c]) best[c] = ms;
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != PBR_OK) return err;
+    *schedule = best[1] < best[0] ? cands[1] : cands[0];
+    return PBR_OK;
+}
+
 int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal,
                                void *g_roughness, void *g_metallic, void *g_specular, void *stream) {
     using namespace pbr;
@@ -278,6 +335,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_BLOCK_LOG2: slot = &pbr::g_block_log2; break;
         case PBR_TUNE_F16_VEC: slot = &pbr::g_f16_vec; break;
         case PBR_TUNE_LDS_BYTES: slot = &pbr::g_lds_bytes; break;
+        case PBR_TUNE_XCD_LOG2: slot = &pbr::g_xcd_log2; break;
         default: return -1;
     }
     const int old = *slot;

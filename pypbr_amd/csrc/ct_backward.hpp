@@ -123,8 +123,9 @@ __device__ __forceinline__ void backprop_light(const PixelTerms &t, const LightG
 //   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_*    VEC: 4 | 1    fp32 maps
 template <int LIGHT, int WF, int VEC, bool MULTI>
 __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
-    const int ty = (int)a.div_tx.div(blockIdx.x);
-    const LanePos p = lane_pos<VEC>(a, (int)blockIdx.x - ty * a.tiles_x, ty);
+    const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
+    const int ty = (int)a.div_tx.div(tile);
+    const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);
     if (!p.valid) return;
     Texels<VEC> t;
     load_texels<WF, float, VEC, true>(a, p, t);

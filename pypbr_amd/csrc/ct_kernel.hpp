@@ -58,6 +58,8 @@ struct KArgs {
     int32_t bt_log2;         // log2 of the workgroup size (64..256 lanes)
     int32_t tiles_x;         // tiles per row
     int32_t n_tiles;         // tiles_x * ceil(rows / tile rows)
+    int32_t xcd_log2;        // workgroup -> tile remap: each XCD takes runs of (1 << xcd_log2) consecutive tiles (0 = identity)
+    int32_t xcd_tiles;       // tiles covered by the remap: n_tiles rounded down to a multiple of 8 << xcd_log2
     FastDiv div_h;           // row / H
     FastDiv div_tx;          // tile / tiles_x
     int32_t y_offset, H_total;
@@ -146,6 +148,16 @@ template <> struct Ld<float, 8> {
 __device__ __forceinline__ float linspace_at(float a, float b, float step, int n, int i) {
     const bool lo = i < (n >> 1);
     return fmaf(lo ? step : -step, (float)(lo ? i : n - 1 - i), lo ? a : b);
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup i runs on XCD i % 8).  With the identity order every
+// XCD therefore walks each plane in 1 KiB steps 8 KiB apart; the remap hands XCD x the tiles
+// [x << c, (x + 1) << c) of every block of 8 << c tiles, i.e. (1 KiB << c)-contiguous runs per XCD, while the chip-wide
+// front stays one compact window.  Scalar arithmetic only.
+__device__ __forceinline__ uint32_t tile_of_workgroup(const KArgs &a, uint32_t wg) {
+    if (a.xcd_log2 == 0 || wg >= (uint32_t)a.xcd_tiles) return wg;
+    const uint32_t c = (uint32_t)a.xcd_log2, xcd = wg & 7u, slot = wg >> 3;
+    return ((slot >> c) << (c + 3)) + (xcd << c) + (slot & ((1u << c) - 1u));
 }
 
 // ------------------------------------------------------------------ one lane's share of a tile
@@ -363,8 +375,9 @@ template <int LIGHT, int WF, typename TI, typename TO, int VEC, bool MULTI, bool
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(MULTI ? 4 : PBR_WAVES_PER_EU, MULTI ? 8 : PBR_WAVES_PER_EU)))
 void cook_torrance_kernel(const KArgs a) {
-    const int ty = (int)a.div_tx.div(blockIdx.x);
-    const LanePos p = lane_pos<VEC>(a, (int)blockIdx.x - ty * a.tiles_x, ty);
+    const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
+    const int ty = (int)a.div_tx.div(tile);
+    const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);
     if (!p.valid) return;
     Texels<VEC> t;
     load_texels<WF, TI, VEC, NT>(a, p, t);

@@ -66,7 +66,7 @@ def _pbr_map(t: Optional[torch.Tensor]) -> N.PbrMap:
 
 def build_descriptor(albedo, normal, roughness, metallic, specular, out, *, view_dir, light, light_intensity,
                      light_type, light_size, albedo_is_srgb, specular_is_srgb, return_srgb,
-                     convert_to_diffuse_specular, y_offset, height_total) -> N.RenderDesc:
+                     convert_to_diffuse_specular, y_offset, height_total, schedule=0) -> N.RenderDesc:
     """Fills the C-ABI descriptor (include/pbr_hip.h: pbr_render_desc) from [B,C,H,W] tensors.
     Pure host logic: no device access, so it is testable without a GPU."""
     lt = str(light_type).lower()
@@ -118,6 +118,7 @@ def build_descriptor(albedo, normal, roughness, metallic, specular, out, *, view
     for c in range(3):
         d.view_dir[c] = v[c]
     d.light_size = float(light_size) if light_size else 0.0   # falsy -> 1.0 inside (cooktorrance.py:130)
+    d.schedule = int(schedule)
     for i, (l, it) in enumerate(zip(lights, intens)):
         for c in range(3):
             d.lights[i][c] = l[c]
@@ -149,6 +150,16 @@ class RenderPlan:
     def bytes_per_pixel(self) -> int:
         return N.lib().pbr_bytes_per_pixel(self._ref)
 
+    def autotune(self, stream: Optional[int] = None) -> int:
+        """pbr_cook_torrance_autotune on this plan's buffers: blocks, rewrites `out`, stores and returns the
+        fastest schedule.  Not inside a stream capture."""
+        best = ctypes.c_int32(0)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().pbr_cook_torrance_autotune(self._ref, _stream_ptr(self.device) if stream is None else stream,
+                                                       ctypes.byref(best)))
+        self.desc.schedule = best.value
+        return best.value
+
     def launch(self, stream: Optional[int] = None) -> torch.Tensor:
         """Enqueue on `stream` (raw hipStream_t) or torch's current stream of the maps' device."""
         rc = self._fn(self._ref, _stream_ptr(self.device) if stream is None else stream)
@@ -164,8 +175,12 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                        albedo_is_srgb: bool = True, specular_is_srgb: bool = True, return_srgb: bool = True,
                        convert_to_diffuse_specular: bool = False, y_offset: int = 0,
                        height_total: Optional[int] = None, out_dtype: Optional[torch.dtype] = None,
-                       out: Optional[torch.Tensor] = None) -> RenderPlan:
-    """Validates the maps, allocates the output and fills the C-ABI descriptor; see `cook_torrance`."""
+                       out: Optional[torch.Tensor] = None, schedule: int = N.SCHEDULE_AUTO,
+                       autotune: bool = False) -> RenderPlan:
+    """Validates the maps, allocates the output and fills the C-ABI descriptor; see `cook_torrance`.
+    `schedule`: workgroup order (N.SCHEDULE_AUTO | N.SCHEDULE_LINEAR | N.schedule_xcd(c)), results do not depend
+    on it; `autotune=True` measures the candidates on these very buffers once (blocking, a few launches) and
+    keeps the fastest -- for plans that are launched many times."""
     if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda:
         raise RuntimeError("pypbr_amd.functional.cook_torrance needs maps on a ROCm device "
                            "(use material.to('cuda')); there is no CPU path")
@@ -184,8 +199,11 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                             light_type=light_type, light_size=light_size, albedo_is_srgb=albedo_is_srgb,
                             specular_is_srgb=specular_is_srgb, return_srgb=return_srgb,
                             convert_to_diffuse_specular=convert_to_diffuse_specular, y_offset=y_offset,
-                            height_total=height_total)
-    return RenderPlan(desc, out, (a, n, r, m, s), squeeze and out.dim() == 4)
+                            height_total=height_total, schedule=schedule)
+    plan = RenderPlan(desc, out, (a, n, r, m, s), squeeze and out.dim() == 4)
+    if autotune:
+        plan.autotune()
+    return plan
 
 
 def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughness: torch.Tensor,
@@ -224,11 +242,15 @@ class _CookTorranceFn(torch.autograd.Function):
             raise NotImplementedError("gradients need float32 maps and output")
         ctx.plan = plan
         ctx.in_shapes = [None if t is None else tuple(t.shape) for t in maps]
+        ctx.save_for_backward(*[t for t in maps if t is not None])   # for autograd's in-place-modification check
         with torch.cuda.device(plan.device):
-            return plan.launch()
+            result = plan.launch()
+        plan.out = None          # backward recomputes; keeping the output in ctx would be a reference cycle
+        return result
 
     @staticmethod
     def backward(ctx, grad_out):
+        ctx.saved_tensors        # raises if a map was modified in place since forward (the kernel re-reads the maps)
         plan = ctx.plan
         d = plan.desc
         B, H, W = d.batch, d.height, d.width

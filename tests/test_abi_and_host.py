@@ -117,6 +117,13 @@ def test_validation_codes_without_a_device():
     assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_DTYPE
     d = _desc(); d.abi_version = 99
     assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_SHAPE
+    d = _desc(); d.schedule = N.schedule_xcd(13)                # runs of more than 4096 tiles are not a schedule
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_SHAPE
+    assert _desc().schedule == N.SCHEDULE_AUTO and _desc(schedule=N.schedule_xcd(6)).schedule == 7
+    best = ctypes.c_int32(-1)
+    d = _desc(); d.workflow = 7                                  # autotune validates like a launch and needs a result slot
+    assert lib.pbr_cook_torrance_autotune(ctypes.byref(d), None, ctypes.byref(best)) == N.ERR_WORKFLOW
+    assert lib.pbr_cook_torrance_autotune(ctypes.byref(_desc()), None, None) == N.ERR_NULL_MAP and best.value == -1
     assert lib.pbr_decode_normal(ctypes.c_void_p(16), ctypes.c_void_p(16), 4, 10, N.F32, ctypes.c_void_p(16), None) == N.ERR_CHANNELS
     assert lib.pbr_srgb_to_linear(None, None, 10, N.F32, None) == N.ERR_NULL_MAP
     assert b"metallic" in lib.pbr_error_string(N.ERR_WORKFLOW) and b"2 or 3 channels" in lib.pbr_error_string(N.ERR_CHANNELS)

@@ -127,3 +127,17 @@ def test_backward_through_the_fused_conversion(quirk, light_type, light, size):
     for name, d, l in zip(("albedo", "normal", "roughness", "metallic"), dev, leaves):
         err = (d.grad.cpu().double() - l.grad).abs()
         assert (err <= 2e-5 * (1 + l.grad.abs())).all(), (name, float(err.max()))
+
+
+def test_in_place_edit_between_forward_and_backward_is_detected():
+    """The backward kernel re-reads the maps, so autograd's version check must guard them."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    a = torch.rand(3, 16, 16, generator=g).cuda().requires_grad_(True)
+    n = torch.cat([torch.zeros(2, 16, 16), torch.ones(1, 16, 16)], 0).cuda()
+    r = (torch.rand(1, 16, 16, generator=g) * 0.5 + 0.4).cuda()
+    m = torch.rand(1, 16, 16, generator=g).cuda()
+    out = F.cook_torrance(a, n, r, m, view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_size=1.0)
+    r.mul_(0.5)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        out.sum().backward()

@@ -16,11 +16,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_material  # noqa: E402
 from pypbr_amd import _native as N, functional as F  # noqa: E402
 
-KNOBS = {"nt": 0, "blk": 1, "f16vec": 2, "lds": 3}
-DEFAULTS = {"nt": 1, "blk": 6, "lds": -1}
+KNOBS = {"nt": 0, "blk": 1, "f16vec": 2, "lds": 3, "xcd": 4}
+DEFAULTS = {"nt": 1, "blk": 6, "lds": -1, "xcd": -1}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)
+ap.add_argument("--height", type=int, default=0, help="rows (default: --size); maps are the top rows of a size x size material")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--configs", type=str, default="blk=6;blk=7;blk=8;blk=6,nt=0")
@@ -42,7 +43,8 @@ for path in filter(None, args.altlib.split(",")):       # alt=1 -> first path, a
     assert alt.pbr_render_desc_size() == ctypes.sizeof(N.RenderDesc), "descriptor layouts differ"
     libs.append(alt)
 nsets = 3 if args.batch == 1 else 1
-sets = [[torch.stack([t] * args.batch).to(getattr(torch, args.dtype)) for t in synth_material(args.size, dev, 1234 + i)]
+H = args.height or args.size
+sets = [[torch.stack([t[:, :H].contiguous()] * args.batch).to(getattr(torch, args.dtype)) for t in synth_material(args.size, dev, 1234 + i)]
         for i in range(nsets)]
 if args.lights > 1:
     import math
@@ -93,7 +95,7 @@ for r in range(args.rounds):
         e1.record()
         torch.cuda.synchronize()
         times[ci].append(e0.elapsed_time(e1) / args.iters * 1e3)
-px = args.batch * args.size * args.size
+px = args.batch * H * args.size
 bpp = plans[0].bytes_per_pixel
 for cfg, t in zip(configs, times):
     med, mn = statistics.median(t), min(t)

@@ -22,6 +22,7 @@ DEFAULTS = {"nt": 1, "blk": 6, "lds": -1, "xcd": -1}
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)
 ap.add_argument("--height", type=int, default=0, help="rows (default: --size); maps are the top rows of a size x size material")
+ap.add_argument("--sets", type=int, default=0, help="rotating map sets (default 3 for --batch 1, else 1)")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--configs", type=str, default="blk=6;blk=7;blk=8;blk=6,nt=0")
@@ -42,7 +43,7 @@ for path in filter(None, args.altlib.split(",")):       # alt=1 -> first path, a
     alt.pbr_render_desc_size.restype = ctypes.c_size_t
     assert alt.pbr_render_desc_size() == ctypes.sizeof(N.RenderDesc), "descriptor layouts differ"
     libs.append(alt)
-nsets = 3 if args.batch == 1 else 1
+nsets = args.sets or (3 if args.batch == 1 else 1)
 H = args.height or args.size
 sets = [[torch.stack([t[:, :H].contiguous()] * args.batch).to(getattr(torch, args.dtype)) for t in synth_material(args.size, dev, 1234 + i)]
         for i in range(nsets)]

@@ -103,6 +103,11 @@ typedef struct pbr_render_desc {
     int32_t schedule;             /* workgroup -> tile order: PBR_SCHEDULE_AUTO (built-in rule), PBR_SCHEDULE_LINEAR, or
                                      PBR_SCHEDULE_XCD(c): every XCD takes runs of 1 << c consecutive tiles.  Results do
                                      not depend on it (bit-identical); pbr_cook_torrance_autotune measures the best */
+    int32_t map_height;           /* MaterialBase.tile (base.py:524-537) fused as wrap-around addressing: when both are */
+    int32_t map_width;            /* non-zero the maps are [B][C][map_height][map_width] and repeat over the
+                                     height_total x width output (both must divide it); texel of output pixel (y, x)
+                                     = ((y_offset + y) mod map_height, x mod map_width).  The point-light grid spans
+                                     the OUTPUT, as it does after the reference's tile().  0/0: maps are output-sized */
     int32_t reserved;             /* 0 */
 } pbr_render_desc;
 
@@ -130,7 +135,8 @@ int pbr_cook_torrance_autotune(const pbr_render_desc *desc, void *stream, int32_
  * in-kernel conversion); `grad_out` is [B][3][H][W] contiguous.
  * Each non-NULL g_* receives a contiguous fp32 gradient shaped like its map
  * ([B][3|1][H][W]); NULL skips it.  Same sub-gradient conventions as torch (clamp passes on the
- * closed interval).
+ * closed interval).  With tiled maps (map_height/map_width) the g_* are OUTPUT-sized: one value per
+ * output pixel; the gradient of a texel is the sum over its repeats, which is left to the caller.
  */
 int pbr_cook_torrance_backward(const pbr_render_desc *desc, const void *grad_out, void *g_albedo,
                                void *g_normal, void *g_roughness, void *g_metallic, void *g_specular,

@@ -46,7 +46,8 @@ class RenderDesc(ctypes.Structure):
         ("out", ctypes.c_void_p),
         ("view_dir", ctypes.c_float * 3), ("light_size", ctypes.c_float),
         ("lights", (ctypes.c_float * 3) * MAX_LIGHTS), ("intensities", (ctypes.c_float * 3) * MAX_LIGHTS),
-        ("schedule", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("schedule", ctypes.c_int32), ("map_height", ctypes.c_int32), ("map_width", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 

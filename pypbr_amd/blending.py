@@ -70,6 +70,7 @@ def blend_with_mask(material1: MaterialBase, material2: MaterialBase, mask: torc
         mask = mask.unsqueeze(0)
     elif mask.dim() != 3 or mask.size(0) != 1:
         raise ValueError("Mask must have shape [1, H, W] or [H, W].")
+    material1.materialize_tile(); material2.materialize_tile()      # blending reads the maps themselves
     blended = material1.__class__()
     blended.device = material1.device
     names = list(material1._maps.keys()) + [k for k in material2._maps.keys() if k not in material1._maps]
@@ -93,6 +94,7 @@ def _resized_like(prop2: torch.Tensor, prop1: torch.Tensor) -> torch.Tensor:
 
 def blend_on_height(material1: MaterialBase, material2: MaterialBase, blend_width: float = 0.1, shift: float = 0.0):
     """functional.py:148-196."""
+    material1.materialize_tile(); material2.materialize_tile()
     h1, h2 = material1._maps.get("height"), material2._maps.get("height")
     if h1 is None or h2 is None:
         raise ValueError("Both materials must have height maps for height-based blending.")
@@ -104,6 +106,7 @@ def blend_on_height(material1: MaterialBase, material2: MaterialBase, blend_widt
 def blend_on_properties(material1: MaterialBase, material2: MaterialBase, property_name: str = "metallic",
                         blend_width: float = 0.1):
     """functional.py:199-239."""
+    material1.materialize_tile(); material2.materialize_tile()
     p1, p2 = material1._maps.get(property_name), material2._maps.get(property_name)
     if p1 is None or p2 is None:
         raise ValueError(f"Both materials must have '{property_name}' maps for property-based blending.")

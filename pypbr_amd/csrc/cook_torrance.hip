@@ -68,13 +68,23 @@ static int validate(const pbr_render_desc *d) {
         return PBR_ERR_DTYPE;
     if (d->map_dtype == PBR_F32 && d->out_dtype == PBR_F16) return PBR_ERR_DTYPE;   // not built
     if (d->schedule < PBR_SCHEDULE_AUTO || d->schedule > PBR_SCHEDULE_XCD(12)) return PBR_ERR_SHAPE;
+    if (d->map_height || d->map_width) {             // tiled maps: whole repeats only
+        if (d->map_height < 1 || d->map_width < 1 || d->height_total % d->map_height || d->width % d->map_width)
+            return PBR_ERR_SHAPE;
+    }
     return PBR_OK;
+}
+
+static inline bool is_tiled(const pbr_render_desc *d) {
+    return d->map_height > 0 && (d->map_height != d->height_total || d->map_width != d->width);
 }
 
 // 16-byte path: every plane start and every row start must be 16-byte (fp16: 8-byte) aligned.
 static int pick_vec(const pbr_render_desc *d) {
     const int esz_in = d->map_dtype == PBR_F32 ? 4 : 2, esz_out = d->out_dtype == PBR_F32 ? 4 : 2;
     if (d->width % 4) return 1;
+    const bool tiled = is_tiled(d);
+    if (tiled && d->map_width % 4) return 1;          // a lane's pixels must not straddle a seam
     auto ok = [&](const pbr_map &m, int esz, bool three) {
         if (!m.data) return true;
         const uintptr_t align = esz == 4 ? 15u : 7u;
@@ -89,7 +99,7 @@ static int pick_vec(const pbr_render_desc *d) {
     if (reinterpret_cast<uintptr_t>(d->out) & (esz_out == 4 ? 15u : 7u)) return 1;
     // fp16 maps, ONE light (HBM-bound): 8 pixels per lane keep the loads 16 bytes wide.  With several
     // lights the kernel is VALU-bound and the 4-pixel body's lower register count wins.
-    if (esz_in == 2 && d->width % 8 == 0 && d->n_lights == 1 && g_f16_vec == 8) {
+    if (esz_in == 2 && d->width % 8 == 0 && (!tiled || d->map_width % 8 == 0) && d->n_lights == 1 && g_f16_vec == 8) {
         auto ok16 = [&](const pbr_map &m, bool three) {
             return !m.data || ((reinterpret_cast<uintptr_t>(m.data) & 15u) == 0 && m.batch_stride % 8 == 0 &&
                                (!three || m.channel_stride % 8 == 0));
@@ -144,6 +154,9 @@ static void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     k.xcd_tiles = k.n_tiles < 0 ? 0 : (k.n_tiles >> (k.xcd_log2 + 3)) << (k.xcd_log2 + 3);
     k.div_h.init((uint32_t)d->height);
     k.div_tx.init((uint32_t)k.tiles_x);
+    k.tiled = is_tiled(d);
+    k.map_h = k.tiled ? d->map_height : d->height_total; k.map_w = k.tiled ? d->map_width : d->width;
+    k.div_mh.init((uint32_t)k.map_h); k.div_mw.init((uint32_t)k.map_w);
     k.y_offset = d->y_offset; k.H_total = d->height_total;
     // `light_size or 1.0` (:130): 0 / NaN / negative are treated as "not given".
     const float size = (d->light_size > 0.0f) ? d->light_size : 1.0f;
@@ -236,9 +249,13 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     KArgs k;
     fill_args(d, vec, k);
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
-    const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0);
+    // Tiled maps are re-read from L2 / Infinity Cache, so their loads must not carry the streaming hint, and the
+    // launch is then VALU-bound and wants every wave it can get (2048^2 tile(2): 81 us vs 122 us with the streaming
+    // settings, 120 us for the materialised 4096^2 maps; tools/tile_probe.py).
+    const bool tiled = k.tiled != 0;
+    const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0 && !tiled);
     // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane
-    const bool fp32_one_light = d->map_dtype == PBR_F32 && d->n_lights == 1 && k.bt_log2 == 6;
+    const bool fp32_one_light = d->map_dtype == PBR_F32 && d->n_lights == 1 && k.bt_log2 == 6 && !tiled;
     const size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (fp32_one_light ? kLdsFor11WavesPerCu : 0);
     hipLaunchKernelGGL(e.fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), lds,
                        static_cast<hipStream_t>(stream), k);
@@ -325,6 +342,10 @@ int pbr_bytes_per_pixel(const pbr_render_desc *d) {
     int ch = 3 + 1;                                        // albedo + roughness
     if (d->normal.data) ch += 3;
     ch += d->workflow == PBR_WORKFLOW_SPECULAR ? 3 : 1;    // specular | metallic
+    if (pbr::is_tiled(d)) {                                // every texel is needed from HBM once, whatever the repeat count
+        const int64_t reps = ((int64_t)d->height_total / d->map_height) * ((int64_t)d->width / d->map_width);
+        return (int)((ch * ein + reps - 1) / reps) + 3 * eout;
+    }
     return ch * ein + 3 * eout;
 }
 

@@ -62,6 +62,9 @@ struct KArgs {
     int32_t xcd_tiles;       // tiles covered by the remap: n_tiles rounded down to a multiple of 8 << xcd_log2
     FastDiv div_h;           // row / H
     FastDiv div_tx;          // tile / tiles_x
+    int32_t tiled;           // maps are (map_h, map_w) and repeat over the (H_total, W) output (MaterialBase.tile)
+    int32_t map_h, map_w;
+    FastDiv div_mh, div_mw;  // (y_offset + y) / map_h, x / map_w
     int32_t y_offset, H_total;
     float x0, x1, xstep;     // torch.linspace(-s/2, s/2, W)   :132
     float y0, y1, ystep;     // torch.linspace(-s/2, s/2, H_total)   :133
@@ -163,7 +166,8 @@ __device__ __forceinline__ uint32_t tile_of_workgroup(const KArgs &a, uint32_t w
 // ------------------------------------------------------------------ one lane's share of a tile
 struct LanePos {
     int b, y, x;          // material, row inside the band, first pixel column
-    int64_t pix;          // y * W + x
+    int64_t pix;          // y * W + x: where the result goes
+    int64_t src;          // where the texels come from: pix, or the wrapped position inside the (map_h, map_w) maps
     bool valid;
 };
 
@@ -178,6 +182,13 @@ __device__ __forceinline__ LanePos lane_pos(const KArgs &a, int tile_x, int tile
     p.y = row - p.b * a.H;
     p.x = xv * VEC;
     p.pix = (int64_t)p.y * a.W + p.x;
+    p.src = p.pix;
+    if (a.tiled) {        // MaterialBase.tile (base.py:524-537) as wrap-around addressing: texel (y mod h, x mod w)
+        const uint32_t yg = (uint32_t)(p.y + a.y_offset), xg = (uint32_t)p.x;
+        const uint32_t ys = yg - a.div_mh.div(yg) * (uint32_t)a.map_h;
+        const uint32_t xs = xg - a.div_mw.div(xg) * (uint32_t)a.map_w;     // VEC divides map_w: a lane never straddles a seam
+        p.src = (int64_t)ys * a.map_w + xs;
+    }
     return p;
 }
 
@@ -187,16 +198,16 @@ template <int VEC> struct Texels { float al[3][VEC], nm[3][VEC], ro[VEC], me[VEC
 template <int WF, typename TI, int VEC, bool NT>
 __device__ __forceinline__ void load_texels(const KArgs &a, const LanePos &p, Texels<VEC> &t) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(a.albedo, p.b * a.a_bs + c * a.a_cs + p.pix, t.al[c]);
+    for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(a.albedo, p.b * a.a_bs + c * a.a_cs + p.src, t.al[c]);
     if (a.has_normal) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(a.normal, p.b * a.n_bs + c * a.n_cs + p.pix, t.nm[c]);
+        for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(a.normal, p.b * a.n_bs + c * a.n_cs + p.src, t.nm[c]);
     }
-    Ld<TI, VEC>::template load<NT>(a.rough, p.b * a.r_bs + p.pix, t.ro);
-    if (WF != PBR_WORKFLOW_SPECULAR) Ld<TI, VEC>::template load<NT>(a.metal, p.b * a.m_bs + p.pix, t.me);
+    Ld<TI, VEC>::template load<NT>(a.rough, p.b * a.r_bs + p.src, t.ro);
+    if (WF != PBR_WORKFLOW_SPECULAR) Ld<TI, VEC>::template load<NT>(a.metal, p.b * a.m_bs + p.src, t.me);
     if (WF == PBR_WORKFLOW_SPECULAR) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(a.spec, p.b * a.s_bs + c * a.s_cs + p.pix, t.sp[c]);
+        for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(a.spec, p.b * a.s_bs + c * a.s_cs + p.src, t.sp[c]);
     }
 }
 

@@ -64,11 +64,21 @@ def _pbr_map(t: Optional[torch.Tensor]) -> N.PbrMap:
     return N.PbrMap(t.data_ptr(), t.stride(0) if t.shape[0] > 1 else 0, t.stride(1))
 
 
+def tile_counts(tile) -> Tuple[int, int]:
+    """MaterialBase.tile(num_tiles) repeats both axes num_tiles times (base.py:524-537); (ny, nx) is accepted too."""
+    ny, nx = (tile, tile) if isinstance(tile, int) else (int(tile[0]), int(tile[1]))
+    if ny < 1 or nx < 1:
+        raise ValueError("tile counts must be >= 1, got %s" % (tile,))
+    return ny, nx
+
+
 def build_descriptor(albedo, normal, roughness, metallic, specular, out, *, view_dir, light, light_intensity,
                      light_type, light_size, albedo_is_srgb, specular_is_srgb, return_srgb,
-                     convert_to_diffuse_specular, y_offset, height_total, schedule=0) -> N.RenderDesc:
+                     convert_to_diffuse_specular, y_offset, height_total, schedule=0, tile=(1, 1)) -> N.RenderDesc:
     """Fills the C-ABI descriptor (include/pbr_hip.h: pbr_render_desc) from [B,C,H,W] tensors.
-    Pure host logic: no device access, so it is testable without a GPU."""
+    Pure host logic: no device access, so it is testable without a GPU.  `tile=(ny, nx)` != (1, 1): the maps
+    repeat over a (ny*H, nx*W) output (wrap-around addressing); `out` [B,3,rows,nx*W] then holds the rows
+    [y_offset, y_offset + rows) of it."""
     lt = str(light_type).lower()
     if lt not in _LIGHT_TYPES:   # cooktorrance.py:62-65
         raise ValueError(f"Unsupported light_type: {lt}. Must be 'directional' or 'point'.")
@@ -103,8 +113,17 @@ def build_descriptor(albedo, normal, roughness, metallic, specular, out, *, view
 
     d = N.RenderDesc()
     d.abi_version = N.ABI_VERSION
-    d.batch, d.height, d.width = B, H, W
-    d.height_total = H if height_total is None else int(height_total)
+    ny, nx = tile_counts(tile)
+    if (ny, nx) == (1, 1):
+        d.batch, d.height, d.width = B, H, W
+        d.height_total = H if height_total is None else int(height_total)
+    else:
+        if height_total not in (None, ny * H):
+            raise ValueError("with tile=%s the full map has %d rows, not height_total=%s" % ((ny, nx), ny * H, height_total))
+        d.batch, d.height, d.width = B, out.shape[-2], nx * W
+        d.height_total, d.map_height, d.map_width = ny * H, H, W
+        if tuple(out.shape[-2:]) != (d.height, d.width) or int(y_offset) + d.height > d.height_total:
+            raise ValueError("out %s is not a band of the tiled %dx%d map" % (tuple(out.shape), ny * H, nx * W))
     d.y_offset = int(y_offset)
     d.map_dtype, d.out_dtype = _DTYPES[albedo.dtype], _DTYPES[out.dtype]
     d.workflow, d.light_type, d.n_lights = workflow, _LIGHT_TYPES[lt], len(lights)
@@ -176,11 +195,14 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                        convert_to_diffuse_specular: bool = False, y_offset: int = 0,
                        height_total: Optional[int] = None, out_dtype: Optional[torch.dtype] = None,
                        out: Optional[torch.Tensor] = None, schedule: int = N.SCHEDULE_AUTO,
-                       autotune: bool = False) -> RenderPlan:
+                       autotune: bool = False, tile=1, rows: Optional[int] = None) -> RenderPlan:
     """Validates the maps, allocates the output and fills the C-ABI descriptor; see `cook_torrance`.
     `schedule`: workgroup order (N.SCHEDULE_AUTO | N.SCHEDULE_LINEAR | N.schedule_xcd(c)), results do not depend
     on it; `autotune=True` measures the candidates on these very buffers once (blocking, a few launches) and
-    keeps the fastest -- for plans that are launched many times."""
+    keeps the fastest -- for plans that are launched many times.
+    `tile=n | (ny, nx)`: evaluate `material.tile(n)` (base.py:524-537) without materialising the repeated maps --
+    the kernel wraps its texel addresses, so each texel leaves HBM once instead of ny*nx times; the result is the
+    (ny*H, nx*W) image (or its rows [y_offset, y_offset + rows))."""
     if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda:
         raise RuntimeError("pypbr_amd.functional.cook_torrance needs maps on a ROCm device "
                            "(use material.to('cuda')); there is no CPU path")
@@ -191,6 +213,11 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
     m = _as_batched(metallic, (1,), "metallic")
     s = _as_batched(specular, (3,), "specular")
     B, _, H, W = a.shape
+    ny, nx = tile_counts(tile)
+    if (ny, nx) != (1, 1):
+        H, W = (ny * H - int(y_offset)) if rows is None else int(rows), nx * W
+    elif rows is not None:
+        raise ValueError("`rows` selects a band of a tiled map; without `tile` pass the band's own maps")
     if out is None:
         out = torch.empty((B, 3, H, W), dtype=out_dtype or torch.float32, device=a.device)
     elif tuple(out.shape[-3:]) != (3, H, W) or not out.is_contiguous() or out.device != a.device:
@@ -199,7 +226,7 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                             light_type=light_type, light_size=light_size, albedo_is_srgb=albedo_is_srgb,
                             specular_is_srgb=specular_is_srgb, return_srgb=return_srgb,
                             convert_to_diffuse_specular=convert_to_diffuse_specular, y_offset=y_offset,
-                            height_total=height_total, schedule=schedule)
+                            height_total=height_total, schedule=schedule, tile=(ny, nx))
     plan = RenderPlan(desc, out, (a, n, r, m, s), squeeze and out.dim() == 4)
     if autotune:
         plan.autotune()
@@ -215,7 +242,8 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
     [B,1,H,W]; all on one ROCm device, float32 or float16.  Keyword arguments:
     view_dir, light, light_intensity (required), light_type="point", light_size=None,
     albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True,
-    convert_to_diffuse_specular=False, y_offset=0, height_total=None, out_dtype=None, out=None.
+    convert_to_diffuse_specular=False, y_offset=0, height_total=None, out_dtype=None, out=None,
+    schedule=0, autotune=False, tile=1, rows=None (see `plan_cook_torrance`).
     Returns [3,H,W] or [B,3,H,W] (float32 unless `out_dtype`), on the same device,
     enqueued on the current stream without synchronising.
     """
@@ -269,6 +297,10 @@ class _CookTorranceFn(torch.autograd.Function):
             if b is None:
                 grads.append(None)
                 continue
+            if d.map_height and (d.map_height, d.map_width) != (H, W):     # tiled maps: a texel's gradient is the sum over its repeats
+                if H != d.height_total:
+                    raise NotImplementedError("gradients of a tiled evaluation need the whole output, not a row band")
+                b = b.view(B, b.shape[1], H // d.map_height, d.map_height, W // d.map_width, d.map_width).sum((2, 4))
             if len(shape) == 3:                      # unbatched map
                 b = b[0] if B == 1 else b.sum(0)
             elif shape[0] == 1 and B > 1:            # one map shared by the whole batch

@@ -156,9 +156,10 @@ class MaterialBase:
     @property
     def size(self) -> Optional[Tuple[int, int]]:
         """(height, width) of the first map that is present (base.py:293-307)."""
+        ny, nx = self.lazy_tile
         for t in self._maps.values():
             if t is not None:
-                return (t.shape[-2], t.shape[-1])
+                return (t.shape[-2] * ny, t.shape[-1] * nx)
         return None
 
     def as_dict(self):
@@ -182,17 +183,43 @@ class MaterialBase:
     # -- the two calls around the BRDF in examples/example_brdf.py:11
     def resize(self, size, antialias: bool = True):
         """Resize every map (base.py:490-504): bilinear, antialiased by default; in place, returns self."""
+        self.materialize_tile()
         for name, t in self._maps.items():
             if t is not None:
                 self._maps[name] = _through_device(t, lambda x: F_.resize(x, size, antialias=antialias))
         return self
 
     # -- pure indexing (base.py:524-537); no arithmetic involved
-    def tile(self, num_tiles: int):
+    def tile(self, num_tiles: int, lazy: bool = False):
+        """Repeat every map num_tiles x num_tiles (base.py:524-537).  `lazy=True` (build extension) only records
+        the repeat: the maps stay as they are, `CookTorranceBRDF` hands the count to the kernel, which wraps its
+        texel addresses -- each texel then leaves HBM once instead of num_tiles^2 times and no copy is made."""
+        if num_tiles < 1:
+            raise ValueError("num_tiles must be >= 1")
+        if lazy:
+            ny, nx = self.lazy_tile
+            object.__setattr__(self, "_lazy_tile", (ny * num_tiles, nx * num_tiles))
+            return self
+        self.materialize_tile()
         for name, t in self._maps.items():
             if t is not None:
                 reps = (1,) * (t.dim() - 2) + (num_tiles, num_tiles)
                 self._maps[name] = t.repeat(*reps)
+        return self
+
+    @property
+    def lazy_tile(self) -> Tuple[int, int]:
+        """Pending (ny, nx) repeat recorded by tile(n, lazy=True); (1, 1) if none."""
+        return self.__dict__.get("_lazy_tile", (1, 1))
+
+    def materialize_tile(self):
+        """Turns a pending lazy repeat into real maps (anything but the BRDF needs them)."""
+        ny, nx = self.lazy_tile
+        if (ny, nx) != (1, 1):
+            object.__setattr__(self, "_lazy_tile", (1, 1))
+            for name, t in self._maps.items():
+                if t is not None:
+                    self._maps[name] = t.repeat(*((1,) * (t.dim() - 2) + (ny, nx)))
         return self
 
     def clone(self):

@@ -80,5 +80,5 @@ class CookTorranceBRDF(BRDFModel):
             view_dir=view_dir, light=light_dir_or_position, light_intensity=light_intensity,
             light_type=self.light_type, light_size=light_size,
             albedo_is_srgb=bool(material.albedo_is_srgb), specular_is_srgb=specular_is_srgb,
-            return_srgb=return_srgb)
+            return_srgb=return_srgb, tile=getattr(material, "lazy_tile", (1, 1)))
         return color if color.device == out_device else color.to(out_device)

@@ -51,6 +51,7 @@ def _desc(**over):
     kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=None,
               albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True, convert_to_diffuse_specular=False,
               y_offset=0, height_total=None)
+    o = over.pop("out", o)
     kw.update(over)
     d = F.build_descriptor(a, n, r, m, None, o, **kw)
     d._keep = (a, n, r, m, o)
@@ -120,6 +121,14 @@ def test_validation_codes_without_a_device():
     d = _desc(); d.schedule = N.schedule_xcd(13)                # runs of more than 4096 tiles are not a schedule
     assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_SHAPE
     assert _desc().schedule == N.SCHEDULE_AUTO and _desc(schedule=N.schedule_xcd(6)).schedule == 7
+    d = _desc(); d.map_height, d.map_width = 3, 16              # tiled maps: whole repeats only (8 rows are not 3k)
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_SHAPE
+    o = torch.empty(2, 3, 16, 48)
+    d = _desc(out=o, tile=(2, 3))                                # 8x16 maps over a 16x48 output
+    assert (d.height, d.width, d.height_total, d.map_height, d.map_width) == (16, 48, 16, 8, 16)
+    assert lib.pbr_bytes_per_pixel(ctypes.byref(d)) == 12 + 6    # 32 B of texels shared by 6 repeats, rounded up
+    with pytest.raises(ValueError):
+        _desc(out=torch.empty(2, 3, 16, 40), tile=(2, 3))
     best = ctypes.c_int32(-1)
     d = _desc(); d.workflow = 7                                  # autotune validates like a launch and needs a result slot
     assert lib.pbr_cook_torrance_autotune(ctypes.byref(d), None, ctypes.byref(best)) == N.ERR_WORKFLOW

@@ -128,6 +128,22 @@ int pbr_cook_torrance(const pbr_render_desc *desc, void *stream);
 int pbr_cook_torrance_autotune(const pbr_render_desc *desc, void *stream, int32_t *schedule);
 
 /*
+ * Material blending fused in front of the evaluation: what examples/example_blend.py:14-32 does with
+ * blend_with_mask (pypbr/blending/functional.py:64-145: every map mask*map1 + (1-mask)*map2, normals normalised,
+ * blended, normalised), the re-assignment of the blended normal map (MaterialBase._process_normal_map again,
+ * base.py:191-242) and CookTorranceBRDF.forward, in one pass: both materials are read once and the blended
+ * maps are never written.  `desc` describes material 1 and the evaluation exactly as for pbr_cook_torrance;
+ * `blend` holds material 2 (same dtype -- fp32 only --, workflow and extent; all of albedo, normal, roughness and
+ * metallic|specular present in both) and the weights of material 1.  `workspace`: `batch` ints of device memory
+ * (one "blended normal has a negative component" flag per material, set by a first small kernel on `stream`).
+ */
+typedef struct pbr_blend_desc {
+    pbr_map albedo, normal, roughness, metallic, specular;   /* material 2 */
+    pbr_map mask;                 /* 1 channel fp32 in [0,1], [B|1][map rows][map cols]; batch_stride 0 = shared */
+} pbr_blend_desc;
+int pbr_cook_torrance_blend(const pbr_render_desc *desc, const pbr_blend_desc *blend, void *workspace, void *stream);
+
+/*
  * Gradient of pbr_cook_torrance w.r.t. the maps (what torch.autograd computes through
  * cooktorrance.py:92-182 in the reference's rendering-loss use,
  * docs/source/tutorials/06_advanced.rst:73-107).  `desc` is the forward descriptor (its `out` is

@@ -353,6 +353,10 @@ def blend_set(manifest):
         d[f"out_{name}_mask"] = mask.numpy()
         for k, v in out._maps.items():
             d[f"out_{name}_{k}"] = v.numpy()
+        # example_blend.py:22-32: the blended material goes straight into the BRDF
+        for lk, (ltype, lvec, lsize) in {"pt1": ("point", [0.1, 0.1, 1.0], 1.0), "dir": ("directional", [0.3, -0.2, 1.0], None)}.items():
+            brdf = CookTorranceBRDF(light_type=ltype)
+            d[f"render_{name}_{lk}"] = brdf(out, torch.tensor(VIEW0), torch.tensor(lvec), torch.tensor(INT0), lsize).numpy()
     np.savez_compressed(os.path.join(GOLDEN, "blend.npz"), **d)
     manifest["sets"]["blend"] = {k: _entry(v) for k, v in d.items()}
 
@@ -360,6 +364,13 @@ def blend_set(manifest):
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["--only", "blend"]:         # refresh one set, keep the rest of the manifest
+        with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
+            manifest = json.load(f)
+        blend_set(manifest)
+        with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
+            json.dump(manifest, f, indent=1, sort_keys=True)
+        return
     manifest = {
         "generator": "oracle/gen_golden.py",
         "reference": "giuvecchio/PyPBR at /root/reference (imported, unmodified)",

@@ -28,6 +28,7 @@ EXPORTS = (
     "pbr_kernel_name", "pbr_bytes_per_pixel", "pbr_set_tuning", "pbr_render_desc_size",
     "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
     "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask", "pbr_cook_torrance_autotune",
+    "pbr_cook_torrance_blend",
 )
 
 
@@ -49,6 +50,12 @@ class RenderDesc(ctypes.Structure):
         ("schedule", ctypes.c_int32), ("map_height", ctypes.c_int32), ("map_width", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
     ]
+
+
+class BlendDesc(ctypes.Structure):
+    """pbr_blend_desc: material 2 of a fused blend + the weights of material 1."""
+    _fields_ = [("albedo", PbrMap), ("normal", PbrMap), ("roughness", PbrMap), ("metallic", PbrMap), ("specular", PbrMap),
+                ("mask", PbrMap)]
 
 
 SCHEDULE_AUTO, SCHEDULE_LINEAR = 0, 1
@@ -86,6 +93,8 @@ def lib():
     L.pbr_cook_torrance.restype = ctypes.c_int
     L.pbr_cook_torrance_autotune.argtypes = [ctypes.POINTER(RenderDesc), vp, ctypes.POINTER(ctypes.c_int32)]
     L.pbr_cook_torrance_autotune.restype = ctypes.c_int
+    L.pbr_cook_torrance_blend.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(BlendDesc), vp, vp]
+    L.pbr_cook_torrance_blend.restype = ctypes.c_int
     L.pbr_cook_torrance_backward.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp]
     L.pbr_cook_torrance_backward.restype = ctypes.c_int
     L.pbr_srgb_to_linear.argtypes = [vp, vp, sz, ctypes.c_int, vp]

@@ -4,6 +4,7 @@ pypbr.blending that examples/example_blend.py uses -- the functional API
 (/root/reference/pypbr/blending/blending.py:28-214).  Every blend returns `(material, mask)`
 exactly like the reference.  All arithmetic (mask generation, per-map lerp, normal blend)
 runs in libpbr_hip.so; CPU-resident materials are staged through the device."""
+import contextlib
 from abc import ABC, abstractmethod
 from typing import Optional
 
@@ -64,8 +65,52 @@ def gradient_mask(height: int, width: int, direction: str, device) -> torch.Tens
 
 
 # ---------------------------------------------------------------- functional API (functional.py)
-def blend_with_mask(material1: MaterialBase, material2: MaterialBase, mask: torch.Tensor):
-    """functional.py:64-116.  Returns (blended material of material1's class, mask as (1,H,W))."""
+_LAZY = False
+
+
+@contextlib.contextmanager
+def lazy_blending(enabled: bool = True):
+    """Inside this context every blend of this module (functions and the Blend* classes) is lazy, see
+    `blend_with_mask(..., lazy=True)`:   with lazy_blending(): blended, mask = HeightBlend(0.1, -0.5)(m1, m2)"""
+    global _LAZY
+    previous, _LAZY = _LAZY, bool(enabled)
+    try:
+        yield
+    finally:
+        _LAZY = previous
+
+
+def _blend_dicts(maps1: dict, maps2: dict, mask: torch.Tensor) -> dict:
+    """The per-map loop of blend_with_mask (functional.py:96-112) on two name -> tensor dicts."""
+    out = {}
+    for name in list(maps1.keys()) + [k for k in maps2.keys() if k not in maps1]:
+        m1, m2 = maps1.get(name), maps2.get(name)
+        if m1 is None or m2 is None:
+            out[name] = m2 if m1 is None else m1
+        else:
+            normal = name == "normal"
+            out[name] = _through_device(m1, lambda a: blend_maps(a, m2.to(a.device), mask.to(a.device), is_normal=normal))
+    return out
+
+
+def _fusable(maps1: dict, maps2: dict, mask: torch.Tensor) -> bool:
+    """Can CookTorranceBRDF hand both materials to pbr_cook_torrance_blend?  Both complete, same workflow, same
+    (C,H,W) float32 shapes."""
+    second = "metallic" if maps1.get("metallic") is not None else "specular"
+    for name in ("albedo", "normal", "roughness", second):
+        a, b = maps1.get(name), maps2.get(name)
+        if a is None or b is None or a.dim() != 3 or a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
+            return False
+    if second == "metallic" and maps2.get("metallic") is None:
+        return False
+    return mask.dtype == torch.float32 and tuple(mask.shape[-2:]) == tuple(maps1["albedo"].shape[-2:])
+
+
+def blend_with_mask(material1: MaterialBase, material2: MaterialBase, mask: torch.Tensor, lazy: bool = False):
+    """functional.py:64-116.  Returns (blended material of material1's class, mask as (1,H,W)).
+    `lazy=True` (build extension): nothing is blended yet -- the result remembers both materials and the mask,
+    `CookTorranceBRDF` evaluates it with the fused blend + render kernel (both materials read once, no blended
+    copy written), and the first look at its maps (`material.albedo`, `_maps`, resize, save ...) blends them for real."""
     if mask.dim() == 2:
         mask = mask.unsqueeze(0)
     elif mask.dim() != 3 or mask.size(0) != 1:
@@ -73,15 +118,13 @@ def blend_with_mask(material1: MaterialBase, material2: MaterialBase, mask: torc
     material1.materialize_tile(); material2.materialize_tile()      # blending reads the maps themselves
     blended = material1.__class__()
     blended.device = material1.device
-    names = list(material1._maps.keys()) + [k for k in material2._maps.keys() if k not in material1._maps]
-    for name in names:
-        m1, m2 = material1._maps.get(name), material2._maps.get(name)
-        if m1 is None or m2 is None:
-            result = m2 if m1 is None else m1
-        else:
-            normal = name == "normal"
-            result = _through_device(m1, lambda a: blend_maps(a, m2.to(a.device), mask.to(a.device), is_normal=normal))
-        setattr(blended, name, result)              # normals pass through _process_normal_map again, as upstream
+    maps1, maps2 = material1._maps, material2._maps
+    if (lazy or _LAZY) and _fusable(maps1, maps2, mask):
+        blended.__dict__["_store"] = dict(maps1)
+        blended.__dict__["_lazy_blend"] = (dict(maps2), mask)
+    else:
+        for name, result in _blend_dicts(maps1, maps2, mask).items():
+            setattr(blended, name, result)          # normals pass through _process_normal_map again, as upstream
     blended.albedo_is_srgb = material1.albedo_is_srgb
     return blended, mask
 

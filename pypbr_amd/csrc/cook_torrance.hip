@@ -29,6 +29,7 @@
 
 #include "../../include/pbr_hip.h"
 #include "ct_backward.hpp"
+#include "ct_blend.hpp"
 #include "ct_kernel.hpp"
 
 namespace pbr {
@@ -259,6 +260,59 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     const size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (fp32_one_light ? kLdsFor11WavesPerCu : 0);
     hipLaunchKernelGGL(e.fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), lds,
                        static_cast<hipStream_t>(stream), k);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
+
+int pbr_cook_torrance_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, void *stream) {
+    using namespace pbr;
+    const int rc = validate(d);
+    if (rc != PBR_OK) return rc;
+    if (!bl || !workspace) return PBR_ERR_NULL_MAP;
+    if (d->map_dtype != PBR_F32 || d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;
+    if (!d->normal.data || !bl->albedo.data || !bl->normal.data || !bl->roughness.data || !bl->mask.data)
+        return PBR_ERR_NULL_MAP;
+    if (d->workflow == PBR_WORKFLOW_SPECULAR ? !bl->specular.data : !bl->metallic.data) return PBR_ERR_WORKFLOW;
+    int vec = pick_vec(d);
+    for (const pbr_map *m : {&bl->albedo, &bl->normal, &bl->roughness, &bl->metallic, &bl->specular, &bl->mask})
+        if (m->data && ((reinterpret_cast<uintptr_t>(m->data) & 15u) || m->batch_stride % 4 || m->channel_stride % 4)) vec = 1;
+    KArgs k;
+    fill_args(d, vec, k);
+    if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+    KBlend b;
+    std::memset(&b, 0, sizeof(b));
+    b.albedo = bl->albedo.data; b.normal = bl->normal.data; b.rough = bl->roughness.data;
+    b.metal = bl->metallic.data; b.spec = bl->specular.data;
+    b.a_bs = bl->albedo.batch_stride; b.a_cs = bl->albedo.channel_stride;
+    b.n_bs = bl->normal.batch_stride; b.n_cs = bl->normal.channel_stride;
+    b.r_bs = bl->roughness.batch_stride; b.m_bs = bl->metallic.batch_stride;
+    b.s_bs = bl->specular.batch_stride; b.s_cs = bl->specular.channel_stride;
+    b.mask = static_cast<const float *>(bl->mask.data); b.k_bs = bl->mask.batch_stride;
+    b.normal_signed = static_cast<const int *>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // pass 1: one flag per material -- does the blended normal map have a negative component?  (base.py:212)
+    if (hipMemsetAsync(workspace, 0, sizeof(int) * (size_t)d->batch, st) != hipSuccess) return 1000 + (int)hipGetLastError();
+    const int64_t P = (int64_t)k.map_h * k.map_w, total = P * d->batch;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(blend_normal_sign_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st,
+                       static_cast<const float *>(d->normal.data), static_cast<const float *>(bl->normal.data), b.mask,
+                       k.n_bs, k.n_cs, b.n_bs, b.n_cs, b.k_bs, P, total, static_cast<int *>(workspace));
+    // pass 2: blend + evaluate
+    const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
+    void (*fn)(const KArgs, const KBlend) = nullptr;
+#define PBR_BLEND(L, W)                                                                                              \
+    fn = vec == 4 ? (multi ? cook_torrance_blend_kernel<L, W, 4, true> : cook_torrance_blend_kernel<L, W, 4, false>) \
+                  : (multi ? cook_torrance_blend_kernel<L, W, 1, true> : cook_torrance_blend_kernel<L, W, 1, false>)
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: PBR_BLEND(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC); break;
+        case 1: PBR_BLEND(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR); break;
+        case 2: PBR_BLEND(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED); break;
+        case 3: PBR_BLEND(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC); break;
+        case 4: PBR_BLEND(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR); break;
+        default: PBR_BLEND(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED); break;
+    }
+#undef PBR_BLEND
+    hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0, st, k, b);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? PBR_OK : 1000 + (int)err;
 }

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
     const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);
     if (!p.valid) return;
     Texels<VEC> t;
-    load_texels<WF, float, VEC, true>(a, p, t);
+    load_texels<WF, float, VEC, true>(a, a.has_normal != 0, p, t);
     float go[3][VEC];
     const int64_t opix = p.b * a.o_bs + p.pix;
 #pragma unroll

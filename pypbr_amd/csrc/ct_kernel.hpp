@@ -195,11 +195,12 @@ __device__ __forceinline__ LanePos lane_pos(const KArgs &a, int tile_x, int tile
 template <int VEC> struct Texels { float al[3][VEC], nm[3][VEC], ro[VEC], me[VEC], sp[3][VEC]; };
 
 // Issues every load of the lane's texels; nothing here waits on memory.
-template <int WF, typename TI, int VEC, bool NT>
-__device__ __forceinline__ void load_texels(const KArgs &a, const LanePos &p, Texels<VEC> &t) {
+// `Src` is KArgs, or KBlend (the second material of a fused blend): same member names.
+template <int WF, typename TI, int VEC, bool NT, class Src>
+__device__ __forceinline__ void load_texels(const Src &a, bool has_normal, const LanePos &p, Texels<VEC> &t) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(a.albedo, p.b * a.a_bs + c * a.a_cs + p.src, t.al[c]);
-    if (a.has_normal) {
+    if (has_normal) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(a.normal, p.b * a.n_bs + c * a.n_cs + p.src, t.nm[c]);
     }
@@ -391,7 +392,7 @@ void cook_torrance_kernel(const KArgs a) {
     const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);
     if (!p.valid) return;
     Texels<VEC> t;
-    load_texels<WF, TI, VEC, NT>(a, p, t);
+    load_texels<WF, TI, VEC, NT>(a, a.has_normal != 0, p, t);
 #ifdef PBR_PACK_SINGLE   // build-time experiment switch: packed math for the one-light fp32 kernels too
     shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, true>(a, p, t);
 #else

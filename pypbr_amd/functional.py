@@ -179,9 +179,18 @@ class RenderPlan:
         self.desc.schedule = best.value
         return best.value
 
+    def attach_blend(self, blend_desc, workspace, keep_alive):
+        """Turns the plan into blend + evaluate (pbr_cook_torrance_blend): material 2 and the mask."""
+        self._blend, self._blend_ref, self._workspace = blend_desc, ctypes.byref(blend_desc), workspace
+        self._keep = self._keep + tuple(keep_alive)
+
     def launch(self, stream: Optional[int] = None) -> torch.Tensor:
         """Enqueue on `stream` (raw hipStream_t) or torch's current stream of the maps' device."""
-        rc = self._fn(self._ref, _stream_ptr(self.device) if stream is None else stream)
+        st = _stream_ptr(self.device) if stream is None else stream
+        if getattr(self, "_blend", None) is not None:
+            rc = N.lib().pbr_cook_torrance_blend(self._ref, self._blend_ref, self._workspace.data_ptr(), st)
+        else:
+            rc = self._fn(self._ref, st)
         if rc != N.OK:
             N.check(rc)
         return self.result
@@ -195,14 +204,19 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                        convert_to_diffuse_specular: bool = False, y_offset: int = 0,
                        height_total: Optional[int] = None, out_dtype: Optional[torch.dtype] = None,
                        out: Optional[torch.Tensor] = None, schedule: int = N.SCHEDULE_AUTO,
-                       autotune: bool = False, tile=1, rows: Optional[int] = None) -> RenderPlan:
+                       autotune: bool = False, tile=1, rows: Optional[int] = None,
+                       blend: Optional[Sequence[Optional[torch.Tensor]]] = None) -> RenderPlan:
     """Validates the maps, allocates the output and fills the C-ABI descriptor; see `cook_torrance`.
     `schedule`: workgroup order (N.SCHEDULE_AUTO | N.SCHEDULE_LINEAR | N.schedule_xcd(c)), results do not depend
     on it; `autotune=True` measures the candidates on these very buffers once (blocking, a few launches) and
     keeps the fastest -- for plans that are launched many times.
     `tile=n | (ny, nx)`: evaluate `material.tile(n)` (base.py:524-537) without materialising the repeated maps --
     the kernel wraps its texel addresses, so each texel leaves HBM once instead of ny*nx times; the result is the
-    (ny*H, nx*W) image (or its rows [y_offset, y_offset + rows))."""
+    (ny*H, nx*W) image (or its rows [y_offset, y_offset + rows)).
+    `blend=(albedo2, normal2, roughness2, metallic2, specular2, mask)`: blend_with_mask (blending/functional.py:64-145:
+    mask * map1 + (1 - mask) * map2, normals normalised / blended / normalised, the blended normal re-decoded as on
+    assignment) fused in front of the evaluation -- both materials are read once, the blended maps are never written.
+    fp32 maps, both materials complete; `mask` [1,H,W] or [B,1,H,W]."""
     if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda:
         raise RuntimeError("pypbr_amd.functional.cook_torrance needs maps on a ROCm device "
                            "(use material.to('cuda')); there is no CPU path")
@@ -228,7 +242,32 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                             convert_to_diffuse_specular=convert_to_diffuse_specular, y_offset=y_offset,
                             height_total=height_total, schedule=schedule, tile=(ny, nx))
     plan = RenderPlan(desc, out, (a, n, r, m, s), squeeze and out.dim() == 4)
-    if autotune:
+    if blend is not None:
+        if len(blend) != 6:
+            raise ValueError("blend = (albedo2, normal2, roughness2, metallic2, specular2, mask)")
+        if a.dtype != torch.float32 or out.dtype != torch.float32:
+            raise TypeError("the fused blend supports float32 maps and output")
+        if n is None:
+            raise ValueError("the fused blend needs a normal map in both materials")
+        a2, n2, r2 = (_as_batched(blend[0], (3,), "albedo2"), _as_batched(blend[1], (3,), "normal2"),
+                      _as_batched(blend[2], (1,), "roughness2"))
+        m2, s2 = _as_batched(blend[3], (1,), "metallic2"), _as_batched(blend[4], (3,), "specular2")
+        k = _as_batched(blend[5] if blend[5].dim() != 2 else blend[5].unsqueeze(0), (1,), "mask")
+        second = m2 if m is not None else s2
+        if a2 is None or n2 is None or r2 is None or second is None or k is None:
+            raise ValueError("the fused blend needs albedo, normal, roughness and %s of material 2 and a mask"
+                             % ("metallic" if m is not None else "specular"))
+        for name, t, like in (("albedo2", a2, a), ("normal2", n2, n), ("roughness2", r2, r), ("metallic2|specular2", second, m if m is not None else s),
+                              ("mask", k, r)):
+            if t.shape[-2:] != like.shape[-2:] or t.shape[0] not in (1, B) or t.dtype != torch.float32 or t.device != a.device:
+                raise ValueError("%s %s (%s on %s) does not match material 1" % (name, tuple(t.shape), t.dtype, t.device))
+        bd = N.BlendDesc()
+        bd.albedo, bd.normal, bd.roughness = _pbr_map(a2), _pbr_map(n2), _pbr_map(r2)
+        bd.metallic = _pbr_map(m2 if m is not None else None)
+        bd.specular = _pbr_map(s2 if m is None else None)
+        bd.mask = _pbr_map(k)
+        plan.attach_blend(bd, torch.empty(B, dtype=torch.int32, device=a.device), (a2, n2, r2, second, k))
+    elif autotune:
         plan.autotune()
     return plan
 
@@ -264,6 +303,8 @@ class _CookTorranceFn(torch.autograd.Function):
     def forward(ctx, albedo, normal, roughness, metallic, specular, kwargs):
         if kwargs.get("out") is not None:
             raise NotImplementedError("gradients need out=None (the result must be a fresh tensor)")
+        if kwargs.get("blend") is not None:
+            raise NotImplementedError("the fused blend is forward-only; blend with pypbr_amd.blending first to differentiate")
         maps = (albedo, normal, roughness, metallic, specular)
         plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **kwargs)
         if plan.desc.map_dtype != N.F32 or plan.desc.out_dtype != N.F32:

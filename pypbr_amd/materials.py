@@ -103,10 +103,35 @@ class MaterialBase:
             object.__setattr__(self, name, value)
 
     def __getattr__(self, name):
-        maps = self.__dict__.get("_maps", {})
-        if name in maps:
-            return maps[name]
+        if name in self.__dict__.get("_store", {}):
+            return self._maps[name]
         raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    # `_maps` is the reference's name -> tensor dict.  It lives in `_store`; reading it first resolves a pending
+    # lazy blend (blending.blend_with_mask(..., lazy=True)), so whoever looks at the maps sees blended maps --
+    # only CookTorranceBRDF reads `_store` / `_lazy_blend` directly and hands both materials to the fused kernel.
+    @property
+    def _maps(self):
+        d = self.__dict__
+        if d.get("_lazy_blend") is not None:
+            self.materialize_blend()
+        return d.setdefault("_store", {})
+
+    @_maps.setter
+    def _maps(self, value):
+        self.__dict__["_store"] = value
+
+    def materialize_blend(self):
+        """Carries out a pending lazy blend: the maps become real blended tensors (blend.hip kernels)."""
+        pending = self.__dict__.get("_lazy_blend")
+        if pending is not None:
+            from .blending import _blend_dicts
+            self.__dict__["_lazy_blend"] = None
+            other, mask = pending
+            store = self.__dict__["_store"]
+            for name, result in _blend_dicts(dict(store), other, mask).items():
+                store[name] = self._ingest(name, result)      # normals pass through _process_normal_map, as upstream
+        return self
 
     def _ingest(self, name, value):
         if value is None:

@@ -49,22 +49,36 @@ class CookTorranceBRDF(BRDFModel):
         """
         out_device = torch.device(self.override_device or material.device)
 
-        # attribute probes in the reference's order, so a material without a roughness /
-        # normal entry raises the same AttributeError (cooktorrance.py:99-100)
-        roughness = material.roughness
-        normal = material.normal
-        metallic = specular = None
-        specular_is_srgb = True
-        if hasattr(material, "metallic") and material.metallic is not None:
-            metallic = material.metallic
-        elif hasattr(material, "specular") and material.specular is not None:
-            specular = material.specular
+        pending = material.__dict__.get("_lazy_blend")
+        blend = None
+        if pending is not None:
+            # blending.blend_with_mask(..., lazy=True): both materials are complete (checked there); read the raw
+            # stores so that nothing gets blended into a copy -- the fused kernel does it on the fly
+            first, (second, mask) = material.__dict__["_store"], pending
+            albedo, normal, roughness = first["albedo"], first["normal"], first["roughness"]
+            metallic, specular = first.get("metallic"), None
+            if metallic is None:
+                specular = first["specular"]
             specular_is_srgb = bool(getattr(material, "specular_is_srgb", True))
+            blend = (second["albedo"], second["normal"], second["roughness"], second.get("metallic") if metallic is not None else None,
+                     second.get("specular") if metallic is None else None, mask)
         else:
-            raise ValueError("Material must have either 'metallic' or 'specular' property.")
-        albedo = material._maps.get("albedo")
-        if albedo is None:
-            raise AttributeError(f"'{type(material).__name__}' material has no albedo map")
+            # attribute probes in the reference's order, so a material without a roughness /
+            # normal entry raises the same AttributeError (cooktorrance.py:99-100)
+            roughness = material.roughness
+            normal = material.normal
+            metallic = specular = None
+            specular_is_srgb = True
+            if hasattr(material, "metallic") and material.metallic is not None:
+                metallic = material.metallic
+            elif hasattr(material, "specular") and material.specular is not None:
+                specular = material.specular
+                specular_is_srgb = bool(getattr(material, "specular_is_srgb", True))
+            else:
+                raise ValueError("Material must have either 'metallic' or 'specular' property.")
+            albedo = material._maps.get("albedo")
+            if albedo is None:
+                raise AttributeError(f"'{type(material).__name__}' material has no albedo map")
 
         if out_device.type == "cuda":
             compute = out_device
@@ -80,5 +94,6 @@ class CookTorranceBRDF(BRDFModel):
             view_dir=view_dir, light=light_dir_or_position, light_intensity=light_intensity,
             light_type=self.light_type, light_size=light_size,
             albedo_is_srgb=bool(material.albedo_is_srgb), specular_is_srgb=specular_is_srgb,
-            return_srgb=return_srgb, tile=getattr(material, "lazy_tile", (1, 1)))
+            return_srgb=return_srgb, tile=getattr(material, "lazy_tile", (1, 1)),
+            blend=None if blend is None else tuple(dev(t) for t in blend))
         return color if color.device == out_device else color.to(out_device)

@@ -75,3 +75,80 @@ def test_blend_errors():
         B.blend_materials(a, a, method="magic")
     with pytest.raises(ValueError, match="Mask must be provided"):
         B.blend_materials(a, a, method="mask")
+
+
+BLEND_LIGHTS = {"pt1": ("point", [0.1, 0.1, 1.0], 1.0), "dir": ("directional", [0.3, -0.2, 1.0], None)}
+
+
+@pytest.mark.parametrize("device", ["cuda", "cpu"])
+def test_fused_blend_and_render_matches_the_reference_pipeline(device, golden):
+    """N4 as the survey words it: the blend fused in front of the BRDF.  Lazy blends rendered by CookTorranceBRDF
+    (pbr_cook_torrance_blend: both materials read once, no blended copy) against the REAL reference's
+    blend -> render (tests/golden/blend.npz render_*), and bit-for-bit against this package's own unfused path."""
+    import pypbr_amd.blending as B
+    from pypbr_amd.models import CookTorranceBRDF
+    z = golden("blend")
+    m1, m2 = _materials(z, device)
+    blends = {"height": lambda: B.HeightBlend(blend_width=0.1, shift=-0.5), "mask": lambda: B.MaskBlend(torch.from_numpy(z["in_mask"]).to(device)),
+              "prop": lambda: B.PropertyBlend(property_name="roughness", blend_width=0.1),
+              "gradh": lambda: B.GradientBlend("horizontal"), "gradv": lambda: B.GradientBlend("vertical")}
+    view, inten = torch.tensor([0.0, 0.0, 1.0]), torch.tensor([1.0, 1.0, 1.0])
+    for name, make in blends.items():
+        with B.lazy_blending():
+            lazy, mask = make()(m1, m2)
+        assert lazy.__dict__.get("_lazy_blend") is not None and type(lazy) is type(m1)
+        eager, _ = make()(m1, m2)
+        for lk, (ltype, lvec, lsize) in BLEND_LIGHTS.items():
+            brdf = CookTorranceBRDF(ltype)
+            got = brdf(lazy, view, torch.tensor(lvec), inten, lsize)
+            assert lazy.__dict__.get("_lazy_blend") is not None            # rendering does not materialise the blend
+            assert got.device.type == device
+            assert np.abs(got.cpu().numpy() - z[f"render_{name}_{lk}"]).max() <= 1e-5, (name, lk)
+            unfused = brdf(eager, view, torch.tensor(lvec), inten, lsize)
+            assert (got - unfused).abs().max().item() <= 2e-7, (name, lk)
+        # the first look at the maps blends them for real; they equal the eager blend
+        assert lazy.albedo.shape == (3, 96, 96) and lazy.__dict__.get("_lazy_blend") is None
+        for k, v in eager._maps.items():
+            assert torch.equal(lazy._maps[k], v), (name, k)
+
+
+def test_fused_blend_flat_normals_follow_the_redecode_quirk():
+    """Two flat +Z normal maps blend to (0,0,1) everywhere: no negative component, so on assignment the reference
+    re-reads the blended normal as [0,1]-encoded (base.py:212-216).  The fused path carries the same per-map flag."""
+    import pypbr_amd.blending as B
+    from pypbr_amd import functional as F
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    from pypbr_amd.models import CookTorranceBRDF
+    g = torch.Generator().manual_seed(12)
+    H, W = 24, 40
+    dev = torch.device("cuda")
+
+    def mat(seed_shift, flat):
+        m = BasecolorMetallicMaterial(albedo=torch.rand(3, H, W, generator=g), roughness=torch.rand(1, H, W, generator=g) * 0.7 + 0.3,
+                                      metallic=torch.rand(1, H, W, generator=g), device=dev)
+        n = torch.zeros(3, H, W); n[2] = 1.0
+        if not flat:
+            n[:2] = torch.rand(2, H, W, generator=g) - 0.5
+        m._maps["normal"] = n.to(dev)
+        return m
+    mask = torch.rand(1, H, W, generator=g).to(dev)
+    args = (torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0]), 1.0)
+    brdf = CookTorranceBRDF("point")
+    for flat in (True, False):
+        m1, m2 = mat(0, flat), mat(1, flat)
+        lazy, _ = B.blend_with_mask(m1, m2, mask, lazy=True)
+        eager, _ = B.blend_with_mask(m1, m2, mask)
+        assert bool((eager.normal[:2] < 0).all()) == flat                   # flat: re-decoded to (-1,-1,1)/sqrt(3)
+        assert (brdf(lazy, *args) - brdf(eager, *args)).abs().max().item() <= 2e-7
+    # batched call through the functional API: one flag per material
+    a = torch.rand(2, 3, H, W, generator=g).to(dev); r = (torch.rand(2, 1, H, W, generator=g) * 0.7 + 0.3).to(dev)
+    m = torch.rand(2, 1, H, W, generator=g).to(dev)
+    n = torch.zeros(2, 3, H, W); n[:, 2] = 1.0; n[1, :2] = torch.rand(2, H, W, generator=g) - 0.5
+    n = n.to(dev)
+    kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
+    fused = F.cook_torrance(a, n, r, m, blend=(a.flip(0), n, r.flip(0), m.flip(0), None, mask), **kw)
+    for b in range(2):
+        one = F.cook_torrance(a[b], n[b], r[b], m[b], blend=(a.flip(0)[b], n[b], r.flip(0)[b], m.flip(0)[b], None, mask), **kw)
+        assert torch.equal(fused[b], one)
+    with pytest.raises(NotImplementedError):
+        F.cook_torrance(a.requires_grad_(True), n, r, m, blend=(a.detach(), n, r, m, None, mask), **kw)

@@ -62,7 +62,10 @@ __device__ __forceinline__ void blend_texels(Texels<VEC> &t, const Texels<VEC> &
 //   fp32 maps and output; both materials carry all four maps.  Same grid / tile order as cook_torrance_kernel.
 template <int LIGHT, int WF, int VEC, bool MULTI>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(MULTI ? 3 : 2, MULTI ? 4 : 3)))
+#ifndef PBR_BLEND_WAVES
+#define PBR_BLEND_WAVES 2, 3
+#endif
+__attribute__((amdgpu_waves_per_eu(PBR_BLEND_WAVES)))
 void cook_torrance_blend_kernel(const KArgs a, const KBlend b) {
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
     const int ty = (int)a.div_tx.div(tile);

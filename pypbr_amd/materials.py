@@ -182,7 +182,7 @@ class MaterialBase:
     def size(self) -> Optional[Tuple[int, int]]:
         """(height, width) of the first map that is present (base.py:293-307)."""
         ny, nx = self.lazy_tile
-        for t in self._maps.values():
+        for t in self.__dict__.get("_store", {}).values():       # a pending blend does not change the size
             if t is not None:
                 return (t.shape[-2] * ny, t.shape[-1] * nx)
         return None

@@ -299,3 +299,53 @@ def test_loader_workflow_selection_and_alias(tmp_path):
     finally:
         compat.uninstall()
         sys.modules.update(saved)
+
+
+def test_fused_blend_entry_point_validates_without_a_device():
+    lib = N.lib()
+    d = _desc()
+    bd = N.BlendDesc()
+    ws = ctypes.c_void_p(64)
+    assert lib.pbr_cook_torrance_blend(ctypes.byref(d), None, ws, None) == N.ERR_NULL_MAP          # no second material
+    assert lib.pbr_cook_torrance_blend(ctypes.byref(d), ctypes.byref(bd), None, None) == N.ERR_NULL_MAP   # no flag workspace
+    assert lib.pbr_cook_torrance_blend(ctypes.byref(d), ctypes.byref(bd), ws, None) == N.ERR_NULL_MAP      # empty second material
+    bd.albedo = bd.normal = bd.roughness = bd.mask = N.PbrMap(64, 0, 0)
+    assert lib.pbr_cook_torrance_blend(ctypes.byref(d), ctypes.byref(bd), ws, None) == N.ERR_WORKFLOW      # metallic workflow, no metallic2
+    d16 = _desc(); d16.map_dtype = N.F16
+    assert lib.pbr_cook_torrance_blend(ctypes.byref(d16), ctypes.byref(bd), ws, None) == N.ERR_DTYPE       # fp32 only
+
+
+def test_lazy_blend_and_lazy_tile_protocol_on_the_host():
+    """Lazy blends / tiles only RECORD work: creating and inspecting them needs no device; turning them into maps
+    does, and without a device that raises (no CPU arithmetic anywhere in the package)."""
+    import pypbr_amd.blending as B
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    g = torch.Generator().manual_seed(0)
+    H, W = 8, 12
+
+    def mat():
+        m = BasecolorMetallicMaterial()
+        for name, c in (("albedo", 3), ("normal", 3), ("roughness", 1), ("metallic", 1), ("height", 1)):
+            m._maps[name] = torch.rand(c, H, W, generator=g)          # poked in: assignment of a normal map needs the device
+        return m
+    m1, m2 = mat(), mat()
+    mask = torch.rand(H, W, generator=g)
+    with B.lazy_blending():
+        lazy, mk = B.MaskBlend(mask)(m1, m2)
+    assert mk.shape == (1, H, W) and type(lazy) is type(m1) and lazy.albedo_is_srgb == m1.albedo_is_srgb
+    pending = lazy.__dict__["_lazy_blend"]
+    assert pending is not None and pending[0]["albedo"] is m2._maps["albedo"] and lazy.__dict__["_store"]["albedo"] is m1._maps["albedo"]
+    assert lazy.size == (H, W) or lazy.__dict__["_lazy_blend"] is None        # `size` may look at the maps ...
+    # ... and looking at the maps is what triggers the real blend, which has no CPU path
+    lazy2, _ = B.blend_with_mask(m1, m2, mask, lazy=True)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU"):
+            lazy2.albedo
+    # materials that cannot be fused fall back to the eager blend (here: different workflows -> needs the device)
+    assert not B._fusable({k: v for k, v in m1._maps.items() if k != "normal"}, m2._maps, mk)
+    assert not B._fusable(m1._maps, m2._maps, mk.double())
+    # lazy tile: only the reported size changes
+    t = mat().tile(3, lazy=True)
+    assert t.lazy_tile == (3, 3) and t.size == (3 * H, 3 * W) and t._maps["albedo"].shape == (3, H, W)
+    assert t.tile(2, lazy=True).lazy_tile == (6, 6)
+    assert t.materialize_tile().albedo.shape == (3, 6 * H, 6 * W) and t.lazy_tile == (1, 1)     # torch.repeat: indexing only

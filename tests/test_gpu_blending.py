@@ -152,3 +152,28 @@ def test_fused_blend_flat_normals_follow_the_redecode_quirk():
         assert torch.equal(fused[b], one)
     with pytest.raises(NotImplementedError):
         F.cook_torrance(a.requires_grad_(True), n, r, m, blend=(a.detach(), n, r, m, None, mask), **kw)
+
+
+def test_fused_blend_composes_with_fused_tile_and_several_lights():
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(21)
+    h, w, n_t = 24, 32, 2
+    dev = torch.device("cuda")
+    mk = lambda c: torch.rand(c, h, w, generator=g).to(dev)
+    nrm = lambda: torch.cat([torch.rand(2, h, w, generator=g) - 0.5, torch.ones(1, h, w)], 0).to(dev)
+    a1, a2, r1, r2, m1, m2, mask = mk(3), mk(3), mk(1) * 0.7 + 0.3, mk(1) * 0.7 + 0.3, mk(1), mk(1), mk(1)
+    n1, n2 = nrm(), nrm()
+    kw = dict(view_dir=[0, 0, 1], light=[[0.1, 0.1, 1.0], [-0.3, 0.2, 0.8]], light_intensity=[[0.6, 0.6, 0.6], [0.4, 0.5, 0.6]],
+              light_type="point", light_size=1.5)
+    rep = lambda t: t.repeat(1, n_t, n_t)
+    tiled = F.cook_torrance(a1, n1, r1, m1, blend=(a2, n2, r2, m2, None, mask), tile=n_t, **kw)
+    full = F.cook_torrance(rep(a1), rep(n1), rep(r1), rep(m1), blend=(rep(a2), rep(n2), rep(r2), rep(m2), None, rep(mask)), **kw)
+    assert tiled.shape == (3, n_t * h, n_t * w) and torch.equal(tiled, full)
+    # ragged width -> the one-pixel-per-lane instantiation of the blend kernel
+    cut = lambda t: t[..., :w - 3].contiguous()
+    ragged = F.cook_torrance(cut(a1), cut(n1), cut(r1), cut(m1), blend=(cut(a2), cut(n2), cut(r2), cut(m2), None, cut(mask)), **kw)
+    assert (ragged - F.cook_torrance(a1, n1, r1, m1, blend=(a2, n2, r2, m2, None, mask), **kw)[..., :w - 3]).abs().max().item() > 0  # light grid differs
+    import pypbr_amd.blending as B
+    blended = {k: B.blend_maps(cut(x), cut(y), cut(mask), is_normal=(k == "n")) for k, x, y in (("a", a1, a2), ("n", n1, n2), ("r", r1, r2), ("m", m1, m2))}
+    ref = F.cook_torrance(blended["a"], blended["n"], blended["r"], blended["m"], **kw)
+    assert (ragged - ref).abs().max().item() <= 2e-7

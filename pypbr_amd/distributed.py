@@ -107,19 +107,39 @@ def cook_torrance_sharded(maps: Dict[str, Optional[torch.Tensor]], params: Optio
     """Evaluates this rank's shard of `maps` ([B,C,H,W] tensors: albedo, normal, roughness,
     metallic | specular -- every rank holds, or can index, the full batch) with the
     parameters broadcast from `src`.  Returns (shard, output or None for an empty shard).
+    `tile=` and `blend=` (see functional.plan_cook_torrance) shard too: with a fused tile the ranks split the rows of
+    the tiled OUTPUT over whole source maps; a blend's second material and mask are sliced like the first.
     `render` defaults to functional.cook_torrance (tests inject a recorder on CPU)."""
     import torch.distributed as dist
+    from .functional import tile_counts
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     albedo = maps["albedo"]
     B, _, H, _ = albedo.shape
+    ny, nx = tile_counts(flags.pop("tile", 1))
+    blend = flags.pop("blend", None)
     p = broadcast_light_block(params, device=albedo.device, src=src, group=group)
-    shard = partition(B, H, world, rank)
+    shard = partition(B, H * ny, world, rank)          # rows of the OUTPUT: with a fused tile() that is ny * H
     if shard.batch_stop <= shard.batch_start or shard.row_stop <= shard.row_start:
         return shard, None
     if render is None:
         from .functional import cook_torrance as render
-    m = shard_maps(maps, shard)
+    tiled = (ny, nx) != (1, 1)
+    if tiled:      # the kernel wraps its texel addresses: every rank keeps whole source maps and evaluates a band of the output
+        cut = lambda t: None if t is None else t[shard.batch_start:shard.batch_stop]
+        flags.update(tile=(ny, nx), rows=shard.row_stop - shard.row_start)
+        total = None
+    else:
+        cut = lambda t: None if t is None else t[shard.batch_start:shard.batch_stop, :, shard.row_start:shard.row_stop, :]
+        total = H
+    if blend is not None:   # second material and mask are sharded exactly like the first ([B|1,C,H,W] tensors)
+        def cut2(t):
+            if t is None:
+                return None
+            t = t if t.dim() == 4 else t.unsqueeze(0)
+            return cut(t if t.shape[0] > 1 else t.expand(B, *t.shape[1:]))
+        flags["blend"] = tuple(cut2(t) for t in blend)
+    m = {name: cut(t) for name, t in maps.items()}
     out = render(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"),
                  view_dir=p["view_dir"], light=p["light"], light_intensity=p["light_intensity"],
-                 light_type=light_type, light_size=p["light_size"], y_offset=shard.row_start, height_total=H, **flags)
+                 light_type=light_type, light_size=p["light_size"], y_offset=shard.row_start, height_total=total, **flags)
     return shard, out

@@ -84,7 +84,28 @@ def _worker(rank, world, port, batch, tmpdir):
         if out is not None:
             assert calls[0]["height_total"] == H and calls[0]["y_offset"] == shard.row_start
             assert out.shape == (shard.batch_stop - shard.batch_start, 3, shard.row_stop - shard.row_start, W)
-        torch.save({"shard": tuple(shard), "out": out}, os.path.join(tmpdir, f"rank{rank}.pt"))
+        # fused tile(2) + fused blend shard too: bands of the tiled OUTPUT over whole source maps; material 2 and the
+        # mask cut like material 1 (a recorder stands in for the kernel: this checks the plumbing only)
+        seen_kw = []
+
+        def recorder(albedo, normal, roughness, metallic, specular, **kw):
+            seen_kw.append((albedo.shape, kw))
+            return torch.zeros(albedo.shape[0], 3, kw.get("rows") or albedo.shape[-2], albedo.shape[-1] * (kw.get("tile") or (1, 1))[1])
+        mask = torch.rand(1, H, W, generator=g)
+        second = (maps["albedo"].flip(0), maps["normal"], maps["roughness"], maps["metallic"], None, mask)
+        tshard, tout = cook_torrance_sharded(maps, params if rank == 0 else None, light_type="point", render=recorder, tile=2, blend=second)
+        if tout is not None:
+            shape, kw = seen_kw[0]
+            nb = tshard.batch_stop - tshard.batch_start
+            assert shape == (nb, 3, H, W) and kw["tile"] == (2, 2) and kw["rows"] == tshard.row_stop - tshard.row_start
+            assert kw["y_offset"] == tshard.row_start and kw["height_total"] is None and 0 <= tshard.row_start < tshard.row_stop <= 2 * H
+            assert [None if t is None else tuple(t.shape) for t in kw["blend"]] == [(nb, 3, H, W), (nb, 3, H, W), (nb, 1, H, W), (nb, 1, H, W), None, (nb, 1, H, W)]
+            assert torch.equal(kw["blend"][0], maps["albedo"].flip(0)[tshard.batch_start:tshard.batch_stop])
+        bshard, _ = cook_torrance_sharded(maps, params if rank == 0 else None, light_type="point", render=recorder, blend=second)
+        if len(seen_kw) > (1 if tout is not None else 0):
+            shape, kw = seen_kw[-1]
+            assert kw["blend"][5].shape == (bshard.batch_stop - bshard.batch_start, 1, bshard.row_stop - bshard.row_start, W) == shape[:1] + (1,) + shape[2:]
+        torch.save({"shard": tuple(shard), "out": out, "tshard": tuple(tshard)}, os.path.join(tmpdir, f"rank{rank}.pt"))
         dist.barrier()
         if rank == 0:
             full = O.cook_torrance_batched(maps["albedo"], maps["normal"], maps["roughness"], maps["metallic"], None,
@@ -101,6 +122,12 @@ def _worker(rank, world, port, batch, tmpdir):
                 # ATen rounds by position inside a SIMD chunk, so bands agree to the ulp, not always bit for bit
                 assert (rec["out"] - full[b0:b1, :, y0:y1]).abs().max().item() <= 1e-5
             assert bool(seen.all())
+            tiled_rows = torch.zeros(batch, 2 * H, dtype=torch.bool)            # the tiled output is covered exactly once too
+            for r in range(world):
+                b0, b1, y0, y1 = torch.load(os.path.join(tmpdir, f"rank{r}.pt"))["tshard"]
+                assert not tiled_rows[b0:b1, y0:y1].any()
+                tiled_rows[b0:b1, y0:y1] = True
+            assert bool(tiled_rows.all())
     finally:
         dist.destroy_process_group()
 

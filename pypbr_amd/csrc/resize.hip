@@ -13,11 +13,17 @@
 // With antialias off (or when up-scaling) this reduces to the ordinary 2-tap bilinear rule with
 // edge clamping, so one kernel covers both settings.
 //
-// Two HBM-streaming passes; each lane produces one output element and walks its taps (<= 2*scale+2)
-// along the contiguous axis (width pass) or down a column (height pass: lanes of a wave are
-// consecutive in x, so every tap row is a coalesced run).
+// Schedule: ONE kernel, the separable passes fused through LDS.  A workgroup owns a TOH x 64 tile of the output:
+// it runs the width pass for the input rows its tile needs (each lane walks its <= 2*scale+2 taps along the
+// contiguous axis; neighbouring lanes share taps, so the L1 absorbs the overlap and every input texel leaves HBM
+// about once), keeps that fp32 intermediate in LDS -- here there IS reuse: every intermediate value feeds
+// ~2*support output rows -- and runs the height pass out of LDS (lanes consecutive in x: conflict-free column
+// reads, coalesced stores).  Against the two-pass form (kept below for extreme down-scales whose row window
+// does not fit) this saves the write and the re-read of the width-pass result: 4096^2 -> 2048^2, 3 planes,
+// antialiased: 450 MB of HBM traffic -> 252 MB.  Same arithmetic in the same order, so both forms are bit-identical.
 #include <hip/hip_runtime.h>
 
+#include <climits>
 #include <cstdint>
 
 #include "../../include/pbr_hip.h"
@@ -84,6 +90,74 @@ __global__ __launch_bounds__(256) void resize_height_kernel(const float *__restr
     }
 }
 
+// Fused form.  Tile = toh x 64 outputs; LDS holds mid[in_rows][64], in_rows <= max_rows rows of the width pass.
+constexpr int kTileW = 64;
+__global__ __launch_bounds__(256) void resize_fused_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                           int h_out, int w_out, int w_in, int toh, int tiles_x, int tiles_y,
+                                                           AxisFilter fw, AxisFilter fh) {
+    extern __shared__ float mid[];                       // [in_rows][kTileW]
+    const int tile = blockIdx.x;
+    const int plane = tile / (tiles_x * tiles_y);
+    const int t2 = tile - plane * tiles_x * tiles_y;
+    const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
+    const int ox0 = tx * kTileW, oy0 = ty * toh;
+    const int ow = min(kTileW, w_out - ox0), oh = min(toh, h_out - oy0);
+    int ylo, n0, ylast, nlast; float c0;
+    tap_window(fh, oy0, ylo, n0, c0);
+    tap_window(fh, oy0 + oh - 1, ylast, nlast, c0);
+    const int in_rows = ylast + nlast - ylo;             // windows are monotone in the output row
+    const float *sp = src + (int64_t)plane * fh.n_in * w_in;
+    // width pass for rows [ylo, ylo + in_rows), output columns [ox0, ox0 + ow).  256 lanes = 4 rows of 64 columns, so a
+    // lane's column -- hence its tap window and weight sum -- is the same in every iteration: computed once.
+    {
+        const int i = threadIdx.x & (kTileW - 1);
+        int xmin = 0, xsize = 0; float center = 0.0f, wsum = 0.0f;
+        if (i < ow) {
+            tap_window(fw, ox0 + i, xmin, xsize, center);
+            for (int j = 0; j < xsize; ++j) wsum += tap_weight(fw, j, xmin, center);
+        }
+        if (xsize <= 8) {         // scale <= 3: all taps of a row are loaded before the first is used (8 loads in flight)
+            float w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = j < xsize ? tap_weight(fw, j, xmin, center) : 0.0f;
+            for (int r = threadIdx.x / kTileW; r < in_rows && i < ow; r += 256 / kTileW) {
+                const float *p = sp + (int64_t)(ylo + r) * w_in + xmin;
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = j < xsize ? p[j] : 0.0f;
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc = j < xsize ? fmaf(w[j], v[j], acc) : acc;
+                mid[r * kTileW + i] = wsum != 0.0f ? acc / wsum : 0.0f;
+            }
+        } else {
+            for (int r = threadIdx.x / kTileW; r < in_rows && i < ow; r += 256 / kTileW) {
+                const float *p = sp + (int64_t)(ylo + r) * w_in + xmin;
+                float acc = 0.0f;
+                for (int j = 0; j < xsize; ++j) acc = fmaf(tap_weight(fw, j, xmin, center), p[j], acc);
+                mid[r * kTileW + i] = wsum != 0.0f ? acc / wsum : 0.0f;
+            }
+        }
+    }
+    __syncthreads();
+    // height pass out of LDS
+    float *dp = dst + (int64_t)plane * h_out * w_out;
+    for (int e = threadIdx.x; e < oh * kTileW; e += blockDim.x) {
+        const int orow = e / kTileW, i = e - orow * kTileW;
+        if (i >= ow) continue;
+        int ymin, ysize; float center;
+        tap_window(fh, oy0 + orow, ymin, ysize, center);
+        const float *q = mid + (ymin - ylo) * kTileW + i;
+        float acc = 0.0f, wsum = 0.0f;
+        for (int j = 0; j < ysize; ++j) {
+            const float w = tap_weight(fh, j, ymin, center);
+            acc = fmaf(w, q[j * kTileW], acc);
+            wsum += w;
+        }
+        dp[(int64_t)(oy0 + orow) * w_out + ox0 + i] = wsum != 0.0f ? acc / wsum : 0.0f;
+    }
+}
+
 static AxisFilter make_filter(int n_in, int n_out, bool antialias) {
     AxisFilter f;
     f.scale = (float)n_in / (float)n_out;            // area_pixel_compute_scale<float>, align_corners = False
@@ -115,6 +189,21 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *tmp = static_cast<float *>(workspace);
     const AxisFilter fw = make_filter(w_in, w_out, antialias != 0), fh = make_filter(h_in, h_out, antialias != 0);
+    // fused form when the row window of a tile fits LDS: rows needed by toh output rows <= toh*scale + 2*support + 2
+    constexpr int kMaxRows = 160;                                                   // 160 x 64 x 4 B = 40 KiB of LDS
+    int toh = 0;
+    for (int cand : {32, 16, 8, 4}) {
+        if ((int)(cand * fh.scale + 2.0f * fh.support) + 3 <= kMaxRows) { toh = cand; break; }
+    }
+    const int64_t tiles_x = (w_out + kTileW - 1) / kTileW, tiles_y = toh ? (h_out + toh - 1) / toh : 0;
+    if (toh && planes * tiles_x * tiles_y <= INT32_MAX) {
+        const size_t lds = (size_t)kMaxRows * kTileW * sizeof(float);
+        hipLaunchKernelGGL(resize_fused_kernel, dim3((unsigned)(planes * tiles_x * tiles_y)), dim3(256), lds, s,
+                           static_cast<const float *>(src), static_cast<float *>(dst), (int)h_out, (int)w_out, (int)w_in, toh,
+                           (int)tiles_x, (int)tiles_y, fw, fh);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+    }
     hipLaunchKernelGGL(resize_width_kernel, dim3(stream_grid(planes * h_in * w_out)), dim3(256), 0, s,
                        static_cast<const float *>(src), tmp, planes * h_in, (int)w_out, fw);
     hipLaunchKernelGGL(resize_height_kernel, dim3(stream_grid(planes * h_out * w_out)), dim3(256), 0, s,

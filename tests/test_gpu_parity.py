@@ -532,3 +532,20 @@ def test_fused_tile_gradients_and_material_api():
     assert torch.equal(brdf(m1, *args), brdf(m2.tile(2), *args))
     assert m1.materialize_tile().albedo.shape == (3, 2 * h, 2 * w) and m1.lazy_tile == (1, 1)
     assert torch.equal(m1.albedo, m2.albedo)
+
+
+@pytest.mark.parametrize("shape,size", [((3, 300, 500), (37, 41)), ((2, 257, 130), (100, 64)), ((1, 40, 60), (90, 100)),
+                                        ((2, 3, 96, 200), (48, 100)), ((1, 2000, 70), (9, 70)), ((1, 33, 1000), (33, 130))])
+@pytest.mark.parametrize("antialias", [True, False])
+def test_resize_fused_and_two_pass_forms_against_aten(shape, size, antialias):
+    """Both schedules of pbr_resize_bilinear (LDS-fused tile kernel; two-pass for extreme down-scales) against the
+    op the reference ends up in: torch.nn.functional.interpolate(bilinear, align_corners=False, antialias) on CPU."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(sum(shape) + size[0])
+    x = torch.rand(*shape, generator=g)
+    ref = torch.nn.functional.interpolate(x if x.dim() == 4 else x[None], size=size, mode="bilinear", align_corners=False,
+                                          antialias=antialias)
+    ref = ref if x.dim() == 4 else ref[0]
+    got = F.resize(x.cuda(), size, antialias=antialias).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-6

@@ -62,7 +62,27 @@ __device__ __forceinline__ f32x2 rsq(f32x2 x) { return f32x2{rsq(x.x), rsq(x.y)}
 __device__ __forceinline__ f32x2 sqrt_hw(f32x2 x) { return f32x2{sqrt_hw(x.x), sqrt_hw(x.y)}; }
 __device__ __forceinline__ f32x2 log2_hw(f32x2 x) { return f32x2{log2_hw(x.x), log2_hw(x.y)}; }
 __device__ __forceinline__ f32x2 exp2_hw(f32x2 x) { return f32x2{exp2_hw(x.x), exp2_hw(x.y)}; }
-__device__ __forceinline__ f32x2 clamp01(f32x2 x) { return f32x2{clamp01(x.x), clamp01(x.y)}; }
+// Packed fp32 has no min/max/med3, but VOP3P carries the clamp output modifier ([0,1] saturation): one packed
+// instruction clamps two pixels, and where the value to clamp is a product or an fma the clamp rides on it for free.
+// The compiler does not form these (it sees two scalar med3), hence the inline assembly (verified on MI355X against
+// fminf(fmaxf(x,0),1) over sign, range and both halves).
+__device__ __forceinline__ f32x2 clamp01(f32x2 x) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, 1.0 op_sel_hi:[1,0] clamp" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ f32x2 mul_sat(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 fma_sat(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float mul_sat(float a, float b) { return clamp01(a * b); }          // v_mul_f32 ... clamp
+__device__ __forceinline__ float fma_sat(float a, float b, float c) { return clamp01(fmaf(a, b, c)); }
 __device__ __forceinline__ f32x2 fma_(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 max_(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
 __device__ __forceinline__ f32x2 min_(f32x2 a, f32x2 b) { return f32x2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
@@ -85,7 +105,7 @@ template <class R> __device__ __forceinline__ R srgb_to_linear(R x) {
 // utils/functions.py:50-66; `c` must already be in [0,1] (callers clamp).
 template <class R> __device__ __forceinline__ R linear_to_srgb_unit(R c) {
     const R lo = c * 12.92f;
-    const R hi = clamp01(fma_(splat<R>(1.055f), exp2_hw(log2_hw(c) * (1.0f / 2.4f)), splat<R>(-0.055f)));   // clamp = output modifier
+    const R hi = fma_sat(splat<R>(1.055f), exp2_hw(log2_hw(c) * (1.0f / 2.4f)), splat<R>(-0.055f));   // clamp = output modifier
     return select_(le_(c, splat<R>(0.0031308f)), lo, hi);                            // lo <= 0.0405 needs none
 }
 template <class R> __device__ __forceinline__ R linear_to_srgb(R x) { return linear_to_srgb_unit(clamp01(x)); }
@@ -94,6 +114,10 @@ template <class R> struct Vec3T { R x, y, z; };
 using Vec3 = Vec3T<float>;
 template <class R> __device__ __forceinline__ R dot(const Vec3T<R> &a, const Vec3T<R> &b) {
     return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x));
+}
+// a.b + c with c seeding the fma chain: the "+ tiny" that keeps rsq finite on a zero vector costs nothing
+template <class R> __device__ __forceinline__ R dot_plus(const Vec3T<R> &a, const Vec3T<R> &b, float c) {
+    return fma_(a.z, b.z, fma_(a.y, b.y, fma_(a.x, b.x, splat<R>(c))));
 }
 template <class R> __device__ __forceinline__ R dotu(const Vec3T<R> &a, const Vec3 &b) {   // b wave-uniform
     return fma_(a.z, splat<R>(b.z), fma_(a.y, splat<R>(b.y), a.x * b.x));
@@ -117,22 +141,24 @@ template <class R> __device__ __forceinline__ R pow5(R x) { const R x2 = x * x; 
 // Point light (:129-140): surface point (xs, -ys, 0); ys is the lane's row, shared by its pixels.
 //   dist = sqrt(dd) and 1/(dist + 1e-7) come from ONE v_rsq: r = rsq(dd), dist = dd r,
 //   1/(dist + 1e-7) = r / (1 + 1e-7 r) = r (1 - 1e-7 r) + O((1e-7 r)^2) -- exact to 1e-8 relative for any
-//   light further than 1e-3 from the surface point (dd is clamped at 1e-12 so that a light sitting
-//   exactly on a pixel gives L = 0 like the reference instead of NaN).
+//   light further than 1e-3 from the surface point.  dist^2 carries + 1e-12 and |h|^2 + 1e-24, seeded into their
+//   fma chains (below one ulp for any distance above 4e-3 / any |h| above 4e-9): r stays <= 1e6, so a light sitting
+//   exactly on a pixel, or L = -V, give L = 0 / a zero half vector like the reference's F.normalize instead of
+//   NaN.  (They replace max(., tiny): packed fp32 has no max, and the seed is free.)
 template <class R>
 __device__ __forceinline__ LightGeomT<R> point_light_geom(const Vec3 &V, const Vec3 &Lpos, R xs, float ys) {
     LightGeomT<R> g;
     const Vec3T<R> d = {splat<R>(Lpos.x) - xs, splat<R>(Lpos.y + ys), splat<R>(Lpos.z)};
-    const R dd = max_(dot(d, d), splat<R>(1e-12f));                 // dist^2, torch.norm :138
+    const R dd = dot_plus(d, d, 1e-12f);                            // dist^2, torch.norm :138
     const R r = rsq(dd);
     const R rinv = r * fma_(splat<R>(-1e-7f), r, splat<R>(1.0f));   // 1/(dist + 1e-7)  :139
     g.d = d; g.rinv = rinv;
     g.L = {d.x * rinv, d.y * rinv, d.z * rinv};
     g.att = rcp(dd + 1e-7f);                                        // :140
     g.h = {fma_(d.x, rinv, splat<R>(V.x)), fma_(d.y, rinv, splat<R>(V.y)), fma_(d.z, rinv, splat<R>(V.z))};   // :155
-    const R rh = rsq(max_(dot(g.h, g.h), splat<R>(1e-24f)));
+    const R rh = rsq(dot_plus(g.h, g.h, 1e-24f));
     g.rhh = rh * rh;
-    g.p5 = pow5(splat<R>(1.0f) - clamp01(dotu(g.h, V) * rh));        // :156-158, :196
+    g.p5 = pow5(splat<R>(1.0f) - mul_sat(dotu(g.h, V), rh));         // :156-158, :196
     g.om5 = splat<R>(1.0f) - g.p5;
     return g;
 }
@@ -157,7 +183,7 @@ using PixelTerms = PixelTermsT<float>;
 template <class R>
 __device__ __forceinline__ void pixel_terms(const Vec3T<R> &n, const Vec3 &V, R rough, const R base[3], const R f0[3],
                                             R kd_scale, PixelTermsT<R> &t) {
-    const R rn = rsq(max_(dot(n, n), splat<R>(1e-24f)));
+    const R rn = rsq(dot_plus(n, n, 1e-24f));
     t.n = {n.x * rn, n.y * rn, n.z * rn};
     t.ndv_raw = dotu(t.n, V);
     t.ndv = clamp01(t.ndv_raw);
@@ -186,17 +212,24 @@ __device__ __forceinline__ R ggx_den(const PixelTermsT<R> &t, const LightGeomT<R
     return select_(nh_pos, fma_(s2, splat<R>(1.0f) - t.a2, t.a2), splat<R>(1.0f));
 }
 
+// The forward kernels' form: no N.H > 0 select and no clamp of sin^2 at 1.  N.h = N.L + N.V <= 0 means that N.L or
+// N.V is <= 0, so its clamp is 0 and the specular term a2 NdotV NdotL / (...) is exactly 0 whatever D is; and
+// sin^2 <= 1 + 1e-7 keeps den finite and positive.  Two compare/select pairs and a min per light evaluation less.
+template <class R>
+__device__ __forceinline__ R ggx_den_fwd(const PixelTermsT<R> &t, const LightGeomT<R> &g, R nh) {
+    const Vec3T<R> p = {fma_(-nh, t.n.x, g.h.x), fma_(-nh, t.n.y, g.h.y), fma_(-nh, t.n.z, g.h.z)};
+    return fma_(dot(p, p) * g.rhh, splat<R>(1.0f) - t.a2, t.a2);
+}
+
 template <class R> struct MaskOf { using type = bool; };
 template <> struct MaskOf<f32x2> { using type = i32x2; };
 
 // One light's linear RGB contribution, clamped to [0,1] (:160-177).  `inten` is wave-uniform.
 template <class R>
 __device__ __forceinline__ void shade_light(const PixelTermsT<R> &t, const LightGeomT<R> &g, const float inten[3], R out[3]) {
-    const R ndl_raw = dot(t.n, g.d) * g.rinv;
-    const R ndl = clamp01(ndl_raw);                                // :164
-    R s2;
-    typename MaskOf<R>::type nh_pos;
-    const R den = ggx_den(t, g, ndl_raw + t.ndv_raw, s2, nh_pos);
+    const R nd = dot(t.n, g.d);
+    const R ndl = mul_sat(nd, g.rinv);                             // clamp(N.L) :164
+    const R den = ggx_den_fwd(t, g, fma_(nd, g.rinv, t.ndv_raw));  // N.h = N.L + N.V
     // D * G / (4 NdotV NdotL + 1e-7) with one reciprocal (:217, :232-235, :165-166); D's pi sits in a2ndv_pi.
     const R dl = fma_(ndl, t.omk, t.kk);
     const R dD = fma_(den, den, splat<R>(1e-7f * kInvPi));
@@ -207,7 +240,7 @@ __device__ __forceinline__ void shade_light(const PixelTermsT<R> &t, const Light
     for (int ch = 0; ch < 3; ++ch) {
         const R F = fma_(t.f0[ch], g.om5, g.p5);                   // :196
         // F dg + (1 - F) kb  ==  kb + F (dg - kb)                    (:166, :169-174)
-        out[ch] = clamp01(fma_(F, dg - t.kb[ch], t.kb[ch]) * (rad * inten[ch]));   // :175-177
+        out[ch] = mul_sat(fma_(F, dg - t.kb[ch], t.kb[ch]), rad * inten[ch]);      // :175-177
     }
 }
 

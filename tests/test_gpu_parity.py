@@ -549,3 +549,32 @@ def test_resize_fused_and_two_pass_forms_against_aten(shape, size, antialias):
     got = F.resize(x.cuda(), size, antialias=antialias).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize("light_type,size", [("directional", None), ("point", 1.5)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+@pytest.mark.parametrize("workflow", ["metallic", "specular"])
+def test_several_lights_every_light_type_and_storage(light_type, size, dtype, workflow):
+    """The packed-math light loop (two pixels per instruction, clamp riding on v_pk_mul/fma) for both light types,
+    both workflows and both map storages against the oracle's composition of single-light reference evaluations
+    (H12: per-light clamp, sum, clamp, encode once).  Includes lights behind the surface and a grazing view."""
+    import torch_oracle as O
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(31)
+    B, H, W = 2, 18, 44
+    a = torch.rand(B, 3, H, W, generator=g)
+    n = torch.cat([(torch.rand(B, 2, H, W, generator=g) - 0.5) * 1.6, torch.ones(B, 1, H, W)], 1)
+    r = torch.rand(B, 1, H, W, generator=g) * 0.8 + 0.2
+    m = torch.rand(B, 1, H, W, generator=g)
+    s = torch.rand(B, 3, H, W, generator=g)
+    q = lambda t: t.to(dtype).float()                                  # the oracle sees exactly the stored values
+    lights = torch.tensor([[0.3, 0.2, 0.8], [-0.4, 0.1, 0.6], [0.0, -0.5, -0.3], [0.9, 0.9, 0.05]])
+    inten = torch.tensor([[0.6, 0.5, 0.4], [0.3, 0.3, 0.5], [0.4, 0.4, 0.4], [0.2, 0.1, 0.3]])
+    view = torch.tensor([0.3, -0.1, 0.6])
+    second = dict(metallic=q(m)) if workflow == "metallic" else dict(specular=q(s))
+    ref = O.cook_torrance_batched(q(a), q(n), q(r), lights=lights, intensities=inten, view=view, light_type=light_type,
+                                  light_size=size, **second)
+    dev = lambda t: t.to(dtype).cuda()
+    out = F.cook_torrance(dev(a), dev(n), dev(r), dev(m) if workflow == "metallic" else None, dev(s) if workflow == "specular" else None,
+                          view_dir=view, light=lights, light_intensity=inten, light_type=light_type, light_size=size)
+    assert out.dtype == torch.float32 and (out.cpu() - ref).abs().max().item() <= TOL

@@ -19,6 +19,8 @@ for pass in FETCH_SIZE WRITE_SIZE; do
 done
 timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
     --output-format csv -d "$OUT/pmc_SQ" -o run -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/pmc_SQ.log" 2>&1
+timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
+    --output-format csv -d "$OUT/pmc_SQ16" -o run -- python3 "$R/tools/run_multilight.py" 4 > "$OUT/pmc_SQ16.log" 2>&1
 cd "$R"
 timeout 500 python3 tools/bench_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
 cat "$OUT/configs.jsonl"

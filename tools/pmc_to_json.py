@@ -12,13 +12,18 @@ NAME = "ct_point_metallic_f32_f32_v4"
 PIXELS, BPP = 4096 * 4096, 44
 
 
-def per_dispatch(root, pass_name):
+MULTI_KERNEL = "cook_torrance_kernel<1, 0, __half, float, 4, true, true>"
+MULTI_NAME = "ct_point_metallic_f16_f32_v4_multi"
+
+
+def per_dispatch(root, pass_name, kernel=None):
     """counter -> list of per-dispatch values (rows of one dispatch are summed: one row per XCD/instance)."""
+    kernel = kernel or KERNEL
     vals, dur = {}, []
     for path in glob.glob(f"{root}/pmc_{pass_name}/**/*counter_collection.csv", recursive=True):
         acc = {}
         for row in csv.DictReader(open(path)):
-            if KERNEL not in row["Kernel_Name"]:
+            if kernel not in row["Kernel_Name"]:
                 continue
             key = (row["Dispatch_Id"], row["Counter_Name"])
             acc[key] = acc.get(key, 0.0) + float(row["Counter_Value"])
@@ -48,7 +53,18 @@ def main():
         "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
         "algorithmic_bytes_per_launch": PIXELS * BPP, "ratio_traffic_to_algorithmic": round((rd + wr) / (PIXELS * BPP), 4),
     }
+    out = {NAME: rec}
     if sq:
+        rec["sq_counters_third_pass"] = sq_summary(sq, sq_us)
+    sq16, sq16_us = per_dispatch(root, "SQ16", MULTI_KERNEL)
+    if sq16:
+        out[MULTI_NAME] = {"workload": "tools/run_multilight.py: 4 x 4096x4096 fp16 maps, 16 point lights, fp32 out (BASELINE.json configs[4] per-GPU share)",
+                           "sq_counters": sq_summary(sq16, sq16_us)}
+    print(json.dumps(out, indent=1))
+
+
+def sq_summary(sq, sq_us):
+    if True:
         m = {k: statistics.mean(v) for k, v in sq.items()}
         us = statistics.median(sq_us) if sq_us else None
         third = {"median_dispatch_us_under_counters": round(us, 1) if us else None}
@@ -64,8 +80,7 @@ def main():
                 third["valu_busy_fraction"] = round(4 * m["SQ_ACTIVE_INST_VALU"] / (1024 * cycles), 3)
             if "SQ_WAVE_CYCLES" in m:
                 third["mean_resident_waves_per_cu"] = round(4 * m["SQ_WAVE_CYCLES"] / (256 * cycles), 2)
-        rec["sq_counters_third_pass"] = third
-    print(json.dumps({NAME: rec}, indent=1))
+        return third
 
 
 if __name__ == "__main__":

@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", choices=("separate", "arena"), default="arena",
+                    help="arena (default): the material's maps and result in one allocation, as Material.to(device) lays "
+                         "them out (F.pack_maps); separate: five tensors as torch's allocator places them")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--cpu-passes", type=int, default=4)
     args = ap.parse_args()
@@ -134,9 +137,13 @@ def main():
     plans = []
     for i in range(N_BUFFER_SETS):
         a, n, r, m = synth_material(args.size, device, 1234 + rank * 16 + i)
+        out = None
+        if args.layout == "arena":      # the maps of a material and its result in ONE allocation (F.pack_maps)
+            a, n, r, m, out = F.pack_maps(a, n, r, m, reserve_output=True)
+            out = out.unsqueeze(0)
         plans.append(F.plan_cook_torrance(a, n, r, m, view_dir=params["view_dir"], light=params["light"],
                                           light_intensity=params["light_intensity"], light_type="point",
-                                          light_size=params["light_size"]))
+                                          light_size=params["light_size"], out=out))
     kernel = plans[0].kernel_name
     bpp = plans[0].bytes_per_pixel
     pixels = args.size * args.size
@@ -181,7 +188,11 @@ def main():
             "config": {"workload": f"Batch=1 {args.size}x{args.size} BasecolorMetallicMaterial per GPU, point light, "
                                    f"fused HIP kernel, fp32 maps, sRGB in/out (BASELINE.json configs[1])",
                        "kernel": kernel, "pixels_per_launch": pixels, "bytes_per_pixel": bpp,
-                       "parallelism": f"material-sharded x{world}"},
+                       "parallelism": f"material-sharded x{world}",
+                       "layout": "arena: the 8 map planes of a material and its 3 result planes in one allocation "
+                                 "(pypbr_amd.functional.pack_maps, what Material.to(device) does)"
+                                 if args.layout == "arena" else "separate: albedo, normal, roughness, metallic and the result as "
+                                                                "five tensors wherever torch's allocator put them"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(kernel),
                          "kernel_us": round(kernel_ms * 1e3, 2)},

@@ -407,6 +407,41 @@ def diffuse_specular_to_basecolor_metallic(diffuse: torch.Tensor, specular: torc
     return base, met
 
 
+def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool = False):
+    """Copies the maps of ONE material into a single device allocation and returns views of it (same shapes,
+    dtypes and values; `None` stays `None`).  Pure data movement (torch copies), no arithmetic.  Why: a launch
+    streams all planes of a material at once, and planes that live in one allocation sit close together in the
+    address space; `reserve_output=True` also appends room for the (3,H,W) fp32 result and returns it last, so
+    that `out=` can be placed next to its inputs.  See DESIGN.md, "Data layout in HBM", for the measurements."""
+    present = [t for t in maps if t is not None]
+    if not present:
+        return tuple(maps) + ((None,) if reserve_output else ())
+    dev = torch.device(device) if device is not None else present[0].device
+
+    def padded(nbytes):                                  # every map starts 256-byte aligned
+        return -(-nbytes // 256) * 256
+    sizes = [0 if t is None else padded(t.numel() * t.element_size()) for t in maps]
+    out_shape, out_bytes = None, 0
+    if reserve_output:
+        out_shape = tuple(present[0].shape[:-3]) + (3,) + tuple(present[0].shape[-2:])
+        out_bytes = 4
+        for n in out_shape:
+            out_bytes *= n
+    arena = torch.empty(sum(sizes) + padded(out_bytes), dtype=torch.uint8, device=dev)
+    views, off = [], 0
+    for t, nbytes in zip(maps, sizes):
+        if t is None:
+            views.append(None)
+            continue
+        v = arena[off:off + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+        v.copy_(t)
+        views.append(v)
+        off += nbytes
+    if reserve_output:
+        views.append(arena[off:off + out_bytes].view(torch.float32).view(out_shape))
+    return tuple(views)
+
+
 def resize(texture: torch.Tensor, size, antialias: bool = True) -> torch.Tensor:
     """MaterialBase.resize for one map (base.py:490-504 -> torchvision resize of a float tensor):
     bilinear, align_corners=False, optional antialiasing.  `size` = (h, w), or an int that fixes the

@@ -349,3 +349,21 @@ def test_lazy_blend_and_lazy_tile_protocol_on_the_host():
     assert t.lazy_tile == (3, 3) and t.size == (3 * H, 3 * W) and t._maps["albedo"].shape == (3, H, W)
     assert t.tile(2, lazy=True).lazy_tile == (6, 6)
     assert t.materialize_tile().albedo.shape == (3, 6 * H, 6 * W) and t.lazy_tile == (1, 1)     # torch.repeat: indexing only
+
+
+def test_pack_maps_layout_on_the_host():
+    """functional.pack_maps is data movement only, so its layout logic runs on the CPU too: same values, one
+    allocation, 256-byte aligned maps, optional room for the result right behind them."""
+    g = torch.Generator().manual_seed(1)
+    a, r, m = torch.rand(3, 7, 9, generator=g), torch.rand(1, 7, 9, generator=g), torch.rand(1, 7, 9, generator=g).half()
+    pa, pn, pr, pm, out = F.pack_maps(a, None, r, m, reserve_output=True)
+    assert pn is None and torch.equal(pa, a) and torch.equal(pr, r) and torch.equal(pm, m) and pm.dtype == torch.float16
+    assert out.shape == (3, 7, 9) and out.dtype == torch.float32 and out.is_contiguous()
+    base = pa.untyped_storage().data_ptr()
+    assert all(t.untyped_storage().data_ptr() == base for t in (pr, pm, out))            # ONE allocation
+    assert all((t.data_ptr() - base) % 256 == 0 for t in (pa, pr, pm, out))
+    assert pa.data_ptr() < pr.data_ptr() < pm.data_ptr() < out.data_ptr()
+    b = torch.rand(2, 3, 4, 8, generator=g)
+    pb, ob = F.pack_maps(b, reserve_output=True)
+    assert ob.shape == (2, 3, 4, 8) and torch.equal(pb, b)
+    assert F.pack_maps(None, None) == (None, None)

@@ -578,3 +578,24 @@ def test_several_lights_every_light_type_and_storage(light_type, size, dtype, wo
     out = F.cook_torrance(dev(a), dev(n), dev(r), dev(m) if workflow == "metallic" else None, dev(s) if workflow == "specular" else None,
                           view_dir=view, light=lights, light_intensity=inten, light_type=light_type, light_size=size)
     assert out.dtype == torch.float32 and (out.cpu() - ref).abs().max().item() <= TOL
+
+
+def test_material_to_device_packs_maps_into_one_allocation(golden):
+    from pypbr_amd import functional as F
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    from pypbr_amd.models import CookTorranceBRDF
+    z = golden("rand64")
+    a, n, r, m = (torch.from_numpy(z[k]) for k in ("in_albedo", "in_normal", "in_roughness", "in_metallic"))
+    mat = BasecolorMetallicMaterial(albedo=a, roughness=r, metallic=m)
+    mat._maps["normal"] = n
+    mat.to("cuda")
+    maps = [mat._maps[k] for k in ("albedo", "roughness", "metallic", "normal")]
+    assert all(t.is_cuda for t in maps) and len({t.untyped_storage().data_ptr() for t in maps}) == 1
+    assert torch.equal(mat.albedo.cpu(), a) and torch.equal(mat.normal.cpu(), n)
+    out = CookTorranceBRDF("point")(mat, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0]), 1.0)
+    assert np.abs(out.cpu().numpy() - z["out_metallic_pt1_srgb"]).max() <= TOL
+    # the result can live in the same allocation
+    pa, pn, pr, pm, res = F.pack_maps(a, n, r, m, device="cuda", reserve_output=True)
+    got = F.cook_torrance(pa, pn, pr, pm, view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_size=1.0,
+                          out=res.unsqueeze(0))
+    assert got.data_ptr() == res.data_ptr() and torch.equal(got.cpu(), out.cpu())

@@ -169,7 +169,8 @@ class MaterialBase:
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
         maps = self._maps
         names = [k for k, t in maps.items() if t is not None]
-        if self.device.type == "cuda" and names and any(maps[k].device != self.device for k in names):
+        if (self.device.type == "cuda" and names and any(maps[k].device != self.device for k in names)
+                and not any(maps[k].requires_grad for k in names)):
             for k, v in zip(names, F_.pack_maps(*[maps[k] for k in names], device=self.device)):
                 maps[k] = v
         else:

@@ -89,8 +89,14 @@ class CookTorranceBRDF(BRDFModel):
         def dev(t):
             return None if t is None else t.to(compute)
 
+        maps = (albedo, normal, roughness, metallic, specular)
+        if any(t is not None and t.device != compute for t in maps):
+            if any(t is not None and t.requires_grad for t in maps):
+                maps = tuple(dev(t) for t in maps)               # differentiable copies
+            else:
+                maps = F_.pack_maps(*maps, device=compute)       # staged maps land in one allocation
         color = F_.cook_torrance(
-            dev(albedo), dev(normal), dev(roughness), dev(metallic), dev(specular),
+            *maps,
             view_dir=view_dir, light=light_dir_or_position, light_intensity=light_intensity,
             light_type=self.light_type, light_size=light_size,
             albedo_is_srgb=bool(material.albedo_is_srgb), specular_is_srgb=specular_is_srgb,

@@ -31,6 +31,7 @@ ap.add_argument("--light", type=str, default="point")
 ap.add_argument("--lights", type=int, default=1)
 ap.add_argument("--dtype", type=str, default="float32")
 ap.add_argument("--altlib", type=str, default="")
+ap.add_argument("--arena", action="store_true", help="maps of a set + its result in one allocation (F.pack_maps)")
 ap.add_argument("--linear", action="store_true", help="maps already linear, linear output: no sRGB transcendental work")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -56,7 +57,13 @@ else:
 kw = dict(view_dir=[0, 0, 1], light=light, light_intensity=inten, light_type=args.light, light_size=1.0)
 if args.linear:
     kw.update(albedo_is_srgb=False, return_srgb=False)
-plans = [F.plan_cook_torrance(*s, **kw) for s in sets]
+if args.arena:
+    plans = []
+    for s in sets:
+        *packed, out = F.pack_maps(*s, reserve_output=True)
+        plans.append(F.plan_cook_torrance(*packed, out=out, **kw))
+else:
+    plans = [F.plan_cook_torrance(*s, **kw) for s in sets]
 stream = torch.cuda.current_stream(dev).cuda_stream
 configs = [dict(kv.split("=") for kv in c.split(",")) for c in args.configs.split(";")]
 

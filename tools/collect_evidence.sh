@@ -12,7 +12,7 @@ cd /tmp
 timeout 400 python3 "$R/bench.py" > "$OUT/bench.json" 2> "$OUT/bench.err"
 cat "$OUT/bench.json"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- \
-    python3 "$R/bench.py" --steps 200 --warmup 20 --no-cpu-baseline > "$OUT/trace.log" 2>&1
+    python3 "$R/bench.py" --no-cpu-baseline > "$OUT/trace.log" 2>&1
 for pass in FETCH_SIZE WRITE_SIZE; do
     timeout 200 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$pass" -o run -- \
         python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/pmc_$pass.log" 2>&1

@@ -109,6 +109,10 @@ typedef struct pbr_render_desc {
                                      = ((y_offset + y) mod map_height, x mod map_width).  The point-light grid spans
                                      the OUTPUT, as it does after the reference's tile().  0/0: maps are output-sized */
     int32_t reserved;             /* 0 */
+    int64_t out_batch_stride;     /* elements between the results of consecutive materials; 0 = 3 * height * width */
+    int64_t out_channel_stride;   /* elements between the result's channel planes; 0 = height * width (contiguous).
+                                     Rows are always contiguous.  Lets the result of material b sit right behind its
+                                     maps ("material-major" batches) */
 } pbr_render_desc;
 
 #define PBR_SCHEDULE_AUTO 0

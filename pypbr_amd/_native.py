@@ -49,6 +49,7 @@ class RenderDesc(ctypes.Structure):
         ("lights", (ctypes.c_float * 3) * MAX_LIGHTS), ("intensities", (ctypes.c_float * 3) * MAX_LIGHTS),
         ("schedule", ctypes.c_int32), ("map_height", ctypes.c_int32), ("map_width", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
+        ("out_batch_stride", ctypes.c_int64), ("out_channel_stride", ctypes.c_int64),
     ]
 
 

@@ -69,6 +69,8 @@ static int validate(const pbr_render_desc *d) {
         return PBR_ERR_DTYPE;
     if (d->map_dtype == PBR_F32 && d->out_dtype == PBR_F16) return PBR_ERR_DTYPE;   // not built
     if (d->schedule < PBR_SCHEDULE_AUTO || d->schedule > PBR_SCHEDULE_XCD(12)) return PBR_ERR_SHAPE;
+    if (d->out_batch_stride < 0 || d->out_channel_stride < 0) return PBR_ERR_SHAPE;
+    if (d->out_channel_stride && d->out_channel_stride < (int64_t)d->height * d->width) return PBR_ERR_SHAPE;
     if (d->map_height || d->map_width) {             // tiled maps: whole repeats only
         if (d->map_height < 1 || d->map_width < 1 || d->height_total % d->map_height || d->width % d->map_width)
             return PBR_ERR_SHAPE;
@@ -98,6 +100,7 @@ static int pick_vec(const pbr_render_desc *d) {
         !ok(d->metallic, esz_in, false) || !ok(d->specular, esz_in, true))
         return 1;
     if (reinterpret_cast<uintptr_t>(d->out) & (esz_out == 4 ? 15u : 7u)) return 1;
+    if (d->out_batch_stride % 8 || d->out_channel_stride % 8) return 1;      // 0 (contiguous) passes
     // fp16 maps, ONE light (HBM-bound): 8 pixels per lane keep the loads 16 bytes wide.  With several
     // lights the kernel is VALU-bound and the 4-pixel body's lower register count wins.
     if (esz_in == 2 && d->width % 8 == 0 && (!tiled || d->map_width % 8 == 0) && d->n_lights == 1 && g_f16_vec == 8) {
@@ -140,7 +143,8 @@ static void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     k.n_bs = d->normal.batch_stride; k.n_cs = d->normal.channel_stride;
     k.r_bs = d->roughness.batch_stride; k.m_bs = d->metallic.batch_stride;
     k.s_bs = d->specular.batch_stride; k.s_cs = d->specular.channel_stride;
-    k.o_cs = (int64_t)d->height * d->width; k.o_bs = 3 * k.o_cs;
+    k.o_cs = d->out_channel_stride ? d->out_channel_stride : (int64_t)d->height * d->width;
+    k.o_bs = d->out_batch_stride ? d->out_batch_stride : 3 * k.o_cs;
     k.rows = d->batch * d->height; k.H = d->height; k.W = d->width;
     k.wv = d->width / vec;
     k.bt_log2 = g_block_log2 < 6 ? 6 : (g_block_log2 > 8 ? 8 : g_block_log2);
@@ -365,6 +369,7 @@ int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, v
     KArgs k;
     fill_args(d, vec, k);
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+    k.o_cs = (int64_t)d->height * d->width; k.o_bs = 3 * k.o_cs;     // grad_out and the g_* are contiguous, whatever `out` was
     const BArgs b = {grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular};
     const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
     void (*fn)(const KArgs, const BArgs) = nullptr;

@@ -133,6 +133,9 @@ def build_descriptor(albedo, normal, roughness, metallic, specular, out, *, view
     d.albedo, d.normal, d.roughness = _pbr_map(albedo), _pbr_map(normal), _pbr_map(roughness)
     d.metallic, d.specular = _pbr_map(metallic), _pbr_map(specular)
     d.out = out.data_ptr()
+    if out.dim() == 4 and not out.is_contiguous():      # rows contiguous (checked by the caller); planes / materials strided
+        d.out_batch_stride = out.stride(0) if out.shape[0] > 1 else 0
+        d.out_channel_stride = out.stride(1)
     v = _host_vec3(view_dir)
     for c in range(3):
         d.view_dir[c] = v[c]
@@ -234,8 +237,11 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
         raise ValueError("`rows` selects a band of a tiled map; without `tile` pass the band's own maps")
     if out is None:
         out = torch.empty((B, 3, H, W), dtype=out_dtype or torch.float32, device=a.device)
-    elif tuple(out.shape[-3:]) != (3, H, W) or not out.is_contiguous() or out.device != a.device:
-        raise ValueError("out must be a contiguous [B,3,H,W] tensor on the maps' device")
+    elif (tuple(out.shape[-3:]) != (3, H, W) or out.device != a.device or out.stride(-1) != 1 or out.stride(-2) != W
+          or (out.dim() == 4 and out.shape[0] != B) or out.dim() not in (3, 4)):
+        raise ValueError("out must be a [B,3,H,W] tensor with contiguous rows on the maps' device")
+    if out.dim() == 3:
+        out = out.unsqueeze(0)
     desc = build_descriptor(a, n, r, m, s, out, view_dir=view_dir, light=light, light_intensity=light_intensity,
                             light_type=light_type, light_size=light_size, albedo_is_srgb=albedo_is_srgb,
                             specular_is_srgb=specular_is_srgb, return_srgb=return_srgb,
@@ -407,12 +413,15 @@ def diffuse_specular_to_basecolor_metallic(diffuse: torch.Tensor, specular: torc
     return base, met
 
 
-def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool = False):
-    """Copies the maps of ONE material into a single device allocation and returns views of it (same shapes,
-    dtypes and values; `None` stays `None`).  Pure data movement (torch copies), no arithmetic.  Why: a launch
+def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool = False, material_major: bool = False):
+    """Copies the maps of a material (or of a batch) into a single device allocation and returns views of it (same
+    shapes, dtypes and values; `None` stays `None`).  Pure data movement (torch copies), no arithmetic.  Why: a launch
     streams all planes of a material at once, and planes that live in one allocation sit close together in the
-    address space; `reserve_output=True` also appends room for the (3,H,W) fp32 result and returns it last, so
-    that `out=` can be placed next to its inputs.  See DESIGN.md, "Data layout in HBM", for the measurements."""
+    address space; `reserve_output=True` also appends room for the fp32 result and returns it last, so that `out=`
+    can be placed next to its inputs.  `material_major=True` (batched [B,C,H,W] maps): material b's planes and its
+    result next to each other, materials one pitch apart -- strided views, which the C ABI takes as they are.  It
+    is an option, not the default: measured 3-4 % ahead for 16 x 4096^2, level for 64 x 2048^2, 2-5 % behind for
+    64 x 1024^2 (tools/batch_layout_probe.py).  See DESIGN.md, "Data layout in HBM", for the measurements."""
     present = [t for t in maps if t is not None]
     if not present:
         return tuple(maps) + ((None,) if reserve_output else ())
@@ -420,6 +429,9 @@ def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool =
 
     def padded(nbytes):                                  # every map starts 256-byte aligned
         return -(-nbytes // 256) * 256
+    batch = max([t.shape[0] for t in present if t.dim() == 4] or [1])
+    if batch > 1 and material_major:
+        return _pack_material_major(maps, batch, dev, reserve_output, padded)
     sizes = [0 if t is None else padded(t.numel() * t.element_size()) for t in maps]
     out_shape, out_bytes = None, 0
     if reserve_output:
@@ -439,6 +451,39 @@ def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool =
         off += nbytes
     if reserve_output:
         views.append(arena[off:off + out_bytes].view(torch.float32).view(out_shape))
+    return tuple(views)
+
+
+def _pack_material_major(maps, batch, dev, reserve_output, padded):
+    """Batched maps [B,C,H,W]: material b's planes (and its result) next to each other, materials one pitch apart.
+    The views keep their [B,C,H,W] shapes; only the batch stride differs from a free-standing tensor, which the C ABI
+    takes per map.  Maps shared by the whole batch ([1,C,H,W]) are stored once, behind the materials."""
+    per_material = [t for t in maps if t is not None and t.dim() == 4 and t.shape[0] == batch]
+    if any(t is not None and not (t.dim() == 4 and t.shape[0] in (1, batch)) for t in maps):
+        raise ValueError("batched maps must all be [B,C,H,W] or [1,C,H,W]")
+    h, w = per_material[0].shape[-2:]
+    pitch = sum(padded(t[0].numel() * t.element_size()) for t in per_material)
+    out_bytes = padded(3 * h * w * 4) if reserve_output else 0
+    pitch += out_bytes
+    shared_bytes = sum(padded(t.numel() * t.element_size()) for t in maps if t is not None and t.shape[0] == 1)
+    arena = torch.empty(batch * pitch + shared_bytes, dtype=torch.uint8, device=dev)
+    views, off, shared_off = [], 0, batch * pitch
+    for t in maps:
+        if t is None:
+            views.append(None)
+            continue
+        es, plane = t.element_size(), t.shape[-2] * t.shape[-1]
+        typed = arena.view(t.dtype)
+        if t.shape[0] == 1:
+            v = typed.as_strided(tuple(t.shape), (t[0].numel(), plane, t.shape[-1], 1), shared_off // es)
+            shared_off += padded(t.numel() * es)
+        else:
+            v = typed.as_strided(tuple(t.shape), (pitch // es, plane, t.shape[-1], 1), off // es)
+            off += padded(t[0].numel() * es)
+        v.copy_(t)
+        views.append(v)
+    if reserve_output:
+        views.append(arena.view(torch.float32).as_strided((batch, 3, h, w), (pitch // 4, h * w, w, 1), off // 4))
     return tuple(views)
 
 

@@ -129,6 +129,12 @@ def test_validation_codes_without_a_device():
     assert lib.pbr_bytes_per_pixel(ctypes.byref(d)) == 12 + 6    # 32 B of texels shared by 6 repeats, rounded up
     with pytest.raises(ValueError):
         _desc(out=torch.empty(2, 3, 16, 40), tile=(2, 3))
+    strided = torch.empty(2, 3, 8 + 2, 16)[:, :, :8]                # a result whose planes are 10 rows apart
+    d = _desc(out=strided)
+    assert (d.out_batch_stride, d.out_channel_stride) == (3 * 10 * 16, 10 * 16) and lib.pbr_kernel_name(ctypes.byref(d)) == b"ct_point_metallic_f32_f32_v4"
+    d.out_channel_stride = 8 * 16 - 1                            # planes may not overlap
+    assert lib.pbr_cook_torrance(ctypes.byref(d), None) == N.ERR_SHAPE
+    assert (_desc().out_batch_stride, _desc().out_channel_stride) == (0, 0)
     best = ctypes.c_int32(-1)
     d = _desc(); d.workflow = 7                                  # autotune validates like a launch and needs a result slot
     assert lib.pbr_cook_torrance_autotune(ctypes.byref(d), None, ctypes.byref(best)) == N.ERR_WORKFLOW

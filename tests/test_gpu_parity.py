@@ -599,3 +599,34 @@ def test_material_to_device_packs_maps_into_one_allocation(golden):
     got = F.cook_torrance(pa, pn, pr, pm, view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_size=1.0,
                           out=res.unsqueeze(0))
     assert got.data_ptr() == res.data_ptr() and torch.equal(got.cpu(), out.cpu())
+
+
+def test_strided_result_and_material_major_batches():
+    """The result may be strided (descriptor out_batch_stride / out_channel_stride): pack_maps(material_major=True) puts
+    material b's maps and its result next to each other.  Same values as free-standing contiguous tensors; gradients too."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(51)
+    B, H, W = 3, 20, 48
+    a = torch.rand(B, 3, H, W, generator=g).cuda()
+    n = torch.cat([torch.rand(B, 2, H, W, generator=g) - 0.5, torch.ones(B, 1, H, W)], 1).cuda()
+    r = (torch.rand(1, 1, H, W, generator=g) * 0.8 + 0.2).cuda()            # shared by the batch
+    m = torch.rand(B, 1, H, W, generator=g).cuda()
+    kw = dict(view_dir=[0, 0.1, 1], light=[0.2, -0.1, 0.9], light_intensity=[1, 0.9, 0.8], light_type="point", light_size=1.2)
+    ref = F.cook_torrance(a, n, r, m, **kw)
+    pa, pn, pr, pm, res = F.pack_maps(a, n, r, m, reserve_output=True, material_major=True)
+    assert not pa.is_contiguous() and not res.is_contiguous() and pa.untyped_storage().data_ptr() == res.untyped_storage().data_ptr()
+    got = F.cook_torrance(pa, pn, pr, pm, out=res, **kw)
+    assert got.data_ptr() == res.data_ptr() and torch.equal(got, ref)
+    # a channel-strided result of a single material
+    big = torch.empty(3, H + 5, W, device="cuda")
+    view = big[:, :H]
+    one = F.cook_torrance(a[0], n[0], r[0], m[0], out=view, **kw)
+    assert torch.equal(one, ref[0]) and one.data_ptr() == big.data_ptr()
+    with pytest.raises(ValueError):
+        F.cook_torrance(a[0], n[0], r[0], m[0], out=torch.empty(3, H, W + 4, device="cuda")[:, :, :W], **kw)   # rows not contiguous
+    leaves = [t.clone().requires_grad_(True) for t in (pa, pn, pr, pm)]
+    F.cook_torrance(*leaves, **kw).sum().backward()
+    plain = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
+    F.cook_torrance(*plain, **kw).sum().backward()
+    for x, y in zip(leaves, plain):
+        assert torch.equal(x.grad, y.grad)

@@ -9,7 +9,7 @@ path over that batch = ONE launch of the fused kernel through the C ABI
 its own material (independent materials shard with no data-path collective, weak
 scaling); the light/view parameter block is broadcast once from rank 0 over RCCL.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--no-cpu-baseline] [--layout arena|separate] [--settle 300]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--settle", type=int, default=300, help="untimed clock-settle launches before the warm-up steps")
     ap.add_argument("--layout", choices=("separate", "arena"), default="arena",
                     help="arena (default): the material's maps and result in one allocation, as Material.to(device) lays "
                          "them out (F.pack_maps); separate: five tensors as torch's allocator places them")
@@ -153,7 +154,11 @@ def main():
         if distributed:
             dist.barrier(device_ids=[local_rank])
 
-    for i in range(args.warmup):
+    # Clock settle, then the W warm-up steps.  From an idle GPU the first ~20 launches run at boost clocks, the next
+    # ~150 up to 25 % slower while power management reins them in, and the rate is steady from launch ~300 on
+    # (tools/transient_probe.py: 120, 140, 125, 118, 113, 113 ... us).  The timed region should see the steady state
+    # whatever W the caller picked, so a fixed, untimed pre-roll comes first; it is reported in config.
+    for i in range(args.settle + args.warmup):
         plans[i % N_BUFFER_SETS].launch(stream)
     torch.cuda.synchronize()
     barrier()
@@ -188,7 +193,7 @@ def main():
             "config": {"workload": f"Batch=1 {args.size}x{args.size} BasecolorMetallicMaterial per GPU, point light, "
                                    f"fused HIP kernel, fp32 maps, sRGB in/out (BASELINE.json configs[1])",
                        "kernel": kernel, "pixels_per_launch": pixels, "bytes_per_pixel": bpp,
-                       "parallelism": f"material-sharded x{world}",
+                       "parallelism": f"material-sharded x{world}", "clock_settle_launches": args.settle,
                        "layout": "arena: the 8 map planes of a material and its 3 result planes in one allocation "
                                  "(pypbr_amd.functional.pack_maps, what Material.to(device) does)"
                                  if args.layout == "arena" else "separate: albedo, normal, roughness, metallic and the result as "

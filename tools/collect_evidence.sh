@@ -15,10 +15,10 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
     python3 "$R/bench.py" --no-cpu-baseline > "$OUT/trace.log" 2>&1
 for pass in FETCH_SIZE WRITE_SIZE; do
     timeout 200 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$pass" -o run -- \
-        python3 "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/pmc_$pass.log" 2>&1
+        python3 "$R/bench.py" --steps 20 --warmup 5 --settle 0 --no-cpu-baseline > "$OUT/pmc_$pass.log" 2>&1
 done
 timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
-    --output-format csv -d "$OUT/pmc_SQ" -o run -- python3 "$R/bench.py" --steps 50 --warmup 5 --no-cpu-baseline > "$OUT/pmc_SQ.log" 2>&1
+    --output-format csv -d "$OUT/pmc_SQ" -o run -- python3 "$R/bench.py" --steps 50 --warmup 5 --settle 0 --no-cpu-baseline > "$OUT/pmc_SQ.log" 2>&1
 timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
     --output-format csv -d "$OUT/pmc_SQ16" -o run -- python3 "$R/tools/run_multilight.py" 4 > "$OUT/pmc_SQ16.log" 2>&1
 cd "$R"

@@ -188,6 +188,13 @@ int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *ba
  * negative, else x*2-1 and unit length.  `workspace` = 4 bytes of device memory
  * (the min<0 flag; zeroed by the call).
  */
+/* Gradient folding behind pbr_cook_torrance_backward (the sums torch.autograd would perform for a broadcast or a
+ * repeat(): a map shared by the whole batch, or tiled ny x nx by map_height/map_width, owns the sum of the
+ * per-output-pixel gradients).  src [batch][channels][ny*h][nx*w] fp32 contiguous ->
+ * dst [fold_batch ? 1 : batch][channels][h][w]. */
+int pbr_fold_gradient(const void *src, void *dst, int32_t batch, int32_t channels, int32_t h, int32_t w, int32_t ny,
+                      int32_t nx, int fold_batch, void *stream);
+
 int pbr_decode_normal(const void *src, void *dst, int32_t channels, int64_t pixels, int dtype,
                       void *workspace, void *stream);
 

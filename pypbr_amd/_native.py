@@ -28,7 +28,7 @@ EXPORTS = (
     "pbr_kernel_name", "pbr_bytes_per_pixel", "pbr_set_tuning", "pbr_render_desc_size",
     "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
     "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask", "pbr_cook_torrance_autotune",
-    "pbr_cook_torrance_blend",
+    "pbr_cook_torrance_blend", "pbr_fold_gradient",
 )
 
 
@@ -96,6 +96,8 @@ def lib():
     L.pbr_cook_torrance_autotune.restype = ctypes.c_int
     L.pbr_cook_torrance_blend.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(BlendDesc), vp, vp]
     L.pbr_cook_torrance_blend.restype = ctypes.c_int
+    L.pbr_fold_gradient.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_int, vp]
+    L.pbr_fold_gradient.restype = ctypes.c_int
     L.pbr_cook_torrance_backward.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp]
     L.pbr_cook_torrance_backward.restype = ctypes.c_int
     L.pbr_srgb_to_linear.argtypes = [vp, vp, sz, ctypes.c_int, vp]

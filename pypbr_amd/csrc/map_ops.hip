@@ -156,6 +156,29 @@ __global__ __launch_bounds__(256) void decode_normal_kernel(const void *src, voi
     }
 }
 
+// Gradient folding (autograd plumbing of the backward kernel): the backward kernel writes one gradient per OUTPUT
+// pixel and material; a map that is shared by the whole batch, or repeated ny x nx times by a fused tile(), owns the
+// sum of those.  dst[bo][c][y][x] = sum_{b in group} sum_{ty,tx} src[b][c][ty*h + y][tx*w + x], fixed order.
+__global__ __launch_bounds__(256) void fold_gradient_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                            int batch, int channels, int h, int w, int ny, int nx, int fold_batch) {
+    const int64_t plane = (int64_t)h * w, total = (int64_t)(fold_batch ? 1 : batch) * channels * plane;
+    const int64_t W = (int64_t)nx * w, src_plane = (int64_t)ny * h * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t px = i % plane, t = i / plane;
+        const int c = (int)(t % channels), bo = (int)(t / channels);
+        const int y = (int)(px / w), x = (int)(px - (int64_t)y * w);
+        float acc = 0.0f;
+        const int b0 = fold_batch ? 0 : bo, b1 = fold_batch ? batch : bo + 1;
+        for (int b = b0; b < b1; ++b) {
+            const float *p = src + ((int64_t)b * channels + c) * src_plane;
+            for (int ty = 0; ty < ny; ++ty)
+                for (int tx = 0; tx < nx; ++tx) acc += p[((int64_t)ty * h + y) * W + (int64_t)tx * w + x];
+        }
+        dst[i] = acc;
+    }
+}
+
 static inline unsigned stream_grid(size_t work_items) {
     const size_t blocks = (work_items + 255) / 256;
     const size_t cap = 256 * 8;                                     // 256 CUs x 8 blocks, grid-stride beyond
@@ -227,6 +250,18 @@ int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *ba
         hipLaunchKernelGGL((specular_to_metallic_kernel<float>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb);
     else
         hipLaunchKernelGGL((specular_to_metallic_kernel<__half>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb);
+    return hip_status();
+}
+
+int pbr_fold_gradient(const void *src, void *dst, int32_t batch, int32_t channels, int32_t h, int32_t w, int32_t ny,
+                      int32_t nx, int fold_batch, void *stream) {
+    using namespace pbr;
+    if (!src || !dst) return PBR_ERR_NULL_MAP;
+    if (batch < 1 || channels < 1 || h < 1 || w < 1 || ny < 1 || nx < 1) return PBR_ERR_SHAPE;
+    const size_t items = (size_t)(fold_batch ? 1 : batch) * channels * h * w;
+    hipLaunchKernelGGL(fold_gradient_kernel, dim3(stream_grid(items)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(src), static_cast<float *>(dst), (int)batch, (int)channels, (int)h, (int)w,
+                       (int)ny, (int)nx, fold_batch);
     return hip_status();
 }
 

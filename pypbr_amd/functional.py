@@ -344,14 +344,18 @@ class _CookTorranceFn(torch.autograd.Function):
             if b is None:
                 grads.append(None)
                 continue
-            if d.map_height and (d.map_height, d.map_width) != (H, W):     # tiled maps: a texel's gradient is the sum over its repeats
-                if H != d.height_total:
-                    raise NotImplementedError("gradients of a tiled evaluation need the whole output, not a row band")
-                b = b.view(B, b.shape[1], H // d.map_height, d.map_height, W // d.map_width, d.map_width).sum((2, 4))
-            if len(shape) == 3:                      # unbatched map
-                b = b[0] if B == 1 else b.sum(0)
-            elif shape[0] == 1 and B > 1:            # one map shared by the whole batch
-                b = b.sum(0, keepdim=True)
+            # a map repeated by a fused tile(), or shared by the whole batch, owns the SUM of the per-output-pixel gradients
+            tiled = bool(d.map_height) and (d.map_height, d.map_width) != (H, W)
+            if tiled and H != d.height_total:
+                raise NotImplementedError("gradients of a tiled evaluation need the whole output, not a row band")
+            shared = B > 1 and (len(shape) == 3 or shape[0] == 1)
+            if tiled or shared:
+                h, w = (d.map_height, d.map_width) if tiled else (H, W)
+                folded = torch.empty((1 if shared else B, b.shape[1], h, w), dtype=torch.float32, device=b.device)
+                with torch.cuda.device(b.device):
+                    N.check(N.lib().pbr_fold_gradient(b.data_ptr(), folded.data_ptr(), B, b.shape[1], h, w, H // h, W // w,
+                                                      int(shared), _stream_ptr(b.device)))
+                b = folded
             grads.append(b.reshape(shape))
         return (*grads, None)
 

@@ -316,7 +316,10 @@ int pbr_cook_torrance_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, 
         default: PBR_BLEND(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED); break;
     }
 #undef PBR_BLEND
-    hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0, st, k, b);
+    // occupancy governor (see g_lds_bytes): the 17-stream one-light blend streams fastest with 10 waves per CU --
+    // 4096^2: 255 us uncapped, 236 / 232 / 234 / 233 / 248 us at 11 / 10 / 9 / 8 / 6 (tools/blend_probe.py)
+    const size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (multi ? 0 : 16384);
+    hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), lds, st, k, b);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? PBR_OK : 1000 + (int)err;
 }

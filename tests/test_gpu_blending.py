@@ -177,3 +177,33 @@ def test_fused_blend_composes_with_fused_tile_and_several_lights():
     blended = {k: B.blend_maps(cut(x), cut(y), cut(mask), is_normal=(k == "n")) for k, x, y in (("a", a1, a2), ("n", n1, n2), ("r", r1, r2), ("m", m1, m2))}
     ref = F.cook_torrance(blended["a"], blended["n"], blended["r"], blended["m"], **kw)
     assert (ragged - ref).abs().max().item() <= 2e-7
+
+
+def test_fused_blend_guard_bands():
+    """Both materials, the mask and the result inside NaN / sentinel margins: no read or write outside them."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(77)
+
+    def guarded(t, fill, G):
+        flat = torch.full((t.numel() + 2 * G,), fill, dtype=t.dtype, device="cuda")
+        flat[G:G + t.numel()] = t.reshape(-1).cuda()
+        return flat, flat[G:G + t.numel()].view(t.shape)
+
+    for trial in range(12):
+        G = 256 if trial % 2 else 255
+        B = 1 + trial % 2
+        h, w = int(torch.randint(1, 30, (1,), generator=g)), [8, 20, 64, 5, 33, 12][trial % 6]
+        mk = lambda c: torch.rand(B, c, h, w, generator=g)
+        nrm = lambda: torch.cat([torch.rand(B, 2, h, w, generator=g) - 0.5, torch.ones(B, 1, h, w)], 1)
+        mats = [mk(3), nrm(), mk(1) * 0.7 + 0.3, mk(1), mk(3), nrm(), mk(1) * 0.7 + 0.3, mk(1), torch.rand(1, 1, h, w, generator=g)]
+        kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point" if trial % 3 else "directional",
+                  light_size=1.0)
+        dev = [t.cuda() for t in mats]
+        ref = F.cook_torrance(*dev[:4], blend=(dev[4], dev[5], dev[6], dev[7], None, dev[8]), **kw)
+        bufs, v = zip(*[guarded(t, float("nan"), G) for t in mats])
+        obuf = torch.full((B * 3 * h * w + 2 * G,), -7.0, device="cuda")
+        out = obuf[G:G + B * 3 * h * w].view(B, 3, h, w)
+        got = F.cook_torrance(*v[:4], blend=(v[4], v[5], v[6], v[7], None, v[8]), out=out, **kw)
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(got).all()) and (got - ref).abs().max().item() <= 2e-6, (trial, B, h, w)
+        assert bool((obuf[:G] == -7.0).all()) and bool((obuf[-G:] == -7.0).all()), (trial, B, h, w)

@@ -630,3 +630,56 @@ def test_strided_result_and_material_major_batches():
     F.cook_torrance(*plain, **kw).sum().backward()
     for x, y in zip(leaves, plain):
         assert torch.equal(x.grad, y.grad)
+
+
+def test_guard_bands_no_out_of_bounds_reads_or_writes():
+    """Every map and the result sit inside larger buffers whose margins are NaN (inputs) / a sentinel (output).  A read
+    outside a map would poison the result, a write outside the result would damage the sentinel.  Random shapes that
+    hit the 4-pixel, 8-pixel (fp16) and 1-pixel instantiations, fused tiles, row bands, strided results, several lights."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(2024)
+    def guarded(t, fill):
+        flat = torch.full((t.numel() + 2 * G,), fill, dtype=t.dtype, device="cuda")
+        flat[G:G + t.numel()] = t.reshape(-1).cuda()
+        return flat, flat[G:G + t.numel()].view(t.shape)
+
+    for trial in range(36):
+        # guard elements on each side: 256 keeps the maps 16-byte aligned (vector instantiations), 257 moves them off
+        # (1-pixel-per-lane instantiation)
+        G = 256 if trial % 3 else 257
+        B = int(torch.randint(1, 4, (1,), generator=g))
+        h = int(torch.randint(1, 40, (1,), generator=g))
+        w = [4, 8, 12, 16, 24, 40, 64, 7, 30, 1][int(torch.randint(0, 10, (1,), generator=g))]
+        dtype = torch.float16 if trial % 3 == 2 else torch.float32
+        ny, nx = (1, 1) if trial % 2 else (int(torch.randint(1, 4, (1,), generator=g)), int(torch.randint(1, 4, (1,), generator=g)))
+        lights = 1 if trial % 4 else 3
+        a = torch.rand(B, 3, h, w, generator=g).to(dtype)
+        n = torch.cat([torch.rand(B, 2, h, w, generator=g) - 0.5, torch.ones(B, 1, h, w)], 1).to(dtype)
+        r = (torch.rand(B, 1, h, w, generator=g) * 0.8 + 0.2).to(dtype)
+        m = torch.rand(B, 1, h, w, generator=g).to(dtype)
+        H, W = ny * h, nx * w
+        y0 = int(torch.randint(0, H, (1,), generator=g)) if (ny, nx) != (1, 1) else 0
+        rows = int(torch.randint(1, H - y0 + 1, (1,), generator=g)) if (ny, nx) != (1, 1) else H
+        kw = dict(view_dir=[0.1, 0, 1], light=[[0.2, -0.1, 0.9], [-0.3, 0.3, 0.7], [0.0, 0.4, 1.1]][:lights],
+                  light_intensity=[[1, 0.9, 0.8]] * lights, light_type="point" if trial % 5 else "directional", light_size=2.0)
+        if (ny, nx) != (1, 1):
+            kw.update(tile=(ny, nx), y_offset=y0, rows=rows)
+        ref = F.cook_torrance(a.cuda(), n.cuda(), r.cuda(), m.cuda(), **kw)
+        bufs, views = zip(*[guarded(t, float("nan")) for t in (a, n, r, m)])
+        obuf = torch.full((B * 3 * rows * W + 2 * G,), -7.0, device="cuda")
+        out = obuf[G:G + B * 3 * rows * W].view(B, 3, rows, W)
+        got = F.cook_torrance(*views, out=out, **kw)
+        torch.cuda.synchronize()
+        tag = (trial, B, h, w, str(dtype), ny, nx, y0, rows, lights)
+        assert bool(torch.isfinite(got).all()), tag
+        # the odd guard width moves the maps off 16-byte alignment, i.e. onto the 1-pixel-per-lane instantiation: same
+        # arithmetic, different fma contraction -> equal to the aligned run to a few ulp, not bit for bit
+        assert (got - ref).abs().max().item() <= 2e-6, tag
+        assert bool((obuf[:G] == -7.0).all()) and bool((obuf[-G:] == -7.0).all()), tag
+        for bf in bufs:
+            assert bool(torch.isnan(bf[:G]).all()) and bool(torch.isnan(bf[-G:]).all()), tag
+        if dtype == torch.float32 and lights == 1 and (ny, nx) == (1, 1):       # the backward kernel under the same guards
+            gout, gv = guarded(torch.rand(B, 3, h, w, generator=g), float("nan"))
+            leaves = [v.detach().clone().requires_grad_(True) for v in views]
+            F.cook_torrance(*leaves, **kw).backward(gv)
+            assert all(bool(torch.isfinite(t.grad).all()) for t in leaves), tag

@@ -683,3 +683,25 @@ def test_guard_bands_no_out_of_bounds_reads_or_writes():
             leaves = [v.detach().clone().requires_grad_(True) for v in views]
             F.cook_torrance(*leaves, **kw).backward(gv)
             assert all(bool(torch.isfinite(t.grad).all()) for t in leaves), tag
+
+
+def test_resize_guard_bands_and_random_shapes():
+    """Random in/out sizes (up- and down-scales up to ~40x, both schedules of pbr_resize_bilinear) inside NaN margins, against
+    ATen's interpolate on the CPU: a read outside the source would poison the result."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(404)
+    for trial in range(30):
+        c = int(torch.randint(1, 4, (1,), generator=g))
+        hi, wi = int(torch.randint(1, 200, (1,), generator=g)), int(torch.randint(1, 300, (1,), generator=g))
+        ho, wo = int(torch.randint(1, 150, (1,), generator=g)), int(torch.randint(1, 260, (1,), generator=g))
+        aa = bool(trial % 2)
+        x = torch.rand(c, hi, wi, generator=g)
+        G = 300
+        flat = torch.full((x.numel() + 2 * G,), float("nan"), device="cuda")
+        flat[G:G + x.numel()] = x.reshape(-1).cuda()
+        got = F.resize(flat[G:G + x.numel()].view(c, hi, wi), (ho, wo), antialias=aa).cpu()
+        ref = torch.nn.functional.interpolate(x[None], size=(ho, wo), mode="bilinear", align_corners=False, antialias=aa)[0]
+        assert got.shape == ref.shape and bool(torch.isfinite(got).all()), (trial, c, hi, wi, ho, wo, aa)
+        # the source coordinate scale * (i + 0.5) of a large map carries ~1e-5 of fp32 rounding (ulp of 100 is 7.6e-6), and
+        # ATen and this kernel round it at different points: weights, hence values in [0,1], agree to ~1e-5, not to the ulp
+        assert (got - ref).abs().max().item() <= 1e-5, (trial, c, hi, wi, ho, wo, aa, float((got - ref).abs().max()))

@@ -93,7 +93,7 @@ typedef struct pbr_render_desc {
     pbr_map roughness;            /* 1 channel, required */
     pbr_map metallic;             /* 1 channel: METALLIC / CONVERTED */
     pbr_map specular;             /* 3 channels: SPECULAR */
-    void *out;                    /* [B][3][height][width], contiguous */
+    void *out;                    /* [B][3][height][width]; contiguous unless out_*_stride (below) say otherwise */
 
     float view_dir[3];            /* un-normalised, as handed to forward (normalised like F.normalize, :95) */
     float light_size;             /* point lights; <= 0 or NaN means "falsy": 1.0 (cooktorrance.py:130) */

@@ -1,0 +1,48 @@
+"""Degenerate texel values through the forward and backward kernels: zero normals, roughness 0 and 1, metallic 0 and 1,
+albedo at and beyond the [0,1] clamp, a light sitting exactly on a pixel, a view along the surface.  Results and
+gradients must stay finite, and the forward must still agree with the oracle (which evaluates the reference's formulas)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _maps():
+    H, W = 8, 16
+    a = torch.zeros(3, H, W)
+    a[:, 0] = 1.0; a[:, 1] = -0.25; a[:, 2] = 1.5; a[:, 3:] = torch.linspace(0, 1, W).expand(3, H - 3, W)
+    n = torch.zeros(3, H, W)
+    n[2, :, 4:] = 1.0                                   # columns 0-3: the zero vector (F.normalize gives 0)
+    n[0, 4:, 8:] = 0.7; n[1, 5:, 8:] = -0.7
+    r = torch.zeros(1, H, W)
+    r[0, :, 1::4] = 1.0; r[0, :, 2::4] = 0.5; r[0, :, 3::4] = 1e-3
+    m = torch.zeros(1, H, W)
+    m[0, ::2] = 1.0; m[0, 1, :] = 0.5
+    return a, n, r, m
+
+
+CASES = [("point", [0.0, 0.0, 1.0], [0.1, 0.1, 1.0], 1.0), ("point", [0.0, 0.0, 1.0], [-0.5, 0.5, 0.0], 1.0),   # light ON the corner pixel
+         ("point", [1.0, 0.0, 0.0], [0.2, 0.0, 0.3], 2.0), ("directional", [0.0, 0.0, 1.0], [0.0, 0.0, -1.0], None),  # L = -V
+         ("directional", [0.3, 0.1, 1.0], [0.3, -0.2, 1.0], None)]
+
+
+@pytest.mark.parametrize("light_type,view,light,size", CASES)
+@pytest.mark.parametrize("srgb", [True, False])
+def test_degenerate_values_stay_finite_and_match_the_oracle(light_type, view, light, size, srgb):
+    import torch_oracle as O
+    from pypbr_amd import functional as F
+    a, n, r, m = _maps()
+    kw = dict(view_dir=view, light=light, light_intensity=[1.0, 0.8, 0.6], light_type=light_type, light_size=size,
+              albedo_is_srgb=srgb, return_srgb=srgb)
+    out = F.cook_torrance(a.cuda(), n.cuda(), r.cuda(), m.cuda(), **kw)
+    assert bool(torch.isfinite(out).all()) and float(out.min()) >= 0.0 and float(out.max()) <= 1.0
+    ref = O.cook_torrance(a, n, r, m, None, view=torch.tensor(view), light=torch.tensor(light), intensity=torch.tensor([1.0, 0.8, 0.6]),
+                          light_type=light_type, light_size=size, albedo_is_srgb=srgb, return_srgb=srgb)
+    ok = torch.isfinite(ref)                            # the reference itself may produce NaN at 0/0 points; compare where it does not
+    rough_ok = (r >= 0.2).expand_as(ref)                # below that the reference's own fp32 rounding exceeds 1e-5
+    sel = ok & rough_ok
+    assert (out.cpu()[sel] - ref[sel]).abs().max().item() <= 1e-5
+    leaves = [t.clone().cuda().requires_grad_(True) for t in (a, n, r, m)]
+    F.cook_torrance(*leaves, **kw).sum().backward()
+    for name, t in zip(("albedo", "normal", "roughness", "metallic"), leaves):
+        assert bool(torch.isfinite(t.grad).all()), name

@@ -37,6 +37,9 @@ def _stream_ptr(device: torch.device) -> int:
 def _host_vec3(v: TensorLike, rows: Optional[int] = None):
     """Light/view parameters travel in the kernel-argument segment, so they are host
     values; a device tensor costs one small D2H copy (documented in DESIGN.md)."""
+    if isinstance(v, torch.Tensor) and v.requires_grad and torch.is_grad_enabled():
+        # the reference's autograd graph would reach these tensors; the backward kernel only differentiates the maps
+        raise NotImplementedError("gradients with respect to view / light parameters are not implemented: pass them detached")
     t = torch.as_tensor(v, dtype=torch.float32) if not isinstance(v, torch.Tensor) else v.detach().to("cpu", torch.float32)
     if rows is None:
         if t.numel() != 3:

@@ -373,3 +373,14 @@ def test_pack_maps_layout_on_the_host():
     pb, ob = F.pack_maps(b, reserve_output=True)
     assert ob.shape == (2, 3, 4, 8) and torch.equal(pb, b)
     assert F.pack_maps(None, None) == (None, None)
+
+
+def test_light_parameters_that_require_grad_are_refused():
+    """The reference's autograd would differentiate w.r.t. light / view tensors; this build differentiates the maps only and
+    must say so instead of silently returning no gradient."""
+    light = torch.tensor([0.1, 0.1, 1.0], requires_grad=True)
+    with pytest.raises(NotImplementedError, match="view / light"):
+        _desc(light=light)
+    with torch.no_grad():
+        assert _desc(light=light).n_lights == 1
+    assert _desc(light=light.detach()).n_lights == 1

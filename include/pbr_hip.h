@@ -188,6 +188,11 @@ int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *ba
  * negative, else x*2-1 and unit length.  `workspace` = 4 bytes of device memory
  * (the min<0 flag; zeroed by the call).
  */
+/* Gradient of pbr_decode_normal w.r.t. the stored map (what autograd computes through base.py:191-242 when a predicted
+ * normal map is assigned to a material in a rendering loss): fp32, `workspace` = the flag pbr_decode_normal left. */
+int pbr_decode_normal_backward(const void *src, const void *grad_out, void *grad_in, int32_t channels, int64_t pixels,
+                               const void *workspace, void *stream);
+
 /* Gradient folding behind pbr_cook_torrance_backward (the sums torch.autograd would perform for a broadcast or a
  * repeat(): a map shared by the whole batch, or tiled ny x nx by map_height/map_width, owns the sum of the
  * per-output-pixel gradients).  src [batch][channels][ny*h][nx*w] fp32 contiguous ->

@@ -28,7 +28,7 @@ EXPORTS = (
     "pbr_kernel_name", "pbr_bytes_per_pixel", "pbr_set_tuning", "pbr_render_desc_size",
     "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
     "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask", "pbr_cook_torrance_autotune",
-    "pbr_cook_torrance_blend", "pbr_fold_gradient",
+    "pbr_cook_torrance_blend", "pbr_fold_gradient", "pbr_decode_normal_backward",
 )
 
 
@@ -105,6 +105,8 @@ def lib():
     L.pbr_metallic_to_specular.argtypes = [vp, vp, vp, vp, i32, i64, ctypes.c_int, ctypes.c_int, vp]
     L.pbr_specular_to_metallic.argtypes = [vp, vp, vp, vp, sz, ctypes.c_int, ctypes.c_int, vp]
     L.pbr_decode_normal.argtypes = [vp, vp, i32, i64, ctypes.c_int, vp, vp]
+    L.pbr_decode_normal_backward.argtypes = [vp, vp, vp, i32, i64, vp, vp]
+    L.pbr_decode_normal_backward.restype = ctypes.c_int
     for name in ("pbr_srgb_to_linear", "pbr_linear_to_srgb", "pbr_metallic_to_specular",
                  "pbr_specular_to_metallic", "pbr_decode_normal", "pbr_abi_version", "pbr_set_tuning",
                  "pbr_bytes_per_pixel"):

@@ -21,6 +21,7 @@ def _stream(t):
 
 
 def _check_f32(t, what):
+    F_.refuse_grad(t, what)
     if not t.is_cuda:
         raise RuntimeError("%s needs tensors on a ROCm device; there is no CPU path" % what)
     if t.dtype != torch.float32:

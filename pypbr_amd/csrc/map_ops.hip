@@ -179,6 +179,34 @@ __global__ __launch_bounds__(256) void fold_gradient_kernel(const float *__restr
     }
 }
 
+// Gradient of decode_normal_kernel (MaterialBase._process_normal_map, base.py:191-242) w.r.t. the stored map, with
+// torch's conventions: a map that was kept as is passes the gradient through; x*2-1 contributes a factor 2;
+// F.normalize projects out the radial component; clamp(1 - x^2 - y^2, min=1e-6) passes where it did not clamp.
+template <int CH>
+__global__ __launch_bounds__(256) void decode_normal_backward_kernel(const float *__restrict__ src, const float *__restrict__ gout,
+                                                                     float *__restrict__ gin, int64_t P, const int *flag) {
+    const bool keep = CH == 3 && *flag != 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < (size_t)P; p += stride) {
+        const float gx = gout[p], gy = gout[(size_t)P + p], gz = gout[2 * (size_t)P + p];
+        if (keep) { gin[p] = gx; gin[(size_t)P + p] = gy; gin[2 * (size_t)P + p] = gz; continue; }
+        const float x = fmaf(src[p], 2.0f, -1.0f), y = fmaf(src[(size_t)P + p], 2.0f, -1.0f);
+        float z, q = 0.0f;
+        if (CH == 3) z = fmaf(src[2 * (size_t)P + p], 2.0f, -1.0f);
+        else { q = 1.0f - (x * x + y * y); z = sqrt_hw(fmaxf(q, 1e-6f)); }
+        const float r = rsq(fmaxf(fmaf(z, z, fmaf(y, y, x * x)), 1e-24f));
+        const float nx = x * r, ny = y * r, nz = z * r;
+        const float radial = fmaf(nz, gz, fmaf(ny, gy, nx * gx));
+        const float px = (gx - nx * radial) * r, py = (gy - ny * radial) * r, pz = (gz - nz * radial) * r;
+        if (CH == 3) {
+            gin[p] = 2.0f * px; gin[(size_t)P + p] = 2.0f * py; gin[2 * (size_t)P + p] = 2.0f * pz;
+        } else {                                                         // z = sqrt(clamp(q)), dz/dx = -x / z where q >= 1e-6
+            const float dz = q >= 1e-6f ? -pz * rcp(z) : 0.0f;
+            gin[p] = 2.0f * fmaf(dz, x, px); gin[(size_t)P + p] = 2.0f * fmaf(dz, y, py);
+        }
+    }
+}
+
 static inline unsigned stream_grid(size_t work_items) {
     const size_t blocks = (work_items + 255) / 256;
     const size_t cap = 256 * 8;                                     // 256 CUs x 8 blocks, grid-stride beyond
@@ -291,6 +319,20 @@ int pbr_decode_normal(const void *src, void *dst, int32_t channels, int64_t pixe
             hipLaunchKernelGGL((decode_normal_kernel<__half, 2>), dim3(grid), dim3(256), 0, s, src, dst, pixels, flag);
         }
     }
+    return hip_status();
+}
+
+int pbr_decode_normal_backward(const void *src, const void *grad_out, void *grad_in, int32_t channels, int64_t pixels,
+                               const void *workspace, void *stream) {
+    using namespace pbr;
+    if (channels != 2 && channels != 3) return PBR_ERR_CHANNELS;
+    if (!src || !grad_out || !grad_in || !workspace) return PBR_ERR_NULL_MAP;
+    if (pixels < 1) return PBR_ERR_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const unsigned grid = stream_grid((size_t)pixels);
+    auto a = static_cast<const float *>(src), g = static_cast<const float *>(grad_out);
+    if (channels == 3) hipLaunchKernelGGL((decode_normal_backward_kernel<3>), dim3(grid), dim3(256), 0, s, a, g, static_cast<float *>(grad_in), pixels, static_cast<const int *>(workspace));
+    else hipLaunchKernelGGL((decode_normal_backward_kernel<2>), dim3(grid), dim3(256), 0, s, a, g, static_cast<float *>(grad_in), pixels, static_cast<const int *>(workspace));
     return hip_status();
 }
 

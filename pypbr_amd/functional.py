@@ -364,7 +364,16 @@ class _CookTorranceFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ stand-alone conversions
+def refuse_grad(t: torch.Tensor, what: str):
+    """The map-level kernels (colour transfer, conversions, normal decode, resize, blends) have no backward: a tensor
+    that carries a gradient must not pass through them silently losing it (the reference's torch ops would keep it)."""
+    if t.requires_grad and torch.is_grad_enabled():
+        raise NotImplementedError("%s is not differentiable in this build; only cook_torrance has a backward kernel "
+                                  "(detach the tensor, or run under torch.no_grad())" % what)
+
+
 def _device_tensor(t: torch.Tensor, what: str) -> torch.Tensor:
+    refuse_grad(t, what)
     if not t.is_cuda:
         raise RuntimeError("%s needs a tensor on a ROCm device; there is no CPU path" % what)
     if t.dtype not in _DTYPES:
@@ -500,6 +509,7 @@ def resize(texture: torch.Tensor, size, antialias: bool = True) -> torch.Tensor:
     SMALLER edge and keeps the aspect ratio (torchvision semantics).  [..., H, W] float32 on device."""
     if not texture.is_cuda:
         raise RuntimeError("resize needs a tensor on a ROCm device; there is no CPU path")
+    refuse_grad(texture, "resize")
     if texture.dtype != torch.float32:
         raise TypeError("resize supports float32 maps, got %s" % texture.dtype)
     h, w = texture.shape[-2:]
@@ -521,15 +531,46 @@ def resize(texture: torch.Tensor, size, antialias: bool = True) -> torch.Tensor:
     return out
 
 
-def decode_normal(normal_map: torch.Tensor) -> torch.Tensor:
-    """MaterialBase._process_normal_map (base.py:191-242) on the device: (2|3,H,W) -> (3,H,W)."""
-    if normal_map.dim() != 3 or normal_map.shape[0] not in (2, 3):
-        raise ValueError("Normal map must have 2 or 3 channels.")
-    t = _device_tensor(normal_map, "decode_normal")
+def _decode_normal_raw(t: torch.Tensor):
     C, H, W = t.shape
     out = torch.empty((3, H, W), dtype=t.dtype, device=t.device)
     flag = torch.empty(1, dtype=torch.int32, device=t.device)
     with torch.cuda.device(t.device):
         N.check(N.lib().pbr_decode_normal(t.data_ptr(), out.data_ptr(), C, H * W, _DTYPES[t.dtype],
                                           flag.data_ptr(), _stream_ptr(t.device)))
-    return out
+    return out, flag
+
+
+class _DecodeNormalFn(torch.autograd.Function):
+    """A predicted normal map assigned to a material in a rendering loss (06_advanced.rst:73-107) must keep its
+    gradient: forward = pbr_decode_normal, backward = pbr_decode_normal_backward (float32)."""
+
+    @staticmethod
+    def forward(ctx, normal_map):
+        t = normal_map.detach().contiguous()
+        out, flag = _decode_normal_raw(t)
+        ctx.save_for_backward(normal_map)
+        ctx.flag = flag
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (normal_map,) = ctx.saved_tensors
+        t, g = normal_map.detach().contiguous(), grad_out.to(torch.float32).contiguous()
+        gin = torch.empty_like(t)
+        with torch.cuda.device(t.device):
+            N.check(N.lib().pbr_decode_normal_backward(t.data_ptr(), g.data_ptr(), gin.data_ptr(), t.shape[0],
+                                                       t.shape[1] * t.shape[2], ctx.flag.data_ptr(), _stream_ptr(t.device)))
+        return gin
+
+
+def decode_normal(normal_map: torch.Tensor) -> torch.Tensor:
+    """MaterialBase._process_normal_map (base.py:191-242) on the device: (2|3,H,W) -> (3,H,W).  Differentiable for
+    float32 maps (its own backward kernel)."""
+    if normal_map.dim() != 3 or normal_map.shape[0] not in (2, 3):
+        raise ValueError("Normal map must have 2 or 3 channels.")
+    if normal_map.requires_grad and torch.is_grad_enabled():
+        if not normal_map.is_cuda or normal_map.dtype != torch.float32:
+            raise NotImplementedError("gradients through decode_normal need a float32 map on a ROCm device")
+        return _DecodeNormalFn.apply(normal_map)
+    return _decode_normal_raw(_device_tensor(normal_map, "decode_normal"))[0]

@@ -141,3 +141,49 @@ def test_in_place_edit_between_forward_and_backward_is_detected():
     r.mul_(0.5)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         out.sum().backward()
+
+
+@pytest.mark.parametrize("kind", ["signed3", "unit3", "xy2"])
+def test_normal_decode_is_differentiable(kind):
+    """MaterialBase._process_normal_map (base.py:191-242) keeps the gradient of a predicted normal map: pbr_decode_normal_backward
+    against torch autograd through the reference's formulas in float64."""
+    import torch.nn.functional as TF
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed({"signed3": 1, "unit3": 2, "xy2": 3}[kind])
+    H, W = 12, 20
+    if kind == "signed3":
+        x = torch.rand(3, H, W, generator=g) * 2 - 1
+    elif kind == "unit3":
+        x = torch.rand(3, H, W, generator=g)
+    else:
+        x = torch.rand(2, H, W, generator=g)
+        x[:, 0, :4] = 0.98                                           # 1 - x^2 - y^2 below the 1e-6 clamp: zero z-gradient there
+    wt = torch.rand(3, H, W, generator=g) - 0.5
+
+    def reference(t):                                                # the reference's ops, verbatim semantics
+        if t.shape[0] == 2:
+            t = t * 2 - 1
+            z = torch.sqrt(torch.clamp(1.0 - (t[0:1] ** 2 + t[1:2] ** 2), min=1e-6))
+            return TF.normalize(torch.cat([t[0:1], t[1:2], z], 0), dim=0)
+        if t.min() < 0:
+            return t
+        return TF.normalize(t * 2.0 - 1.0, dim=0)
+    x64 = x.double().requires_grad_(True)
+    (reference(x64) * wt.double()).sum().backward()
+    xd = x.clone().cuda().requires_grad_(True)
+    out = F.decode_normal(xd)
+    assert out.requires_grad and (out.detach().cpu().double() - reference(x.double())).abs().max().item() <= 2e-6
+    (out * wt.cuda()).sum().backward()
+    err = (xd.grad.cpu().double() - x64.grad).abs()
+    assert (err <= 2e-5 * (1 + x64.grad.abs())).all(), float(err.max())
+    # through the material: a predicted normal assigned in the constructor reaches the rendering loss
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    from pypbr_amd.models import CookTorranceBRDF
+    pred = x.clone().cuda().requires_grad_(True)
+    mat = BasecolorMetallicMaterial(albedo=torch.rand(3, H, W, generator=g).cuda(), normal=pred, roughness=(torch.rand(1, H, W, generator=g) * 0.6 + 0.3).cuda(),
+                                    metallic=torch.rand(1, H, W, generator=g).cuda(), device=torch.device("cuda"))
+    loss = CookTorranceBRDF("point")(mat, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0]), 1.0).mean()
+    loss.backward()
+    assert pred.grad is not None and bool(torch.isfinite(pred.grad).all()) and float(pred.grad.abs().sum()) > 0
+    with pytest.raises(NotImplementedError, match="not differentiable"):
+        F.srgb_to_linear(torch.rand(3, 4, 4, device="cuda", requires_grad=True))

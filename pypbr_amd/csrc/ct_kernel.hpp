@@ -5,11 +5,11 @@
 // accesses) by T/bx rows, with bx = min(T, next_pow2(W/4)).  For 4K maps every wave touches one
 // 1 KiB-contiguous run of each of the 8 input and 3 output planes.
 //
-// Schedule: one tile per workgroup, 1-D grid in row-major tile order.  A persistent grid-stride
-// variant with register double buffering (next tile's loads issued before the current tile's
-// arithmetic) was built and measured 10-20 % SLOWER (135 VGPRs -> 3 waves/SIMD; DESIGN.md,
-// "Schedule experiments"): with 5 waves/SIMD of independent one-shot waves the memory pipe is
-// already saturated and the chip-wide dispatcher is the cheaper software pipeline.
+// Schedule: one tile per one-wave workgroup, 1-D grid; the workgroup -> tile map is either the identity or
+// XCD-aware runs (tile_of_workgroup below).  A persistent grid-stride variant with register double buffering
+// (next tile's loads issued before the current tile's arithmetic) was built and measured 10-20 % SLOWER
+// ("Schedule experiments"): ~11 independent one-shot waves per CU already saturate the memory
+// pipe, and the chip-wide dispatcher is the cheaper software pipeline.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>

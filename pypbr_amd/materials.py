@@ -73,8 +73,8 @@ def _through_device(t: torch.Tensor, fn):
     _native.require_device()
     res = fn(t.to("cuda"))
     if isinstance(res, tuple):
-        return tuple(r.to(t.device) for r in res)
-    return res.to(t.device)
+        return tuple(F_.to_host(r, t.device) for r in res)
+    return F_.to_host(res, t.device)
 
 
 class MaterialBase:

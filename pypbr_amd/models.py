@@ -102,4 +102,6 @@ class CookTorranceBRDF(BRDFModel):
             albedo_is_srgb=bool(material.albedo_is_srgb), specular_is_srgb=specular_is_srgb,
             return_srgb=return_srgb, tile=getattr(material, "lazy_tile", (1, 1)),
             blend=None if blend is None else tuple(dev(t) for t in blend))
-        return color if color.device == out_device else color.to(out_device)
+        if color.device == out_device:
+            return color
+        return F_.to_host(color, out_device) if out_device.type == "cpu" else color.to(out_device)

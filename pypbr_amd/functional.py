@@ -372,7 +372,10 @@ def to_host(t: torch.Tensor, device=torch.device("cpu")) -> torch.Tensor:
     attached (autograd has to see the transfer)."""
     if not t.is_cuda or t.requires_grad:
         return t.to(device)
-    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    try:
+        host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    except RuntimeError:                  # page-locking refused (RLIMIT_MEMLOCK, exhausted pool): the pageable way still works
+        return t.to(device)
     host.copy_(t, non_blocking=True)
     torch.cuda.current_stream(t.device).synchronize()
     return host

@@ -384,3 +384,16 @@ def test_light_parameters_that_require_grad_are_refused():
     with torch.no_grad():
         assert _desc(light=light).n_lights == 1
     assert _desc(light=light.detach()).n_lights == 1
+
+
+def test_integration_md_binding_stub_matches_the_abi():
+    """INTEGRATION.md shows the ctypes stub a PyPBR maintainer would add: its struct must be the library's."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = text[text.index("# pypbr/models/_pbr_hip.py"):]
+    block = block[:block.index("_lib = ctypes.CDLL")]
+    scope = {}
+    exec(block, scope)                                            # class _Map, class _Desc
+    lib = N.lib()
+    assert ctypes.sizeof(scope["_Desc"]) == lib.pbr_render_desc_size() == ctypes.sizeof(N.RenderDesc)
+    assert [f[0] for f in scope["_Desc"]._fields_] == [f[0] for f in N.RenderDesc._fields_]
+    assert f"pbr_abi_version() == {N.ABI_VERSION}" in text and f"abi_version={N.ABI_VERSION}" in text

@@ -323,6 +323,36 @@ def grad_set(manifest):
     manifest["sets"]["grad"] = {k: _entry(v) for k, v in d.items()}
 
 
+def example_blend_set(manifest):
+    """examples/example_blend.py, literally: load `tiles` and `rocks` (PNG data fixtures under tests/golden/), HeightBlend(0.1,
+    -0.5), resize((512,512)), tile(2), point-light render.  Only the maps the metallic workflow loads are copied for `rocks`."""
+    import shutil
+    import warnings
+    import pypbr.blending as B
+    src, dst = os.path.join(REFERENCE_ROOT, "tests", "data", "rocks"), os.path.join(GOLDEN, "rocks")
+    os.makedirs(dst, exist_ok=True)
+    for f in ("basecolor.png", "height.png", "metallic.png", "normal.png", "roughness.png", "opacity.png"):
+        shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m1 = load_material_from_folder(os.path.join(GOLDEN, "tiles"), preferred_workflow="metallic")
+        m2 = load_material_from_folder(dst, preferred_workflow="metallic")
+    d = {"meta_m2_map_order": np.array(list(m2._maps.keys()))}
+    material, mask = B.HeightBlend(blend_width=0.1, shift=-0.5)(m1, m2)
+    d["mask_mean"] = np.array(float(mask.double().mean()))
+    d["mask_crop"] = mask[:, 500:532, 700:732].numpy()
+    material.resize((512, 512)).tile(2)
+    for k, v in material._maps.items():
+        d[f"blended_crop_{k}"] = v[:, 480:544, 480:544].numpy()
+    out = CookTorranceBRDF(light_type="point")(material, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]),
+                                               torch.tensor([1.0, 1.0, 1.0]), 1.0)
+    d["example_mean"] = np.array(float(out.double().mean()))
+    d["example_crop"] = out[:, 448:576, 448:576].numpy()
+    d["example_rowsum"] = out.double().sum(dim=(0, 2)).numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "example_blend.npz"), **d)
+    manifest["sets"]["example_blend"] = {k: _entry(v) for k, v in d.items() if v.dtype.kind == "f"}
+
+
 def blend_set(manifest):
     """pypbr.blending on 96x96 crops of the reference's two PNG materials (examples/example_blend.py uses
     HeightBlend(blend_width=0.1, shift=-0.5) on the full maps): every blend kind, blended maps + masks."""
@@ -364,10 +394,10 @@ def blend_set(manifest):
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
-    if sys.argv[1:] == ["--only", "blend"]:         # refresh one set, keep the rest of the manifest
+    if sys.argv[1:2] == ["--only"] and sys.argv[2:] in (["blend"], ["example_blend"]):   # refresh one set, keep the rest
         with open(os.path.join(GOLDEN, "MANIFEST.json")) as f:
             manifest = json.load(f)
-        blend_set(manifest)
+        (blend_set if sys.argv[2] == "blend" else example_blend_set)(manifest)
         with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
             json.dump(manifest, f, indent=1, sort_keys=True)
         return
@@ -391,6 +421,7 @@ def main():
     example_set(manifest)
     grad_set(manifest)
     blend_set(manifest)
+    example_blend_set(manifest)
     with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))

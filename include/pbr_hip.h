@@ -151,9 +151,9 @@ int pbr_cook_torrance_blend(const pbr_render_desc *desc, const pbr_blend_desc *b
  * Gradient of pbr_cook_torrance w.r.t. the maps (what torch.autograd computes through
  * cooktorrance.py:92-182 in the reference's rendering-loss use,
  * docs/source/tutorials/06_advanced.rst:73-107).  `desc` is the forward descriptor (its `out` is
- * ignored), fp32 maps, any workflow (CONVERTED: gradients w.r.t. the metallic-workflow maps, through the
- * in-kernel conversion); `grad_out` is [B][3][H][W] contiguous.
- * Each non-NULL g_* receives a contiguous fp32 gradient shaped like its map
+ * ignored; out_dtype must be PBR_F32), fp32 or fp16 maps, any workflow (CONVERTED: gradients w.r.t. the
+ * metallic-workflow maps, through the in-kernel conversion); `grad_out` is [B][3][H][W] fp32 contiguous.
+ * Each non-NULL g_* receives a contiguous gradient in the maps' storage type, shaped like its map
  * ([B][3|1][H][W]); NULL skips it.  Same sub-gradient conventions as torch (clamp passes on the
  * closed interval).  With tiled maps (map_height/map_width) the g_* are OUTPUT-sized: one value per
  * output pixel; the gradient of a texel is the sum over its repeats, which is left to the caller.

@@ -363,7 +363,8 @@ int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, v
     const int rc = validate(d);
     if (rc != PBR_OK) return rc;
     if (!grad_out) return PBR_ERR_NULL_MAP;
-    if (d->map_dtype != PBR_F32 || d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;
+    if (d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;        // the upstream gradient is fp32; maps (and their gradients) fp32 | fp16
+    const bool half_maps = d->map_dtype == PBR_F16;
     int vec = pick_vec(d);
     for (const void *g : {grad_out, (const void *)g_albedo, (const void *)g_normal, (const void *)g_roughness,
                           (const void *)g_metallic, (const void *)g_specular})
@@ -376,9 +377,10 @@ int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, v
     const BArgs b = {grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular};
     const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
     void (*fn)(const KArgs, const BArgs) = nullptr;
-#define PBR_BWD(L, W)                                                                                           \
-    fn = vec == 4 ? (multi ? cook_torrance_backward_kernel<L, W, 4, true> : cook_torrance_backward_kernel<L, W, 4, false>) \
-                  : (multi ? cook_torrance_backward_kernel<L, W, 1, true> : cook_torrance_backward_kernel<L, W, 1, false>)
+#define PBR_BWD_T(L, W, T)                                                                                            \
+    (vec == 4 ? (multi ? cook_torrance_backward_kernel<L, W, 4, true, T> : cook_torrance_backward_kernel<L, W, 4, false, T>) \
+              : (multi ? cook_torrance_backward_kernel<L, W, 1, true, T> : cook_torrance_backward_kernel<L, W, 1, false, T>))
+#define PBR_BWD(L, W) fn = half_maps ? PBR_BWD_T(L, W, __half) : PBR_BWD_T(L, W, float)
     switch ((point ? 3 : 0) + d->workflow) {
         case 0: PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC); break;
         case 1: PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR); break;
@@ -388,6 +390,7 @@ int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, v
         default: PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED); break;
     }
 #undef PBR_BWD
+#undef PBR_BWD_T
     hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0, static_cast<hipStream_t>(stream), k, b);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? PBR_OK : 1000 + (int)err;

@@ -120,15 +120,16 @@ __device__ __forceinline__ void backprop_light(const PixelTerms &t, const LightG
     adj.g_n.z = fmaf(gl, g.L.z, fmaf(gch, g.h.z, adj.g_n.z));
 }
 
-//   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_*    VEC: 4 | 1    fp32 maps
-template <int LIGHT, int WF, int VEC, bool MULTI>
+//   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_*    VEC: 4 | 1    TM: storage type of the maps AND of their gradients
+//   (float | __half; arithmetic and the upstream gradient are fp32)
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM = float>
 __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
     const int ty = (int)a.div_tx.div(tile);
     const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);
     if (!p.valid) return;
     Texels<VEC> t;
-    load_texels<WF, float, VEC, true>(a, a.has_normal != 0, p, t);
+    load_texels<WF, TM, VEC, true>(a, a.has_normal != 0, p, t);
     float go[3][VEC];
     const int64_t opix = p.b * a.o_bs + p.pix;
 #pragma unroll
@@ -240,18 +241,18 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
     const int64_t gp3 = (int64_t)p.b * 3 * a.o_cs + p.pix, gp1 = (int64_t)p.b * a.o_cs + p.pix;
     if (b.g_albedo) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Ld<float, VEC>::template store<true>(b.g_albedo, gp3 + c * a.o_cs, ga[c]);
+        for (int c = 0; c < 3; ++c) Ld<TM, VEC>::template store<true>(b.g_albedo, gp3 + c * a.o_cs, ga[c]);
     }
     if (b.g_normal && a.has_normal) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Ld<float, VEC>::template store<true>(b.g_normal, gp3 + c * a.o_cs, gn[c]);
+        for (int c = 0; c < 3; ++c) Ld<TM, VEC>::template store<true>(b.g_normal, gp3 + c * a.o_cs, gn[c]);
     }
-    if (b.g_rough) Ld<float, VEC>::template store<true>(b.g_rough, gp1, gr);
+    if (b.g_rough) Ld<TM, VEC>::template store<true>(b.g_rough, gp1, gr);
     if (WF != PBR_WORKFLOW_SPECULAR) {
-        if (b.g_metal) Ld<float, VEC>::template store<true>(b.g_metal, gp1, gm);
+        if (b.g_metal) Ld<TM, VEC>::template store<true>(b.g_metal, gp1, gm);
     } else if (b.g_spec) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Ld<float, VEC>::template store<true>(b.g_spec, gp3 + c * a.o_cs, gs[c]);
+        for (int c = 0; c < 3; ++c) Ld<TM, VEC>::template store<true>(b.g_spec, gp3 + c * a.o_cs, gs[c]);
     }
 }
 

@@ -316,8 +316,8 @@ class _CookTorranceFn(torch.autograd.Function):
             raise NotImplementedError("the fused blend is forward-only; blend with pypbr_amd.blending first to differentiate")
         maps = (albedo, normal, roughness, metallic, specular)
         plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **kwargs)
-        if plan.desc.map_dtype != N.F32 or plan.desc.out_dtype != N.F32:
-            raise NotImplementedError("gradients need float32 maps and output")
+        if plan.desc.out_dtype != N.F32:
+            raise NotImplementedError("gradients need a float32 result (fp16 maps are fine: their gradients come back in fp16)")
         ctx.plan = plan
         ctx.in_shapes = [None if t is None else tuple(t.shape) for t in maps]
         ctx.save_for_backward(*[t for t in maps if t is not None])   # for autograd's in-place-modification check
@@ -336,9 +336,10 @@ class _CookTorranceFn(torch.autograd.Function):
         channels = (3, 3, 1, 1, 3)
         present = (True, bool(d.normal.data), True, bool(d.metallic.data), bool(d.specular.data))
         bufs = []
+        gdtype = torch.float32 if d.map_dtype == N.F32 else torch.float16      # gradients in the maps' storage type
         for i in range(5):
             want = ctx.needs_input_grad[i] and present[i] and ctx.in_shapes[i] is not None
-            bufs.append(torch.empty((B, channels[i], H, W), dtype=torch.float32, device=g.device) if want else None)
+            bufs.append(torch.empty((B, channels[i], H, W), dtype=gdtype, device=g.device) if want else None)
         with torch.cuda.device(g.device):
             N.check(N.lib().pbr_cook_torrance_backward(
                 ctypes.byref(d), g.data_ptr(), *[None if b is None else b.data_ptr() for b in bufs], _stream_ptr(g.device)))
@@ -353,6 +354,9 @@ class _CookTorranceFn(torch.autograd.Function):
                 raise NotImplementedError("gradients of a tiled evaluation need the whole output, not a row band")
             shared = B > 1 and (len(shape) == 3 or shape[0] == 1)
             if tiled or shared:
+                if gdtype != torch.float32:
+                    raise NotImplementedError("gradients of fp16 maps that are tiled or shared by the batch are not implemented "
+                                              "(the fold kernel sums in float32 storage)")
                 h, w = (d.map_height, d.map_width) if tiled else (H, W)
                 folded = torch.empty((1 if shared else B, b.shape[1], h, w), dtype=torch.float32, device=b.device)
                 with torch.cuda.device(b.device):

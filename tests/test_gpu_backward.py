@@ -96,7 +96,36 @@ def test_rendering_loss_step_through_the_module():
     with pytest.raises(NotImplementedError):
         from pypbr_amd import functional as F
         F.cook_torrance(pred["albedo"].half(), normal.half(), pred["roughness"].half(), pred["metallic"].half(),
-                        view_dir=[0, 0, 1], light=[0, 0, 1], light_intensity=[1, 1, 1])      # fp16 maps: forward only
+                        view_dir=[0, 0, 1], light=[0, 0, 1], light_intensity=[1, 1, 1], out_dtype=torch.float16)   # fp16 RESULT: forward only
+
+
+@pytest.mark.parametrize("light_type,light,size,lights", [("point", [0.1, 0.1, 1.0], 1.0, 1), ("directional", [0.3, -0.2, 1.0], None, 1),
+                                                          ("point", [[0.1, 0.1, 1.0], [-0.3, 0.2, 0.8]], 1.5, 2)])
+def test_gradients_of_fp16_maps(light_type, light, size, lights):
+    """fp16 map storage (BASELINE config 5): the backward kernel reads fp16 maps and returns fp16 gradients; same arithmetic
+    as for the fp32 up-casts of those maps, so the two agree to fp16 rounding of the gradient."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(61)
+    H, W = 20, 40
+    a = torch.rand(3, H, W, generator=g).half()
+    n = torch.cat([(torch.rand(2, H, W, generator=g) - 0.5), torch.ones(1, H, W)], 0).half()
+    r = (torch.rand(1, H, W, generator=g) * 0.7 + 0.3).half()
+    m = torch.rand(1, H, W, generator=g).half()
+    wt = (torch.rand(3, H, W, generator=g) - 0.3).cuda()
+    kw = dict(view_dir=[0, 0.1, 1], light=light, light_intensity=[[0.8, 0.7, 0.6]] * lights, light_type=light_type, light_size=size)
+    h16 = [t.clone().cuda().requires_grad_(True) for t in (a, n, r, m)]
+    out16 = F.cook_torrance(*h16, **kw)
+    assert out16.dtype == torch.float32
+    (out16 * wt).sum().backward()
+    f32 = [t.float().cuda().requires_grad_(True) for t in (a, n, r, m)]
+    out32 = F.cook_torrance(*f32, **kw)
+    assert (out16 - out32).abs().max().item() <= 2e-6          # packed two-pixel body (fp16 maps) vs the scalar one
+    (out32 * wt).sum().backward()
+    for name, x, y in zip(("albedo", "normal", "roughness", "metallic"), h16, f32):
+        assert x.grad.dtype == torch.float16 and x.grad.shape == x.shape
+        assert bool(torch.isfinite(x.grad).all()), name
+        err = (x.grad.float() - y.grad).abs()
+        assert (err <= 1e-3 * (1e-3 + y.grad.abs())).all(), (name, float(err.max()))      # fp16: 2^-11 relative, denormal floor
 
 
 @pytest.mark.parametrize("quirk", [True, False])

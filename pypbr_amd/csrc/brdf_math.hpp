@@ -55,6 +55,8 @@ __device__ __forceinline__ float min_(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ float select_(bool m, float a, float b) { return m ? a : b; }
 __device__ __forceinline__ bool gt_(float a, float b) { return a > b; }
 __device__ __forceinline__ bool le_(float a, float b) { return a <= b; }
+__device__ __forceinline__ bool ge_(float a, float b) { return a >= b; }
+__device__ __forceinline__ bool and_(bool a, bool b) { return a && b; }
 
 // ---- two pixels per lane: +, -, * on f32x2 compile to v_pk_add/mul_f32, fma to v_pk_fma_f32
 __device__ __forceinline__ f32x2 rcp(f32x2 x) { return f32x2{rcp(x.x), rcp(x.y)}; }
@@ -89,6 +91,8 @@ __device__ __forceinline__ f32x2 min_(f32x2 a, f32x2 b) { return f32x2{fminf(a.x
 __device__ __forceinline__ f32x2 select_(i32x2 m, f32x2 a, f32x2 b) { return m ? a : b; }
 __device__ __forceinline__ i32x2 gt_(f32x2 a, f32x2 b) { return a > b; }
 __device__ __forceinline__ i32x2 le_(f32x2 a, f32x2 b) { return a <= b; }
+__device__ __forceinline__ i32x2 ge_(f32x2 a, f32x2 b) { return a >= b; }
+__device__ __forceinline__ i32x2 and_(i32x2 a, i32x2 b) { return a & b; }
 
 template <class R> __device__ __forceinline__ R splat(float v);
 template <> __device__ __forceinline__ float splat<float>(float v) { return v; }

@@ -112,7 +112,27 @@ def main():
     print(json.dumps({"config": "backward B=1 4096^2 point fp32 (grads of albedo, normal, roughness, metallic)",
                       "bytes_per_pixel": 76, "us_per_launch": round(dt * 1e6, 1), "Mpixels_per_s": round(px / dt / 1e6, 1),
                       "hbm_GBps_algorithmic": round(76 * px / dt / 1e9, 1), "frac_of_8TBps": round(76 * px / dt / 1e9 / PEAK, 4)}), flush=True)
-    del a, n, r, m, plan, gout, grads
+    # the same with fp16 maps and fp16 gradients (16 B maps + 12 B upstream gradient in, 16 B gradients out)
+    h = [t.half() for t in (a, n, r, m)]
+    plan16 = F.plan_cook_torrance(*h, **pt)
+    grads16 = [torch.empty_like(t) for t in h]
+
+    def bwd16():
+        N.check(lib.pbr_cook_torrance_backward(ctypes.byref(plan16.desc), gout.data_ptr(), grads16[0].data_ptr(), grads16[1].data_ptr(),
+                                               grads16[2].data_ptr(), grads16[3].data_ptr(), None, stream))
+    for _ in range(3):
+        bwd16()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        bwd16()
+    e1.record()
+    torch.cuda.synchronize()
+    dt = e0.elapsed_time(e1) / 20 * 1e-3
+    print(json.dumps({"config": "backward B=1 4096^2 point, fp16 maps -> fp16 gradients", "bytes_per_pixel": 44,
+                      "us_per_launch": round(dt * 1e6, 1), "Mpixels_per_s": round(px / dt / 1e6, 1),
+                      "hbm_GBps_algorithmic": round(44 * px / dt / 1e9, 1), "frac_of_8TBps": round(44 * px / dt / 1e9 / PEAK, 4)}), flush=True)
+    del a, n, r, m, plan, gout, grads, h, plan16, grads16
     # PCIe-inclusive: CPU-resident 4096^2 material through the reference-shaped callable
     from pypbr_amd.materials import BasecolorMetallicMaterial
     from pypbr_amd.models import CookTorranceBRDF

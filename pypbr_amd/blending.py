@@ -6,7 +6,6 @@ exactly like the reference.  All arithmetic (mask generation, per-map lerp, norm
 runs in libpbr_hip.so; CPU-resident materials are staged through the device."""
 import contextlib
 from abc import ABC, abstractmethod
-from typing import Optional
 
 import torch
 

@@ -13,7 +13,7 @@ Partitioning:
     that of the full map.
 The reference has no distributed code at all; this module is a build extension.
 """
-from typing import Dict, List, NamedTuple, Optional
+from typing import Dict, NamedTuple, Optional
 
 import torch
 

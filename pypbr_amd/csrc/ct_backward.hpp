@@ -131,10 +131,11 @@ __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const Li
 //   (float | __half; arithmetic and the upstream gradient are fp32)
 template <int LIGHT, int WF, int VEC, bool MULTI, typename TM = float>
 __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
-    // Packed two-pixel arithmetic for fp16 maps only, as in the forward kernels: in-process A/B on 4096^2 maps --
-    // fp16 maps 182 us packed vs 194 us scalar, fp32 maps 221 us packed vs 206 us scalar (the fp32 launch is bound by
-    // the memory system, and there the shorter arithmetic phases only make its 19 streams burstier).
-    constexpr bool kPacked = sizeof(TM) == 2;
+    // Packed two-pixel arithmetic for fp16 maps and for several lights, as in the forward kernels: A/B on 4096^2 maps --
+    // fp16 maps 182 us packed vs 194 us scalar; 4 lights fp32 423 us vs 491 us; one light fp32 221 us packed vs 206 us
+    // scalar (that launch is bound by the memory system, and there the shorter arithmetic phases only make its 19
+    // streams burstier).
+    constexpr bool kPacked = sizeof(TM) == 2 || MULTI;
     using R = typename RealOf<VEC, kPacked>::type;
     constexpr int NG = RealOf<VEC, kPacked>::N;
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);

@@ -15,7 +15,9 @@ from pypbr_amd import _native as N, functional as F  # noqa: E402
 S = 4096
 dev = torch.device("cuda", 0)
 P = S * S
-kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
+L = int(os.environ.get("PBR_PROBE_LIGHTS", "1"))          # several lights: the two-pass form of the backward kernel
+kw = dict(view_dir=[0, 0, 1], light=[[0.1 + 0.05 * i, 0.1 - 0.03 * i, 1.0] for i in range(L)], light_intensity=[[1.0 / L] * 3] * L,
+          light_type="point", light_size=1.0)
 stream = torch.cuda.current_stream(dev).cuda_stream
 lib = N.lib()
 

@@ -10,12 +10,22 @@ its own material (independent materials shard with no data-path collective, weak
 scaling); the light/view parameter block is broadcast once from rank 0 over RCCL.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--no-cpu-baseline] [--layout arena|separate] [--settle 300]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 starts the N ranks itself: the parent process (which never touches a GPU)
+runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+bench.py ...` as a child and exits with its code.  Started under torch.distributed.run already (RANK in the
+environment), the script is a rank.
+
+Timing protocol.  Two timed regions, both K steps bracketed by barrier + synchronize, MAX over ranks:
+  cold    W warm-up launches from whatever state the GPU was in, then K timed steps -- the literal
+          "W warm-up, K steps" protocol -> `ms_per_step_cold`, `value_cold`;
+  steady  `--settle` (default 300) further untimed launches so that power management has settled the clocks
+          (tools/transient_probe.py), then K timed steps -> `ms_per_step`, `value`: the sustained rate.
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
   roofline     -- achieved algorithmic HBM GB/s of the kernel (44 B/pixel x pixels per launch /
-                  average launch duration from HIP events on the launch stream) vs 8 TB/s
+                  average launch duration from HIP events on the launch stream, steady region) vs 8 TB/s
+  per_rank     -- kernel_us of every rank (steady region) and the latency of the light-block broadcast
+  parity       -- bands of the timed output of this run against the float64 C oracle and the ATen restatement
   cpu_baseline -- the ATen-level restatement of the reference's CPU path (oracle/torch_oracle.py,
                   kind "port": bit-equal to the reference in the dev container) timed on this
                   host's cores on a bounded sample, rank 0, N=1 only.
@@ -23,6 +33,8 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,6 +45,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_BUFFER_SETS = 3              # rotate map sets: 704 MiB per step never re-hits the 256 MiB Infinity Cache anyway
+VIEW, LIGHT, INTENSITY, LIGHT_SIZE = [0.0, 0.0, 1.0], [0.1, 0.1, 1.0], [1.0, 1.0, 1.0], 1.0
 
 
 def synth_material(size, device, seed):
@@ -49,13 +62,19 @@ def synth_material(size, device, seed):
     return albedo, normal, rough, metal
 
 
+def _oracle_path():
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
 def cpu_baseline(sample_size, passes):
     """Times the ATen-level oracle (the reference's op sequence) on the host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    _oracle_path()
     import torch_oracle
     a, n, r, m = [t.cpu() for t in synth_material(sample_size, "cpu", 99)]
-    kw = dict(view=torch.tensor([0.0, 0.0, 1.0]), light=torch.tensor([0.1, 0.1, 1.0]),
-              intensity=torch.tensor([1.0, 1.0, 1.0]), light_type="point", light_size=1.0)
+    kw = dict(view=torch.tensor(VIEW), light=torch.tensor(LIGHT), intensity=torch.tensor(INTENSITY),
+              light_type="point", light_size=LIGHT_SIZE)
     small = [t[:, :512, :512].contiguous() for t in (a, n, r, m)]
     torch_oracle.cook_torrance(*small, None, **kw)                                  # warm-up (cold first call ~1 s)
     # ATen's intra-op pool defaults to every host core; the reference's op mix scales badly past a few
@@ -81,17 +100,85 @@ def cpu_baseline(sample_size, passes):
                       f"workload, oracle/torch_oracle.py (ATen ops of the reference) at its fastest ATen thread count, {dt:.1f} s"}
 
 
+def parity_of_timed_output(plan, maps, size, band_rows=8):
+    """The checker's leg (like cpu_baseline: the only place bench.py touches oracle/): three row bands of the
+    output the timed launches wrote -- first rows, middle, LAST rows -- against the float64 C oracle
+    (oracle/ct_oracle.c) and the fp32 ATen restatement of the reference (oracle/torch_oracle.py)."""
+    _oracle_path()
+    import numpy as np
+    import c_oracle
+    import torch_oracle
+    out = plan.result
+    a, n, r, m = maps
+    worst64 = worst32 = 0.0
+    over = values = 0
+    bands = sorted({0, (size - band_rows) // 2, size - band_rows})
+    for y0 in bands:
+        sl = slice(y0, y0 + band_rows)
+        ca, cn, cr, cm = [t[:, sl, :].cpu() for t in (a, n, r, m)]
+        got = out[:, sl, :].cpu().numpy()
+        ref64 = c_oracle.render(ca.numpy(), cn.numpy(), cr.numpy(), cm.numpy(), view=VIEW, lights=LIGHT, intensities=INTENSITY,
+                                light_type="point", light_size=LIGHT_SIZE, y_offset=y0, H_total=size, dtype=np.float64)
+        ref32 = torch_oracle.cook_torrance(ca, cn, cr, cm, None, view=torch.tensor(VIEW), light=torch.tensor(LIGHT),
+                                           intensity=torch.tensor(INTENSITY), light_type="point", light_size=LIGHT_SIZE,
+                                           y_offset=y0, H_total=size).numpy()
+        worst64 = max(worst64, float(np.abs(got - ref64).max()))
+        d32 = np.abs(got - ref32)
+        worst32 = max(worst32, float(d32.max()))
+        over += int((d32 > 1e-5).sum())
+        values += got.size
+    return {"max_abs_err_vs_fp64_oracle": worst64, "max_abs_err_vs_reference_fp32": worst32,
+            "values_over_1e-5_vs_reference_fp32": over, "values": values, "tolerance": 1e-5,
+            "sample": f"rows {[f'{y}..{y + band_rows - 1}' for y in bands]} (all {size} columns) of the output written by the "
+                      f"timed launches of map set 0; fp64: oracle/ct_oracle.c, fp32: oracle/torch_oracle.py (reference's ATen ops)"}
+
+
 def recorded_traffic(kernel_name):
     """HBM bytes per launch from the PMC passes (rocprofv3 --pmc, collected separately and committed
-    under profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE."""
+    under profiles/): FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 + WRITE_SIZE.
+    Returns (bytes or None, which committed run they come from)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
         ent = rec.get(kernel_name)
-        return None if ent is None else ent.get("hbm_bytes_per_launch")
+        if ent is None:
+            return None, None
+        return ent.get("hbm_bytes_per_launch"), ent.get("run", "profiles/pmc_traffic.json: " + ent.get("collected", ""))
     except (OSError, ValueError):
-        return None
+        return None, None
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N`, N > 1, typed as it stands: this process has not touched the GPU (and never will);
+    the N ranks run under torch.distributed.run as a CHILD process, and its exit code becomes ours."""
+    if torch.cuda.device_count() < n:          # counting devices does not initialise HIP
+        raise SystemExit(f"bench.py --gpus {n}: only {torch.cuda.device_count()} ROCm device(s) visible")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def timed_region(plans, steps, stream, barrier, offset=0):
+    """K launches bracketed by barrier + synchronize on both sides; returns (wall seconds, kernel ms per launch from
+    HIP events recorded on the launch stream)."""
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()                                   # same stream the kernels are launched on
+    for i in range(steps):
+        plans[(offset + i) % N_BUFFER_SETS].launch(stream)
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0             # this rank's K steps; MAX over ranks by the caller
+    barrier()
+    return elapsed, ev0.elapsed_time(ev1) / steps
 
 
 def main():
@@ -100,24 +187,25 @@ def main():
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--settle", type=int, default=300, help="untimed clock-settle launches before the warm-up steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the checker's legs (cpu_baseline and parity)")
+    ap.add_argument("--settle", type=int, default=300, help="untimed clock-settle launches between the cold and the steady timed region")
     ap.add_argument("--layout", choices=("separate", "arena"), default="arena",
                     help="arena (default): the material's maps and result in one allocation, as Material.to(device) lays "
                          "them out (F.pack_maps); separate: five tensors as torch's allocator places them")
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--cpu-passes", type=int, default=4)
+    ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1")
     args = ap.parse_args()
+
+    if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
+        launch_ranks(args.gpus)                    # does not return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # PBR_BENCH_FORCE_DIST=1 exercises the RCCL path (init, broadcast, barrier, all-reduce) with one rank
-    distributed = world > 1 or (os.environ.get("PBR_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ)
-    if args.gpus != world and distributed:
+    distributed = "RANK" in os.environ and (world > 1 or args.spawn or os.environ.get("PBR_BENCH_FORCE_DIST") == "1")
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and not distributed:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
 
     from pypbr_amd import functional as F
     from pypbr_amd.distributed import broadcast_light_block
@@ -130,18 +218,31 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
 
-    # light/view parameters: owned by rank 0, broadcast over RCCL/xGMI (400 B, once per change)
-    params = dict(view_dir=[0.0, 0.0, 1.0], light=[[0.1, 0.1, 1.0]], light_intensity=[[1.0, 1.0, 1.0]], light_size=1.0)
+    def barrier():
+        if distributed:
+            dist.barrier(device_ids=[local_rank])
+
+    # light/view parameters: owned by rank 0, broadcast over RCCL/xGMI (404 B, once per change)
+    params = dict(view_dir=VIEW, light=[LIGHT], light_intensity=[INTENSITY], light_size=LIGHT_SIZE)
+    bcast_us = None
     if distributed:
         params = broadcast_light_block(params if rank == 0 else None, device=device, src=0)
+        lat = []
+        for _ in range(20):                        # what one parameter change costs: pack, broadcast, unpack (D2H of 404 B)
+            barrier()
+            t0 = time.perf_counter()
+            broadcast_light_block(params if rank == 0 else None, device=device, src=0)
+            lat.append((time.perf_counter() - t0) * 1e6)
+        bcast_us = sorted(lat)[len(lat) // 2]
 
-    plans = []
+    plans, map_sets = [], []
     for i in range(N_BUFFER_SETS):
         a, n, r, m = synth_material(args.size, device, 1234 + rank * 16 + i)
         out = None
         if args.layout == "arena":      # the maps of a material and its result in ONE allocation (F.pack_maps)
             a, n, r, m, out = F.pack_maps(a, n, r, m, reserve_output=True)
             out = out.unsqueeze(0)
+        map_sets.append((a, n, r, m))
         plans.append(F.plan_cook_torrance(a, n, r, m, view_dir=params["view_dir"], light=params["light"],
                                           light_intensity=params["light_intensity"], light_type="point",
                                           light_size=params["light_size"], out=out))
@@ -150,62 +251,63 @@ def main():
     pixels = args.size * args.size
     stream = torch.cuda.current_stream(device).cuda_stream
 
-    def barrier():
-        if distributed:
-            dist.barrier(device_ids=[local_rank])
-
-    # Clock settle, then the W warm-up steps.  From an idle GPU the first ~20 launches run at boost clocks, the next
-    # ~150 up to 25 % slower while power management reins them in, and the rate is steady from launch ~300 on
-    # (tools/transient_probe.py: 120, 140, 125, 118, 113, 113 ... us).  The timed region should see the steady state
-    # whatever W the caller picked, so a fixed, untimed pre-roll comes first; it is reported in config.
-    for i in range(args.settle + args.warmup):
+    # ---- cold: W warm-up launches, K timed steps (the literal protocol)
+    for i in range(args.warmup):
         plans[i % N_BUFFER_SETS].launch(stream)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()                                   # same stream the kernels are launched on
-    for i in range(args.steps):
+    cold_s, cold_kernel_ms = timed_region(plans, args.steps, stream, barrier, offset=args.warmup)
+    # ---- steady: clock settle (from an idle GPU the first ~20 launches run at boost clocks, the next ~150 up to 25 %
+    # slower while power management reins them in, steady from launch ~300 on: tools/transient_probe.py), K timed steps
+    for i in range(args.settle):
         plans[i % N_BUFFER_SETS].launch(stream)
-    ev1.record()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0             # this rank's K steps; MAX over ranks below
-    barrier()
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps
+    elapsed, kernel_ms = timed_region(plans, args.steps, stream, barrier)
 
+    per_rank_us = [kernel_ms * 1e3]
     if distributed:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        t = torch.tensor([elapsed, cold_s], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, cold_s = float(t[0].item()), float(t[1].item())
+        gathered = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([kernel_ms * 1e3], device=device, dtype=torch.float64))
+        per_rank_us = [float(g.item()) for g in gathered]
 
-    out = plans[0].result
-    assert bool(torch.isfinite(out).all())
+    assert bool(torch.isfinite(plans[0].result).all())
 
     if rank == 0:
         value = world * pixels * args.steps / elapsed / 1e6
         achieved = bpp * pixels / (kernel_ms * 1e-3) / 1e9
+        traffic, traffic_run = recorded_traffic(kernel)
         line = {
             "metric": "Mpixels/s Cook-Torrance eval, 4K maps",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ms_per_step_cold": round(cold_s / args.steps * 1e3, 5),
+            "value_cold": round(world * pixels * args.steps / cold_s / 1e6, 1),
             "config": {"workload": f"Batch=1 {args.size}x{args.size} BasecolorMetallicMaterial per GPU, point light, "
                                    f"fused HIP kernel, fp32 maps, sRGB in/out (BASELINE.json configs[1])",
                        "kernel": kernel, "pixels_per_launch": pixels, "bytes_per_pixel": bpp,
-                       "parallelism": f"material-sharded x{world}", "clock_settle_launches": args.settle,
+                       "parallelism": f"material-sharded x{world}",
+                       "timing": f"value/ms_per_step: {args.steps} steps after {args.warmup} warm-up + {args.steps} cold-timed + "
+                                 f"{args.settle} clock-settle launches (sustained rate); value_cold/ms_per_step_cold: the "
+                                 f"{args.steps} steps right after the {args.warmup} warm-up launches",
+                       "clock_settle_launches": args.settle,
                        "layout": "arena: the 8 map planes of a material and its 3 result planes in one allocation "
                                  "(pypbr_amd.functional.pack_maps, what Material.to(device) does)"
                                  if args.layout == "arena" else "separate: albedo, normal, roughness, metallic and the result as "
                                                                 "five tensors wherever torch's allocator put them"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": recorded_traffic(kernel),
-                         "kernel_us": round(kernel_ms * 1e3, 2)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_run,
+                         "kernel_us": round(kernel_ms * 1e3, 2), "kernel_us_cold": round(cold_kernel_ms * 1e3, 2)},
+            "per_rank": {"kernel_us": [round(u, 2) for u in per_rank_us],
+                         "light_block_broadcast_us": None if bcast_us is None else round(bcast_us, 1)},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_passes)
+        if not args.no_cpu_baseline:
+            line["parity"] = parity_of_timed_output(plans[0], map_sets[0], args.size)
+            if world == 1:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_passes)
         print(json.dumps(line), flush=True)
     if distributed:
+        dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
 
 

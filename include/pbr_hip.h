@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PBR_HIP_ABI_VERSION 2
+#define PBR_HIP_ABI_VERSION 3
 #define PBR_MAX_LIGHTS 16
 
 /* ---- status codes (negative = caller error, positive = HIP runtime error code + 1000) */
@@ -138,13 +138,21 @@ int pbr_cook_torrance_autotune(const pbr_render_desc *desc, void *stream, int32_
  * base.py:191-242) and CookTorranceBRDF.forward, in one pass: both materials are read once and the blended
  * maps are never written.  `desc` describes material 1 and the evaluation exactly as for pbr_cook_torrance;
  * `blend` holds material 2 (same dtype -- fp32 only --, workflow and extent; all of albedo, normal, roughness and
- * metallic|specular present in both) and the weights of material 1.  `workspace`: `batch` ints of device memory
- * (one "blended normal has a negative component" flag per material, set by a first small kernel on `stream`).
+ * metallic|specular present in both) and the weights of material 1.  `workspace`: `batch` ints of device memory,
+ * one "the blended normal map has a negative component" flag per material (base.py:212: a property of the WHOLE map).
+ * sign_mode PBR_BLEND_SIGN_COMPUTE: a first small kernel on `stream` sets the flags from the maps the descriptor
+ * holds -- whole maps only (a row band of an untiled map returns PBR_ERR_UNSUPPORTED).  PBR_BLEND_SIGN_GIVEN: the
+ * caller has filled `workspace`, e.g. for row bands (multi-GPU sharding of one material): zero it, run
+ * pbr_blend_normal_sign on every band (it only ever sets flags), combine the bands' flags (MAX), then evaluate.
  */
+enum { PBR_BLEND_SIGN_COMPUTE = 0, PBR_BLEND_SIGN_GIVEN = 1 };
 typedef struct pbr_blend_desc {
     pbr_map albedo, normal, roughness, metallic, specular;   /* material 2 */
     pbr_map mask;                 /* 1 channel fp32 in [0,1], [B|1][map rows][map cols]; batch_stride 0 = shared */
+    int32_t sign_mode;            /* PBR_BLEND_SIGN_* */
+    int32_t reserved;             /* 0 */
 } pbr_blend_desc;
+int pbr_blend_normal_sign(const pbr_render_desc *desc, const pbr_blend_desc *blend, void *workspace, void *stream);
 int pbr_cook_torrance_blend(const pbr_render_desc *desc, const pbr_blend_desc *blend, void *workspace, void *stream);
 
 /*
@@ -161,6 +169,21 @@ int pbr_cook_torrance_blend(const pbr_render_desc *desc, const pbr_blend_desc *b
 int pbr_cook_torrance_backward(const pbr_render_desc *desc, const void *grad_out, void *g_albedo,
                                void *g_normal, void *g_roughness, void *g_metallic, void *g_specular,
                                void *stream);
+
+/*
+ * The same, plus the gradient w.r.t. the view / light parameters: the reference's forward is plain torch ops on
+ * view_dir, light_dir_or_position and light_intensity (cooktorrance.py:95-96, :126-140), so its autograd reaches them
+ * (e.g. optimising a light position against a photograph).  `g_params`: (3 + 6 L) floats of DEVICE memory, written as
+ * [d/d view_dir (3) | d/d lights (L x 3) | d/d intensities (L x 3)] -- w.r.t. the values in the descriptor (view and
+ * directional lights un-normalised: the F.normalize Jacobian of :95 / :126 is applied); light_size is a Python float
+ * upstream and has no gradient.  `workspace`: pbr_param_grad_workspace_bytes(desc) bytes of device memory (per-workgroup
+ * partial sums, added up in fp64 in a fixed order by a second small kernel on `stream`: deterministic).  Any of the
+ * map gradients may be NULL.
+ */
+size_t pbr_param_grad_workspace_bytes(const pbr_render_desc *desc);
+int pbr_cook_torrance_backward_params(const pbr_render_desc *desc, const void *grad_out, void *g_albedo,
+                                      void *g_normal, void *g_roughness, void *g_metallic, void *g_specular,
+                                      void *g_params, void *workspace, void *stream);
 
 /* ---- stand-alone map conversions (same arithmetic as the fused kernel) ------------- */
 

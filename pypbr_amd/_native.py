@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBR_HIP_LIB") or os.path.join(_HERE, "libpbr_hip.so")   # env override: A/B of two builds
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_LIGHTS = 16
 
 F32, F16 = 0, 1
@@ -29,6 +29,7 @@ EXPORTS = (
     "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
     "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask", "pbr_cook_torrance_autotune",
     "pbr_cook_torrance_blend", "pbr_fold_gradient", "pbr_decode_normal_backward",
+    "pbr_blend_normal_sign", "pbr_param_grad_workspace_bytes", "pbr_cook_torrance_backward_params",
 )
 
 
@@ -56,7 +57,10 @@ class RenderDesc(ctypes.Structure):
 class BlendDesc(ctypes.Structure):
     """pbr_blend_desc: material 2 of a fused blend + the weights of material 1."""
     _fields_ = [("albedo", PbrMap), ("normal", PbrMap), ("roughness", PbrMap), ("metallic", PbrMap), ("specular", PbrMap),
-                ("mask", PbrMap)]
+                ("mask", PbrMap), ("sign_mode", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+BLEND_SIGN_COMPUTE, BLEND_SIGN_GIVEN = 0, 1
 
 
 SCHEDULE_AUTO, SCHEDULE_LINEAR = 0, 1
@@ -96,6 +100,12 @@ def lib():
     L.pbr_cook_torrance_autotune.restype = ctypes.c_int
     L.pbr_cook_torrance_blend.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(BlendDesc), vp, vp]
     L.pbr_cook_torrance_blend.restype = ctypes.c_int
+    L.pbr_blend_normal_sign.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(BlendDesc), vp, vp]
+    L.pbr_blend_normal_sign.restype = ctypes.c_int
+    L.pbr_param_grad_workspace_bytes.argtypes = [ctypes.POINTER(RenderDesc)]
+    L.pbr_param_grad_workspace_bytes.restype = ctypes.c_size_t
+    L.pbr_cook_torrance_backward_params.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pbr_cook_torrance_backward_params.restype = ctypes.c_int
     L.pbr_fold_gradient.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_int, vp]
     L.pbr_fold_gradient.restype = ctypes.c_int
     L.pbr_cook_torrance_backward.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp]

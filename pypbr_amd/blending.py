@@ -32,6 +32,11 @@ def blend_maps(map1: torch.Tensor, map2: torch.Tensor, mask: torch.Tensor, is_no
     """mask * map1 + (1 - mask) * map2 for one (C,H,W) map and a (1,H,W) mask; `is_normal`:
     normalise both, blend, re-normalise (functional.py:119-145)."""
     a, b, m = _check_f32(map1, "blend_maps"), _check_f32(map2, "blend_maps"), _check_f32(mask, "blend_maps")
+    if a.dim() == 3 and b.dim() == 3 and a.shape[0] != b.shape[0] and 1 in (a.shape[0], b.shape[0]) and a.shape[1:] == b.shape[1:]:
+        # `mask * map1 + (1 - mask) * map2` broadcasts a 1-channel map against a 3-channel one upstream (e.g. the
+        # 3-channel metallic map to_basecolor_metallic_material returns, diffuse.py:147, against a 1-channel one)
+        c = max(a.shape[0], b.shape[0])
+        a, b = a.expand(c, -1, -1).contiguous(), b.expand(c, -1, -1).contiguous()
     if a.shape != b.shape or a.dim() != 3 or m.numel() != a.shape[1] * a.shape[2]:
         raise ValueError("maps %s / %s and mask %s do not match" % (tuple(a.shape), tuple(b.shape), tuple(m.shape)))
     out = torch.empty_like(a)

@@ -131,6 +131,7 @@ template <class R> __device__ __forceinline__ R dotu(const Vec3T<R> &a, const Ve
 template <class R> struct LightGeomT {
     Vec3T<R> d;    // point: light position - surface point, un-normalised; directional: L
     R rinv;        // point: 1/(dist + 1e-7); directional: 1.   N.L = (N.d) rinv costs 4 ops, never forming L
+    R rdist;       // point: 1/dist (the v_rsq itself); only the light-parameter gradient reads it
     Vec3T<R> L;    // light direction as the reference uses it (d * rinv); only the backward kernel reads it
     Vec3T<R> h;    // V + L, un-normalised
     R rhh;         // 1/|h|^2  (|h|^2 clamped at 1e-24: F.normalize's 1e-12 on the norm)
@@ -156,7 +157,7 @@ __device__ __forceinline__ LightGeomT<R> point_light_geom(const Vec3 &V, const V
     const R dd = dot_plus(d, d, 1e-12f);                            // dist^2, torch.norm :138
     const R r = rsq(dd);
     const R rinv = r * fma_(splat<R>(-1e-7f), r, splat<R>(1.0f));   // 1/(dist + 1e-7)  :139
-    g.d = d; g.rinv = rinv;
+    g.d = d; g.rinv = rinv; g.rdist = r;
     g.L = {d.x * rinv, d.y * rinv, d.z * rinv};
     g.att = rcp(dd + 1e-7f);                                        // :140
     g.h = {fma_(d.x, rinv, splat<R>(V.x)), fma_(d.y, rinv, splat<R>(V.y)), fma_(d.z, rinv, splat<R>(V.z))};   // :155

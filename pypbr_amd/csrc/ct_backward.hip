@@ -1,0 +1,96 @@
+// ct_backward.hip -- launchers of the backward kernels (C ABI: pbr_cook_torrance_backward, pbr_cook_torrance_backward_params);
+// device code in ct_backward.hpp.
+#include "ct_backward.hpp"
+#include "ct_launch.hpp"
+
+namespace pbr {
+
+using BwdFn = void (*)(const KArgs, const BArgs);
+
+template <int L, int W, typename T, bool PG>
+static BwdFn pick_bwd_variant(int vec, bool multi) {
+    if (vec == 4) return multi ? cook_torrance_backward_kernel<L, W, 4, true, T, PG> : cook_torrance_backward_kernel<L, W, 4, false, T, PG>;
+    return multi ? cook_torrance_backward_kernel<L, W, 1, true, T, PG> : cook_torrance_backward_kernel<L, W, 1, false, T, PG>;
+}
+
+template <bool PG>
+static BwdFn pick_bwd(const pbr_render_desc *d, int vec) {
+    const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT, half_maps = d->map_dtype == PBR_F16;
+#define PBR_BWD(L, W) return half_maps ? pick_bwd_variant<L, W, __half, PG>(vec, multi) : pick_bwd_variant<L, W, float, PG>(vec, multi)
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC);
+        case 1: PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR);
+        case 2: PBR_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED);
+        case 3: PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC);
+        case 4: PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR);
+        default: PBR_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED);
+    }
+#undef PBR_BWD
+}
+
+// Tiles of the 1-pixel-per-lane decomposition: the most any launch of this descriptor can have.
+static int64_t max_tiles(const pbr_render_desc *d) {
+    KArgs k;
+    fill_args(d, 1, k);
+    return k.n_tiles;
+}
+
+static int launch_backward(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal, void *g_roughness,
+                           void *g_metallic, void *g_specular, void *g_params, void *workspace, void *stream) {
+    const int rc = validate(d);
+    if (rc != PBR_OK) return rc;
+    if (!grad_out) return PBR_ERR_NULL_MAP;
+    if (g_params && !workspace) return PBR_ERR_NULL_MAP;
+    if (d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;        // the upstream gradient is fp32; maps (and their gradients) fp32 | fp16
+    int vec = pick_vec(d);
+    for (const void *g : {grad_out, (const void *)g_albedo, (const void *)g_normal, (const void *)g_roughness,
+                          (const void *)g_metallic, (const void *)g_specular})
+        if (g && (reinterpret_cast<uintptr_t>(g) & 15u)) vec = 1;
+    if (vec == 8) vec = 4;
+    KArgs k;
+    fill_args(d, vec, k);
+    if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+    k.o_cs = (int64_t)d->height * d->width; k.o_bs = 3 * k.o_cs;     // grad_out and the g_* are contiguous, whatever `out` was
+    const BArgs b = {grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, static_cast<float *>(workspace)};
+    const BwdFn fn = g_params ? pick_bwd<true>(d, vec) : pick_bwd<false>(d, vec);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0, st, k, b);
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return 1000 + (int)err;
+    if (g_params) {
+        ParamFinishArgs f;
+        std::memset(&f, 0, sizeof(f));
+        f.partials = static_cast<const float *>(workspace); f.out = static_cast<float *>(g_params);
+        f.n_rows = k.n_tiles; f.n_lights = d->n_lights; f.light_type = d->light_type;
+        for (int c = 0; c < 3; ++c) f.view[c] = d->view_dir[c];
+        for (int i = 0; i < d->n_lights; ++i)
+            for (int c = 0; c < 3; ++c) f.lights[i][c] = d->lights[i][c];
+        hipLaunchKernelGGL(param_grad_finish_kernel, dim3(1u + 2u * (unsigned)d->n_lights), dim3(256), 0, st, f);
+        err = hipGetLastError();
+    }
+    return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
+
+}  // namespace pbr
+
+extern "C" {
+
+int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal,
+                               void *g_roughness, void *g_metallic, void *g_specular, void *stream) {
+    return pbr::launch_backward(d, grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, nullptr, nullptr, stream);
+}
+
+size_t pbr_param_grad_workspace_bytes(const pbr_render_desc *d) {
+    if (pbr::validate(d) != PBR_OK) return 0;
+    const int64_t tiles = pbr::max_tiles(d);
+    return tiles < 0 ? 0 : (size_t)tiles * (size_t)(3 + 6 * d->n_lights) * sizeof(float);
+}
+
+int pbr_cook_torrance_backward_params(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal,
+                                      void *g_roughness, void *g_metallic, void *g_specular, void *g_params,
+                                      void *workspace, void *stream) {
+    if (!g_params) return PBR_ERR_NULL_MAP;
+    return pbr::launch_backward(d, grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, g_params, workspace, stream);
+}
+
+}  // extern "C"

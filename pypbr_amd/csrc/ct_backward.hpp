@@ -23,7 +23,25 @@ namespace pbr {
 struct BArgs {
     const void *gout;                      // upstream gradient, [B][3][H][W] contiguous fp32
     void *g_albedo, *g_normal, *g_rough, *g_metal, *g_spec;   // contiguous, NULL = not wanted
+    float *g_param_partials;               // PGRAD kernels: [n_tiles][3 + 6 L] per-workgroup sums of the adjoints of
+                                           // V (3), the lights' L | position (L x 3) and their intensities (L x 3)
 };
+
+// Adjoints of one light's parameters, for the lane's pixel group (the reference's autograd reaches view_dir,
+// light_dir_or_position and light_intensity: cooktorrance.py:95-96, :126-140 are plain torch ops on them).
+template <class R> struct LightParamAdjT {
+    Vec3T<R> g_L;     // directional: adjoint of the normalised L; point: of the light position
+    Vec3T<R> g_V;     // this light's share of the adjoint of the normalised view vector (through h = V + L and Hv.V)
+    R g_I[3];
+};
+
+__device__ __forceinline__ float hsum(float v) { return v; }
+__device__ __forceinline__ float hsum(f32x2 v) { return v.x + v.y; }
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 
 template <class R> using MaskT = typename MaskOf<R>::type;
 template <class R> __device__ __forceinline__ MaskT<R> in_unit(R x) {
@@ -80,10 +98,11 @@ template <class R> struct PixelAdjointT {
 };
 
 // Chain rule through one light's contribution, given the adjoint of its clamped colour.
-template <class R>
+template <int LIGHT, bool PG, class R>
 __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const LightGeomT<R> &g, const float inten[3],
-                                               const LightEvalT<R> &e, const R g_col[3], PixelAdjointT<R> &adj) {
-    R g_dg = splat<R>(0.0f), g_rad = splat<R>(0.0f);
+                                               const LightEvalT<R> &e, const R g_col[3], PixelAdjointT<R> &adj,
+                                               const Vec3 &V, LightParamAdjT<R> &pa) {
+    R g_dg = splat<R>(0.0f), g_rad = splat<R>(0.0f), g_p5 = splat<R>(0.0f);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const R gu = masked(in_unit(e.u[ch]), g_col[ch]);                    // clamp :177
@@ -94,6 +113,10 @@ __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const Li
         g_dg = fma_(gS, e.F[ch], g_dg);
         const R gF = gS * (e.dg - t.kb[ch]);
         adj.g_f0[ch] = fma_(gF, g.om5, adj.g_f0[ch]);                        // F = f0 + (1-f0) p5, :196
+        if constexpr (PG) {
+            g_p5 = fma_(gF, splat<R>(1.0f) - t.f0[ch], g_p5);
+            pa.g_I[ch] = (gu * S) * e.rad;                                   // u = S rad I   (:175-176)
+        }
     }
     R g_ndl = g_rad * g.att;                                                 // :175
     // dg = (a2 ndv ndl) q,  q = 1 / (dD dv dl ds)
@@ -125,11 +148,40 @@ __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const Li
     adj.g_n.x = fma_(gl, g.L.x, fma_(gch, g.h.x, adj.g_n.x));
     adj.g_n.y = fma_(gl, g.L.y, fma_(gch, g.h.y, adj.g_n.y));
     adj.g_n.z = fma_(gl, g.L.z, fma_(gch, g.h.z, adj.g_n.z));
+    if constexpr (PG) {
+        // ---- light / view parameters.  h = V + L (un-normalised); c = (n.h)/|h| (:215), cos = clamp((h.V)/|h|) (:156-158),
+        // p5 = (1 - cos)^5 (:196).  d(x.h / |h|)/dh = (x - (x.h / |h|^2) h) / |h|.
+        const R rh = sqrt_hw(g.rhh);
+        const R hv = dotu(g.h, V);
+        const R cos_raw = hv * rh;
+        const R om = splat<R>(1.0f) - clamp01(cos_raw), om2 = om * om;
+        const R gcs = masked(in_unit(cos_raw), g_p5 * (om2 * om2) * -5.0f) * rh;
+        const R nhr = (e.ndl_raw + t.ndv_raw) * g.rhh, hvr = hv * g.rhh;
+        const R wh = fma_(gch, nhr, gcs * hvr);                              // g_h = gch n + gcs V - wh h
+        const Vec3T<R> g_h = {fma_(gch, t.n.x, fma_(gcs, splat<R>(V.x), -wh * g.h.x)),
+                              fma_(gch, t.n.y, fma_(gcs, splat<R>(V.y), -wh * g.h.y)),
+                              fma_(gch, t.n.z, fma_(gcs, splat<R>(V.z), -wh * g.h.z))};
+        pa.g_V = {fma_(gcs, g.h.x, g_h.x), fma_(gcs, g.h.y, g_h.y), fma_(gcs, g.h.z, g_h.z)};   // + the direct V of Hv.V
+        const Vec3T<R> g_Ld = {fma_(gl, t.n.x, g_h.x), fma_(gl, t.n.y, g_h.y), fma_(gl, t.n.z, g_h.z)};   // N.L and h
+        if (LIGHT == PBR_LIGHT_POINT) {
+            // L = d rinv, rinv = 1/(|d| + 1e-7) (:139); att = 1/(|d|^2 + 1e-7) (:140); rad = ndl att (:175)
+            const R g_rinv = dot(g_Ld, g.d);
+            const R g_att = g_rad * e.ndl;
+            const R coef = fma_(g_rinv * g.rdist, -(g.rinv * g.rinv), (g_att * -2.0f) * (g.att * g.att));
+            pa.g_L = {fma_(g_Ld.x, g.rinv, coef * g.d.x), fma_(g_Ld.y, g.rinv, coef * g.d.y), fma_(g_Ld.z, g.rinv, coef * g.d.z)};
+        } else {
+            pa.g_L = g_Ld;
+        }
+    }
 }
 
 //   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_*    VEC: 4 | 1    TM: storage type of the maps AND of their gradients
 //   (float | __half; arithmetic and the upstream gradient are fp32)
-template <int LIGHT, int WF, int VEC, bool MULTI, typename TM = float>
+//   PGRAD: also the adjoints of view / light / intensity, summed over the workgroup's pixels into b.g_param_partials
+//   (one row per workgroup; param_grad_finish_kernel adds the rows up).  In these instantiations no lane leaves early:
+//   lanes outside the map shade a clamped (valid) position with a zero upstream gradient, so that every lane takes
+//   part in the wave reductions.
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM = float, bool PGRAD = false>
 __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
     // Packed two-pixel arithmetic for fp16 maps and for several lights, as in the forward kernels: A/B on 4096^2 maps --
     // fp16 maps 182 us packed vs 194 us scalar; 4 lights fp32 423 us vs 491 us; one light fp32 221 us packed vs 206 us
@@ -140,14 +192,28 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
     constexpr int NG = RealOf<VEC, kPacked>::N;
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
     const int ty = (int)a.div_tx.div(tile);
-    const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);
-    if (!p.valid) return;
+    const LanePos p = lane_pos<VEC, PGRAD>(a, (int)tile - ty * a.tiles_x, ty);
+    if (!PGRAD && !p.valid) return;
+    constexpr int kParamSlots = 3 + 6 * PBR_MAX_LIGHTS;
+    __shared__ float s_param[PGRAD ? kParamSlots : 1];
+    const int n_param = 3 + 6 * a.n_lights;
+    if constexpr (PGRAD) {
+        for (int i = threadIdx.x; i < n_param; i += blockDim.x) s_param[i] = 0.0f;
+        __syncthreads();
+    }
     Texels<VEC> t;
     load_texels<WF, TM, VEC, true>(a, a.has_normal != 0, p, t);
     float go[3][VEC];
     const int64_t opix = p.b * a.o_bs + p.pix;
 #pragma unroll
     for (int c = 0; c < 3; ++c) Ld<float, VEC>::template load<true>(b.gout, opix + c * a.o_cs, go[c]);
+    if (PGRAD && !p.valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) go[c][j] = 0.0f;
+    }
+    float accV[3] = {0.0f, 0.0f, 0.0f}, accL[3] = {0.0f, 0.0f, 0.0f}, accI[3] = {0.0f, 0.0f, 0.0f};   // one-light PGRAD
     if (!a.has_normal) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { t.nm[0][j] = 0.0f; t.nm[1][j] = 0.0f; t.nm[2][j] = 1.0f; }
@@ -225,7 +291,22 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
                 for (int c = 0; c < 3; ++c)
                     g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(clamp01(e.u[c])) : gout_c[c];
             }
-            backprop_light(pt, lg, lu.inten, e, g_col, adj);
+            LightParamAdjT<R> pa;
+            backprop_light<LIGHT, PGRAD>(pt, lg, lu.inten, e, g_col, adj, V, pa);
+            if constexpr (PGRAD) {
+                accV[0] += hsum(pa.g_V.x); accV[1] += hsum(pa.g_V.y); accV[2] += hsum(pa.g_V.z);
+                if constexpr (MULTI) {        // per-light sums leave the lane here: the light loop is a run-time loop
+                    const float v6[6] = {hsum(pa.g_L.x), hsum(pa.g_L.y), hsum(pa.g_L.z), hsum(pa.g_I[0]), hsum(pa.g_I[1]), hsum(pa.g_I[2])};
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        const float w = wave_sum(v6[j]);
+                        if ((threadIdx.x & 63) == 0) atomicAdd(&s_param[j < 3 ? 3 + 3 * l + j : 3 + 3 * a.n_lights + 3 * l + (j - 3)], w);
+                    }
+                } else {
+                    accL[0] += hsum(pa.g_L.x); accL[1] += hsum(pa.g_L.y); accL[2] += hsum(pa.g_L.z);
+                    accI[0] += hsum(pa.g_I[0]); accI[1] += hsum(pa.g_I[1]); accI[2] += hsum(pa.g_I[2]);
+                }
+            }
         }
         // ---- light-independent tail
         // kb = kd_scale * base / pi ; kd_scale = 1 - m  (:169-174)
@@ -250,12 +331,29 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
         scatter(gr, g, fma_(adj.g_k, (rough + 1.0f) * 0.25f, adj.g_a2 * (rough * 2.0f)));   // k = (r+1)^2/8, a2 = r^2
         // N.V clamp, then F.normalize: g_n = (g - n (n.g)) / |n|
         const R gv = masked(in_unit(pt.ndv_raw), adj.g_ndv);
+        if constexpr (PGRAD) {                                                // N.V (:163): the direct share of V
+            accV[0] += hsum(gv * pt.n.x); accV[1] += hsum(gv * pt.n.y); accV[2] += hsum(gv * pt.n.z);
+        }
         const Vec3T<R> gnh = {fma_(gv, splat<R>(V.x), adj.g_n.x), fma_(gv, splat<R>(V.y), adj.g_n.y), fma_(gv, splat<R>(V.z), adj.g_n.z)};
         const R rn = rsq(dot_plus(nraw, nraw, 1e-24f));
         const R radial = dot(pt.n, gnh);
         scatter(gn[0], g, (gnh.x - pt.n.x * radial) * rn);
         scatter(gn[1], g, (gnh.y - pt.n.y * radial) * rn);
         scatter(gn[2], g, (gnh.z - pt.n.z * radial) * rn);
+    }
+    if constexpr (PGRAD) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float wv = wave_sum(accV[j]);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&s_param[j], wv);
+            if constexpr (!MULTI) {
+                const float wl = wave_sum(accL[j]), wi = wave_sum(accI[j]);
+                if ((threadIdx.x & 63) == 0) { atomicAdd(&s_param[3 + j], wl); atomicAdd(&s_param[6 + j], wi); }
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_param; i += blockDim.x) b.g_param_partials[(int64_t)blockIdx.x * n_param + i] = s_param[i];
+        if (!p.valid) return;
     }
     const int64_t gp3 = (int64_t)p.b * 3 * a.o_cs + p.pix, gp1 = (int64_t)p.b * a.o_cs + p.pix;
     if (b.g_albedo) {
@@ -273,6 +371,49 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
 #pragma unroll
         for (int c = 0; c < 3; ++c) Ld<TM, VEC>::template store<true>(b.g_spec, gp3 + c * a.o_cs, gs[c]);
     }
+}
+
+// Adds up the per-workgroup rows of the PGRAD kernels (fp64 sums, fixed order: deterministic) and applies the part of
+// the chain rule that sits in front of the kernel: view_dir and a directional light enter through F.normalize
+// (cooktorrance.py:95, :126), whose Jacobian is (I - v v^T) / max(|x|, 1e-12).  One workgroup per 3-vector:
+// vector 0 = view, 1..L = lights, L+1..2L = intensities.  out: [3 + 6 L] floats in that order.
+struct ParamFinishArgs {
+    const float *partials; float *out; int32_t n_rows, n_lights, light_type;
+    float view[3]; float lights[PBR_MAX_LIGHTS][3];
+};
+__global__ __launch_bounds__(256) void param_grad_finish_kernel(const ParamFinishArgs a) {
+    const int vec = blockIdx.x, n_param = 3 + 6 * a.n_lights;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int r = threadIdx.x; r < a.n_rows; r += 256) {
+        const float *row = a.partials + (int64_t)r * n_param + 3 * vec;
+        s[0] += row[0]; s[1] += row[1]; s[2] += row[2];
+    }
+    __shared__ double red[3][256];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) red[j][threadIdx.x] = s[j];
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    double g[3] = {red[0][0], red[1][0], red[2][0]};
+    const bool normalised = vec == 0 || (vec <= a.n_lights && a.light_type == PBR_LIGHT_DIRECTIONAL);
+    if (normalised) {
+        const float *x = vec == 0 ? a.view : a.lights[vec - 1];
+        const double nrm = sqrt((double)x[0] * x[0] + (double)x[1] * x[1] + (double)x[2] * x[2]);
+        if (nrm > 1e-12) {
+            const double u[3] = {x[0] / nrm, x[1] / nrm, x[2] / nrm};
+            const double ug = u[0] * g[0] + u[1] * g[1] + u[2] * g[2];
+            for (int j = 0; j < 3; ++j) g[j] = (g[j] - u[j] * ug) / nrm;
+        } else {                     // F.normalize divides by the clamp there: d(x / 1e-12)/dx
+            for (int j = 0; j < 3; ++j) g[j] *= 1e12;
+        }
+    }
+    for (int j = 0; j < 3; ++j) a.out[3 * vec + j] = (float)g[j];
 }
 
 }  // namespace pbr

@@ -1,0 +1,98 @@
+// ct_blend.hip -- launcher of the fused blend + evaluate kernels (C ABI: pbr_cook_torrance_blend); device code in ct_blend.hpp.
+#include "ct_blend.hpp"
+#include "ct_launch.hpp"
+
+namespace pbr {
+
+static int check_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, const void *workspace) {
+    const int rc = validate(d);
+    if (rc != PBR_OK) return rc;
+    if (!bl || !workspace) return PBR_ERR_NULL_MAP;
+    if (d->map_dtype != PBR_F32 || d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;
+    if (!d->normal.data || !bl->albedo.data || !bl->normal.data || !bl->roughness.data || !bl->mask.data)
+        return PBR_ERR_NULL_MAP;
+    if (d->workflow == PBR_WORKFLOW_SPECULAR ? !bl->specular.data : !bl->metallic.data) return PBR_ERR_WORKFLOW;
+    if (bl->sign_mode != PBR_BLEND_SIGN_COMPUTE && bl->sign_mode != PBR_BLEND_SIGN_GIVEN) return PBR_ERR_SHAPE;
+    return PBR_OK;
+}
+
+// Sets flag[b] = 1 where the blended normal of material b has a negative component, over the rows the descriptor
+// holds: the whole (map_height, map_width) source maps when they are tiled, else the band's `height` rows.
+static int launch_normal_sign(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, hipStream_t st) {
+    const bool tiled = is_tiled(d);
+    const int64_t P = tiled ? (int64_t)d->map_height * d->map_width : (int64_t)d->height * d->width;
+    const int64_t total = P * d->batch, blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(blend_normal_sign_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st,
+                       static_cast<const float *>(d->normal.data), static_cast<const float *>(bl->normal.data),
+                       static_cast<const float *>(bl->mask.data), d->normal.batch_stride, d->normal.channel_stride,
+                       bl->normal.batch_stride, bl->normal.channel_stride, bl->mask.batch_stride, P, total,
+                       static_cast<int *>(workspace));
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
+
+}  // namespace pbr
+
+extern "C" {
+
+int pbr_blend_normal_sign(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, void *stream) {
+    using namespace pbr;
+    const int rc = check_blend(d, bl, workspace);
+    if (rc != PBR_OK) return rc;
+    return launch_normal_sign(d, bl, workspace, static_cast<hipStream_t>(stream));
+}
+
+int pbr_cook_torrance_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, void *stream) {
+    using namespace pbr;
+    const int rc = check_blend(d, bl, workspace);
+    if (rc != PBR_OK) return rc;
+    // "Is the blended normal already signed?" is a property of the WHOLE map (base.py:212).  A row band of an untiled map
+    // only holds its own rows, so its flags must come from the caller (pbr_blend_normal_sign over every band, combined).
+    if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE && !is_tiled(d) && d->height != d->height_total) return PBR_ERR_UNSUPPORTED;
+    int vec = pick_vec(d);
+    for (const pbr_map *m : {&bl->albedo, &bl->normal, &bl->roughness, &bl->metallic, &bl->specular, &bl->mask})
+        if (m->data && ((reinterpret_cast<uintptr_t>(m->data) & 15u) || m->batch_stride % 4 || m->channel_stride % 4)) vec = 1;
+    KArgs k;
+    fill_args(d, vec, k);
+    if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+    KBlend b;
+    std::memset(&b, 0, sizeof(b));
+    b.albedo = bl->albedo.data; b.normal = bl->normal.data; b.rough = bl->roughness.data;
+    b.metal = bl->metallic.data; b.spec = bl->specular.data;
+    b.a_bs = bl->albedo.batch_stride; b.a_cs = bl->albedo.channel_stride;
+    b.n_bs = bl->normal.batch_stride; b.n_cs = bl->normal.channel_stride;
+    b.r_bs = bl->roughness.batch_stride; b.m_bs = bl->metallic.batch_stride;
+    b.s_bs = bl->specular.batch_stride; b.s_cs = bl->specular.channel_stride;
+    b.mask = static_cast<const float *>(bl->mask.data); b.k_bs = bl->mask.batch_stride;
+    b.normal_signed = static_cast<const int *>(workspace);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE) {
+        // pass 1: one flag per material -- does the blended normal map have a negative component?  (base.py:212)
+        if (hipMemsetAsync(workspace, 0, sizeof(int) * (size_t)d->batch, st) != hipSuccess) return 1000 + (int)hipGetLastError();
+        const int src = launch_normal_sign(d, bl, workspace, st);
+        if (src != PBR_OK) return src;
+    }
+    // pass 2: blend + evaluate
+    const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
+    void (*fn)(const KArgs, const KBlend) = nullptr;
+#define PBR_BLEND(L, W)                                                                                              \
+    fn = vec == 4 ? (multi ? cook_torrance_blend_kernel<L, W, 4, true> : cook_torrance_blend_kernel<L, W, 4, false>) \
+                  : (multi ? cook_torrance_blend_kernel<L, W, 1, true> : cook_torrance_blend_kernel<L, W, 1, false>)
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: PBR_BLEND(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC); break;
+        case 1: PBR_BLEND(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR); break;
+        case 2: PBR_BLEND(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED); break;
+        case 3: PBR_BLEND(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC); break;
+        case 4: PBR_BLEND(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR); break;
+        default: PBR_BLEND(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED); break;
+    }
+#undef PBR_BLEND
+    // occupancy governor (see g_lds_bytes): the 17-stream one-light blend streams fastest with 10 waves per CU --
+    // 4096^2: 255 us uncapped, 236 / 232 / 234 / 233 / 248 us at 11 / 10 / 9 / 8 / 6 (tools/blend_probe.py)
+    const size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (multi ? 0 : 16384);
+    hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), lds, st, k, b);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
+
+}  // extern "C"

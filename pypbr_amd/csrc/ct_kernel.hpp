@@ -171,13 +171,15 @@ struct LanePos {
     bool valid;
 };
 
-template <int VEC>
+// CLAMP: lanes outside the map get the nearest position inside it (valid = false): they may load, must not store.
+template <int VEC, bool CLAMP = false>
 __device__ __forceinline__ LanePos lane_pos(const KArgs &a, int tile_x, int tile_y) {
     const int tid = threadIdx.x;
-    const int xv = (tile_x << a.bx_log2) + (tid & ((1 << a.bx_log2) - 1));
-    const int row = (tile_y << (a.bt_log2 - a.bx_log2)) + (tid >> a.bx_log2);  // b * H + y
+    int xv = (tile_x << a.bx_log2) + (tid & ((1 << a.bx_log2) - 1));
+    int row = (tile_y << (a.bt_log2 - a.bx_log2)) + (tid >> a.bx_log2);  // b * H + y
     LanePos p;
     p.valid = xv < a.wv && row < a.rows;
+    if (CLAMP) { xv = xv < a.wv ? xv : a.wv - 1; row = row < a.rows ? row : a.rows - 1; }
     p.b = (int)a.div_h.div((uint32_t)row);
     p.y = row - p.b * a.H;
     p.x = xv * VEC;
@@ -262,7 +264,7 @@ __device__ __forceinline__ LightGeomT<R> light_geom(const LightU &lu, const Vec3
     if (LIGHT == PBR_LIGHT_POINT) return point_light_geom<R>(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, xs, ys);
     LightGeomT<R> g;                       // directional: everything folded on the host, wave-uniform
     g.L = {splat<R>(lu.l[0]), splat<R>(lu.l[1]), splat<R>(lu.l[2])};
-    g.d = g.L; g.rinv = splat<R>(1.0f);
+    g.d = g.L; g.rinv = splat<R>(1.0f); g.rdist = splat<R>(1.0f);
     g.h = {splat<R>(lu.h[0]), splat<R>(lu.h[1]), splat<R>(lu.h[2])};
     g.rhh = splat<R>(lu.rhh); g.p5 = splat<R>(lu.p5); g.om5 = splat<R>(1.0f - lu.p5); g.att = splat<R>(1.0f);
     return g;

@@ -1,0 +1,176 @@
+// ct_launch.hpp -- host side shared by the launchers (cook_torrance.hip, ct_backward.hip, ct_blend.hip): descriptor
+// validation, the 16-byte-path test, the workgroup-order rule and the translation of a pbr_render_desc into the
+// kernel-argument block.  Tuning knobs live in cook_torrance.hip (pbr_set_tuning).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/pbr_hip.h"
+#include "ct_kernel.hpp"
+
+namespace pbr {
+
+// Measured A/B on MI355X, 4096x4096 point/metallic (tools/tune.py, DESIGN.md "Schedule experiments"):
+// nt hint on: -5 % time; one-wave workgroups: -2 % vs 256 lanes (no LDS/barrier, so nothing is lost).
+extern int g_nontemporal;
+extern int g_block_log2;           // workgroup size: 64 (6), 128 (7) or 256 (8) lanes
+extern int g_f16_vec;              // pixels per lane for fp16 maps with one light: 8 (16-byte loads) or 4
+// Dynamic LDS per one-wave workgroup, unused by the kernel: an occupancy governor finer than whole waves per
+// SIMD (160 KiB / value = waves per CU).  amdgpu_waves_per_eu(3,3) on the kernel allows 12 waves per CU; the
+// fp32 one-light kernels stream fastest with 11 in flight (in-process A/B, DESIGN.md 3.2: 115.3 vs 118.5 us on
+// 4096^2, 33.3 vs 34.0 us on 2048^2, 249.8 vs 254.1 us on 8 x 2048^2 directional), the fp16 and multi-light
+// kernels with no cap.  -1 = that rule; >= 0 = this many bytes for every launch (A/B runs).
+extern int g_lds_bytes;
+extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
+constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
+
+inline void normalize_host(const float v[3], float o[3]) {   // F.normalize(v, dim=0), fp32
+    const float nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    const float d = nrm > 1e-12f ? nrm : 1e-12f;
+    o[0] = v[0] / d; o[1] = v[1] / d; o[2] = v[2] / d;
+}
+
+inline int validate(const pbr_render_desc *d) {
+    if (!d) return PBR_ERR_NULL_MAP;
+    if (d->abi_version != PBR_HIP_ABI_VERSION) return PBR_ERR_SHAPE;
+    if (d->light_type != PBR_LIGHT_DIRECTIONAL && d->light_type != PBR_LIGHT_POINT) return PBR_ERR_LIGHT_TYPE;
+    if (d->workflow < 0 || d->workflow > PBR_WORKFLOW_CONVERTED) return PBR_ERR_WORKFLOW;
+    if (d->workflow == PBR_WORKFLOW_SPECULAR ? !d->specular.data : !d->metallic.data) return PBR_ERR_WORKFLOW;
+    if (!d->albedo.data || !d->roughness.data || !d->out) return PBR_ERR_NULL_MAP;
+    if (d->batch < 1 || d->height < 1 || d->width < 1 || d->y_offset < 0 ||
+        d->height_total < d->y_offset + d->height || d->n_lights < 1 || d->n_lights > PBR_MAX_LIGHTS)
+        return PBR_ERR_SHAPE;
+    if ((int64_t)d->batch * d->height > INT32_MAX) return PBR_ERR_SHAPE;
+    if ((d->map_dtype != PBR_F32 && d->map_dtype != PBR_F16) || (d->out_dtype != PBR_F32 && d->out_dtype != PBR_F16))
+        return PBR_ERR_DTYPE;
+    if (d->schedule < PBR_SCHEDULE_AUTO || d->schedule > PBR_SCHEDULE_XCD(12)) return PBR_ERR_SHAPE;
+    if (d->out_batch_stride < 0 || d->out_channel_stride < 0) return PBR_ERR_SHAPE;
+    if (d->out_channel_stride && d->out_channel_stride < (int64_t)d->height * d->width) return PBR_ERR_SHAPE;
+    if (d->map_height || d->map_width) {             // tiled maps: whole repeats only
+        if (d->map_height < 1 || d->map_width < 1 || d->height_total % d->map_height || d->width % d->map_width)
+            return PBR_ERR_SHAPE;
+    }
+    return PBR_OK;
+}
+
+inline bool is_tiled(const pbr_render_desc *d) {
+    return d->map_height > 0 && (d->map_height != d->height_total || d->map_width != d->width);
+}
+
+// 16-byte path: every plane start and every row start must be 16-byte (fp16: 8-byte) aligned.
+inline int pick_vec(const pbr_render_desc *d) {
+    const int esz_in = d->map_dtype == PBR_F32 ? 4 : 2, esz_out = d->out_dtype == PBR_F32 ? 4 : 2;
+    if (d->width % 4) return 1;
+    const bool tiled = is_tiled(d);
+    if (tiled && d->map_width % 4) return 1;          // a lane's pixels must not straddle a seam
+    auto ok = [&](const pbr_map &m, int esz, bool three) {
+        if (!m.data) return true;
+        const uintptr_t align = esz == 4 ? 15u : 7u;
+        if (reinterpret_cast<uintptr_t>(m.data) & align) return false;
+        if (m.batch_stride % 4) return false;
+        if (three && (m.channel_stride % 4)) return false;
+        return true;
+    };
+    if (!ok(d->albedo, esz_in, true) || !ok(d->normal, esz_in, true) || !ok(d->roughness, esz_in, false) ||
+        !ok(d->metallic, esz_in, false) || !ok(d->specular, esz_in, true))
+        return 1;
+    if (reinterpret_cast<uintptr_t>(d->out) & (esz_out == 4 ? 15u : 7u)) return 1;
+    if (d->out_batch_stride % 8 || d->out_channel_stride % 8) return 1;      // 0 (contiguous) passes
+    // fp16 maps, ONE light (HBM-bound): 8 pixels per lane keep the loads 16 bytes wide.  With several
+    // lights the kernel is VALU-bound and the 4-pixel body's lower register count wins.
+    if (esz_in == 2 && d->width % 8 == 0 && (!tiled || d->map_width % 8 == 0) && d->n_lights == 1 && g_f16_vec == 8) {
+        auto ok16 = [&](const pbr_map &m, bool three) {
+            return !m.data || ((reinterpret_cast<uintptr_t>(m.data) & 15u) == 0 && m.batch_stride % 8 == 0 &&
+                               (!three || m.channel_stride % 8 == 0));
+        };
+        if (ok16(d->albedo, true) && ok16(d->normal, true) && ok16(d->roughness, false) && ok16(d->metallic, false) &&
+            ok16(d->specular, true) && (reinterpret_cast<uintptr_t>(d->out) & 15u) == 0)
+            return 8;
+    }
+    return 4;
+}
+
+// Workgroup -> tile order (ct_kernel.hpp: tile_of_workgroup).  Workgroups are dealt to the 8 XCDs round-robin, so
+// with the linear order XCD x touches byte offsets ~ x KiB (mod 8 KiB) of every plane, all XCDs inside one narrow
+// window; with runs of 64 tiles every XCD streams 64 KiB-contiguous pieces.  Measured on MI355X (tools/tune.py,
+// "xcd" knob): the run order gives 6.1-6.3 TB/s whatever the shape; the linear order gives
+// 6.4-6.6 TB/s when the plane streams happen to spread over the HBM channels (1024^2, 4096^2, 3072^2, ...) and
+// 5.4-5.8 TB/s when they do not: rows that are not a whole number of tiles (1000^2, 3000^2: -12..14 %) and
+// 8 / 16 MiB plane strides (2048^2, 4096x1024: -2..12 %).  AUTO encodes exactly that; pbr_cook_torrance_autotune
+// measures instead of guessing.
+inline int schedule_xcd_log2(const pbr_render_desc *d, int vec) {
+    if (g_xcd_log2 >= 0) return g_xcd_log2 > 12 ? 12 : g_xcd_log2;
+    if (d->schedule >= PBR_SCHEDULE_LINEAR) return d->schedule - PBR_SCHEDULE_LINEAR;
+    const int64_t esz = d->map_dtype == PBR_F32 ? 4 : 2;
+    const int64_t row_bytes = (int64_t)d->width * esz, tile_bytes = 64 * (int64_t)vec * esz;
+    const int64_t plane_bytes = d->albedo.channel_stride * esz;
+    if (d->map_dtype == PBR_F16) return 6;           // fp16 maps: runs are 1.5-5 % ahead on every shape tried
+    if (row_bytes % tile_bytes) return 6;
+    if (plane_bytes == (8ll << 20) || plane_bytes == (16ll << 20)) return 6;
+    return 0;
+}
+
+inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
+    std::memset(&k, 0, sizeof(k));
+    k.albedo = d->albedo.data; k.normal = d->normal.data; k.rough = d->roughness.data;
+    k.metal = d->metallic.data; k.spec = d->specular.data; k.out = d->out;
+    k.a_bs = d->albedo.batch_stride; k.a_cs = d->albedo.channel_stride;
+    k.n_bs = d->normal.batch_stride; k.n_cs = d->normal.channel_stride;
+    k.r_bs = d->roughness.batch_stride; k.m_bs = d->metallic.batch_stride;
+    k.s_bs = d->specular.batch_stride; k.s_cs = d->specular.channel_stride;
+    k.o_cs = d->out_channel_stride ? d->out_channel_stride : (int64_t)d->height * d->width;
+    k.o_bs = d->out_batch_stride ? d->out_batch_stride : 3 * k.o_cs;
+    k.rows = d->batch * d->height; k.H = d->height; k.W = d->width;
+    k.wv = d->width / vec;
+    k.bt_log2 = g_block_log2 < 6 ? 6 : (g_block_log2 > 8 ? 8 : g_block_log2);
+    int lg = 0;
+    while ((1 << lg) < k.wv && lg < k.bt_log2) ++lg;
+    k.bx_log2 = lg;
+    const int bx = 1 << lg, by = (1 << k.bt_log2) >> lg;
+    k.tiles_x = (k.wv + bx - 1) / bx;
+    const int64_t tiles = (int64_t)k.tiles_x * ((k.rows + by - 1) / by);
+    k.n_tiles = tiles > INT32_MAX ? -1 : (int32_t)tiles;      // -1: more tiles than a 1-D grid holds, rejected by the callers
+    k.xcd_log2 = schedule_xcd_log2(d, vec);
+    k.xcd_tiles = k.n_tiles < 0 ? 0 : (k.n_tiles >> (k.xcd_log2 + 3)) << (k.xcd_log2 + 3);
+    k.div_h.init((uint32_t)d->height);
+    k.div_tx.init((uint32_t)k.tiles_x);
+    k.tiled = is_tiled(d);
+    k.map_h = k.tiled ? d->map_height : d->height_total; k.map_w = k.tiled ? d->map_width : d->width;
+    k.div_mh.init((uint32_t)k.map_h); k.div_mw.init((uint32_t)k.map_w);
+    k.y_offset = d->y_offset; k.H_total = d->height_total;
+    // `light_size or 1.0` (:130): 0 / NaN / negative are treated as "not given".
+    const float size = (d->light_size > 0.0f) ? d->light_size : 1.0f;
+    const float lo = (float)(-(double)size / 2), hi = (float)((double)size / 2);
+    k.x0 = lo; k.x1 = hi; k.xstep = d->width > 1 ? (hi - lo) / (float)(d->width - 1) : 0.0f;
+    k.y0 = lo; k.y1 = hi; k.ystep = d->height_total > 1 ? (hi - lo) / (float)(d->height_total - 1) : 0.0f;
+    if (d->width == 1) k.x1 = k.x0;          // torch.linspace(a, b, 1) == [a]
+    if (d->height_total == 1) k.y1 = k.y0;
+    normalize_host(d->view_dir, k.V);
+    k.n_lights = d->n_lights;
+    k.albedo_srgb = d->albedo_is_srgb != 0; k.spec_srgb = d->specular_is_srgb != 0;
+    k.out_srgb = d->return_srgb != 0; k.has_normal = d->normal.data != nullptr;
+    for (int i = 0; i < d->n_lights; ++i) {
+        LightU &u = k.lights[i];
+        for (int c = 0; c < 3; ++c) u.inten[c] = d->intensities[i][c];
+        if (d->light_type == PBR_LIGHT_DIRECTIONAL) {
+            normalize_host(d->lights[i], u.l);                                   // :126
+            float hn[3];
+            for (int c = 0; c < 3; ++c) u.h[c] = k.V[c] + u.l[c];                // :155
+            const float hh = u.h[0] * u.h[0] + u.h[1] * u.h[1] + u.h[2] * u.h[2];
+            u.rhh = 1.0f / (hh > 1e-24f ? hh : 1e-24f);
+            normalize_host(u.h, hn);
+            float ct = hn[0] * k.V[0] + hn[1] * k.V[1] + hn[2] * k.V[2];          // :156-158
+            ct = ct < 0.0f ? 0.0f : (ct > 1.0f ? 1.0f : ct);
+            const float om = 1.0f - ct;
+            u.p5 = (om * om) * (om * om) * om;                                   // :196
+        } else {
+            for (int c = 0; c < 3; ++c) u.l[c] = d->lights[i][c];
+        }
+    }
+}
+
+}  // namespace pbr

@@ -83,6 +83,7 @@ def broadcast_light_block(params: Optional[Dict], device: torch.device, src: int
     """Rank `src` passes its parameters, the others pass None; everyone returns the same
     dict.  One broadcast of a 404-byte block (RCCL over xGMI on GPUs)."""
     import torch.distributed as dist
+    device = _collective_device(device, group)
     if dist.get_rank(group) == src:
         if params is None:
             raise ValueError("the source rank must provide the parameters")
@@ -91,6 +92,13 @@ def broadcast_light_block(params: Optional[Dict], device: torch.device, src: int
         blk = torch.empty(_BLOCK_FLOATS, dtype=torch.float32, device=device)
     dist.broadcast(blk, src=src, group=group)
     return unpack_light_block(blk)
+
+
+def _collective_device(device, group=None) -> torch.device:
+    """Where the small collectives' buffers live: on the GPU for "nccl" (RCCL over xGMI), on the host for "gloo"
+    (CPU tests; several ranks sharing one GPU on a single-GPU box)."""
+    import torch.distributed as dist
+    return torch.device(device) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
 def shard_maps(maps: Dict[str, Optional[torch.Tensor]], shard: Shard) -> Dict[str, Optional[torch.Tensor]]:
@@ -108,8 +116,11 @@ def cook_torrance_sharded(maps: Dict[str, Optional[torch.Tensor]], params: Optio
     metallic | specular -- every rank holds, or can index, the full batch) with the
     parameters broadcast from `src`.  Returns (shard, output or None for an empty shard).
     `tile=` and `blend=` (see functional.plan_cook_torrance) shard too: with a fused tile the ranks split the rows of
-    the tiled OUTPUT over whole source maps; a blend's second material and mask are sliced like the first.
-    `render` defaults to functional.cook_torrance (tests inject a recorder on CPU)."""
+    the tiled OUTPUT over whole source maps; a blend's second material and mask are sliced like the first.  A fused
+    blend over ROW BANDS has the path's one real exchange step: whether the blended normal map counts as already
+    signed is a property of the whole map (base.py:212), so every rank works the flag out for its rows
+    (pbr_blend_normal_sign) and the ranks that share a material combine them with one all-reduce (MAX) of B ints.
+    `render` defaults to the HIP path (tests inject a recorder on CPU)."""
     import torch.distributed as dist
     from .functional import tile_counts
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -119,11 +130,12 @@ def cook_torrance_sharded(maps: Dict[str, Optional[torch.Tensor]], params: Optio
     blend = flags.pop("blend", None)
     p = broadcast_light_block(params, device=albedo.device, src=src, group=group)
     shard = partition(B, H * ny, world, rank)          # rows of the OUTPUT: with a fused tile() that is ny * H
-    if shard.batch_stop <= shard.batch_start or shard.row_stop <= shard.row_start:
-        return shard, None
-    if render is None:
-        from .functional import cook_torrance as render
+    empty = shard.batch_stop <= shard.batch_start or shard.row_stop <= shard.row_start
     tiled = (ny, nx) != (1, 1)
+    # untiled row bands of a fused blend: the one exchange step (every rank takes part, also one with an empty shard)
+    exchange = blend is not None and not tiled and B < world and render is None
+    if empty and not exchange:
+        return shard, None
     if tiled:      # the kernel wraps its texel addresses: every rank keeps whole source maps and evaluates a band of the output
         cut = lambda t: None if t is None else t[shard.batch_start:shard.batch_stop]
         flags.update(tile=(ny, nx), rows=shard.row_stop - shard.row_start)
@@ -138,8 +150,25 @@ def cook_torrance_sharded(maps: Dict[str, Optional[torch.Tensor]], params: Optio
             t = t if t.dim() == 4 else t.unsqueeze(0)
             return cut(t if t.shape[0] > 1 else t.expand(B, *t.shape[1:]))
         flags["blend"] = tuple(cut2(t) for t in blend)
+    kw = dict(view_dir=p["view_dir"], light=p["light"], light_intensity=p["light_intensity"], light_type=light_type,
+              light_size=p["light_size"], y_offset=shard.row_start, height_total=total, **flags)
     m = {name: cut(t) for name, t in maps.items()}
-    out = render(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"),
-                 view_dir=p["view_dir"], light=p["light"], light_intensity=p["light_intensity"],
-                 light_type=light_type, light_size=p["light_size"], y_offset=shard.row_start, height_total=total, **flags)
-    return shard, out
+    if render is not None:
+        return shard, render(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"), **kw)
+    from .functional import cook_torrance, plan_cook_torrance
+    if not exchange:
+        return shard, cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"), **kw)
+    signed = torch.zeros(B, dtype=torch.int32, device=albedo.device)       # one flag per material of the FULL batch
+    plan = None
+    if not empty:
+        plan = plan_cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"),
+                                  blend_flags=signed[shard.batch_start:shard.batch_stop], **kw)
+        signed[shard.batch_start:shard.batch_stop] = plan.blend_normal_sign()
+    where = _collective_device(albedo.device, group)
+    combined = signed.to(where)
+    dist.all_reduce(combined, op=dist.ReduceOp.MAX, group=group)
+    if empty:
+        return shard, None
+    plan.use_blend_flags(combined[shard.batch_start:shard.batch_stop])
+    with torch.cuda.device(plan.device):
+        return shard, plan.launch()

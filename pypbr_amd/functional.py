@@ -18,6 +18,8 @@ Build extensions over the reference:
     fused in front of the specular-workflow evaluation.
 """
 import ctypes
+import os
+import weakref
 from typing import Optional, Sequence, Tuple, Union
 
 import torch
@@ -34,13 +36,31 @@ def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+_HOST_COPIES = {}          # id(tensor) -> (weakref to it, its version, host copy) for device-resident parameter tensors
+_HOST_COPIES_MAX = 64
+
+
 def _host_vec3(v: TensorLike, rows: Optional[int] = None):
-    """Light/view parameters travel in the kernel-argument segment, so they are host
-    values; a device tensor costs one small D2H copy (documented in DESIGN.md)."""
-    if isinstance(v, torch.Tensor) and v.requires_grad and torch.is_grad_enabled():
-        # the reference's autograd graph would reach these tensors; the backward kernel only differentiates the maps
-        raise NotImplementedError("gradients with respect to view / light parameters are not implemented: pass them detached")
-    t = torch.as_tensor(v, dtype=torch.float32) if not isinstance(v, torch.Tensor) else v.detach().to("cpu", torch.float32)
+    """Light/view parameters travel in the kernel-argument segment, so they are host values.  A device tensor costs one
+    small blocking D2H copy -- once: the host values are remembered per tensor object and version counter, so a caller
+    that keeps its light / view tensors on the GPU and passes the same unchanged tensors call after call (the
+    reference's override_device usage) synchronises on the first call only.  Tensors that require grad are read
+    detached; their gradient comes from the backward kernel (see _CookTorranceFn)."""
+    if not isinstance(v, torch.Tensor):
+        t = torch.as_tensor(v, dtype=torch.float32)
+    elif v.is_cuda:
+        hit = _HOST_COPIES.get(id(v))
+        if hit is not None and hit[0]() is v and hit[1] == v._version:
+            t = hit[2]
+        else:
+            t = v.detach().to("cpu", torch.float32)
+            for k in [k for k, e in _HOST_COPIES.items() if e[0]() is None]:
+                del _HOST_COPIES[k]
+            if len(_HOST_COPIES) >= _HOST_COPIES_MAX:
+                _HOST_COPIES.clear()
+            _HOST_COPIES[id(v)] = (weakref.ref(v), v._version, t)
+    else:
+        t = v.detach().to(torch.float32)
     if rows is None:
         if t.numel() != 3:
             raise ValueError("expected a vector of 3 components, got shape %s" % (tuple(t.shape),))
@@ -190,6 +210,23 @@ class RenderPlan:
         self._blend, self._blend_ref, self._workspace = blend_desc, ctypes.byref(blend_desc), workspace
         self._keep = self._keep + tuple(keep_alive)
 
+    def blend_normal_sign(self, stream: Optional[int] = None) -> torch.Tensor:
+        """pbr_blend_normal_sign over the rows this plan holds: an int32 [B] tensor, 1 where the blended normal of
+        material b has a negative component there.  For row bands: combine the bands' flags (max) and hand them to the
+        plans as `blend_flags`."""
+        if getattr(self, "_blend", None) is None:
+            raise ValueError("not a blend plan")
+        flags = torch.zeros(self.desc.batch, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().pbr_blend_normal_sign(self._ref, self._blend_ref, flags.data_ptr(),
+                                                  _stream_ptr(self.device) if stream is None else stream))
+        return flags
+
+    def use_blend_flags(self, flags: torch.Tensor):
+        """Whole-map flags worked out by the caller (see `blend_normal_sign`)."""
+        self._blend.sign_mode = N.BLEND_SIGN_GIVEN
+        self._workspace = flags.to(self.device, torch.int32).contiguous()
+
     def launch(self, stream: Optional[int] = None) -> torch.Tensor:
         """Enqueue on `stream` (raw hipStream_t) or torch's current stream of the maps' device."""
         st = _stream_ptr(self.device) if stream is None else stream
@@ -211,7 +248,8 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                        height_total: Optional[int] = None, out_dtype: Optional[torch.dtype] = None,
                        out: Optional[torch.Tensor] = None, schedule: int = N.SCHEDULE_AUTO,
                        autotune: bool = False, tile=1, rows: Optional[int] = None,
-                       blend: Optional[Sequence[Optional[torch.Tensor]]] = None) -> RenderPlan:
+                       blend: Optional[Sequence[Optional[torch.Tensor]]] = None,
+                       blend_flags: Optional[torch.Tensor] = None) -> RenderPlan:
     """Validates the maps, allocates the output and fills the C-ABI descriptor; see `cook_torrance`.
     `schedule`: workgroup order (N.SCHEDULE_AUTO | N.SCHEDULE_LINEAR | N.schedule_xcd(c)), results do not depend
     on it; `autotune=True` measures the candidates on these very buffers once (blocking, a few launches) and
@@ -222,7 +260,10 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
     `blend=(albedo2, normal2, roughness2, metallic2, specular2, mask)`: blend_with_mask (blending/functional.py:64-145:
     mask * map1 + (1 - mask) * map2, normals normalised / blended / normalised, the blended normal re-decoded as on
     assignment) fused in front of the evaluation -- both materials are read once, the blended maps are never written.
-    fp32 maps, both materials complete; `mask` [1,H,W] or [B,1,H,W]."""
+    fp32 maps, both materials complete; `mask` [1,H,W] or [B,1,H,W].  Whether a blended normal map counts as already
+    signed is decided over the WHOLE map (base.py:212); the launch works that out itself unless the maps are a row band
+    of a taller untiled map -- then pass `blend_flags` (int32 [B] on the device: `RenderPlan.blend_normal_sign()` of
+    every band, combined with max; distributed.cook_torrance_sharded does this)."""
     if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda:
         raise RuntimeError("pypbr_amd.functional.cook_torrance needs maps on a ROCm device "
                            "(use material.to('cuda')); there is no CPU path")
@@ -275,7 +316,14 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
         bd.metallic = _pbr_map(m2 if m is not None else None)
         bd.specular = _pbr_map(s2 if m is None else None)
         bd.mask = _pbr_map(k)
-        plan.attach_blend(bd, torch.empty(B, dtype=torch.int32, device=a.device), (a2, n2, r2, second, k))
+        if blend_flags is not None:
+            if blend_flags.dtype != torch.int32 or blend_flags.numel() != B or blend_flags.device != a.device:
+                raise ValueError("blend_flags must be an int32 tensor of %d flags on the maps' device" % B)
+            bd.sign_mode = N.BLEND_SIGN_GIVEN
+            flags = blend_flags.contiguous()
+        else:
+            flags = torch.empty(B, dtype=torch.int32, device=a.device)
+        plan.attach_blend(bd, flags, (a2, n2, r2, second, k))
     elif autotune:
         plan.autotune()
     return plan
@@ -296,30 +344,47 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
     enqueued on the current stream without synchronising.
     """
     maps = (albedo, normal, roughness, metallic, specular)
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in maps):
-        return _CookTorranceFn.apply(albedo, normal, roughness, metallic, specular, kwargs)
+    params = tuple(kwargs.get(k) for k in _PARAM_KEYS)
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in maps + params):
+        kw = {k: v for k, v in kwargs.items() if k not in _PARAM_KEYS}
+        return _CookTorranceFn.apply(albedo, normal, roughness, metallic, specular, *params, kw)
     plan = plan_cook_torrance(albedo, normal, roughness, metallic, specular, **kwargs)
     with torch.cuda.device(plan.device):
         return plan.launch()
 
 
+_PARAM_KEYS = ("view_dir", "light", "light_intensity")
+
+
+def _param_grad(g: torch.Tensor, like, n_lights: int):
+    """Shapes a [L,3] (or [3]) gradient like the parameter the caller passed: same shape, dtype and device; an intensity
+    given once for several lights owns the sum."""
+    if not isinstance(like, torch.Tensor) or not like.requires_grad:
+        return None
+    if g.dim() == 2 and like.numel() == 3 and n_lights > 1:
+        g = g.sum(dim=0)
+    return g.reshape(like.shape).to(device=like.device, dtype=like.dtype)
+
+
 class _CookTorranceFn(torch.autograd.Function):
-    """Autograd bridge: forward = the fused kernel, backward = pbr_cook_torrance_backward (one
-    more streaming kernel that recomputes the forward terms).  Gradients flow to the maps only;
-    view/light parameters are host scalars (as in the reference's rendering-loss use)."""
+    """Autograd bridge: forward = the fused kernel, backward = pbr_cook_torrance_backward[_params] (one more streaming
+    kernel that recomputes the forward terms).  Gradients flow to the maps and -- like the reference's autograd graph,
+    cooktorrance.py:95-96, :126-140 -- to view_dir / light / light_intensity when those are tensors that require grad."""
 
     @staticmethod
-    def forward(ctx, albedo, normal, roughness, metallic, specular, kwargs):
+    def forward(ctx, albedo, normal, roughness, metallic, specular, view_dir, light, light_intensity, kwargs):
         if kwargs.get("out") is not None:
             raise NotImplementedError("gradients need out=None (the result must be a fresh tensor)")
         if kwargs.get("blend") is not None:
             raise NotImplementedError("the fused blend is forward-only; blend with pypbr_amd.blending first to differentiate")
         maps = (albedo, normal, roughness, metallic, specular)
-        plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **kwargs)
+        plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], view_dir=view_dir, light=light,
+                                  light_intensity=light_intensity, **kwargs)
         if plan.desc.out_dtype != N.F32:
             raise NotImplementedError("gradients need a float32 result (fp16 maps are fine: their gradients come back in fp16)")
         ctx.plan = plan
         ctx.in_shapes = [None if t is None else tuple(t.shape) for t in maps]
+        ctx.params = (view_dir, light, light_intensity)
         ctx.save_for_backward(*[t for t in maps if t is not None])   # for autograd's in-place-modification check
         with torch.cuda.device(plan.device):
             result = plan.launch()
@@ -340,9 +405,18 @@ class _CookTorranceFn(torch.autograd.Function):
         for i in range(5):
             want = ctx.needs_input_grad[i] and present[i] and ctx.in_shapes[i] is not None
             bufs.append(torch.empty((B, channels[i], H, W), dtype=gdtype, device=g.device) if want else None)
+        ptrs = [None if b is None else b.data_ptr() for b in bufs]
+        want_params = any(ctx.needs_input_grad[5:8])
+        lib = N.lib()
         with torch.cuda.device(g.device):
-            N.check(N.lib().pbr_cook_torrance_backward(
-                ctypes.byref(d), g.data_ptr(), *[None if b is None else b.data_ptr() for b in bufs], _stream_ptr(g.device)))
+            if want_params:
+                L = d.n_lights
+                gp = torch.empty(3 + 6 * L, dtype=torch.float32, device=g.device)
+                ws = torch.empty(max(1, lib.pbr_param_grad_workspace_bytes(ctypes.byref(d)) // 4), dtype=torch.float32, device=g.device)
+                N.check(lib.pbr_cook_torrance_backward_params(ctypes.byref(d), g.data_ptr(), *ptrs, gp.data_ptr(), ws.data_ptr(),
+                                                              _stream_ptr(g.device)))
+            else:
+                N.check(lib.pbr_cook_torrance_backward(ctypes.byref(d), g.data_ptr(), *ptrs, _stream_ptr(g.device)))
         grads = []
         for b, shape in zip(bufs, ctx.in_shapes):
             if b is None:
@@ -364,17 +438,35 @@ class _CookTorranceFn(torch.autograd.Function):
                                                       int(shared), _stream_ptr(b.device)))
                 b = folded
             grads.append(b.reshape(shape))
-        return (*grads, None)
+        pgrads = [None, None, None]
+        if want_params:
+            L = d.n_lights
+            view, light, inten = ctx.params
+            pgrads = [_param_grad(gp[0:3], view, 1) if ctx.needs_input_grad[5] else None,
+                      _param_grad(gp[3:3 + 3 * L].reshape(L, 3), light, 1) if ctx.needs_input_grad[6] else None,
+                      _param_grad(gp[3 + 3 * L:].reshape(L, 3), inten, L) if ctx.needs_input_grad[7] else None]
+        return (*grads, *pgrads, None)
 
 
 # ------------------------------------------------------------------ stand-alone conversions
+_PINNED_OUT = []            # weak references to page-locked results still held by callers
+PINNED_RESULT_CAP = int(os.environ.get("PBR_PINNED_RESULT_CAP", str(1 << 30)))
+
+
 def to_host(t: torch.Tensor, device=torch.device("cpu")) -> torch.Tensor:
     """Device -> CPU for results handed back to CPU-resident materials (the reference's default).  `t.cpu()` allocates a
     fresh pageable tensor every time: 26 ms for the 192 MiB result of a 4096^2 material, page faults included.  The
     pinned caching allocator hands back recycled page-locked blocks instead: 3.5 ms, the rate of the link
-    (tools/pcie_path_probe.py).  Synchronises the current stream, as `.cpu()` does.  Plain copy when a gradient is
-    attached (autograd has to see the transfer)."""
+    (tools/pcie_path_probe.py).  Page-locked memory is a bounded resource and torch never returns such blocks to the OS,
+    so at most PINNED_RESULT_CAP bytes (PBR_PINNED_RESULT_CAP, default 1 GiB) of results that callers still hold are
+    page-locked; beyond that (a loop that stores its results) the copy is an ordinary pageable one.  Synchronises the
+    current stream, as `.cpu()` does.  Plain copy when a gradient is attached (autograd has to see the transfer)."""
     if not t.is_cuda or t.requires_grad:
+        return t.to(device)
+    nbytes = t.numel() * t.element_size()
+    _PINNED_OUT[:] = [r for r in _PINNED_OUT if r() is not None]
+    held = sum(r().numel() * r().element_size() for r in _PINNED_OUT if r() is not None)
+    if held + nbytes > PINNED_RESULT_CAP:
         return t.to(device)
     try:
         host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
@@ -382,6 +474,7 @@ def to_host(t: torch.Tensor, device=torch.device("cpu")) -> torch.Tensor:
         return t.to(device)
     host.copy_(t, non_blocking=True)
     torch.cuda.current_stream(t.device).synchronize()
+    _PINNED_OUT.append(weakref.ref(host))
     return host
 
 

@@ -103,7 +103,11 @@ class MaterialBase:
             object.__setattr__(self, name, value)
 
     def __getattr__(self, name):
-        if name in self.__dict__.get("_store", {}):
+        d = self.__dict__
+        pending = d.get("_lazy_blend")
+        if name in d.get("_store", {}) or (pending is not None and name in pending[0]):   # a map only material 2 has
+            if d.get("_lazy_tile", (1, 1)) != (1, 1):
+                self.materialize_tile()   # anything but the BRDF sees the repeated maps (CookTorranceBRDF reads _store itself)
             return self._maps[name]
         raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
 
@@ -197,7 +201,13 @@ class MaterialBase:
         return None
 
     def as_dict(self):
+        self.materialize_tile()
         return dict(self._maps)
+
+    def drop_device_cache(self):
+        """Frees the device copy CookTorranceBRDF keeps of a CPU-resident material between calls."""
+        self.__dict__.pop("_device_cache", None)
+        return self
 
     # -- colour space, in place, returning self (base.py:754-778)
     def to_linear(self):
@@ -258,7 +268,10 @@ class MaterialBase:
 
     def clone(self):
         """Deep copy: tensors cloned, flags copied (base.py:880-912)."""
+        self.materialize_blend()          # a pending lazy blend is carried out first: the copy must not blend again
         new = copy.copy(self)
+        new.__dict__.pop("_device_cache", None)
+        new.__dict__["_lazy_blend"] = None
         object.__setattr__(new, "_maps", {k: (None if v is None else v.clone()) for k, v in self._maps.items()})
         return new
 
@@ -288,11 +301,13 @@ class BasecolorMetallicMaterial(MaterialBase):
         """metallic.py:71-120.  The new material shares normal/roughness, holds LINEAR
         diffuse and specular maps and -- as upstream -- is flagged specular_is_srgb=True
         unless told otherwise."""
+        self.materialize_tile()
         albedo, metallic = self._maps.get("albedo"), self._maps.get("metallic")
         if albedo is None or metallic is None:
             raise ValueError("Both albedo and metallic maps are required for conversion.")
-        if metallic.shape[-2:] != albedo.shape[-2:]:
-            raise NotImplementedError("metallic map of a different size: resize it first")
+        if metallic.shape[-2:] != albedo.shape[-2:]:       # metallic.py:93-96: TF.resize(metallic, albedo.shape[1:], antialias=True)
+            size = tuple(albedo.shape[-2:])
+            metallic = _through_device(metallic, lambda t: F_.resize(t, size, antialias=True))
         srgb = self.albedo_is_srgb
         diffuse, specular = _through_device(
             albedo, lambda a: F_.metallic_to_diffuse_specular(a, metallic.to(a.device), albedo_is_srgb=srgb))
@@ -329,6 +344,7 @@ class DiffuseSpecularMaterial(MaterialBase):
 
     def to_basecolor_metallic_material(self, albedo_is_srgb: bool = False):
         """diffuse.py:93-158: RAW specular (not linear_specular), 3-channel metallic."""
+        self.materialize_tile()
         albedo, specular = self._maps.get("albedo"), self._maps.get("specular")
         if albedo is None or specular is None:
             raise ValueError("Both albedo (diffuse) and specular maps are required for conversion.")

@@ -14,6 +14,7 @@ from torch import Tensor
 
 from . import _native
 from . import functional as F_
+from .materials import MaterialBase
 
 
 class BRDFModel(nn.Module, ABC):
@@ -36,6 +37,28 @@ class CookTorranceBRDF(BRDFModel):
                 f"Unsupported light_type: {self.light_type}. Must be 'directional' or 'point'."
             )
         self.override_device = override_device
+
+    @staticmethod
+    def _staged(material, maps, blend, compute):
+        """Device copies of maps that live elsewhere (CPU-resident materials: the reference's default, e.g.
+        examples/example_brdf.py).  The copies land in ONE allocation (functional.pack_maps) and are kept on the
+        material, so a loop that evaluates an unchanged material again and again uploads it once (a 4096^2 material:
+        9.6 ms of PCIe per call otherwise).  The cache is keyed on the very tensor objects and their
+        version counters: assigning a new map, or modifying one in place, uploads afresh.  Maps that carry a gradient
+        are copied differentiably, uncached.  `material.drop_device_cache()` frees the device copy."""
+        tensors = tuple(maps) + tuple(blend or ())
+        if any(t is not None and t.requires_grad for t in tensors):
+            moved = tuple(None if t is None else t.to(compute) for t in tensors)
+        else:
+            versions = tuple(None if t is None else t._version for t in tensors)
+            hit = material.__dict__.get("_device_cache")
+            if (hit is not None and hit[0] == compute and hit[1] == versions and len(hit[2]) == len(tensors)
+                    and all(a is b for a, b in zip(hit[2], tensors))):
+                moved = hit[3]
+            else:
+                moved = F_.pack_maps(*tensors, device=compute)
+                material.__dict__["_device_cache"] = (compute, versions, tensors, moved)
+        return moved[:5], (None if blend is None else moved[5:])
 
     def forward(self, material, view_dir: Tensor, light_dir_or_position: Tensor, light_intensity: Tensor,
                 light_size: Optional[float] = None, return_srgb: bool = True) -> Tensor:
@@ -64,19 +87,33 @@ class CookTorranceBRDF(BRDFModel):
                      second.get("specular") if metallic is None else None, mask)
         else:
             # attribute probes in the reference's order, so a material without a roughness /
-            # normal entry raises the same AttributeError (cooktorrance.py:99-100)
-            roughness = material.roughness
-            normal = material.normal
+            # normal entry raises the same AttributeError (cooktorrance.py:99-100).  A material of this
+            # package is read through its raw store: attribute access would materialise a pending tile(n, lazy=True),
+            # which this call hands to the kernel as wrap-around addressing instead.
+            store = material.__dict__.get("_store") if isinstance(material, MaterialBase) else None
+
+            def probe(name):
+                if store is None:
+                    return getattr(material, name)
+                if name not in store:
+                    raise AttributeError(f"'{type(material).__name__}' object has no attribute '{name}'")
+                return store[name]
+
+            def has(name):
+                return (name in store) if store is not None else hasattr(material, name)
+
+            roughness = probe("roughness")
+            normal = probe("normal")
             metallic = specular = None
             specular_is_srgb = True
-            if hasattr(material, "metallic") and material.metallic is not None:
-                metallic = material.metallic
-            elif hasattr(material, "specular") and material.specular is not None:
-                specular = material.specular
+            if has("metallic") and probe("metallic") is not None:
+                metallic = probe("metallic")
+            elif has("specular") and probe("specular") is not None:
+                specular = probe("specular")
                 specular_is_srgb = bool(getattr(material, "specular_is_srgb", True))
             else:
                 raise ValueError("Material must have either 'metallic' or 'specular' property.")
-            albedo = material._maps.get("albedo")
+            albedo = store.get("albedo") if store is not None else material._maps.get("albedo")
             if albedo is None:
                 raise AttributeError(f"'{type(material).__name__}' material has no albedo map")
 
@@ -86,22 +123,16 @@ class CookTorranceBRDF(BRDFModel):
             _native.require_device()
             compute = torch.device("cuda", torch.cuda.current_device())
 
-        def dev(t):
-            return None if t is None else t.to(compute)
-
         maps = (albedo, normal, roughness, metallic, specular)
-        if any(t is not None and t.device != compute for t in maps):
-            if any(t is not None and t.requires_grad for t in maps):
-                maps = tuple(dev(t) for t in maps)               # differentiable copies
-            else:
-                maps = F_.pack_maps(*maps, device=compute)       # staged maps land in one allocation
+        if any(t is not None and t.device != compute for t in maps + (blend or ())):
+            maps, blend = self._staged(material, maps, blend, compute)
         color = F_.cook_torrance(
             *maps,
             view_dir=view_dir, light=light_dir_or_position, light_intensity=light_intensity,
             light_type=self.light_type, light_size=light_size,
             albedo_is_srgb=bool(material.albedo_is_srgb), specular_is_srgb=specular_is_srgb,
             return_srgb=return_srgb, tile=getattr(material, "lazy_tile", (1, 1)),
-            blend=None if blend is None else tuple(dev(t) for t in blend))
+            blend=blend)
         if color.device == out_device:
             return color
         return F_.to_host(color, out_device) if out_device.type == "cpu" else color.to(out_device)

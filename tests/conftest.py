@@ -15,6 +15,16 @@ GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a ROCm device (MI355X); run with -m gpu on the GPU box")
+    # Multi-process GPU tests start their ranks from a fork server that is launched HERE, before anything in this
+    # process has touched the GPU: a process that has initialised HIP must not exec another program, and the ranks
+    # must not inherit an initialised HIP runtime through fork() either.
+    try:
+        import multiprocessing
+        from multiprocessing import forkserver
+        multiprocessing.get_context("forkserver")
+        forkserver.ensure_running()
+    except Exception:  # pragma: no cover  (the CPU suite does not need it)
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
@@ -67,3 +77,27 @@ def parse_case(key, manifest):
 
 def render_keys(z):
     return sorted(k for k in z if k.startswith("out_") and not k.startswith(("out_conv_", "out_back_")))
+
+
+def oracle_render(z, case, prefix="in_", dtype=None):
+    """The ATen-level oracle (oracle/torch_oracle.py, pinned bit-equal to the reference) on one golden case;
+    dtype=torch.float64 gives the float64 evaluation of the reference's formulas on the same inputs."""
+    import torch
+    import torch_oracle as O
+
+    def T(x):
+        t = torch.from_numpy(x)
+        return t if dtype is None else t.to(dtype)
+    kind = case["kind"]
+    a, r = T(z[prefix + "albedo"]), T(z[prefix + "roughness"])
+    n = None if case["no_normal"] else T(z[prefix + "normal"])
+    fdt = torch.float32 if dtype is None else dtype
+    kw = dict(view=torch.tensor(case["view"], dtype=fdt), light=torch.tensor(case["light"], dtype=fdt),
+              intensity=torch.tensor(case["intensity"], dtype=fdt), light_type=case["light_type"],
+              light_size=case["light_size"], return_srgb=case["return_srgb"])
+    if kind == "converted":
+        return O.cook_torrance_converted(a, n, r, T(z[prefix + "metallic"]), quirk_specular_srgb=(case["extra"] == "quirk"), **kw)
+    lin = case["linear_maps"]
+    return O.cook_torrance(a, n, r, T(z[prefix + "metallic"]) if kind == "metallic" else None,
+                           T(z[prefix + "specular"]) if kind == "specular" else None,
+                           albedo_is_srgb=not lin, specular_is_srgb=not lin, **kw)

@@ -1,29 +1,56 @@
 """GPU parity: the HIP path (through the C ABI) against the committed golden vectors
 (outputs of the real reference) and against the oracles on seeded inputs.
 
-Tolerances (DESIGN.md "Parity criterion"):
-  TOL = 1e-5 absolute on fp32 outputs -- the tolerance BASELINE.json's north_star states.
-  (i)  |hip - ref32| <= TOL on every pixel of the crops of the reference's own PNG fixtures
-       (tiles, rocks), and on synthetic maps wherever roughness >= 0.2;
-  (ii) at lower roughness the reference's OWN fp32 output is not reproducible to 1e-5: its GGX
-       denominator NdotH^2 (a^2-1) + 1 cancels, and the fixtures show it up to 1.1e-5 (a >= 0.15)
-       and 5e-5 (a >= 0.05) away from the same code run in float64.  There the HIP result must be
-       (a) within TOL of the float64 evaluation of the reference -- i.e. at least as close to the
-       exact value of the reference's formula as the reference's fp32 run is -- and
-       (b) inside the reference's own fp32 rounding envelope: |hip - ref32| <= |ref32 - ref64| + TOL.
-       Variants without a float64 twin in the fixtures are bounded by 1e-4 (twice the largest
-       envelope measured on the variants that have one).
+Criterion (DESIGN.md "Parity criterion").  TOL = 1e-5 absolute on fp32 outputs is the
+tolerance BASELINE.json's north_star states.  ref32 = the reference's own fp32 output (golden vectors; on seeded
+inputs the ATen restatement, pinned bit-equal to it), ref64 = the same reference code run in float64.
+  (i)   |hip - ref32| <= TOL on EVERY value of: crops of the reference's own PNG fixtures (tiles, rocks), both example
+        scripts, and synthetic maps wherever roughness >= ROUGH_OK.
+  (ii)  Below that roughness the reference's OWN fp32 output is not reproducible to 1e-5 by anything that is not
+        bit-identical to ATen: its GGX denominator NdotH^2 (a^2-1) + 1 cancels, and its fp32 run is up to 5.6e-5 away
+        from its own float64 run on these very fixtures.  There, on every value of every variant:
+        (a) |hip - ref64| <= TOL (measured <= 6e-7: TRACK asserts <= 2e-6) -- the build is far closer to the exact value
+            of the reference's formula than the reference's fp32 run is;
+        (b) |hip - ref32| <= |ref32 - ref64| + TOL -- every difference above TOL lies inside the reference's own fp32
+            rounding envelope;
+        (c) count(|hip - ref32| > TOL) <= count(|ref32 - ref64| > TOL - TRACK): the build exceeds TOL against ref32 on
+            no more values than the reference exceeds it against its own float64 run.  (SURVEY.md's absolute bound
+            2e-5 * N is printed next to it; the reference itself misses it on low-roughness sets: 3.4e-5 * N on rand64,
+            1.4e-4 * N on real48.)
+        No blanket bound: variants whose float64 twin is not in the fixtures get it from the pinned oracle's float64
+        mode (tests/test_oracle_pin.py checks that mode bit-equal to the committed float64 runs).
 """
 import numpy as np
 import pytest
 import torch
 
-from conftest import RANDOM_SETS, parse_case, render_keys
+from conftest import RANDOM_SETS, oracle_render, parse_case, render_keys
 
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
-ROUGH_OK = 0.2
+TRACK = 2e-6          # |hip - ref64|: what the cancellation-free kernel is held to (measured 5.4e-7)
+ROUGH_OK = 0.185      # smallest roughness from which (i) holds on every fixture and on the 4096^2 map (measured: 0.180, printed per test)
+
+
+def parity_report(got, ref32, ref64, rough=None, what=""):
+    """Asserts criterion (i) where `rough` >= ROUGH_OK and (ii a-c) everywhere; returns the numbers for the log."""
+    got64 = got.astype(np.float64)
+    err, e64 = np.abs(got64 - ref32), np.abs(got64 - ref64)
+    env = np.abs(ref32.astype(np.float64) - ref64)
+    n_hip, n_ref = int((err > TOL).sum()), int((env > TOL - TRACK).sum())
+    assert e64.max() <= TRACK, (what, "vs float64 reference", float(e64.max()))
+    assert (err <= env + TOL).all(), (what, "outside the reference's own envelope", float((err - env).max()))
+    assert n_hip <= n_ref, (what, "more values over TOL than the reference has against its own float64 run", n_hip, n_ref)
+    need = 0.0
+    if rough is not None:
+        well = np.broadcast_to(rough >= ROUGH_OK, err.shape)
+        if well.any():
+            assert err[well].max() <= TOL, (what, "roughness >= %.2f" % ROUGH_OK, float(err[well].max()))
+        bad = err > TOL
+        if bad.any():
+            need = float(np.broadcast_to(rough, err.shape)[bad].max())
+    return dict(max32=float(err.max()), max64=float(e64.max()), n_hip=n_hip, n_ref=n_ref, n=err.size, rough_needed=need)
 
 
 def _dev(x):
@@ -53,30 +80,21 @@ def _hip_render(z, case, prefix="in_"):
 def test_golden_random_sets(name, golden, manifest):
     z = golden(name)
     rough = z["in_roughness"]                       # (1,H,W)
-    well = np.broadcast_to(rough >= ROUGH_OK, (3,) + rough.shape[1:])
-    worst_well, worst_all, n_over = 0.0, 0.0, 0
+    tot = dict(max32=0.0, max64=0.0, n_hip=0, n_ref=0, n=0, rough_needed=0.0)
     for key in render_keys(z):
         case = parse_case(key, manifest)
         got, ref = _hip_render(z, case), z[key]
         assert got.shape == ref.shape and got.dtype == np.float32
-        err = np.abs(got - ref)
-        worst_all = max(worst_all, float(err.max()))
-        n_over += int((err > TOL).sum())
-        if well.any():
-            worst_well = max(worst_well, float(err[well].max()))
-            assert err[well].max() <= TOL, (key, float(err[well].max()))
         k64 = "f64_" + key[4:]
-        if k64 in z:                                 # criterion (ii)
-            ref64 = z[k64]
-            e64 = np.abs(got.astype(np.float64) - ref64)
-            env = np.abs(ref.astype(np.float64) - ref64)
-            assert e64.max() <= TOL, (key, "vs float64 reference", float(e64.max()))
-            assert (err <= env + TOL).all(), (key, float((err - env).max()))
-    print(f"\n[{name}] max|hip-ref32| rough>={ROUGH_OK}: {worst_well:.2e}; all pixels: {worst_all:.2e}; "
-          f"values > {TOL:g}: {n_over}")
-    # sets without a float64 twin: the ill-conditioned pixels stay inside the envelope measured for the
-    # reference itself on the sets that have one (<= 1e-4)
-    assert worst_all <= 1e-4
+        ref64 = z[k64] if k64 in z else oracle_render(z, case, dtype=torch.float64).numpy()
+        rep = parity_report(got, ref, ref64, rough, what=(name, key))
+        for k in ("max32", "max64", "rough_needed"):
+            tot[k] = max(tot[k], rep[k])
+        for k in ("n_hip", "n_ref", "n"):
+            tot[k] += rep[k]
+    print(f"\n[{name}] {tot['n']} values: max|hip-ref32| {tot['max32']:.2e}, max|hip-ref64| {tot['max64']:.2e}; values > {TOL:g} vs ref32: "
+          f"{tot['n_hip']} (reference vs its own float64 run: {tot['n_ref']}; 2e-5*N = {2e-5 * tot['n']:.1f}); "
+          f"criterion (i) holds from roughness {tot['rough_needed']:.3f} up (asserted from {ROUGH_OK})")
 
 
 @pytest.mark.parametrize("name", ["tiles96", "rocks96"])
@@ -308,14 +326,10 @@ def test_full_size_4k_properties_and_sampled_parity():
     ref32 = C.render(*host, None, **ckw)
     ref64 = C.render(*host, None, dtype=np.float64, **ckw)
     got = out.cpu().numpy()
-    err32, err64 = np.abs(got - ref32), np.abs(got.astype(np.float64) - ref64)
-    env = np.abs(ref32.astype(np.float64) - ref64)
-    print(f"\n[4096x4096] max|hip - C oracle fp32| = {err32.max():.2e} ({(err32 > TOL).sum()} of {err32.size} values > 1e-5); "
-          f"max|hip - C oracle fp64| = {err64.max():.2e}; max|C fp32 - C fp64| = {env.max():.2e}")
-    assert err64.max() <= TOL                      # criterion (ii a) at full size
-    assert (err32 <= env + TOL).all()              # criterion (ii b): every > TOL difference is the fp32 oracle's own error
-    assert np.abs(got[np.broadcast_to(host[2] >= ROUGH_OK, got.shape)] -
-                  ref32[np.broadcast_to(host[2] >= ROUGH_OK, got.shape)]).max() <= TOL      # criterion (i)
+    rep = parity_report(got, ref32, ref64, host[2], what="4096x4096 vs the C oracle")
+    print(f"\n[4096x4096] max|hip - C oracle fp32| = {rep['max32']:.2e} ({rep['n_hip']} of {rep['n']} values > 1e-5; the fp32 C oracle "
+          f"against its own fp64 build: {rep['n_ref']}); max|hip - C oracle fp64| = {rep['max64']:.2e}; "
+          f"criterion (i) holds from roughness {rep['rough_needed']:.3f} up")
 
 
 def test_launch_is_stream_ordered_and_graph_capturable():
@@ -528,9 +542,10 @@ def test_fused_tile_gradients_and_material_api():
     m1._maps["normal"], m2._maps["normal"] = n.cuda(), n.cuda()
     brdf = CookTorranceBRDF("point")
     args = (torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0]), 1.0)
-    assert m1.tile(2, lazy=True) is m1 and m1.size == (2 * h, 2 * w) and m1.albedo.shape == (3, h, w)
+    assert m1.tile(2, lazy=True) is m1 and m1.size == (2 * h, 2 * w) and m1.__dict__["_store"]["albedo"].shape == (3, h, w)
     assert torch.equal(brdf(m1, *args), brdf(m2.tile(2), *args))
-    assert m1.materialize_tile().albedo.shape == (3, 2 * h, 2 * w) and m1.lazy_tile == (1, 1)
+    assert m1.lazy_tile == (2, 2) and m1.__dict__["_store"]["albedo"].shape == (3, h, w)      # the BRDF materialised nothing
+    assert m1.albedo.shape == (3, 2 * h, 2 * w) and m1.lazy_tile == (1, 1)                    # reading a map does
     assert torch.equal(m1.albedo, m2.albedo)
 
 

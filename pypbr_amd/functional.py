@@ -343,6 +343,8 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
     Returns [3,H,W] or [B,3,H,W] (float32 unless `out_dtype`), on the same device,
     enqueued on the current stream without synchronising.
     """
+    if USE_TORCH_OPS and _torch_op_can_take(albedo, kwargs):
+        return _cook_torrance_via_torch_op(albedo, normal, roughness, metallic, specular, **kwargs)
     maps = (albedo, normal, roughness, metallic, specular)
     params = tuple(kwargs.get(k) for k in _PARAM_KEYS)
     if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in maps + params):
@@ -351,6 +353,61 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
     plan = plan_cook_torrance(albedo, normal, roughness, metallic, specular, **kwargs)
     with torch.cuda.device(plan.device):
         return plan.launch()
+
+
+USE_TORCH_OPS = True       # tests flip this to compare the two bindings of the same C ABI
+
+
+def _torch_op_can_take(albedo, kw) -> bool:
+    """`torch.ops.pbr_hip.cook_torrance` (pypbr_amd/torch_ops.py) covers the plain evaluation; explicit output buffers,
+    schedules, autotuning and the fused blend stay on the ctypes plan."""
+    if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda:
+        return False
+    if kw.get("out") is not None or kw.get("blend") is not None or kw.get("autotune") or kw.get("schedule", N.SCHEDULE_AUTO) != N.SCHEDULE_AUTO:
+        return False
+    if kw.get("out_dtype") not in (None, torch.float32, torch.float16):
+        return False
+    from . import torch_ops
+    return torch_ops.available()
+
+
+def _param_tensor(v, rows):
+    """view / light / intensity for the operator: a tensor that requires grad goes in as it is (the operator's autograd
+    formula returns its gradient); anything else as a small CPU tensor, device tensors through the cached host copy."""
+    if isinstance(v, torch.Tensor):
+        if (v.requires_grad and torch.is_grad_enabled()) or not v.is_cuda:
+            return v
+        return torch.tensor(_host_vec3(v, rows=rows), dtype=torch.float32)
+    t = torch.tensor(v, dtype=torch.float32)                 # Python numbers: no round trip (traceable by torch.compile)
+    return t.reshape(3) if rows is None else t.reshape(-1, 3)
+
+
+def _cook_torrance_via_torch_op(albedo, normal, roughness, metallic=None, specular=None, *, view_dir, light, light_intensity,
+                                light_type="point", light_size=None, albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True,
+                                convert_to_diffuse_specular=False, y_offset=0, height_total=None, out_dtype=None, tile=1, rows=None,
+                                **_ignored):
+    lt = str(light_type).lower()
+    if lt not in _LIGHT_TYPES:   # cooktorrance.py:62-65
+        raise ValueError(f"Unsupported light_type: {lt}. Must be 'directional' or 'point'.")
+    squeeze = albedo.dim() == 3
+    a = _as_batched(albedo, (3,), "albedo")
+    n = _as_batched(normal, (3,), "normal")
+    r = _as_batched(roughness, (1,), "roughness")
+    m = _as_batched(metallic, (1,), "metallic")
+    s = _as_batched(specular, (3,), "specular")
+    if m is None and s is None:                         # cooktorrance.py:115-118
+        raise ValueError("Material must have either 'metallic' or 'specular' property.")
+    if m is not None:
+        s = None
+    if out_dtype == torch.float16 and torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (a, n, r, m, s)):
+        raise NotImplementedError("gradients need a float32 result (fp16 maps are fine: their gradients come back in fp16)")
+    ny, nx = tile_counts(tile)
+    out = torch.ops.pbr_hip.cook_torrance(
+        a, n, r, m, s, _param_tensor(view_dir, None), _param_tensor(light, -1), _param_tensor(light_intensity, -1),
+        float(light_size) if light_size else 0.0, _LIGHT_TYPES[lt], bool(albedo_is_srgb), bool(specular_is_srgb),
+        bool(convert_to_diffuse_specular), bool(return_srgb), int(y_offset), int(height_total or 0), ny, nx, int(rows or 0),
+        out_dtype == torch.float16)
+    return out[0] if squeeze else out
 
 
 _PARAM_KEYS = ("view_dir", "light", "light_intensity")

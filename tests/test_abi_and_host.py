@@ -396,3 +396,29 @@ def test_integration_md_binding_stub_matches_the_abi():
     assert ctypes.sizeof(scope["_Desc"]) == lib.pbr_render_desc_size() == ctypes.sizeof(N.RenderDesc)
     assert [f[0] for f in scope["_Desc"]._fields_] == [f[0] for f in N.RenderDesc._fields_]
     assert f"pbr_abi_version() == {N.ABI_VERSION}" in text and f"abi_version={N.ABI_VERSION}" in text
+
+
+def test_torch_ops_are_registered_with_fake_kernels():
+    """torch.ops.pbr_hip.* (SURVEY.md 8b): the extension loads, every operator has a schema, and the fake kernels give
+    the result's shape / dtype / device without a GPU (FakeTensor and meta tensors) -- what torch.compile traces with."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from pypbr_amd import torch_ops
+    assert torch_ops.available() and os.path.exists(torch_ops.LIB_PATH)
+    for op in ("cook_torrance", "cook_torrance_backward", "fold_gradient", "srgb_to_linear", "linear_to_srgb",
+               "metallic_to_diffuse_specular", "diffuse_specular_to_basecolor_metallic"):
+        assert getattr(torch.ops.pbr_hip, op).default._schema.name == "pbr_hip::" + op
+    v, l, i = torch.tensor([0.0, 0.0, 1.0]), torch.tensor([[0.1, 0.1, 1.0], [0.0, 0.5, 1.0]]), torch.ones(1, 3)
+    with FakeTensorMode(allow_non_fake_inputs=True):
+        a, n, r, m = (torch.empty(2, c, 8, 16, device="cuda") for c in (3, 3, 1, 1))
+        out = torch.ops.pbr_hip.cook_torrance(a, n, r, m, None, v, l, i, 1.0, 1, True, True, False, True)
+        assert out.shape == (2, 3, 8, 16) and out.dtype == torch.float32 and out.device.type == "cuda"
+        out = torch.ops.pbr_hip.cook_torrance(a.half(), None, r.half(), m.half(), None, v, l, i, 0.0, 0, True, True, True, False, 4, 0, 2, 3, 10, True)
+        assert out.shape == (2, 3, 10, 48) and out.dtype == torch.float16
+        grads = torch.ops.pbr_hip.cook_torrance_backward(torch.empty(2, 3, 8, 16, device="cuda"), a, n, r, m, None, v, l, i, 1.0, 1, True, True,
+                                                         False, True, 0, 0, 1, 1, 0, True, False, True, True, False, True)
+        assert [tuple(g.shape) for g in grads] == [(2, 3, 8, 16), (0,), (2, 1, 8, 16), (2, 1, 8, 16), (0,), (15,)]
+        assert torch.ops.pbr_hip.fold_gradient(torch.empty(2, 3, 16, 48, device="cuda"), 8, 16, True).shape == (1, 3, 8, 16)
+        d, s = torch.ops.pbr_hip.metallic_to_diffuse_specular(a, m, True)
+        assert d.shape == s.shape == a.shape
+    with pytest.raises(NotImplementedError):          # no CPU kernels: the product has no CPU path
+        torch.ops.pbr_hip.srgb_to_linear(torch.rand(3, 4, 4))

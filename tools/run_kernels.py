@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Launches every kernel of libpbr_hip.so a few times at a probe shape large enough to stream from HBM: the target of
+the rocprofv3 passes of tools/collect_kernels.sh (kernel trace + FETCH_SIZE / WRITE_SIZE / SQ counters in separate
+passes).  Prints one JSON line per case: which kernel (substring of the rocprof name), the algorithmic bytes of one
+launch (SURVEY.md 8d accounting: every map plane read once, every result plane written once) and its own HIP-event
+timing.   python tools/run_kernels.py [reps] [only-substring]"""
+import ctypes
+import json
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import synth_material  # noqa: E402
+from pypbr_amd import _native as N, blending as B, functional as F  # noqa: E402
+
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
+DEV = torch.device("cuda", 0)
+S = 4096
+PX = S * S
+
+
+def timed(fn, reps=REPS, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def report(case, kernel, alg_bytes, us, **extra):
+    line = {"case": case, "kernel": kernel, "algorithmic_bytes_per_launch": int(alg_bytes), "us_per_launch_hip_events": round(us, 1),
+            "GBps_algorithmic": round(alg_bytes / us / 1e3, 1), "frac_of_8TBps": round(alg_bytes / us / 1e3 / 8000.0, 4)}
+    line.update(extra)
+    print(json.dumps(line), flush=True)
+
+
+def batch(B_, size, dtype=torch.float32, seed=0):
+    ms = [synth_material(size, DEV, seed + i) for i in range(B_)]
+    return [torch.stack([m[k] for m in ms]).to(dtype) for k in range(4)]
+
+
+def want(name):
+    return ONLY in name
+
+
+PT = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
+stream = torch.cuda.current_stream(DEV).cuda_stream
+lib = N.lib()
+
+if want("fwd_f32"):
+    a, n, r, m, out = F.pack_maps(*synth_material(S, DEV, 1), reserve_output=True)
+    p = F.plan_cook_torrance(a, n, r, m, out=out.unsqueeze(0), **PT)
+    report("fwd_f32: 1 x 4096^2 point metallic fp32 (bench.py workload)", "cook_torrance_kernel<1, 0, float, float, 4, false, true>",
+           p.bytes_per_pixel * PX, timed(lambda: p.launch(stream), reps=max(REPS, 50), warm=20))
+    del a, n, r, m, out, p
+if want("fwd_f16"):
+    h = batch(4, S, torch.float16, 10)
+    p = F.plan_cook_torrance(*h, **PT)
+    report("fwd_f16: 4 x 4096^2 point metallic, fp16 maps -> fp32", "cook_torrance_kernel<1, 0, __half, float, 8, false, true>",
+           p.bytes_per_pixel * 4 * PX, timed(lambda: p.launch(stream)))
+    p2 = F.plan_cook_torrance(*h, out_dtype=torch.float16, **PT)
+    report("fwd_f16_f16: same, fp16 result", "cook_torrance_kernel<1, 0, __half, __half, 8, false, true>",
+           p2.bytes_per_pixel * 4 * PX, timed(lambda: p2.launch(stream)))
+    lights = [[math.cos(t), math.sin(t), 1.0] for t in [2 * math.pi * i / 16 for i in range(16)]]
+    p16 = F.plan_cook_torrance(*h, view_dir=[0, 0, 1], light=lights, light_intensity=[[1.0 / 16] * 3] * 16, light_type="point", light_size=1.0)
+    us = timed(lambda: p16.launch(stream), reps=3, warm=1)
+    report("fwd_16_lights: 4 x 4096^2, 16 point lights, fp16 maps -> fp32 (config 5 share)", "cook_torrance_kernel<1, 0, __half, float, 4, true, true>",
+           p16.bytes_per_pixel * 4 * PX, us, Gpixels_per_s=round(4 * PX / us / 1e3, 1))
+    del h, p, p2, p16
+if want("bwd"):
+    for dtype, tag, kern in ((torch.float32, "bwd_f32", "cook_torrance_backward_kernel<1, 0, 4, false, float, false>"),
+                             (torch.float16, "bwd_f16", "cook_torrance_backward_kernel<1, 0, 4, false, __half, false>")):
+        maps = [t.to(dtype) for t in synth_material(S, DEV, 7)]
+        plan = F.plan_cook_torrance(*maps, **PT)
+        gout = torch.rand(1, 3, S, S, device=DEV)
+        grads = [torch.empty_like(t) for t in maps]
+
+        def bwd():
+            N.check(lib.pbr_cook_torrance_backward(ctypes.byref(plan.desc), gout.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
+                                                   grads[2].data_ptr(), grads[3].data_ptr(), None, stream))
+        es = maps[0].element_size()
+        report(f"{tag}: backward 1 x 4096^2 point metallic ({dtype}) maps 8 planes + grad_out 3 fp32 in, 8 gradient planes out", kern,
+               (8 * es + 12 + 8 * es) * PX, timed(bwd))
+        del maps, plan, gout, grads
+if want("blend_fused"):
+    m1, m2 = synth_material(S, DEV, 21), synth_material(S, DEV, 22)
+    mask = torch.rand(1, S, S, device=DEV)
+    p = F.plan_cook_torrance(*m1, blend=(m2[0], m2[1], m2[2], m2[3], None, mask), **PT)
+    report("blend_fused: blend_with_mask + re-decode + render, 4096^2 (17 planes in, 3 out)", "cook_torrance_blend_kernel<1, 0, 4, false>",
+           80 * PX, timed(lambda: p.launch(stream)))
+    del m1, m2, mask, p
+if want("tiled"):
+    maps = synth_material(2048, DEV, 31)
+    p = F.plan_cook_torrance(*maps, tile=2, **PT)
+    report("tiled: 2048^2 maps, fused tile(2) -> 4096^2 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out)",
+           "cook_torrance_kernel<1, 0, float, float, 4, false, false>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
+    del maps, p
+if want("map_ops"):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    a = torch.rand(3, S, S, device=DEV, generator=g)
+    n = torch.rand(3, S, S, device=DEV, generator=g)
+    m = torch.rand(1, S, S, device=DEV, generator=g)
+    o3, o3b, o1 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(m)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    report("map_ops srgb_to_linear 3 x 4096^2 fp32", "colour_kernel", 24 * PX,
+           timed(lambda: lib.pbr_srgb_to_linear(a.data_ptr(), o3.data_ptr(), a.numel(), N.F32, stream)))
+    report("map_ops linear_to_srgb 3 x 4096^2 fp32", "colour_kernel", 24 * PX,
+           timed(lambda: lib.pbr_linear_to_srgb(a.data_ptr(), o3.data_ptr(), a.numel(), N.F32, stream)))
+    report("map_ops metallic -> diffuse/specular 4096^2 (4 planes in, 6 out)", "metallic_to_specular_kernel", 40 * PX,
+           timed(lambda: lib.pbr_metallic_to_specular(a.data_ptr(), m.data_ptr(), o3.data_ptr(), o3b.data_ptr(), 1, PX, 1, N.F32, stream)))
+    report("map_ops diffuse/specular -> basecolor/metallic 4096^2 (6 planes in, 6 out)", "specular_to_metallic_kernel", 48 * PX,
+           timed(lambda: lib.pbr_specular_to_metallic(a.data_ptr(), n.data_ptr(), o3.data_ptr(), o3b.data_ptr(), a.numel(), 0, N.F32, stream)))
+    report("map_ops decode_normal 3 ch [0,1]-encoded 4096^2 (flag pass reads 3 planes; transform 3 in, 3 out)", "decode_normal", 36 * PX,
+           timed(lambda: lib.pbr_decode_normal(n.data_ptr(), o3.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
+    report("blend_maps 3 ch 4096^2 (7 planes in, 3 out)", "blend_kernel", 40 * PX,
+           timed(lambda: lib.pbr_blend_maps(a.data_ptr(), n.data_ptr(), m.data_ptr(), o3.data_ptr(), 3, PX, 0, stream)))
+    report("blend_maps normals 4096^2 (7 planes in, 3 out)", "blend_kernel", 40 * PX,
+           timed(lambda: lib.pbr_blend_maps(a.data_ptr(), n.data_ptr(), m.data_ptr(), o3.data_ptr(), 3, PX, 1, stream)))
+    report("sigmoid mask 4096^2 (2 in, 1 out)", "sigmoid_mask_kernel", 12 * PX,
+           timed(lambda: lib.pbr_blend_sigmoid_mask(m.data_ptr(), m.data_ptr(), o1.data_ptr(), PX, 0.0, 0.1, stream)))
+    del a, n, m, o3, o3b, o1
+if want("resize"):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    a = torch.rand(3, S, S, device=DEV, generator=g)
+    for (ho, wo), aa in (((S // 2, S // 2), True), ((S // 4, S // 4), True), ((S * 3 // 2, S * 3 // 2), False)):
+        out = torch.empty(3, ho, wo, device=DEV)
+        ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, S, wo) // 4), device=DEV)
+        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", "resize_", 12 * (PX + ho * wo),
+               timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), 3, S, S, ho, wo, int(aa), ws.data_ptr(), stream)))
+        del out, ws

@@ -22,6 +22,8 @@
 //   * no LDS: there is no inter-pixel reuse to stage ("LDS staging").
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "ct_launch.hpp"
 
 namespace pbr {
@@ -32,6 +34,7 @@ int g_block_log2 = 6;
 int g_f16_vec = 8;
 int g_lds_bytes = -1;
 int g_xcd_log2 = -1;
+int g_bwd_vec = 4;
 
 using KernelFn = void (*)(const KArgs);
 struct KernelEntry { KernelFn fn; const char *name; };
@@ -101,7 +104,8 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0 && !tiled);
     // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane
     const bool fp32_one_light = d->map_dtype == PBR_F32 && d->n_lights == 1 && k.bt_log2 == 6 && !tiled;
-    const size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (fp32_one_light ? kLdsFor11WavesPerCu : 0);
+    size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (fp32_one_light ? kLdsFor11WavesPerCu : 0);
+    if (k.xpose) lds = std::max(lds, (size_t)kXposeLdsPerWave << (k.bt_log2 - 6));     // the kernel's piece exchange needs this much
     hipLaunchKernelGGL(e.fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), lds,
                        static_cast<hipStream_t>(stream), k);
     const hipError_t err = hipGetLastError();
@@ -167,6 +171,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_F16_VEC: slot = &pbr::g_f16_vec; break;
         case PBR_TUNE_LDS_BYTES: slot = &pbr::g_lds_bytes; break;
         case PBR_TUNE_XCD_LOG2: slot = &pbr::g_xcd_log2; break;
+        case PBR_TUNE_BWD_VEC: slot = &pbr::g_bwd_vec; break;
         default: return -1;
     }
     const int old = *slot;

@@ -9,6 +9,7 @@ using BwdFn = void (*)(const KArgs, const BArgs);
 
 template <int L, int W, typename T, bool PG>
 static BwdFn pick_bwd_variant(int vec, bool multi) {
+    if (vec == 2) return multi ? cook_torrance_backward_kernel<L, W, 2, true, T, PG> : cook_torrance_backward_kernel<L, W, 2, false, T, PG>;
     if (vec == 4) return multi ? cook_torrance_backward_kernel<L, W, 4, true, T, PG> : cook_torrance_backward_kernel<L, W, 4, false, T, PG>;
     return multi ? cook_torrance_backward_kernel<L, W, 1, true, T, PG> : cook_torrance_backward_kernel<L, W, 1, false, T, PG>;
 }
@@ -47,6 +48,9 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
                           (const void *)g_metallic, (const void *)g_specular})
         if (g && (reinterpret_cast<uintptr_t>(g) & 15u)) vec = 1;
     if (vec == 8) vec = 4;
+    // Two pixels per lane where the four-pixel body does not fit two waves per SIMD: with the light / view adjoints
+    // (PGRAD) it needs 256 VGPRs + 40 AGPRs = one wave per SIMD, the two-pixel body 155 = three.  (g_bwd_vec: A/B knob.)
+    if (vec == 4 && (g_bwd_vec == 2 || g_params)) vec = 2;
     KArgs k;
     fill_args(d, vec, k);
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;

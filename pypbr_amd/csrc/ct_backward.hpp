@@ -56,6 +56,16 @@ template <class R> __device__ __forceinline__ R srgb_to_linear_grad(R x) {
     return masked(in_unit(x), d);
 }
 
+// utils.srgb_to_linear and its derivative from ONE log / exp pair: with u = clamp(x) + 0.055 and
+// e = (u / 1.055)^1.4 = exp2(1.4 log2 u - 1.4 log2 1.055), the value is e u / 1.055 and the slope 2.4 e / 1.055.
+template <class R> __device__ __forceinline__ void srgb_to_linear_and_grad(R x, R &value, R &slope) {
+    const R t = clamp01(x), u = t + 0.055f;
+    const R e = exp2_hw(fma_(splat<R>(1.4f), log2_hw(u), splat<R>(-0.10814020f) /* 1.4*log2(1.055) */));
+    const MaskT<R> low = le_(t, splat<R>(0.04045f));
+    value = select_(low, t * (1.0f / 12.92f), (e * u) * (1.0f / 1.055f));
+    slope = masked(in_unit(x), select_(low, splat<R>(1.0f / 12.92f), e * 2.2748815f /* 2.4/1.055 */));
+}
+
 // d/dc of utils.linear_to_srgb (functions.py:50-66) for c already in [0,1].
 template <class R> __device__ __forceinline__ R linear_to_srgb_grad_unit(R c) {
     const R hi = exp2_hw(log2_hw(c) * (1.0f / 2.4f - 1.0f)) * 0.43958333f /* 1.055/2.4 */;
@@ -223,6 +233,8 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
     if (LIGHT == PBR_LIGHT_POINT) ys = linspace_at(a.y0, a.y1, a.ystep, a.H_total, p.y + a.y_offset);
 
     float ga[3][VEC], gn[3][VEC], gr[VEC], gm[VEC], gs[3][VEC];
+    R xgrid[NG];
+    if (LIGHT == PBR_LIGHT_POINT) x_grid<R, NG, VEC>(a, p.x, xgrid);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         // ---- forward: decoded colours and their derivatives
@@ -232,20 +244,21 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const R al = gather<R>(t.al[c], g);
-            alin[c] = base[c] = a.albedo_srgb ? srgb_to_linear(al) : al;
-            dbase[c] = a.albedo_srgb ? srgb_to_linear_grad(al) : splat<R>(1.0f);
+            alin[c] = base[c] = al; dbase[c] = splat<R>(1.0f);
+            if (a.albedo_srgb) srgb_to_linear_and_grad(al, base[c], dbase[c]);
+            alin[c] = base[c];
             if (WF == PBR_WORKFLOW_METALLIC) {
                 f0[c] = fma_(m, base[c], om * kDielectricF0);                  // lerp(0.04, base, m) :107
                 df0[c] = splat<R>(0.0f);
             } else if (WF == PBR_WORKFLOW_SPECULAR) {
                 const R sp = gather<R>(t.sp[c], g);
-                f0[c] = a.spec_srgb ? srgb_to_linear(sp) : sp;
-                df0[c] = a.spec_srgb ? srgb_to_linear_grad(sp) : splat<R>(1.0f);
+                f0[c] = sp; df0[c] = splat<R>(1.0f);
+                if (a.spec_srgb) srgb_to_linear_and_grad(sp, f0[c], df0[c]);
             } else {   // CONVERTED: to_diffuse_specular_material (metallic.py:98-108), then the specular workflow
                 const R sp = fma_(alin[c], m, om * kDielectricF0);
                 base[c] = alin[c] * om;
-                f0[c] = a.spec_srgb ? srgb_to_linear(sp) : sp;
-                df0[c] = a.spec_srgb ? srgb_to_linear_grad(sp) : splat<R>(1.0f);
+                f0[c] = sp; df0[c] = splat<R>(1.0f);
+                if (a.spec_srgb) srgb_to_linear_and_grad(sp, f0[c], df0[c]);
             }
         }
         if (WF == PBR_WORKFLOW_METALLIC) kd_scale = om;
@@ -253,7 +266,7 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
         const R rough = gather<R>(t.ro, g);
         PixelTermsT<R> pt;
         pixel_terms(nraw, V, rough, base, f0, kd_scale, pt);
-        const R xs = LIGHT == PBR_LIGHT_POINT ? xs_of<R>(a, p.x, g) : splat<R>(0.0f);
+        const R xs = LIGHT == PBR_LIGHT_POINT ? xgrid[g] : splat<R>(0.0f);
         R gout_c[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], g);

@@ -60,6 +60,7 @@ struct KArgs {
     int32_t n_tiles;         // tiles_x * ceil(rows / tile rows)
     int32_t xcd_log2;        // workgroup -> tile remap: each XCD takes runs of (1 << xcd_log2) consecutive tiles (0 = identity)
     int32_t xcd_tiles;       // tiles covered by the remap: n_tiles rounded down to a multiple of 8 << xcd_log2
+    int32_t xpose;           // 8-pixel lanes, fp32 result: exchange the lanes' 16-byte pieces through LDS before storing
     FastDiv div_h;           // row / H
     FastDiv div_tx;          // tile / tiles_x
     int32_t tiled;           // maps are (map_h, map_w) and repeat over the (H_total, W) output (MaterialBase.tile)
@@ -120,6 +121,34 @@ template <> struct Ld<__half, 1> {
     }
 };
 
+// 2 pixels per lane (one packed pair): the register-light form of the backward kernel for fp16 maps
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+template <> struct Ld<float, 2> {
+    template <bool NT> static __device__ __forceinline__ void load(const void *p, int64_t i, float v[2]) {
+        const f32x2v *q = reinterpret_cast<const f32x2v *>(static_cast<const float *>(p) + i);
+        const f32x2v t = NT ? __builtin_nontemporal_load(q) : *q;
+        v[0] = t.x; v[1] = t.y;
+    }
+    template <bool NT> static __device__ __forceinline__ void store(void *p, int64_t i, const float v[2]) {
+        const f32x2v t = {v[0], v[1]};
+        f32x2v *q = reinterpret_cast<f32x2v *>(static_cast<float *>(p) + i);
+        if (NT) __builtin_nontemporal_store(t, q); else *q = t;
+    }
+};
+template <> struct Ld<__half, 2> {
+    template <bool NT> static __device__ __forceinline__ void load(const void *p, int64_t i, float v[2]) {
+        const f16x2 *q = reinterpret_cast<const f16x2 *>(static_cast<const _Float16 *>(p) + i);
+        const f16x2 t = NT ? __builtin_nontemporal_load(q) : *q;
+        v[0] = (float)t.x; v[1] = (float)t.y;
+    }
+    template <bool NT> static __device__ __forceinline__ void store(void *p, int64_t i, const float v[2]) {
+        const f16x2 t = {(_Float16)v[0], (_Float16)v[1]};
+        f16x2 *q = reinterpret_cast<f16x2 *>(static_cast<_Float16 *>(p) + i);
+        if (NT) __builtin_nontemporal_store(t, q); else *q = t;
+    }
+};
+
 // 8 pixels per lane: fp16 maps read as one 16-byte load per plane; fp32 results leave as two 16-byte stores.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <> struct Ld<__half, 8> {
@@ -162,6 +191,8 @@ __device__ __forceinline__ uint32_t tile_of_workgroup(const KArgs &a, uint32_t w
     const uint32_t c = (uint32_t)a.xcd_log2, xcd = wg & 7u, slot = wg >> 3;
     return ((slot >> c) << (c + 3)) + (xcd << c) + (slot & ((1u << c) - 1u));
 }
+
+constexpr int kXposeLdsPerWave = 3 * 144 * 16;       // shade_and_store's piece exchange (8-pixel lanes, fp32 result)
 
 // ------------------------------------------------------------------ one lane's share of a tile
 struct LanePos {
@@ -250,13 +281,40 @@ __device__ __forceinline__ void material_terms(const Texels<VEC> &t, int g, cons
     pixel_terms(n, V, gather<R>(t.ro, g), base, f0, kd_scale, pt);
 }
 
-// x grid values of pixel group g (torch.linspace over W, :132)
-template <class R> __device__ __forceinline__ R xs_of(const KArgs &a, int x0, int g);
-template <> __device__ __forceinline__ float xs_of<float>(const KArgs &a, int x0, int g) {
+// x grid values of the lane's pixels (torch.linspace over W, :132), per pixel group.  The two-ended formula is
+// x_i = a + step i below the midpoint, b - step (n-1-i) above it.  A lane's VEC pixels are consecutive, so unless the
+// lane straddles the midpoint they share the side, and float(i0 + k) = float(i0) + k exactly (integers below 2^24):
+// one conversion and three selects per LANE, then one add and one fma per pixel (packed: per pair) -- bit-identical
+// to evaluating the formula per pixel, which costs a compare, three selects, a conversion, a subtraction and the fma
+// per PIXEL (8 % of the fp16 kernel's VALU work).  Straddling lanes (only when VEC does not divide n/2) take the
+// per-pixel form; the choice is made per wave.
+template <class R> __device__ __forceinline__ R xs_slow(const KArgs &a, int x0, int g);
+template <> __device__ __forceinline__ float xs_slow<float>(const KArgs &a, int x0, int g) {
     return linspace_at(a.x0, a.x1, a.xstep, a.W, x0 + g);
 }
-template <> __device__ __forceinline__ f32x2 xs_of<f32x2>(const KArgs &a, int x0, int g) {
+template <> __device__ __forceinline__ f32x2 xs_slow<f32x2>(const KArgs &a, int x0, int g) {
     return f32x2{linspace_at(a.x0, a.x1, a.xstep, a.W, x0 + 2 * g), linspace_at(a.x0, a.x1, a.xstep, a.W, x0 + 2 * g + 1)};
+}
+template <class R> __device__ __forceinline__ R lane_offsets(int g);           // {first pixel of group g, ...} as floats
+template <> __device__ __forceinline__ float lane_offsets<float>(int g) { return (float)g; }
+template <> __device__ __forceinline__ f32x2 lane_offsets<f32x2>(int g) { return f32x2{(float)(2 * g), (float)(2 * g + 1)}; }
+
+template <class R, int NG, int VEC>
+__device__ __forceinline__ void x_grid(const KArgs &a, int x0, R xs[NG]) {
+    const int half = a.W >> 1;
+    const bool lo = x0 < half;
+    const bool one_side = lo == (x0 + VEC - 1 < half);
+    if (__all(one_side)) {
+        const float sgn = lo ? 1.0f : -1.0f;
+        const float f0 = (float)(lo ? x0 : a.W - 1 - x0);
+        const float st = lo ? a.xstep : -a.xstep, base = lo ? a.x0 : a.x1;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            xs[g] = fma_(splat<R>(st), fma_(splat<R>(sgn), lane_offsets<R>(g), splat<R>(f0)), splat<R>(base));
+    } else {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xs[g] = xs_slow<R>(a, x0, g);
+    }
 }
 
 template <int LIGHT, class R>
@@ -316,11 +374,13 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
     if constexpr (!MULTI) {
         // ---- one light: group by group, terms and shading back to back (shortest live ranges)
         const LightU &lu = a.lights[0];
+        R xs[NG];
+        if (LIGHT == PBR_LIGHT_POINT) x_grid<R, NG, VEC>(a, p.x, xs);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             PixelTermsT<R> pt;
             material_terms<WF, VEC, R>(t, g, V, pt);
-            const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs_of<R>(a, p.x, g), ys);
+            const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, LIGHT == PBR_LIGHT_POINT ? xs[g] : splat<R>(0.0f), ys);
             R col[3];
             shade_light(pt, lg, lu.inten, col);
 #pragma unroll
@@ -332,11 +392,14 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
         // loop overhead are paid once per VEC pixels and the groups' transcendental latencies interleave
         PixelTermsT<R> pt[NG];
         R xs[NG];
+        if (LIGHT == PBR_LIGHT_POINT) {
+            x_grid<R, NG, VEC>(a, p.x, xs);
+        } else {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            material_terms<WF, VEC, R>(t, g, V, pt[g]);
-            xs[g] = LIGHT == PBR_LIGHT_POINT ? xs_of<R>(a, p.x, g) : splat<R>(0.0f);
+            for (int g = 0; g < NG; ++g) xs[g] = splat<R>(0.0f);
         }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) material_terms<WF, VEC, R>(t, g, V, pt[g]);
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -362,6 +425,44 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int g = 0; g < NG; ++g) res[c][g] = linear_to_srgb_unit(res[c][g]);
+    }
+    if constexpr (VEC == 8 && sizeof(TO) == 4) {
+        // A lane of the 8-pixel kernels holds 32 contiguous bytes of every result plane.  Stored as they stand, each
+        // global_store_dwordx4 covers 16 of every 32 bytes of a 2 KiB span -- half-filled write requests, measured
+        // 5 % slower (4 x 4096^2 fp16 maps: 329 -> 313 us) than stores that each cover a contiguous 1 KiB.  So the lanes
+        // of a row swap their 16-byte pieces first: piece q of the row's 2 bx pieces is produced by lane q / 2 and
+        // stored by lane q mod bx, through 2.25 KiB of LDS per wave and plane (first halves in one 1 KiB block, second
+        // halves 128 bytes -- 32 banks -- further on, so both the b128 writes and the interleaved reads are
+        // conflict-free).  One wave only ever talks to itself here: a wave barrier orders the LDS traffic.
+        if (a.xpose) {
+            extern __shared__ f32x4 xp_all[];                                 // kXposeLdsPerWave bytes per wave, sized by the launcher
+            f32x4 (*xp)[3][144] = reinterpret_cast<f32x4 (*)[3][144]>(xp_all);   // [wave of the workgroup][plane][64 + 8 pad + 64 + 8]
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const int bx = 1 << a.bx_log2, col = lane & (bx - 1), row0 = lane - col;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float o[VEC];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) scatter(o, g, res[c][g]);
+                xp[wave][c][lane] = f32x4{o[0], o[1], o[2], o[3]};
+                xp[wave][c][72 + lane] = f32x4{o[4], o[5], o[6], o[7]};
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int64_t base = p.b * a.o_bs + p.pix - 4 * col;              // where piece `col` of the row goes
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int q = s2 * bx + col;                              // piece index inside the row
+                    const f32x4 v = xp[wave][c][(q & 1) * 72 + row0 + (q >> 1)];
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + base + c * a.o_cs + 4 * s2 * bx);
+                    if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
+                }
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {

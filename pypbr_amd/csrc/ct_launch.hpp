@@ -25,6 +25,7 @@ extern int g_f16_vec;              // pixels per lane for fp16 maps with one lig
 // 4096^2, 33.3 vs 34.0 us on 2048^2, 249.8 vs 254.1 us on 8 x 2048^2 directional), the fp16 and multi-light
 // kernels with no cap.  -1 = that rule; >= 0 = this many bytes for every launch (A/B runs).
 extern int g_lds_bytes;
+extern int g_bwd_vec;              // pixels per lane of the backward kernels: 4, or 2 (A/B knob)
 extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
 constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
 
@@ -136,6 +137,9 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     k.n_tiles = tiles > INT32_MAX ? -1 : (int32_t)tiles;      // -1: more tiles than a 1-D grid holds, rejected by the callers
     k.xcd_log2 = schedule_xcd_log2(d, vec);
     k.xcd_tiles = k.n_tiles < 0 ? 0 : (k.n_tiles >> (k.xcd_log2 + 3)) << (k.xcd_log2 + 3);
+    // 8-pixel lanes with an fp32 result swap 16-byte pieces between the lanes of a row before storing (ct_kernel.hpp):
+    // only when every row of every tile is full, so that the lane a piece comes from always exists
+    k.xpose = vec == 8 && d->out_dtype == PBR_F32 && k.wv % bx == 0;
     k.div_h.init((uint32_t)d->height);
     k.div_tx.init((uint32_t)k.tiles_x);
     k.tiled = is_tiled(d);

@@ -35,8 +35,8 @@ int g_f16_vec = 8;
 int g_lds_bytes = -1;
 int g_xcd_log2 = -1;
 int g_bwd_vec = 4;
+int g_batch_inner = -1;
 
-using KernelFn = void (*)(const KArgs);
 struct KernelEntry { KernelFn fn; const char *name; };
 
 // Storage-type pairs built: (f32 -> f32), (f32 -> f16), (f16 -> f32), (f16 -> f16).
@@ -71,6 +71,12 @@ static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
     static const char *const wf_names[3] = {"metallic", "specular", "converted"};
     const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
     const int idt = d->map_dtype, odt = d->out_dtype;
+    const int nb = batch_group(d, vec);
+    if (nb) {
+        std::snprintf(name, sizeof(name), "ctb_%s_%s_%s_%s_v2_b%d", point ? "point" : "directional", wf_names[d->workflow],
+                      idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", nb);
+        return KernelEntry{pick_batch_kernel(d, nb, nt), name};
+    }
     std::snprintf(name, sizeof(name), "ct_%s_%s_%s_%s_v%d%s", point ? "point" : "directional", wf_names[d->workflow],
                   idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", vec, multi ? "_multi" : "");
     KernelFn fn = nullptr;
@@ -95,7 +101,14 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     if (rc != PBR_OK) return rc;
     const int vec = pick_vec(d);
     KArgs k;
-    fill_args(d, vec, k);
+    const int nb = batch_group(d, vec);
+    if (nb) {                        // lane_pos' material index is the group of nb consecutive materials; 2 pixels per lane
+        pbr_render_desc g = *d;
+        g.batch = d->batch / nb;
+        fill_args(&g, 2, k);
+    } else {
+        fill_args(d, vec, k);
+    }
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
     // Tiled maps are re-read from L2 / Infinity Cache, so their loads must not carry the streaming hint, and the
     // launch is then VALU-bound and wants every wave it can get (2048^2 tile(2): 81 us vs 122 us with the streaming
@@ -172,6 +185,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_LDS_BYTES: slot = &pbr::g_lds_bytes; break;
         case PBR_TUNE_XCD_LOG2: slot = &pbr::g_xcd_log2; break;
         case PBR_TUNE_BWD_VEC: slot = &pbr::g_bwd_vec; break;
+        case PBR_TUNE_BATCH_INNER: slot = &pbr::g_batch_inner; break;
         default: return -1;
     }
     const int old = *slot;

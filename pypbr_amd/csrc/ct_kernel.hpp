@@ -328,14 +328,13 @@ __device__ __forceinline__ LightGeomT<R> light_geom(const LightU &lu, const Vec3
     return g;
 }
 
-// Everything between the loads and the stores (cooktorrance.py:99-180 and the conversions it calls).
-// Run-time flags (sRGB decode/encode, normal present) are wave-uniform and each guards ONE hoisted
-// block over all VEC pixels, so the shading code stays one basic block and the scheduler can
-// interleave the pixel groups' transcendental latencies.
-template <int LIGHT, int WF, typename TO, int VEC, bool MULTI, bool NT, bool PACKED>
-__device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p, Texels<VEC> &t) {
+// Decodes the lane's texels in place (cooktorrance.py:99-118 and the conversions it calls): +Z for a missing normal map,
+// sRGB -> linear albedo, the in-kernel metallic -> diffuse/specular conversion, sRGB -> linear specular.  Run-time flags
+// are wave-uniform and each guards ONE hoisted block over all VEC pixels.
+template <int WF, int VEC, bool PACKED>
+__device__ __forceinline__ void decode_texels(const KArgs &a, Texels<VEC> &t) {
     using R = typename RealOf<VEC, PACKED>::type;
-    constexpr int NG = RealOf<VEC, PACKED>::N;                             // pixel groups per lane
+    constexpr int NG = RealOf<VEC, PACKED>::N;
     if (!a.has_normal) {                                                    // +Z, :147-152
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { t.nm[0][j] = 0.0f; t.nm[1][j] = 0.0f; t.nm[2][j] = 1.0f; }
@@ -365,6 +364,18 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
 #pragma unroll
             for (int g = 0; g < NG; ++g) scatter(t.sp[c], g, srgb_to_linear(gather<R>(t.sp[c], g)));
     }
+
+}
+
+// Everything between the loads and the stores (cooktorrance.py:99-180 and the conversions it calls).
+// Run-time flags (sRGB decode/encode, normal present) are wave-uniform and each guards ONE hoisted
+// block over all VEC pixels, so the shading code stays one basic block and the scheduler can
+// interleave the pixel groups' transcendental latencies.
+template <int LIGHT, int WF, typename TO, int VEC, bool MULTI, bool NT, bool PACKED>
+__device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p, Texels<VEC> &t) {
+    using R = typename RealOf<VEC, PACKED>::type;
+    constexpr int NG = RealOf<VEC, PACKED>::N;                             // pixel groups per lane
+    decode_texels<WF, VEC, PACKED>(a, t);
 
     const Vec3 V = {a.V[0], a.V[1], a.V[2]};
     float ys = 0.0f;
@@ -501,6 +512,84 @@ void cook_torrance_kernel(const KArgs a) {
 #else
     shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, (MULTI || sizeof(TI) == 2)>(a, p, t);
 #endif
+}
+
+// ------------------------------------------------------------------ batch-inner kernel (several lights)
+// With several lights the launch is VALU-bound (config 5: 16 lights, VALUs 94 % busy, HBM at 15 %), and ~45 % of a
+// light evaluation -- the light geometry: d, 1/dist, attenuation, half vector, 1/|h|^2, the Fresnel power -- depends on
+// the pixel POSITION only, not on the material ("batch reuse of light geometry").  Here a lane owns
+// VEC pixel positions and NB materials of the batch at those positions: lights in the outer loop, the geometry of a
+// light once per position, then the NB materials' shading (NB independent dependency chains per light: the ILP a
+// VALU-bound body wants).  Same functions, same operation order per pixel as cook_torrance_kernel<.., MULTI = true>.
+//   rows = (B / NB) * H: lane_pos' "material" index is the GROUP of NB consecutive materials.
+template <int LIGHT, int WF, typename TI, typename TO, int VEC, int NB, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void cook_torrance_batch_kernel(const KArgs a) {
+    using R = typename RealOf<VEC, true>::type;
+    constexpr int NG = RealOf<VEC, true>::N;
+    const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
+    const int ty = (int)a.div_tx.div(tile);
+    const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);
+    if (!p.valid) return;
+    Texels<VEC> t[NB];
+    LanePos pj[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        pj[j] = p; pj[j].b = p.b * NB + j;
+        load_texels<WF, TI, VEC, NT>(a, a.has_normal != 0, pj[j], t[j]);
+    }
+    const Vec3 V = {a.V[0], a.V[1], a.V[2]};
+    PixelTermsT<R> pt[NB][NG];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        decode_texels<WF, VEC, true>(a, t[j]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) material_terms<WF, VEC, R>(t[j], g, V, pt[j][g]);
+    }
+    float ys = 0.0f;
+    R xs[NG];
+    if (LIGHT == PBR_LIGHT_POINT) {
+        ys = linspace_at(a.y0, a.y1, a.ystep, a.H_total, p.y + a.y_offset);
+        x_grid<R, NG, VEC>(a, p.x, xs);
+    } else {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xs[g] = splat<R>(0.0f);
+    }
+    R res[NB][3][NG];
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) res[j][c][g] = splat<R>(0.0f);
+    for (int l = 0; l < a.n_lights; ++l) {
+        const LightU &lu = a.lights[l];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[g], ys);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                R col[3];
+                shade_light(pt[j][g], lg, lu.inten, col);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) res[j][c][g] += col[c];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float o[VEC];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                R v = clamp01(res[j][c][g]);                                  // sum of per-light clamped terms, clamped
+                if (a.out_srgb) v = linear_to_srgb_unit(v);                     // :179-180
+                scatter(o, g, v);
+            }
+            Ld<TO, VEC>::template store<NT>(a.out, pj[j].b * a.o_bs + c * a.o_cs + p.pix, o);
+        }
+    }
 }
 
 }  // namespace pbr

@@ -25,6 +25,7 @@ extern int g_f16_vec;              // pixels per lane for fp16 maps with one lig
 // 4096^2, 33.3 vs 34.0 us on 2048^2, 249.8 vs 254.1 us on 8 x 2048^2 directional), the fp16 and multi-light
 // kernels with no cap.  -1 = that rule; >= 0 = this many bytes for every launch (A/B runs).
 extern int g_lds_bytes;
+extern int g_batch_inner;          // materials per lane of the several-lights kernels: -1 = rule (4 | 2 | off), 0 = off, 2 | 4 = forced
 extern int g_bwd_vec;              // pixels per lane of the backward kernels: 4, or 2 (A/B knob)
 extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
 constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
@@ -175,6 +176,17 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
             for (int c = 0; c < 3; ++c) u.l[c] = d->lights[i][c];
         }
     }
+}
+
+using KernelFn = void (*)(const KArgs);
+KernelFn pick_batch_kernel(const pbr_render_desc *d, int nb, bool nt);      // ct_batch.hip
+
+// Materials per lane for this launch, or 0 for the one-material kernels.  Several lights make the launch VALU-bound, and
+// the light geometry is shared by every material at a pixel position: groups of 4 (or 2) consecutive materials per lane.
+inline int batch_group(const pbr_render_desc *d, int vec) {
+    if (g_batch_inner == 0 || d->n_lights < 2 || vec < 4 || is_tiled(d)) return 0;
+    if (g_batch_inner == 2 || g_batch_inner == 4) return d->batch % g_batch_inner == 0 ? g_batch_inner : 0;
+    return d->batch % 4 == 0 ? 4 : (d->batch % 2 == 0 ? 2 : 0);
 }
 
 }  // namespace pbr

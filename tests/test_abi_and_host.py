@@ -70,7 +70,11 @@ def test_descriptor_contents_and_kernel_selection():
     d2 = _desc(light_type="Directional", light=[[0, 0, 1], [1, 0, 1]], light_intensity=[[1, 1, 1], [0.5, 0.5, 0.5]],
                convert_to_diffuse_specular=True)
     assert d2.light_type == N.LIGHT_DIRECTIONAL and d2.n_lights == 2 and d2.workflow == N.WORKFLOW_CONVERTED
+    # several lights, an even batch: the batch-inner kernel (2 materials per lane share the light geometry) ...
+    assert lib.pbr_kernel_name(ctypes.byref(d2)) == b"ctb_directional_converted_f32_f32_v2_b2"
+    lib.pbr_set_tuning(N.TUNE_BATCH_INNER, 0)                     # ... unless switched off: one material per lane
     assert lib.pbr_kernel_name(ctypes.byref(d2)) == b"ct_directional_converted_f32_f32_v4_multi"
+    lib.pbr_set_tuning(N.TUNE_BATCH_INNER, -1)
     assert [d2.lights[1][c] for c in range(3)] == [1.0, 0.0, 1.0] and d2.intensities[1][0] == 0.5
     # one intensity for several lights is broadcast; mismatched counts are rejected
     assert _desc(light=[[0, 0, 1], [1, 0, 1]], light_intensity=[1, 1, 1]).n_lights == 2

@@ -13,14 +13,12 @@
 // With antialias off (or when up-scaling) this reduces to the ordinary 2-tap bilinear rule with
 // edge clamping, so one kernel covers both settings.
 //
-// Schedule: ONE kernel, the separable passes fused through LDS.  A workgroup owns a TOH x 64 tile of the output:
-// it runs the width pass for the input rows its tile needs (each lane walks its <= 2*scale+2 taps along the
-// contiguous axis; neighbouring lanes share taps, so the L1 absorbs the overlap and every input texel leaves HBM
-// about once), keeps that fp32 intermediate in LDS -- here there IS reuse: every intermediate value feeds
-// ~2*support output rows -- and runs the height pass out of LDS (lanes consecutive in x: conflict-free column
-// reads, coalesced stores).  Against the two-pass form (kept below for extreme down-scales whose row window
-// does not fit) this saves the write and the re-read of the width-pass result: 4096^2 -> 2048^2, 3 planes,
-// antialiased: 450 MB of HBM traffic -> 252 MB.  Same arithmetic in the same order, so both forms are bit-identical.
+// Schedule: ONE kernel (resize_tile_kernel below), the separable passes fused through LDS: a workgroup stages the raw
+// input window of its output tile with 16-byte loads, runs the width pass LDS -> LDS and the height pass LDS -> output,
+// with the tap weights normalised once per tile (as ATen does) instead of per output.  Against the two-pass form (kept
+// for extreme down-scales whose windows do not fit) this saves the write and the re-read of the width-pass result:
+// 4096^2 -> 2048^2, 3 planes, antialiased: 450 MB of HBM traffic -> 252 MB.  Measured (profiles/, rocprofv3 SQ / LDS
+// counters): the kernel is bound by the LDS pipe (65 % busy; VALUs 40 %), not by HBM (2.8 TB/s of algorithmic bytes).
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -90,72 +88,179 @@ __global__ __launch_bounds__(256) void resize_height_kernel(const float *__restr
     }
 }
 
-// Fused form.  Tile = toh x 64 outputs; LDS holds mid[in_rows][64], in_rows <= max_rows rows of the width pass.
 constexpr int kTileW = 64;
-__global__ __launch_bounds__(256) void resize_fused_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                           int h_out, int w_out, int w_in, int toh, int tiles_x, int tiles_y,
-                                                           AxisFilter fw, AxisFilter fh) {
-    extern __shared__ float mid[];                       // [in_rows][kTileW]
-    const int tile = blockIdx.x;
-    const int plane = tile / (tiles_x * tiles_y);
-    const int t2 = tile - plane * tiles_x * tiles_y;
-    const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
-    const int ox0 = tx * kTileW, oy0 = ty * toh;
-    const int ow = min(kTileW, w_out - ox0), oh = min(toh, h_out - oy0);
-    int ylo, n0, ylast, nlast; float c0;
+
+// Tile form (the default).  A workgroup owns a toh x 64 tile of the output and works in three phases through LDS:
+//   0. tap tables: per output column / row of the tile its first tap, and its taps' weights NORMALISED once (ATen
+//      normalises the weights, then accumulates sum w_j x_j: _compute_indices_weights_aa) -- the inner loops below are
+//      pure fma streams, no weight arithmetic, no division;
+//   1. the raw input window of the tile, [in_rows][in_cols], fetched with 16-byte loads, all of a lane's loads in
+//      flight together (the previous form walked taps with dword loads, two rows in flight per wave: 2.8 TB/s and
+//      VALU-bound on address arithmetic);
+//   2. width pass raw -> mid[in_rows][64];   3. height pass mid -> output, coalesced stores.
+// Both passes read LDS with lanes consecutive in x and touch exactly the taps ATen touches (a tap outside a window is never
+// read: 0 x inf would be NaN).  LDS: wx[K][64] wy[K][toh] | xo[64] xn[64] yo[toh] yn[toh] | mid[rows][64] raw[rows][pitch].
+struct TileGeom { int toh, tiles_x, tiles_y, kx, ky, rows_max, pitch, vec_ok, vec_out; };
+
+// The two tap loops, unrolled to a compile-time bound K >= the largest tap count in the tile (taps past a lane's own count
+// are loaded -- from LDS the kernel owns -- but replaced by 0 before use).
+template <int K>
+__device__ __forceinline__ void width_pass(const float *raw, float *mid, const float *wx, const int *xo, const int *xn, int pitch,
+                                           int in_rows, int tid) {
+    const int i = tid & (kTileW - 1), off = xo[i], n = xn[i];
+    float w[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) w[j] = j < n ? wx[j * kTileW + i] : 0.0f;
+    for (int r = tid / kTileW; r < in_rows; r += 2 * (256 / kTileW)) {       // a lane keeps its column; two rows per step for ILP
+        const int r2 = r + 256 / kTileW;
+        const bool second = r2 < in_rows;
+        const float *q0 = raw + r * pitch + off, *q1 = raw + (second ? r2 : r) * pitch + off;
+        float v0[K], v1[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) { v0[j] = j < n ? q0[j] : 0.0f; v1[j] = j < n ? q1[j] : 0.0f; }
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) { a0 = fmaf(w[j], v0[j], a0); a1 = fmaf(w[j], v1[j], a1); }
+        mid[r * kTileW + i] = a0;
+        if (second) mid[r2 * kTileW + i] = a1;
+    }
+}
+
+// Four consecutive output columns per lane: one ds_read_b128 per tap, one 16-byte store per output row (when the output
+// row pitch and the tile allow; else column by column).
+template <int K>
+__device__ __forceinline__ void height_pass(const float *mid, float *dp, const float *wy, const int *yo, const int *yn, int toh, int oh,
+                                            int ow, int oy0, int ox0, int w_out, bool vec_out, int tid) {
+    if (vec_out) {
+        for (int e = tid; e < oh * (kTileW / 4); e += 256) {
+            const int o = e / (kTileW / 4), i = (e - o * (kTileW / 4)) * 4;
+            if (i >= ow) continue;
+            const float *q = mid + yo[o] * kTileW + i;
+            const int n = yn[o];
+            float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const float4 v = *reinterpret_cast<const float4 *>(q + j * kTileW);
+                const float w = j < n ? wy[j * toh + o] : 0.0f;
+                acc.x = fmaf(w, j < n ? v.x : 0.0f, acc.x); acc.y = fmaf(w, j < n ? v.y : 0.0f, acc.y);
+                acc.z = fmaf(w, j < n ? v.z : 0.0f, acc.z); acc.w = fmaf(w, j < n ? v.w : 0.0f, acc.w);
+            }
+            *reinterpret_cast<float4 *>(dp + (int64_t)(oy0 + o) * w_out + ox0 + i) = acc;     // ow % 4 == 0 here
+        }
+        return;
+    }
+    for (int e = tid; e < oh * kTileW; e += 256) {
+        const int o = e / kTileW, i = e - o * kTileW;
+        if (i >= ow) continue;
+        const float *q = mid + yo[o] * kTileW + i;
+        const int n = yn[o];
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc = fmaf(j < n ? wy[j * toh + o] : 0.0f, j < n ? q[j * kTileW] : 0.0f, acc);
+        dp[(int64_t)(oy0 + o) * w_out + ox0 + i] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_tile_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_out,
+                                                          int w_out, int w_in, TileGeom tg, AxisFilter fw, AxisFilter fh) {
+    extern __shared__ float lds[];
+    float *wx = lds, *wy = wx + tg.kx * kTileW;
+    int *xo = reinterpret_cast<int *>(wy + tg.ky * tg.toh), *xn = xo + kTileW, *yo = xn + kTileW, *yn = yo + tg.toh;
+    // mid before raw, 16 floats of slack behind raw: the unrolled tap loops may LOAD (never use) up to 16 taps past a window
+    float *mid = reinterpret_cast<float *>(yn + tg.toh), *raw = mid + tg.rows_max * kTileW;
+    __shared__ int tap_max[2];
+    const int tile = blockIdx.x, per_plane = tg.tiles_x * tg.tiles_y;
+    const int plane = tile / per_plane, t2 = tile - plane * per_plane;
+    const int ty = t2 / tg.tiles_x, tx = t2 - ty * tg.tiles_x;
+    const int ox0 = tx * kTileW, oy0 = ty * tg.toh;
+    const int ow = min(kTileW, w_out - ox0), oh = min(tg.toh, h_out - oy0);
+    const int tid = threadIdx.x;
+    // window of the tile (tap windows are monotone in the output index)
+    int xlo, ylo, n0, xl, nl, yl, nyl; float c0;
+    tap_window(fw, ox0, xlo, n0, c0);
+    tap_window(fw, ox0 + ow - 1, xl, nl, c0);
     tap_window(fh, oy0, ylo, n0, c0);
-    tap_window(fh, oy0 + oh - 1, ylast, nlast, c0);
-    const int in_rows = ylast + nlast - ylo;             // windows are monotone in the output row
-    const float *sp = src + (int64_t)plane * fh.n_in * w_in;
-    // width pass for rows [ylo, ylo + in_rows), output columns [ox0, ox0 + ow).  256 lanes = 4 rows of 64 columns, so a
-    // lane's column -- hence its tap window and weight sum -- is the same in every iteration: computed once.
-    {
-        const int i = threadIdx.x & (kTileW - 1);
-        int xmin = 0, xsize = 0; float center = 0.0f, wsum = 0.0f;
-        if (i < ow) {
-            tap_window(fw, ox0 + i, xmin, xsize, center);
-            for (int j = 0; j < xsize; ++j) wsum += tap_weight(fw, j, xmin, center);
+    tap_window(fh, oy0 + oh - 1, yl, nyl, c0);
+    const int xbase = tg.vec_ok ? (xlo & ~3) : xlo;
+    const int in_cols = xl + nl - xbase, in_rows = yl + nyl - ylo;
+    // ---- phase 0: tap tables (wave 0: columns, wave 1: rows) and the largest tap count per axis
+    if (tid < kTileW) {
+        int xmin = 0, n = 0; float center = 0.0f, wsum = 0.0f;
+        if (tid < ow) {
+            tap_window(fw, ox0 + tid, xmin, n, center);
+            for (int j = 0; j < n; ++j) wsum += tap_weight(fw, j, xmin, center);
         }
-        if (xsize <= 8) {         // scale <= 3: all taps of a row are loaded before the first is used (8 loads in flight)
-            float w[8];
+        const float inv = wsum != 0.0f ? 1.0f / wsum : 0.0f;
+        for (int j = 0; j < tg.kx; ++j) wx[j * kTileW + tid] = j < n ? tap_weight(fw, j, xmin, center) * inv : 0.0f;
+        xo[tid] = tid < ow ? xmin - xbase : 0;
+        xn[tid] = n;
+        int m = n;
+        for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+        if (tid == 0) tap_max[0] = m;
+    } else if (tid < 2 * kTileW) {
+        const int o = tid - kTileW;
+        int ymin = 0, n = 0; float center = 0.0f, wsum = 0.0f;
+        if (o < oh) {
+            tap_window(fh, oy0 + o, ymin, n, center);
+            for (int j = 0; j < n; ++j) wsum += tap_weight(fh, j, ymin, center);
+        }
+        const float inv = wsum != 0.0f ? 1.0f / wsum : 0.0f;
+        if (o < tg.toh) {
+            for (int j = 0; j < tg.ky; ++j) wy[j * tg.toh + o] = j < n ? tap_weight(fh, j, ymin, center) * inv : 0.0f;
+            yo[o] = o < oh ? ymin - ylo : 0;
+            yn[o] = n;
+        }
+        int m = n;
+        for (int k = 32; k > 0; k >>= 1) m = max(m, __shfl_xor(m, k, 64));
+        if (o == 0) tap_max[1] = m;
+    }
+    // ---- phase 1: raw window -> LDS.  A wave takes a row at a time, lanes along x: no index arithmetic beyond an add
+    const float *sp = src + ((int64_t)plane * fh.n_in + ylo) * w_in + xbase;
+    if (tg.vec_ok) {
+        // lanes along x (a power of two >= the 16-byte pieces of a row), the rest of the workgroup along rows; four rows of
+        // loads in flight per lane before the first LDS store
+        const int c4n = (in_cols + 3) >> 2;
+        int lg = 2;
+        while ((1 << lg) < c4n && lg < 8) ++lg;
+        const int c4 = tid & ((1 << lg) - 1), rstep = 256 >> lg;
+        const bool inside = c4 < c4n && xbase + 4 * c4 < w_in;                             // w_in % 4 == 0
+        for (int cc = c4; cc < c4n; cc += 256) {                                           // one pass unless a row has > 256 pieces
+            for (int r0 = tid >> lg; r0 < in_rows; r0 += 4 * rstep) {
+                float4 v[4];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = j < xsize ? tap_weight(fw, j, xmin, center) : 0.0f;
-            for (int r = threadIdx.x / kTileW; r < in_rows && i < ow; r += 256 / kTileW) {
-                const float *p = sp + (int64_t)(ylo + r) * w_in + xmin;
-                float v[8];
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u * rstep;
+                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (inside && r < in_rows) v[u] = *reinterpret_cast<const float4 *>(sp + (int64_t)r * w_in + 4 * cc);
+                }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = j < xsize ? p[j] : 0.0f;
-                float acc = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc = j < xsize ? fmaf(w[j], v[j], acc) : acc;
-                mid[r * kTileW + i] = wsum != 0.0f ? acc / wsum : 0.0f;
-            }
-        } else {
-            for (int r = threadIdx.x / kTileW; r < in_rows && i < ow; r += 256 / kTileW) {
-                const float *p = sp + (int64_t)(ylo + r) * w_in + xmin;
-                float acc = 0.0f;
-                for (int j = 0; j < xsize; ++j) acc = fmaf(tap_weight(fw, j, xmin, center), p[j], acc);
-                mid[r * kTileW + i] = wsum != 0.0f ? acc / wsum : 0.0f;
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u * rstep;
+                    if (r < in_rows) *reinterpret_cast<float4 *>(raw + r * tg.pitch + 4 * cc) = v[u];
+                }
             }
         }
+    } else {
+        for (int c = tid & 63; c < in_cols; c += 64)
+            for (int r = tid >> 6; r < in_rows; r += 4) raw[r * tg.pitch + c] = sp[(int64_t)r * w_in + c];
     }
     __syncthreads();
-    // height pass out of LDS
+    const int kx = tap_max[0], ky = tap_max[1];
+    // ---- phase 2: width pass raw -> mid
+    if (kx <= 4) width_pass<4>(raw, mid, wx, xo, xn, tg.pitch, in_rows, tid);
+    else if (kx <= 6) width_pass<6>(raw, mid, wx, xo, xn, tg.pitch, in_rows, tid);
+    else if (kx <= 8) width_pass<8>(raw, mid, wx, xo, xn, tg.pitch, in_rows, tid);
+    else if (kx <= 12) width_pass<12>(raw, mid, wx, xo, xn, tg.pitch, in_rows, tid);
+    else width_pass<16>(raw, mid, wx, xo, xn, tg.pitch, in_rows, tid);
+    __syncthreads();
+    // ---- phase 3: height pass mid -> output
     float *dp = dst + (int64_t)plane * h_out * w_out;
-    for (int e = threadIdx.x; e < oh * kTileW; e += blockDim.x) {
-        const int orow = e / kTileW, i = e - orow * kTileW;
-        if (i >= ow) continue;
-        int ymin, ysize; float center;
-        tap_window(fh, oy0 + orow, ymin, ysize, center);
-        const float *q = mid + (ymin - ylo) * kTileW + i;
-        float acc = 0.0f, wsum = 0.0f;
-        for (int j = 0; j < ysize; ++j) {
-            const float w = tap_weight(fh, j, ymin, center);
-            acc = fmaf(w, q[j * kTileW], acc);
-            wsum += w;
-        }
-        dp[(int64_t)(oy0 + orow) * w_out + ox0 + i] = wsum != 0.0f ? acc / wsum : 0.0f;
-    }
+    const bool vec_out = tg.vec_out && (ow & 3) == 0;
+    if (ky <= 4) height_pass<4>(mid, dp, wy, yo, yn, tg.toh, oh, ow, oy0, ox0, w_out, vec_out, tid);
+    else if (ky <= 6) height_pass<6>(mid, dp, wy, yo, yn, tg.toh, oh, ow, oy0, ox0, w_out, vec_out, tid);
+    else if (ky <= 8) height_pass<8>(mid, dp, wy, yo, yn, tg.toh, oh, ow, oy0, ox0, w_out, vec_out, tid);
+    else if (ky <= 12) height_pass<12>(mid, dp, wy, yo, yn, tg.toh, oh, ow, oy0, ox0, w_out, vec_out, tid);
+    else height_pass<16>(mid, dp, wy, yo, yn, tg.toh, oh, ow, oy0, ox0, w_out, vec_out, tid);
 }
 
 static AxisFilter make_filter(int n_in, int n_out, bool antialias) {
@@ -189,21 +294,32 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *tmp = static_cast<float *>(workspace);
     const AxisFilter fw = make_filter(w_in, w_out, antialias != 0), fh = make_filter(h_in, h_out, antialias != 0);
-    // fused form when the row window of a tile fits LDS: rows needed by toh output rows <= toh*scale + 2*support + 2
-    constexpr int kMaxRows = 160;                                                   // 160 x 64 x 4 B = 40 KiB of LDS
-    int toh = 0;
-    for (int cand : {32, 16, 8, 4}) {
-        if ((int)(cand * fh.scale + 2.0f * fh.support) + 3 <= kMaxRows) { toh = cand; break; }
+    // tile form: the raw window of a toh x 64 output tile, its width pass and the tap tables in at most 40 KiB of LDS (4
+    // workgroups per CU; 64 KiB if no tile height fits that), for up to 16 taps per axis (scale <= 6.5)
+    {
+        const int kx = (int)(2.0f * fw.support) + 3, ky = (int)(2.0f * fh.support) + 3;      // taps per output: xsize <= 2 support + 2
+        const bool vec_ok = w_in % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
+        const bool vec_out = w_out % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+        const bool fits = kx <= 16 && ky <= 16;
+        for (size_t budget : {(size_t)40 * 1024, (size_t)64 * 1024}) {
+            for (int toh : {32, 16, 8, 4}) {
+                if (!fits) break;
+                const int rows_max = (int)(toh * fh.scale + 2.0f * fh.support) + 4;
+                const int cols_max = (int)(kTileW * fw.scale + 2.0f * fw.support) + 4 + 3;   // + 3: window start aligned down to 16 bytes
+                const int pitch = ((cols_max + 3) & ~3) + 4;                                  // + 4 floats: rows land on different banks
+                const size_t lds = sizeof(float) * ((size_t)kx * kTileW + (size_t)ky * toh + 2 * (kTileW + toh) + (size_t)rows_max * pitch +
+                                                    (size_t)rows_max * kTileW + 16);
+                const int64_t tx = (w_out + kTileW - 1) / kTileW, tyy = (h_out + toh - 1) / toh;
+                if (lds > budget || planes * tx * tyy > INT32_MAX) continue;
+                const TileGeom tg = {toh, (int)tx, (int)tyy, kx, ky, rows_max, pitch, vec_ok ? 1 : 0, vec_out ? 1 : 0};
+                hipLaunchKernelGGL(resize_tile_kernel, dim3((unsigned)(planes * tx * tyy)), dim3(256), lds, s,
+                                   static_cast<const float *>(src), static_cast<float *>(dst), (int)h_out, (int)w_out, (int)w_in, tg, fw, fh);
+                const hipError_t e = hipGetLastError();
+                return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+            }
+        }
     }
-    const int64_t tiles_x = (w_out + kTileW - 1) / kTileW, tiles_y = toh ? (h_out + toh - 1) / toh : 0;
-    if (toh && planes * tiles_x * tiles_y <= INT32_MAX) {
-        const size_t lds = (size_t)kMaxRows * kTileW * sizeof(float);
-        hipLaunchKernelGGL(resize_fused_kernel, dim3((unsigned)(planes * tiles_x * tiles_y)), dim3(256), lds, s,
-                           static_cast<const float *>(src), static_cast<float *>(dst), (int)h_out, (int)w_out, (int)w_in, toh,
-                           (int)tiles_x, (int)tiles_y, fw, fh);
-        const hipError_t e = hipGetLastError();
-        return e == hipSuccess ? PBR_OK : 1000 + (int)e;
-    }
+    // windows too large for the tile form (more than 16 taps per axis, i.e. down-scales beyond ~6.5x): two passes through `workspace`
     hipLaunchKernelGGL(resize_width_kernel, dim3(stream_grid(planes * h_in * w_out)), dim3(256), 0, s,
                        static_cast<const float *>(src), tmp, planes * h_in, (int)w_out, fw);
     hipLaunchKernelGGL(resize_height_kernel, dim3(stream_grid(planes * h_out * w_out)), dim3(256), 0, s,

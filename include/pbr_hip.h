@@ -248,6 +248,11 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
  */
 int pbr_blend_maps(const void *map1, const void *map2, const void *mask, void *out, int32_t channels,
                    int64_t pixels, int is_normal, void *stream);
+/* Gradient of pbr_blend_maps (autograd through functional.py:103-110 / :119-145): g_map1, g_map2 [channels][pixels] and
+ * g_mask [pixels], any of them NULL = not wanted; accumulate_mask: g_mask += (a material's maps share one mask). */
+int pbr_blend_maps_backward(const void *map1, const void *map2, const void *mask, const void *grad_out, void *g_map1,
+                            void *g_map2, void *g_mask, int32_t channels, int64_t pixels, int is_normal,
+                            int accumulate_mask, void *stream);
 int pbr_blend_sigmoid_mask(const void *prop1, const void *prop2, void *mask, int64_t n, float shift,
                            float blend_width, void *stream);
 int pbr_blend_gradient_mask(void *mask, int32_t height, int32_t width, int vertical, void *stream);

@@ -29,7 +29,7 @@ EXPORTS = (
     "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
     "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask", "pbr_cook_torrance_autotune",
     "pbr_cook_torrance_blend", "pbr_fold_gradient", "pbr_decode_normal_backward",
-    "pbr_blend_normal_sign", "pbr_param_grad_workspace_bytes", "pbr_cook_torrance_backward_params",
+    "pbr_blend_normal_sign", "pbr_blend_maps_backward", "pbr_param_grad_workspace_bytes", "pbr_cook_torrance_backward_params",
 )
 
 
@@ -132,6 +132,8 @@ def lib():
     L.pbr_resize_bilinear.argtypes = [vp, vp, i64, i32, i32, i32, i32, ctypes.c_int, vp, vp]
     L.pbr_resize_bilinear.restype = ctypes.c_int
     L.pbr_blend_maps.argtypes = [vp, vp, vp, vp, i32, i64, ctypes.c_int, vp]
+    L.pbr_blend_maps_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, ctypes.c_int, ctypes.c_int, vp]
+    L.pbr_blend_maps_backward.restype = ctypes.c_int
     L.pbr_blend_sigmoid_mask.argtypes = [vp, vp, vp, i64, ctypes.c_float, ctypes.c_float, vp]
     L.pbr_blend_gradient_mask.argtypes = [vp, i32, i32, ctypes.c_int, vp]
     for name in ("pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask"):

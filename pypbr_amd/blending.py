@@ -19,6 +19,14 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def _check_device_f32(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("%s needs tensors on a ROCm device; there is no CPU path" % what)
+    if t.dtype != torch.float32:
+        raise TypeError("%s supports float32 maps, got %s" % (what, t.dtype))
+    return t.contiguous()
+
+
 def _check_f32(t, what):
     F_.refuse_grad(t, what)
     if not t.is_cuda:
@@ -28,10 +36,45 @@ def _check_f32(t, what):
     return t.contiguous()
 
 
+def _blend_maps_raw(a, b, m, is_normal):
+    out = torch.empty_like(a)
+    with torch.cuda.device(a.device):
+        _native.check(_native.lib().pbr_blend_maps(a.data_ptr(), b.data_ptr(), m.data_ptr(), out.data_ptr(), a.shape[0],
+                                                   a.shape[1] * a.shape[2], int(bool(is_normal)), _stream(a)))
+    return out
+
+
+class _BlendMapsFn(torch.autograd.Function):
+    """blend_maps with a gradient (pbr_blend_maps_backward): the reference's blend is plain torch arithmetic
+    (functional.py:103-110, :119-145), so a rendering loss on a blended material reaches both materials and the mask."""
+
+    @staticmethod
+    def forward(ctx, a, b, m, is_normal):
+        ctx.save_for_backward(a, b, m)
+        ctx.is_normal = bool(is_normal)
+        return _blend_maps_raw(a, b, m, is_normal)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        a, b, m = ctx.saved_tensors
+        g = grad_out.to(torch.float32).contiguous()
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gb = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        gm = torch.empty_like(m) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(a.device):
+            _native.check(_native.lib().pbr_blend_maps_backward(
+                a.data_ptr(), b.data_ptr(), m.data_ptr(), g.data_ptr(), None if ga is None else ga.data_ptr(),
+                None if gb is None else gb.data_ptr(), None if gm is None else gm.data_ptr(), a.shape[0], a.shape[1] * a.shape[2],
+                int(ctx.is_normal), 0, _stream(a)))
+        return ga, gb, gm, None
+
+
 def blend_maps(map1: torch.Tensor, map2: torch.Tensor, mask: torch.Tensor, is_normal: bool = False) -> torch.Tensor:
     """mask * map1 + (1 - mask) * map2 for one (C,H,W) map and a (1,H,W) mask; `is_normal`:
-    normalise both, blend, re-normalise (functional.py:119-145)."""
-    a, b, m = _check_f32(map1, "blend_maps"), _check_f32(map2, "blend_maps"), _check_f32(mask, "blend_maps")
+    normalise both, blend, re-normalise (functional.py:119-145).  Differentiable (its own backward kernel)."""
+    wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (map1, map2, mask))
+    check = _check_device_f32 if wants_grad else _check_f32
+    a, b, m = check(map1, "blend_maps"), check(map2, "blend_maps"), check(mask, "blend_maps")
     if a.dim() == 3 and b.dim() == 3 and a.shape[0] != b.shape[0] and 1 in (a.shape[0], b.shape[0]) and a.shape[1:] == b.shape[1:]:
         # `mask * map1 + (1 - mask) * map2` broadcasts a 1-channel map against a 3-channel one upstream (e.g. the
         # 3-channel metallic map to_basecolor_metallic_material returns, diffuse.py:147, against a 1-channel one)
@@ -39,11 +82,9 @@ def blend_maps(map1: torch.Tensor, map2: torch.Tensor, mask: torch.Tensor, is_no
         a, b = a.expand(c, -1, -1).contiguous(), b.expand(c, -1, -1).contiguous()
     if a.shape != b.shape or a.dim() != 3 or m.numel() != a.shape[1] * a.shape[2]:
         raise ValueError("maps %s / %s and mask %s do not match" % (tuple(a.shape), tuple(b.shape), tuple(m.shape)))
-    out = torch.empty_like(a)
-    with torch.cuda.device(a.device):
-        _native.check(_native.lib().pbr_blend_maps(a.data_ptr(), b.data_ptr(), m.data_ptr(), out.data_ptr(), a.shape[0],
-                                                   a.shape[1] * a.shape[2], int(bool(is_normal)), _stream(a)))
-    return out
+    if wants_grad:
+        return _BlendMapsFn.apply(a, b, m.reshape(1, a.shape[1], a.shape[2]), bool(is_normal))
+    return _blend_maps_raw(a, b, m, is_normal)
 
 
 def sigmoid_mask(prop1: torch.Tensor, prop2: torch.Tensor, blend_width: float, shift: float = 0.0) -> torch.Tensor:

@@ -36,6 +36,50 @@ __global__ __launch_bounds__(256) void blend_kernel(const float *__restrict__ m1
     }
 }
 
+// Gradient of blend_kernel (what autograd derives from functional.py:103-110 / :119-145): g1, g2 [C][P] (NULL = not wanted),
+// gmask [P] (NULL = not wanted; `accumulate`: added to what is there -- the mask is shared by every map of a material).
+template <bool NORMAL>
+__global__ __launch_bounds__(256) void blend_backward_kernel(const float *__restrict__ m1, const float *__restrict__ m2,
+                                                             const float *__restrict__ mask, const float *__restrict__ gout,
+                                                             float *__restrict__ g1, float *__restrict__ g2, float *__restrict__ gmask,
+                                                             int channels, int64_t P, int accumulate) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
+        const float w = mask[p], iw = 1.0f - w;
+        float gw = 0.0f;
+        if (NORMAL) {
+            const Vec3 a = {m1[p], m1[P + p], m1[2 * P + p]}, b = {m2[p], m2[P + p], m2[2 * P + p]};
+            const Vec3 g = {gout[p], gout[P + p], gout[2 * P + p]};
+            const float ra = rsq(fmaxf(dot(a, a), 1e-24f)), rb = rsq(fmaxf(dot(b, b), 1e-24f));
+            const Vec3 ah = {a.x * ra, a.y * ra, a.z * ra}, bh = {b.x * rb, b.y * rb, b.z * rb};
+            const Vec3 c = {fmaf(w, ah.x, iw * bh.x), fmaf(w, ah.y, iw * bh.y), fmaf(w, ah.z, iw * bh.z)};
+            const float rc = rsq(fmaxf(dot(c, c), 1e-24f));
+            const Vec3 o = {c.x * rc, c.y * rc, c.z * rc};
+            const float og = dot(o, g);                                  // F.normalize: (g - o (o.g)) / |c|
+            const Vec3 gc = {(g.x - o.x * og) * rc, (g.y - o.y * og) * rc, (g.z - o.z * og) * rc};
+            gw = gc.x * (ah.x - bh.x) + gc.y * (ah.y - bh.y) + gc.z * (ah.z - bh.z);
+            if (g1) {
+                const Vec3 ga = {w * gc.x, w * gc.y, w * gc.z};
+                const float d = dot(ah, ga);
+                g1[p] = (ga.x - ah.x * d) * ra; g1[P + p] = (ga.y - ah.y * d) * ra; g1[2 * P + p] = (ga.z - ah.z * d) * ra;
+            }
+            if (g2) {
+                const Vec3 gb = {iw * gc.x, iw * gc.y, iw * gc.z};
+                const float d = dot(bh, gb);
+                g2[p] = (gb.x - bh.x * d) * rb; g2[P + p] = (gb.y - bh.y * d) * rb; g2[2 * P + p] = (gb.z - bh.z * d) * rb;
+            }
+        } else {
+            for (int ch = 0; ch < channels; ++ch) {
+                const float g = gout[ch * P + p];
+                if (g1) g1[ch * P + p] = w * g;
+                if (g2) g2[ch * P + p] = iw * g;
+                gw = fmaf(g, m1[ch * P + p] - m2[ch * P + p], gw);
+            }
+        }
+        if (gmask) gmask[p] = accumulate ? gmask[p] + gw : gw;
+    }
+}
+
 // torch.sigmoid((p1 + shift - p2) / (width + 1e-6))
 __global__ __launch_bounds__(256) void sigmoid_mask_kernel(const float *__restrict__ p1, const float *__restrict__ p2,
                                                            float *__restrict__ mask, int64_t n, float shift, float inv_width) {
@@ -103,6 +147,24 @@ int pbr_blend_gradient_mask(void *mask, int32_t height, int32_t width, int verti
     hipLaunchKernelGGL(gradient_mask_kernel, dim3(blend_grid((int64_t)height * width)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), static_cast<float *>(mask), (int)height, (int)width, vertical);
     return blend_status();
+}
+
+int pbr_blend_maps_backward(const void *map1, const void *map2, const void *mask, const void *grad_out, void *g_map1, void *g_map2,
+                            void *g_mask, int32_t channels, int64_t pixels, int is_normal, int accumulate_mask, void *stream) {
+    using namespace pbr;
+    if (!map1 || !map2 || !mask || !grad_out) return PBR_ERR_NULL_MAP;
+    if (channels < 1 || pixels < 1) return PBR_ERR_SHAPE;
+    if (is_normal && channels != 3) return PBR_ERR_CHANNELS;
+    const int64_t blocks = (pixels + 255) / 256;
+    const dim3 grid((unsigned)(blocks > 256 * 16 ? 256 * 16 : blocks));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float *a = static_cast<const float *>(map1), *b = static_cast<const float *>(map2), *k = static_cast<const float *>(mask);
+    const float *g = static_cast<const float *>(grad_out);
+    float *ga = static_cast<float *>(g_map1), *gb = static_cast<float *>(g_map2), *gk = static_cast<float *>(g_mask);
+    if (is_normal) hipLaunchKernelGGL(blend_backward_kernel<true>, grid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
+    else hipLaunchKernelGGL(blend_backward_kernel<false>, grid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PBR_OK : 1000 + (int)e;
 }
 
 }  // extern "C"

@@ -343,6 +343,10 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
     Returns [3,H,W] or [B,3,H,W] (float32 unless `out_dtype`), on the same device,
     enqueued on the current stream without synchronising.
     """
+    if kwargs.get("blend") is not None and torch.is_grad_enabled() and any(
+            isinstance(t, torch.Tensor) and t.requires_grad
+            for t in (albedo, normal, roughness, metallic, specular) + tuple(kwargs["blend"]) + tuple(kwargs.get(k) for k in _PARAM_KEYS)):
+        return _blend_then_render_with_grad(albedo, normal, roughness, metallic, specular, **kwargs)
     if USE_TORCH_OPS and _torch_op_can_take(albedo, kwargs):
         return _cook_torrance_via_torch_op(albedo, normal, roughness, metallic, specular, **kwargs)
     maps = (albedo, normal, roughness, metallic, specular)
@@ -353,6 +357,42 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
     plan = plan_cook_torrance(albedo, normal, roughness, metallic, specular, **kwargs)
     with torch.cuda.device(plan.device):
         return plan.launch()
+
+
+def _blend_then_render_with_grad(albedo, normal, roughness, metallic, specular, *, blend, **kwargs):
+    """The fused blend + render kernel is forward-only.  With a gradient attached the same computation runs unfused
+    through the differentiable pieces -- blend_maps (pbr_blend_maps + pbr_blend_maps_backward) for every map, the
+    re-decode of the blended normal (decode_normal and its backward: base.py:191-242 runs again on assignment), then the
+    evaluation with its backward kernel -- so a rendering loss on a blended material (example_blend.py:14-32 inside a
+    training loop) reaches both materials, the mask and the light / view parameters."""
+    from .blending import blend_maps
+    if kwargs.get("out") is not None or kwargs.get("tile", 1) not in (1, (1, 1)):
+        raise NotImplementedError("gradients through the fused blend need out=None and untiled maps")
+    a2, n2, r2, m2, s2, mask = blend
+    squeeze = albedo.dim() == 3
+
+    def batched(t):
+        return None if t is None else (t if t.dim() == 4 else t.unsqueeze(0))
+    first = [batched(t) for t in (albedo, normal, roughness, metallic, specular)]
+    second = [batched(t) for t in (a2, n2, r2, m2, s2)]
+    k = batched(mask if mask.dim() != 2 else mask.unsqueeze(0))
+    B = first[0].shape[0]
+
+    def pick(t, b):
+        return t[b if t.shape[0] > 1 else 0]
+    outs = [[], [], [], [], []]
+    for b in range(B):
+        for i, (x, y) in enumerate(zip(first, second)):
+            if x is None or y is None:
+                outs[i].append(None)
+                continue
+            v = blend_maps(pick(x, b), pick(y, b), pick(k, b), is_normal=(i == 1))
+            outs[i].append(decode_normal(v) if i == 1 else v)
+    maps = [None if col[0] is None else torch.stack(col) for col in outs]
+    if maps[3] is not None:
+        maps[4] = None
+    out = cook_torrance(*maps, **kwargs)
+    return out[0] if squeeze else out
 
 
 USE_TORCH_OPS = True       # tests flip this to compare the two bindings of the same C ABI

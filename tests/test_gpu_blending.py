@@ -150,8 +150,12 @@ def test_fused_blend_flat_normals_follow_the_redecode_quirk():
     for b in range(2):
         one = F.cook_torrance(a[b], n[b], r[b], m[b], blend=(a.flip(0)[b], n[b], r.flip(0)[b], m.flip(0)[b], None, mask), **kw)
         assert torch.equal(fused[b], one)
-    with pytest.raises(NotImplementedError):
-        F.cook_torrance(a.requires_grad_(True), n, r, m, blend=(a.detach(), n, r, m, None, mask), **kw)
+    # with a gradient attached the same call runs the differentiable (unfused) pieces and gives the same image
+    leaf = a.clone().requires_grad_(True)
+    with_grad = F.cook_torrance(leaf, n, r, m, blend=(a.flip(0), n, r.flip(0), m.flip(0), None, mask), **kw)
+    assert with_grad.requires_grad and (with_grad.detach() - fused).abs().max().item() <= 2e-6
+    with_grad.sum().backward()
+    assert leaf.grad is not None and bool(torch.isfinite(leaf.grad).all()) and float(leaf.grad.abs().sum()) > 0
 
 
 def test_fused_blend_composes_with_fused_tile_and_several_lights():
@@ -207,3 +211,75 @@ def test_fused_blend_guard_bands():
         torch.cuda.synchronize()
         assert bool(torch.isfinite(got).all()) and (got - ref).abs().max().item() <= 2e-6, (trial, B, h, w)
         assert bool((obuf[:G] == -7.0).all()) and bool((obuf[-G:] == -7.0).all()), (trial, B, h, w)
+
+
+def test_blend_maps_gradients_against_oracle_autograd():
+    """pbr_blend_maps_backward: the reference's blend is plain torch arithmetic (functional.py:103-110, :119-145), so its
+    autograd reaches both maps and the mask.  Ground truth: float64 autograd through oracle/blend_oracle.py."""
+    import blend_oracle as BO
+    from pypbr_amd.blending import blend_maps
+    g = torch.Generator().manual_seed(31)
+    H, W = 24, 40
+    for C, normal in ((3, False), (1, False), (3, True)):
+        a, b = torch.rand(C, H, W, generator=g) - (0.5 if normal else 0), torch.rand(C, H, W, generator=g) - (0.5 if normal else 0)
+        m, wt = torch.rand(1, H, W, generator=g), torch.rand(C, H, W, generator=g) - 0.4
+        ref_leaves = [t.double().requires_grad_(True) for t in (a, b, m)]
+        ref = (BO.blend_normals if normal else BO.blend_maps)(*ref_leaves)
+        (ref * wt.double()).sum().backward()
+        leaves = [t.clone().cuda().requires_grad_(True) for t in (a, b, m)]
+        out = blend_maps(*leaves, is_normal=normal)
+        assert out.requires_grad and (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 2e-6
+        (out * wt.cuda()).sum().backward()
+        for name, x, y in zip(("map1", "map2", "mask"), leaves, ref_leaves):
+            err = (x.grad.cpu().double() - y.grad).abs()
+            assert x.grad.shape == x.shape and (err <= 2e-5 * (1 + y.grad.abs())).all(), (C, normal, name, float(err.max()))
+    # only the mask wants a gradient (a learned blend mask): no map gradient buffers
+    a, b = torch.rand(3, H, W, generator=g).cuda(), torch.rand(3, H, W, generator=g).cuda()
+    m = torch.rand(1, H, W, generator=g).cuda().requires_grad_(True)
+    blend_maps(a, b, m).sum().backward()
+    assert (m.grad - (a - b).sum(dim=0, keepdim=True)).abs().max().item() <= 1e-5
+
+
+def test_rendering_loss_through_a_blend_reaches_both_materials_and_the_mask():
+    """examples/example_blend.py:14-32 inside a training loop: F.cook_torrance(blend=...) with gradients attached runs the
+    differentiable pieces (blend, re-decode of the blended normal, evaluation) and matches float64 autograd through the
+    oracles; without gradients the same call is the fused kernel, and both give the same image."""
+    import blend_oracle as BO
+    import torch_oracle as O
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(41)
+    H, W = 24, 48
+
+    def material():
+        n = torch.cat([(torch.rand(2, H, W, generator=g) - 0.5), torch.ones(1, H, W)], 0)
+        return {"albedo": torch.rand(3, H, W, generator=g), "normal": n / n.norm(dim=0, keepdim=True),
+                "roughness": torch.rand(1, H, W, generator=g) * 0.7 + 0.3, "metallic": torch.rand(1, H, W, generator=g)}
+    m1, m2 = material(), material()
+    mask, wt = torch.rand(1, H, W, generator=g), torch.rand(3, H, W, generator=g) - 0.4
+    view, light, inten = torch.tensor([0.0, 0.1, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 0.9, 0.8])
+    # float64 ground truth
+    r1 = {k: v.double().requires_grad_(True) for k, v in m1.items()}
+    r2 = {k: v.double().requires_grad_(True) for k, v in m2.items()}
+    rm = mask.double().requires_grad_(True)
+    bl = BO.blend_materials(r1, r2, rm)
+    ref = O.cook_torrance(bl["albedo"], bl["normal"], bl["roughness"], bl["metallic"], None, view=view.double(), light=light.double(),
+                          intensity=inten.double(), light_type="point", light_size=1.0)
+    (ref * wt.double()).sum().backward()
+    d1 = {k: v.clone().cuda().requires_grad_(True) for k, v in m1.items()}
+    d2 = {k: v.clone().cuda().requires_grad_(True) for k, v in m2.items()}
+    dm = mask.clone().cuda().requires_grad_(True)
+    kw = dict(view_dir=view, light=light, light_intensity=inten, light_type="point", light_size=1.0)
+    out = F.cook_torrance(d1["albedo"], d1["normal"], d1["roughness"], d1["metallic"],
+                          blend=(d2["albedo"], d2["normal"], d2["roughness"], d2["metallic"], None, dm), **kw)
+    assert out.requires_grad and (out.detach().cpu() - ref.detach().float()).abs().max().item() <= 1e-5
+    (out * wt.cuda()).sum().backward()
+    for name in m1:
+        for got, want in ((d1[name], r1[name]), (d2[name], r2[name])):
+            err = (got.grad.cpu().double() - want.grad).abs()
+            assert (err <= 2e-5 * (1 + want.grad.abs())).all(), (name, float(err.max()))
+    err = (dm.grad.cpu().double() - rm.grad).abs()
+    assert (err <= 2e-5 * (1 + rm.grad.abs())).all(), float(err.max())
+    with torch.no_grad():
+        fused = F.cook_torrance(d1["albedo"], d1["normal"], d1["roughness"], d1["metallic"],
+                                blend=(d2["albedo"], d2["normal"], d2["roughness"], d2["metallic"], None, dm), **kw)
+    assert (fused - out.detach()).abs().max().item() <= 2e-6

@@ -76,10 +76,33 @@ __global__ __launch_bounds__(256) void colour_kernel(const void *src, void *dst,
 template <typename T>
 __global__ __launch_bounds__(256) void metallic_to_specular_kernel(const void *albedo, const void *metallic,
                                                                    void *diffuse, void *specular, int batch,
-                                                                   int64_t P, int albedo_srgb) {
+                                                                   int64_t P, int albedo_srgb, int vec_ok) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec_ok) {                       // P % 4 == 0, 16-byte accesses: 4 pixels of one material per lane
+        const size_t P4 = (size_t)P / 4, total4 = (size_t)batch * P4;
+        for (size_t q = tid; q < total4; q += stride) {
+            const size_t b = q / P4, pq = q - b * P4;
+            float m[4];
+            Quad<T>::ld(metallic, q, m);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t o = (b * 3 + c) * P4 + pq;
+                float a[4], d[4], sp[4];
+                Quad<T>::ld(albedo, o, a);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lin = albedo_srgb ? srgb_to_linear(a[j]) : a[j], om = 1.0f - m[j];
+                    d[j] = lin * om;
+                    sp[j] = fmaf(lin, m[j], kDielectricF0 * om);
+                }
+                Quad<T>::st(diffuse, o, d);
+                Quad<T>::st(specular, o, sp);
+            }
+        }
+        return;
+    }
     const size_t total = (size_t)batch * (size_t)P;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    for (size_t i = tid; i < total; i += stride) {
         const size_t b = i / (size_t)P, p = i - b * (size_t)P;
         const float m = Elem<T>::ld(metallic, i), om = 1.0f - m;
 #pragma unroll
@@ -104,23 +127,37 @@ __device__ __forceinline__ float div_refined(float a, float b) {
     return fmaf(fmaf(-b, q, a), r, q);
 }
 
+__device__ __forceinline__ void specular_to_metallic_one(float d, float s, int albedo_srgb, float &bc, float &m) {
+    const float eps = 1e-6f;
+    if (albedo_srgb) d = srgb_to_linear(d);
+    const float num = s - kDielectricF0;                           // RAW specular (diffuse.py:120-124)
+    const float den = d - kDielectricF0 + eps;
+    m = clamp01(div_refined(num, den + eps));
+    if (den < eps) m = 0.0f;
+    bc = div_refined(d, 1.0f - m + eps);
+    if (m >= 0.95f) bc = s;
+    bc = clamp01(bc);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void specular_to_metallic_kernel(const void *diffuse, const void *specular,
                                                                    void *basecolor, void *metallic, size_t n,
-                                                                   int albedo_srgb) {
-    const float eps = 1e-6f;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        float d = Elem<T>::ld(diffuse, i);
-        if (albedo_srgb) d = srgb_to_linear(d);
-        const float s = Elem<T>::ld(specular, i);                   // RAW specular (diffuse.py:120-124)
-        const float num = s - kDielectricF0;
-        const float den = d - kDielectricF0 + eps;
-        float m = clamp01(div_refined(num, den + eps));
-        if (den < eps) m = 0.0f;
-        float bc = div_refined(d, 1.0f - m + eps);
-        if (m >= 0.95f) bc = s;
-        Elem<T>::st(basecolor, i, clamp01(bc));
+                                                                   int albedo_srgb, int vec_ok) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nq = vec_ok ? n / 4 : 0;
+    for (size_t q = tid; q < nq; q += stride) {
+        float d[4], sp[4], bc[4], m[4];
+        Quad<T>::ld(diffuse, q, d);
+        Quad<T>::ld(specular, q, sp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) specular_to_metallic_one(d[j], sp[j], albedo_srgb, bc[j], m[j]);
+        Quad<T>::st(basecolor, q, bc);
+        Quad<T>::st(metallic, q, m);
+    }
+    for (size_t i = nq * 4 + tid; i < n; i += stride) {
+        float bc, m;
+        specular_to_metallic_one(Elem<T>::ld(diffuse, i), Elem<T>::ld(specular, i), albedo_srgb, bc, m);
+        Elem<T>::st(basecolor, i, bc);
         Elem<T>::st(metallic, i, m);
     }
 }
@@ -257,12 +294,15 @@ int pbr_metallic_to_specular(const void *albedo, const void *metallic, void *dif
     if (!albedo || !metallic || !diffuse || !specular) return PBR_ERR_NULL_MAP;
     if (batch < 1 || pixels < 1) return PBR_ERR_SHAPE;
     if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
-    const unsigned grid = stream_grid((size_t)batch * (size_t)pixels);
+    const size_t al = dtype == PBR_F32 ? 16 : 8;
+    const int vec_ok = pixels % 4 == 0 && is_aligned(albedo, al) && is_aligned(metallic, al) && is_aligned(diffuse, al) && is_aligned(specular, al);
+    const size_t items = (size_t)batch * (size_t)pixels;
+    const unsigned grid = stream_grid(vec_ok ? items / 4 : items);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == PBR_F32)
-        hipLaunchKernelGGL((metallic_to_specular_kernel<float>), dim3(grid), dim3(256), 0, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb);
+        hipLaunchKernelGGL((metallic_to_specular_kernel<float>), dim3(grid), dim3(256), 0, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb, vec_ok);
     else
-        hipLaunchKernelGGL((metallic_to_specular_kernel<__half>), dim3(grid), dim3(256), 0, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb);
+        hipLaunchKernelGGL((metallic_to_specular_kernel<__half>), dim3(grid), dim3(256), 0, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb, vec_ok);
     return hip_status();
 }
 
@@ -272,12 +312,14 @@ int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *ba
     if (!diffuse || !specular || !basecolor || !metallic) return PBR_ERR_NULL_MAP;
     if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
     if (n == 0) return PBR_OK;
-    const unsigned grid = stream_grid(n);
+    const size_t al = dtype == PBR_F32 ? 16 : 8;
+    const int vec_ok = is_aligned(diffuse, al) && is_aligned(specular, al) && is_aligned(basecolor, al) && is_aligned(metallic, al);
+    const unsigned grid = stream_grid(vec_ok ? (n + 3) / 4 : n);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == PBR_F32)
-        hipLaunchKernelGGL((specular_to_metallic_kernel<float>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb);
+        hipLaunchKernelGGL((specular_to_metallic_kernel<float>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb, vec_ok);
     else
-        hipLaunchKernelGGL((specular_to_metallic_kernel<__half>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb);
+        hipLaunchKernelGGL((specular_to_metallic_kernel<__half>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb, vec_ok);
     return hip_status();
 }
 

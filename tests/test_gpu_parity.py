@@ -149,10 +149,28 @@ def test_conversions_and_colour(golden):
         assert np.abs(s.cpu().numpy() - g["out_conv_specular"]).max() <= 2e-6
         b, m = F.diffuse_specular_to_basecolor_metallic(_dev(g["in_albedo"]), _dev(g["in_specular"]), albedo_is_srgb=True)
         eb, em = np.abs(b.cpu().numpy() - g["out_back_basecolor"]), np.abs(m.cpu().numpy() - g["out_back_metallic"])
-        # thresholded selects (den < eps, metallic >= 0.95): a 1-ulp input difference may flip a branch at a
-        # handful of values; everywhere else the maps agree to a few ulp of the quotient
-        assert (em > 1e-4).sum() <= 2 and (eb > 1e-4).sum() <= 4, (name, int((em > 1e-4).sum()), int((eb > 1e-4).sum()))
+        # diffuse.py:128-147 is discontinuous and, near diffuse = 0.04, ill-conditioned: metallic = (s - 0.04) / (den + 1e-6)
+        # with den = d - 0.04 + 1e-6, zeroed where den < 1e-6; basecolor switches to the specular colour at metallic >= 0.95.
+        # Every value that is off by more than 1e-4 must be explained by the float64 evaluation of the reference's own
+        # formula: (a) den within 1e-4 of 0 -- one ulp of d (3.7e-9) then moves the quotient by > 1e-5 relative, and the
+        # den < eps branch sits there too -- or (b) metallic within 1e-5 of the 0.95 threshold (a tie).  No allowance by count.
+        lin = O_srgb_to_linear64(g["in_albedo"])
+        den64 = lin - 0.04 + 1e-6
+        m64 = np.clip((g["in_specular"].astype(np.float64) - 0.04) / (den64 + 1e-6), 0.0, 1.0)
+        m64 = np.where(den64 < 1e-6, 0.0, m64)
+        explained = (np.abs(den64) <= 1e-4) | (np.abs(m64 - 0.95) <= 1e-5)
+        bad = (em > 1e-4) | (eb > 1e-4)
+        assert not (bad & ~explained).any(), (name, int((bad & ~explained).sum()), float(em[bad & ~explained].max(initial=0)), float(eb[bad & ~explained].max(initial=0)))
+        print(f"\n[{name}] to_basecolor_metallic: {int(bad.sum())} of {bad.size} values off by > 1e-4, all at den ~ 0 or metallic ~ 0.95 "
+              f"({int(explained.sum())} such values in the set); elsewhere max {max(float(em[~explained].max()), float(eb[~explained].max())):.2e}")
+        assert em[~explained].max() <= 1e-4 and eb[~explained].max() <= 1e-4
         assert np.median(em) <= 1e-7 and np.median(eb) <= 1e-7
+
+
+def O_srgb_to_linear64(x):
+    """float64 evaluation of utils.srgb_to_linear (functions.py:31-47) for the conditioning analysis above."""
+    t = np.clip(x.astype(np.float64), 0.0, 1.0)
+    return np.clip(np.where(t <= 0.04045, t / 12.92, ((t + 0.055) / 1.055) ** 2.4), 0.0, 1.0)
 
 
 def test_multilight_matches_composition_of_reference_calls(golden):

@@ -22,7 +22,7 @@ timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAI
 timeout 200 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU \
     --output-format csv -d "$OUT/pmc_SQ16" -o run -- python3 "$R/tools/run_multilight.py" 4 > "$OUT/pmc_SQ16.log" 2>&1
 cd "$R"
-timeout 500 python3 tools/bench_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
+timeout 900 python3 tools/bench_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
 cat "$OUT/configs.jsonl"
 timeout 300 python3 -m pytest tests/test_gpu_parity.py -q -s -k full_size 2>&1 | grep -E "4096x4096|passed|failed" > "$OUT/fullsize.log"
 cat "$OUT/fullsize.log"

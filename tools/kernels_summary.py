@@ -90,7 +90,7 @@ for key in sorted(rec):
         sq["wait_any_fraction_of_wave_cycles"] = round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3)
         sq["wait_inst_any_fraction_of_wave_cycles"] = round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 3)
         ent["sq"] = sq
-    match = [cs for cs in cases if cs["kernel"] in name + "(" or name.startswith(cs["kernel"])]
+    match = [cs for cs in cases if name.startswith(cs["kernel"])] or [cs for cs in cases if cs["kernel"] in name + "("]
     if len(match) == 1 or (match and len({cs["algorithmic_bytes_per_launch"] for cs in match}) == 1):
         alg = match[0]["algorithmic_bytes_per_launch"]
         ent["case"] = match[0]["case"]

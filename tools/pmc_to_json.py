@@ -12,8 +12,8 @@ NAME = "ct_point_metallic_f32_f32_v4"
 PIXELS, BPP = 4096 * 4096, 44
 
 
-MULTI_KERNEL = "cook_torrance_kernel<1, 0, __half, float, 4, true, true>"
-MULTI_NAME = "ct_point_metallic_f16_f32_v4_multi"
+MULTI_KERNEL = "cook_torrance_batch_kernel<1, 0, __half, float, 2, 4, true>"
+MULTI_NAME = "ctb_point_metallic_f16_f32_v2_b4"
 
 
 def per_dispatch(root, pass_name, kernel=None):
@@ -45,6 +45,7 @@ def main():
     f_kib, w_kib = statistics.mean(fetch["FETCH_SIZE"]), statistics.mean(write["WRITE_SIZE"])
     rd, wr = int(round(f_kib * 1024 * 2)), int(round(w_kib * 1024))
     rec = {
+        "run": f"{root} (tools/collect_evidence.sh on an MI355X via gpurun; committed as profiles/{sys.argv[2] if len(sys.argv) > 2 else 'pmc_traffic.json'})",
         "workload": "bench.py default: 1 x 4096x4096 BasecolorMetallicMaterial, point light, fp32, sRGB in/out",
         "collected": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in two separate passes (gpurun, MI355X), per-dispatch mean over "
                      f"{len(fetch['FETCH_SIZE'])} / {len(write['WRITE_SIZE'])} launches; tools/collect_evidence.sh + tools/pmc_to_json.py",

@@ -23,5 +23,9 @@ plan = F.plan_cook_torrance(a, n, r, m, view_dir=[0, 0, 1], light=[[0.1, 0.1, 1.
                             light_type="point", light_size=1.0, autotune=True)
 print(plan.launch().shape, plan.desc.schedule)
 a2 = a.clone().requires_grad_()
-F.cook_torrance(a2, n, r, m, view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1]).mean().backward()
-print(a2.grad.abs().sum().item() > 0, [t.shape for t in F.pack_maps(a, n, r, m)])
+light = torch.tensor([0.1, 0.1, 1.0], device="cuda", requires_grad=True)
+F.cook_torrance(a2, n, r, m, view_dir=[0, 0, 1], light=light, light_intensity=[1, 1, 1]).mean().backward()
+print(a2.grad.abs().sum().item() > 0, light.grad, [t.shape for t in F.pack_maps(a, n, r, m)])
+out = torch.ops.pbr_hip.cook_torrance(a[None], n[None], r[None], m[None], None, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([[0.1, 0.1, 1.0]]),
+                                      torch.ones(1, 3), 1.0, 1, True, True, False, True)
+print(out.shape, torch.equal(out[0], color))

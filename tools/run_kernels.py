@@ -72,7 +72,7 @@ if want("fwd_f16"):
     lights = [[math.cos(t), math.sin(t), 1.0] for t in [2 * math.pi * i / 16 for i in range(16)]]
     p16 = F.plan_cook_torrance(*h, view_dir=[0, 0, 1], light=lights, light_intensity=[[1.0 / 16] * 3] * 16, light_type="point", light_size=1.0)
     us = timed(lambda: p16.launch(stream), reps=3, warm=1)
-    report("fwd_16_lights: 4 x 4096^2, 16 point lights, fp16 maps -> fp32 (config 5 share)", "cook_torrance_kernel<1, 0, __half, float, 4, true, true>",
+    report("fwd_16_lights: 4 x 4096^2, 16 point lights, fp16 maps -> fp32 (config 5 share)", "cook_torrance_batch_kernel<1, 0, __half, float, 2, 4, true>",
            p16.bytes_per_pixel * 4 * PX, us, Gpixels_per_s=round(4 * PX / us / 1e3, 1))
     del h, p, p2, p16
 if want("bwd"):
@@ -110,19 +110,19 @@ if want("map_ops"):
     m = torch.rand(1, S, S, device=DEV, generator=g)
     o3, o3b, o1 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(m)
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-    report("map_ops srgb_to_linear 3 x 4096^2 fp32", "colour_kernel", 24 * PX,
+    report("map_ops srgb_to_linear 3 x 4096^2 fp32", "colour_kernel<float, true>", 24 * PX,
            timed(lambda: lib.pbr_srgb_to_linear(a.data_ptr(), o3.data_ptr(), a.numel(), N.F32, stream)))
-    report("map_ops linear_to_srgb 3 x 4096^2 fp32", "colour_kernel", 24 * PX,
+    report("map_ops linear_to_srgb 3 x 4096^2 fp32", "colour_kernel<float, false>", 24 * PX,
            timed(lambda: lib.pbr_linear_to_srgb(a.data_ptr(), o3.data_ptr(), a.numel(), N.F32, stream)))
     report("map_ops metallic -> diffuse/specular 4096^2 (4 planes in, 6 out)", "metallic_to_specular_kernel", 40 * PX,
            timed(lambda: lib.pbr_metallic_to_specular(a.data_ptr(), m.data_ptr(), o3.data_ptr(), o3b.data_ptr(), 1, PX, 1, N.F32, stream)))
     report("map_ops diffuse/specular -> basecolor/metallic 4096^2 (6 planes in, 6 out)", "specular_to_metallic_kernel", 48 * PX,
            timed(lambda: lib.pbr_specular_to_metallic(a.data_ptr(), n.data_ptr(), o3.data_ptr(), o3b.data_ptr(), a.numel(), 0, N.F32, stream)))
-    report("map_ops decode_normal 3 ch [0,1]-encoded 4096^2 (flag pass reads 3 planes; transform 3 in, 3 out)", "decode_normal", 36 * PX,
+    report("map_ops decode_normal 3 ch [0,1]-encoded 4096^2: the transform kernel (3 planes in, 3 out; the any-negative flag pass before it reads the 3 planes once more)", "decode_normal_kernel", 24 * PX,
            timed(lambda: lib.pbr_decode_normal(n.data_ptr(), o3.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
-    report("blend_maps 3 ch 4096^2 (7 planes in, 3 out)", "blend_kernel", 40 * PX,
+    report("blend_maps 3 ch 4096^2 (7 planes in, 3 out)", "blend_kernel<false>", 40 * PX,
            timed(lambda: lib.pbr_blend_maps(a.data_ptr(), n.data_ptr(), m.data_ptr(), o3.data_ptr(), 3, PX, 0, stream)))
-    report("blend_maps normals 4096^2 (7 planes in, 3 out)", "blend_kernel", 40 * PX,
+    report("blend_maps normals 4096^2 (7 planes in, 3 out)", "blend_kernel<true>", 40 * PX,
            timed(lambda: lib.pbr_blend_maps(a.data_ptr(), n.data_ptr(), m.data_ptr(), o3.data_ptr(), 3, PX, 1, stream)))
     report("sigmoid mask 4096^2 (2 in, 1 out)", "sigmoid_mask_kernel", 12 * PX,
            timed(lambda: lib.pbr_blend_sigmoid_mask(m.data_ptr(), m.data_ptr(), o1.data_ptr(), PX, 0.0, 0.1, stream)))

@@ -425,7 +425,9 @@ def _param_tensor(v, rows):
 def _cook_torrance_via_torch_op(albedo, normal, roughness, metallic=None, specular=None, *, view_dir, light, light_intensity,
                                 light_type="point", light_size=None, albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True,
                                 convert_to_diffuse_specular=False, y_offset=0, height_total=None, out_dtype=None, tile=1, rows=None,
-                                **_ignored):
+                                out=None, schedule=N.SCHEDULE_AUTO, autotune=False, blend=None):
+    # (out / schedule / autotune / blend are at their defaults here -- _torch_op_can_take -- and named so that an unknown
+    # keyword raises TypeError exactly as on the plan path)
     lt = str(light_type).lower()
     if lt not in _LIGHT_TYPES:   # cooktorrance.py:62-65
         raise ValueError(f"Unsupported light_type: {lt}. Must be 'directional' or 'point'.")

@@ -283,3 +283,32 @@ def test_rendering_loss_through_a_blend_reaches_both_materials_and_the_mask():
         fused = F.cook_torrance(d1["albedo"], d1["normal"], d1["roughness"], d1["metallic"],
                                 blend=(d2["albedo"], d2["normal"], d2["roughness"], d2["metallic"], None, dm), **kw)
     assert (fused - out.detach()).abs().max().item() <= 2e-6
+
+
+def test_blend_sign_pass_reads_only_the_rows_of_its_band():
+    """for an untiled row band the sign pass used to run over height_total rows from the band's start -- past
+    the band, possibly past the tensor.  Here the rows BEHIND the band (same allocation) hold negative normals and the
+    band itself none: the band's flag must stay 0, the full map's flag is 1, and a band without given flags is refused."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(77)
+    H, W, cut = 64, 64, 24
+    a = torch.rand(1, 3, H, W, generator=g).cuda(); r = (torch.rand(1, 1, H, W, generator=g) * 0.7 + 0.3).cuda()
+    m = torch.rand(1, 1, H, W, generator=g).cuda(); mask = torch.rand(1, 1, H, W, generator=g).cuda()
+    n = torch.zeros(1, 3, H, W); n[:, 0] = 0.3; n[:, 1] = 0.2; n[:, 2] = 0.9
+    n[:, 0, cut:] = -0.6                                         # negative x only in the rows after the band
+    n = (n / n.norm(dim=1, keepdim=True)).cuda()
+    kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
+    band = lambda t: t[:, :, :cut]
+    second = (a.flip(-1), n, r, m, None, mask)
+    flags = torch.zeros(1, dtype=torch.int32, device="cuda")
+    plan = F.plan_cook_torrance(band(a), band(n), band(r), band(m), y_offset=0, height_total=H,
+                                blend=tuple(None if t is None else band(t) for t in second), blend_flags=flags, **kw)
+    assert plan.blend_normal_sign().item() == 0
+    whole = F.plan_cook_torrance(a, n, r, m, blend=second, **kw)
+    assert whole.blend_normal_sign().item() == 1
+    full = whole.launch().clone()
+    plan.use_blend_flags(torch.ones(1, dtype=torch.int32, device="cuda"))      # the whole-map answer, as the ranks would combine it
+    assert torch.equal(plan.launch(), full[:, :, :cut])
+    with pytest.raises(NotImplementedError):
+        F.cook_torrance(band(a), band(n), band(r), band(m), y_offset=0, height_total=H,
+                        blend=tuple(None if t is None else band(t) for t in second), **kw)

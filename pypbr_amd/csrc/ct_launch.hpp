@@ -111,8 +111,13 @@ inline int schedule_xcd_log2(const pbr_render_desc *d, int vec) {
     const int64_t row_bytes = (int64_t)d->width * esz, tile_bytes = 64 * (int64_t)vec * esz;
     const int64_t plane_bytes = d->albedo.channel_stride * esz;
     if (d->map_dtype == PBR_F16) return 6;           // fp16 maps: runs are 1.5-5 % ahead on every shape tried
-    if (row_bytes % tile_bytes) return 6;
-    if (plane_bytes == (8ll << 20) || plane_bytes == (16ll << 20)) return 6;
+    if (row_bytes % tile_bytes) return 6;            // ragged rows: a tile row does not end where a plane row ends
+    // Plane strides that are a multiple of 8 MiB put the same offset of all 11 planes of a material onto the same HBM
+    // channel group; under the linear order every XCD then works on that group at once.  Runs hand each XCD its own
+    // 64 KiB pieces.  Measured (round 2, tools/order_sweep.sh + tune.py, runs vs linear): 8 MiB planes +0.5 %, 16 MiB
+    // +8..10 %, 24 MiB -0.9 %, 32 MiB +4 %, 64 MiB +-0.5 %; other strides prefer the linear order: 4 MiB -3.8 %,
+    // 9 MiB -3.7 %, 36 MiB -1.6 %.
+    if (plane_bytes % (8ll << 20) == 0) return 6;
     return 0;
 }
 

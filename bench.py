@@ -22,8 +22,9 @@ Timing protocol.  Two timed regions, both K steps bracketed by barrier + synchro
   steady  `--settle` (default 300) further untimed launches so that power management has settled the clocks
           (tools/transient_probe.py), then K timed steps -> `ms_per_step`, `value`: the sustained rate.
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
-  roofline     -- achieved algorithmic HBM GB/s of the kernel (44 B/pixel x pixels per launch /
-                  average launch duration from HIP events on the launch stream, steady region) vs 8 TB/s
+  roofline     -- achieved algorithmic HBM GB/s of the kernel (44 B/pixel x pixels per launch / average launch
+                  duration from HIP events on the launch stream over ALL 2K timed launches, cold + steady: the figure a
+                  rocprofv3 --kernel-trace average of the same command reproduces) vs 8 TB/s
   per_rank     -- kernel_us of every rank (steady region) and the latency of the light-block broadcast
   parity       -- bands of the timed output of this run against the float64 C oracle and the ATen restatement
   cpu_baseline -- the ATen-level restatement of the reference's CPU path (oracle/torch_oracle.py,
@@ -274,7 +275,8 @@ def main():
 
     if rank == 0:
         value = world * pixels * args.steps / elapsed / 1e6
-        achieved = bpp * pixels / (kernel_ms * 1e-3) / 1e9
+        kernel_all_ms = 0.5 * (kernel_ms + cold_kernel_ms)      # every timed launch of this run (K cold + K steady): what a
+        achieved = bpp * pixels / (kernel_all_ms * 1e-3) / 1e9   # rocprofv3 --kernel-trace average of the same command shows
         traffic, traffic_run = recorded_traffic(kernel)
         line = {
             "metric": "Mpixels/s Cook-Torrance eval, 4K maps",
@@ -297,7 +299,8 @@ def main():
                                                                 "five tensors wherever torch's allocator put them"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_run,
-                         "kernel_us": round(kernel_ms * 1e3, 2), "kernel_us_cold": round(cold_kernel_ms * 1e3, 2)},
+                         "kernel_us": round(kernel_all_ms * 1e3, 2), "kernel_us_steady": round(kernel_ms * 1e3, 2),
+                         "kernel_us_cold": round(cold_kernel_ms * 1e3, 2)},
             "per_rank": {"kernel_us": [round(u, 2) for u in per_rank_us],
                          "light_block_broadcast_us": None if bcast_us is None else round(bcast_us, 1)},
         }

@@ -131,3 +131,38 @@ def test_config5_share_full_shape_4x4096_16_lights_fp16(out_dtype):
             worst64 = max(worst64, float(e64.max()))
             assert e64.max() <= 4.9e-4 + 2e-6, (b, y0, float(e64.max()))
     print(f"\n[cfg5 share 4x4096^2 16 lights fp16 -> {out_dtype}] 8 bands of 4 rows: max|hip-ref32| {worst32:.2e}, max|hip-ref64| {worst64:.2e}")
+
+
+def test_offsets_beyond_2_to_31_elements():
+    """Maximum sizes: a batch whose planes lie more than 2^31 ELEMENTS into their tensors (12 x 8192^2: the last
+    material's albedo starts 2.2e9 elements in, its result 2.2e9 floats in) -- every index in the kernels must be 64-bit.
+    fp16 maps to keep it at 12 GiB in, 9 GiB out; bands of the first and the LAST material against the oracles."""
+    from pypbr_amd import functional as F
+    B, H, W = 12, 8192, 8192
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("needs 40 GiB of free device memory")
+    g = torch.Generator(device="cuda").manual_seed(8)
+    a = torch.rand(B, 3, H, W, device="cuda", generator=g, dtype=torch.float16)
+    n = torch.rand(B, 3, H, W, device="cuda", generator=g, dtype=torch.float16)
+    n[:, 2] += 1.0                                                    # z-dominant, un-normalised (the kernel normalises)
+    n[:, :2] -= 0.5
+    r = torch.rand(B, 1, H, W, device="cuda", generator=g, dtype=torch.float16) * 0.8 + 0.2
+    m = torch.rand(B, 1, H, W, device="cuda", generator=g, dtype=torch.float16)
+    assert a[B - 1].storage_offset() > 2 ** 31
+    view, light, inten = [0.0, 0.0, 1.0], [0.1, 0.1, 1.0], [1.0, 1.0, 1.0]
+    out = F.cook_torrance(a, n, r, m, view_dir=view, light=light, light_intensity=inten, light_type="point", light_size=1.0)
+    assert out.shape == (B, 3, H, W) and out[B - 1].storage_offset() > 2 ** 31
+    worst = 0.0
+    for b, y0 in ((0, 0), (B - 1, 0), (B - 1, H - 4), (B // 2, 4097)):
+        crop = [t[b, :, y0:y0 + 4].float().cpu() for t in (a, n, r, m)]
+        got = out[b, :, y0:y0 + 4].cpu().numpy()
+        ref64 = C.render(*[t.numpy() for t in crop], None, view=view, lights=light, intensities=inten, light_type="point",
+                         light_size=1.0, y_offset=y0, H_total=H, dtype=np.float64)
+        ref32 = O.cook_torrance(*crop, None, view=torch.tensor(view), light=torch.tensor(light), intensity=torch.tensor(inten),
+                                light_type="point", light_size=1.0, y_offset=y0, H_total=H).numpy()
+        rep = parity_report(got, ref32, ref64, crop[2].numpy(), what=("8192^2 x 12", b, y0))
+        worst = max(worst, rep["max64"])
+    # the tail of the last plane was written, and nothing is left unwritten in between (an empty() buffer would show garbage / NaN)
+    assert bool(torch.isfinite(out[B - 1, 2, H - 1]).all()) and float(out[B - 1].min()) >= 0.0 and float(out[B - 1].max()) <= 1.0
+    print(f"\n[12 x 8192^2 fp16 maps, offsets > 2^31 elements] max|hip-ref64| {worst:.2e}")

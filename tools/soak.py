@@ -19,7 +19,7 @@ dev = torch.device("cuda", 0)
 t_end = time.time() + seconds
 n_cfg = n_bwd = n_blend = 0
 while time.time() < t_end:
-    B = rng.choice([1, 1, 2, 3, 5])
+    B = rng.choice([1, 1, 2, 3, 4, 5, 8])
     h = rng.choice([1, 2, 7, 16, 33, 64, 100, 257, 512])
     w = rng.choice([1, 3, 4, 8, 12, 20, 64, 100, 256, 1000, 1024])
     dtype = rng.choice([torch.float32, torch.float32, torch.float16])
@@ -43,11 +43,23 @@ while time.time() < t_end:
     out1 = F.cook_torrance(a, n, r, m, s, schedule=N.SCHEDULE_LINEAR, **kw)
     out2 = F.cook_torrance(a, n, r, m, s, schedule=N.schedule_xcd(rng.randrange(1, 9)), **kw)
     assert bool(torch.isfinite(out1).all()) and torch.equal(out1, out2), (B, h, w, dtype, lights, ny, nx, wf, ltype)
+    # a material of the batch evaluated on its own (one-material kernels) == its slice of the batched launch (several lights:
+    # the batch-inner kernel, 2 or 4 materials per lane)
+    b = rng.randrange(B)
+    one = F.cook_torrance(a[b], n[b], r[b if r.shape[0] == B else 0], None if m is None else m[b], None if s is None else s[b], **kw)
+    assert torch.equal(one, out1[b]), ("batch slice", B, b, h, w, dtype, lights, ny, nx, wf, ltype)
+    if dtype == torch.float16 and lights == 1:       # 8-pixel lanes (LDS piece exchange) == 4-pixel lanes
+        lib = N.lib()
+        lib.pbr_set_tuning(N.TUNE_F16_VEC, 4)
+        out4 = F.cook_torrance(a, n, r, m, s, schedule=N.SCHEDULE_LINEAR, **kw)
+        lib.pbr_set_tuning(N.TUNE_F16_VEC, 8)
+        assert torch.equal(out4, out1), ("f16 vec", B, h, w, lights, ny, nx, wf, ltype)
     n_cfg += 1
     if n_cfg % 8 == 0 and (ny, nx) == (1, 1) and r.shape[0] == B:
         leaves = [None if t is None else t.clone().requires_grad_(True) for t in (a, n, r, m, s)]
-        F.cook_torrance(*leaves, **kw).sum().backward()
-        assert all(t is None or bool(torch.isfinite(t.grad).all()) for t in leaves), ("backward", B, h, w, dtype, lights, wf, ltype)
+        lt = torch.tensor(lv, device=dev, requires_grad=True)            # light / view gradients too (PGRAD kernels)
+        F.cook_torrance(*leaves, **{**kw, "light": lt}).sum().backward()
+        assert all(t is None or bool(torch.isfinite(t.grad).all()) for t in leaves + [lt]), ("backward", B, h, w, dtype, lights, wf, ltype)
         n_bwd += 1
         if dtype == torch.float32 and wf != "converted":
             mask = torch.rand(1, 1, h, w, device=dev, generator=g)

@@ -661,26 +661,54 @@ def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool =
     batch = max([t.shape[0] for t in present if t.dim() == 4] or [1])
     if batch > 1 and material_major:
         return _pack_material_major(maps, batch, dev, reserve_output, padded)
-    sizes = [0 if t is None else padded(t.numel() * t.element_size()) for t in maps]
-    out_shape, out_bytes = None, 0
+    out_shape = None
     if reserve_output:
         out_shape = tuple(present[0].shape[:-3]) + (3,) + tuple(present[0].shape[-2:])
-        out_bytes = 4
-        for n in out_shape:
-            out_bytes *= n
-    arena = torch.empty(sum(sizes) + padded(out_bytes), dtype=torch.uint8, device=dev)
+
+    def pitch_of(shape, esz):
+        """Bytes from one plane of a map to the next.  Planes whose size is a multiple of 8 MiB (2048^2, 4096^2 fp32 ...)
+        all start on the same HBM channel group when packed back to back; PLANE_SKEW_BYTES (when set) more per plane
+        spread them (tools/skew_probe.py: 16 x 2048^2 with every tensor skewed, linear order: 6.16 -> 6.44 TB/s; inside
+        one arena the effect is ~1 %, see below).  Other sizes stay dense."""
+        plane = shape[-2] * shape[-1] * esz
+        return plane + (PLANE_SKEW_BYTES if PLANE_SKEW_BYTES and plane % (8 << 20) == 0 else 0)
+
+    def extent(shape, esz):
+        n_planes = 1
+        for d in shape[:-2]:
+            n_planes *= d
+        return padded(n_planes * pitch_of(shape, esz))
+    sizes = [0 if t is None else extent(t.shape, t.element_size()) for t in maps]
+    out_bytes = extent(out_shape, 4) if reserve_output else 0
+    arena = torch.empty(sum(sizes) + out_bytes, dtype=torch.uint8, device=dev)
+
+    def view(off, shape, dtype, esz):
+        pitch = pitch_of(shape, esz) // esz
+        strides = [1, shape[-1]]
+        step = pitch
+        for d in reversed(shape[:-2]):
+            strides.append(step)
+            step *= d
+        strides = tuple(reversed(strides))            # (..., planes, rows, 1): dense rows, `pitch` elements between planes
+        return arena.view(dtype).as_strided(tuple(shape), strides, off // esz)
     views, off = [], 0
     for t, nbytes in zip(maps, sizes):
         if t is None:
             views.append(None)
             continue
-        v = arena[off:off + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+        v = view(off, t.shape, t.dtype, t.element_size())
         v.copy_(t)
         views.append(v)
         off += nbytes
     if reserve_output:
-        views.append(arena[off:off + out_bytes].view(torch.float32).view(out_shape))
+        views.append(view(off, out_shape, torch.float32, 4))
     return tuple(views)
+
+
+# 0 = dense planes (the default).  Measured with 4352 (17 x 256 B, tools/skew_ab.sh): batches of 2048^2 maps +1 %
+# (16 maps: 467.6 -> 462.5 us), 64 x 2048^2 +0.6 %, 4 x 4096^2 level, the bench workload (one 4096^2 material) 1.5 % SLOWER
+# (114.0 -> 116.1 us) -- so it stays an experiment knob.
+PLANE_SKEW_BYTES = int(os.environ.get("PBR_PLANE_SKEW_BYTES", "0"))
 
 
 def _pack_material_major(maps, batch, dev, reserve_output, padded):

@@ -173,7 +173,9 @@ template <class R> struct PixelTermsT {
     Vec3T<R> n;        // unit normal: stored normal * 1/max(|n|, 1e-12)   (F.normalize :154)
     R ndv_raw;         // N.V before the clamp: N.h = N.L + N.V, one add per light
     R ndv;             // clamp(N.V)                  (:163)
+    R ndv4;            // 4 clamp(N.V): the specular denominator 4 NdotV NdotL + 1e-7 is one fma per light
     R a2;              // roughness^2                 (alpha = roughness, :213-214)
+    R oma2;            // 1 - a2: the GGX denominator a2 + (1 - a2) sin^2 is one fma per light
     R k;               // (r+1)^2/8                   (:232-233)
     R omk, kk;         // 1 - k, k + 1e-7: both G denominators are one fma, ndx omk + kk
     R dv;              // NdotV (1-k) + k + 1e-7      (:234)
@@ -192,7 +194,9 @@ __device__ __forceinline__ void pixel_terms(const Vec3T<R> &n, const Vec3 &V, R 
     t.n = {n.x * rn, n.y * rn, n.z * rn};
     t.ndv_raw = dotu(t.n, V);
     t.ndv = clamp01(t.ndv_raw);
+    t.ndv4 = t.ndv * 4.0f;
     t.a2 = rough * rough;
+    t.oma2 = splat<R>(1.0f) - t.a2;
     const R r1 = rough + 1.0f;
     t.k = r1 * r1 * 0.125f;
     t.omk = splat<R>(1.0f) - t.k;
@@ -223,14 +227,15 @@ __device__ __forceinline__ R ggx_den(const PixelTermsT<R> &t, const LightGeomT<R
 template <class R>
 __device__ __forceinline__ R ggx_den_fwd(const PixelTermsT<R> &t, const LightGeomT<R> &g, R nh) {
     const Vec3T<R> p = {fma_(-nh, t.n.x, g.h.x), fma_(-nh, t.n.y, g.h.y), fma_(-nh, t.n.z, g.h.z)};
-    return fma_(dot(p, p) * g.rhh, splat<R>(1.0f) - t.a2, t.a2);
+    return fma_(dot(p, p) * g.rhh, t.oma2, t.a2);
 }
 
 template <class R> struct MaskOf { using type = bool; };
 template <> struct MaskOf<f32x2> { using type = i32x2; };
 
-// One light's linear RGB contribution, clamped to [0,1] (:160-177).  `inten` is wave-uniform.
-template <class R>
+// One light's linear RGB contribution, clamped to [0,1] (:160-177).  `inten` is wave-uniform.  GREY: the light's three
+// intensities are equal (decided on the host for the whole launch), so radiance * intensity is computed once.
+template <bool GREY = false, class R>
 __device__ __forceinline__ void shade_light(const PixelTermsT<R> &t, const LightGeomT<R> &g, const float inten[3], R out[3]) {
     const R nd = dot(t.n, g.d);
     const R ndl = mul_sat(nd, g.rinv);                             // clamp(N.L) :164
@@ -238,14 +243,15 @@ __device__ __forceinline__ void shade_light(const PixelTermsT<R> &t, const Light
     // D * G / (4 NdotV NdotL + 1e-7) with one reciprocal (:217, :232-235, :165-166); D's pi sits in a2ndv_pi.
     const R dl = fma_(ndl, t.omk, t.kk);
     const R dD = fma_(den, den, splat<R>(1e-7f * kInvPi));
-    const R ds = fma_(t.ndv * 4.0f, ndl, splat<R>(1e-7f));
+    const R ds = fma_(t.ndv4, ndl, splat<R>(1e-7f));
     const R dg = t.a2ndv_pi * ndl * rcp((dD * t.dv) * (dl * ds));
     const R rad = ndl * g.att;                                     // :175
+    const R w0 = rad * inten[0];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const R F = fma_(t.f0[ch], g.om5, g.p5);                   // :196
         // F dg + (1 - F) kb  ==  kb + F (dg - kb)                    (:166, :169-174)
-        out[ch] = mul_sat(fma_(F, dg - t.kb[ch], t.kb[ch]), rad * inten[ch]);      // :175-177
+        out[ch] = mul_sat(fma_(F, dg - t.kb[ch], t.kb[ch]), (GREY || ch == 0) ? w0 : rad * inten[ch]);      // :175-177
     }
 }
 

@@ -15,6 +15,7 @@
 #include <hip/hip_fp16.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "../../include/pbr_hip.h"
 #include "brdf_math.hpp"
@@ -72,6 +73,7 @@ struct KArgs {
     float V[3];              // F.normalize(view_dir)   :95
     int32_t n_lights;
     int32_t albedo_srgb, spec_srgb, out_srgb, has_normal;
+    int32_t grey_lights;     // every light's three intensities are equal: radiance * intensity once per light, not per channel
     LightU lights[PBR_MAX_LIGHTS];
 };
 
@@ -562,20 +564,23 @@ void cook_torrance_batch_kernel(const KArgs a) {
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int g = 0; g < NG; ++g) res[j][c][g] = splat<R>(0.0f);
-    for (int l = 0; l < a.n_lights; ++l) {
-        const LightU &lu = a.lights[l];
+    auto light_loop = [&](auto grey) {
+        for (int l = 0; l < a.n_lights; ++l) {
+            const LightU &lu = a.lights[l];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[g], ys);
+            for (int g = 0; g < NG; ++g) {
+                const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[g], ys);
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                R col[3];
-                shade_light(pt[j][g], lg, lu.inten, col);
+                for (int j = 0; j < NB; ++j) {
+                    R col[3];
+                    shade_light<decltype(grey)::value>(pt[j][g], lg, lu.inten, col);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) res[j][c][g] += col[c];
+                    for (int c = 0; c < 3; ++c) res[j][c][g] += col[c];
+                }
             }
         }
-    }
+    };
+    if (a.grey_lights) light_loop(std::true_type{}); else light_loop(std::false_type{});
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
 #pragma unroll

@@ -163,6 +163,9 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     k.n_lights = d->n_lights;
     k.albedo_srgb = d->albedo_is_srgb != 0; k.spec_srgb = d->specular_is_srgb != 0;
     k.out_srgb = d->return_srgb != 0; k.has_normal = d->normal.data != nullptr;
+    k.grey_lights = 1;
+    for (int i = 0; i < d->n_lights; ++i)
+        if (d->intensities[i][0] != d->intensities[i][1] || d->intensities[i][0] != d->intensities[i][2]) k.grey_lights = 0;
     for (int i = 0; i < d->n_lights; ++i) {
         LightU &u = k.lights[i];
         for (int c = 0; c < 3; ++c) u.inten[c] = d->intensities[i][c];

@@ -8,9 +8,9 @@ OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-timeout 600 python3 "$R/tools/run_kernels.py" 10 > "$OUT/cases.jsonl" 2> "$OUT/cases.err"
+timeout 900 python3 "$R/tools/run_kernels.py" 100 "" 150 > "$OUT/cases.jsonl" 2> "$OUT/cases.err"
 cat "$OUT/cases.jsonl"
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$R/tools/run_kernels.py" 10 > "$OUT/trace.log" 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o run -- python3 "$R/tools/run_kernels.py" 100 "" 150 > "$OUT/trace.log" 2>&1
 for pass in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $pass --output-format csv -d "$OUT/pmc_$pass" -o run -- python3 "$R/tools/run_kernels.py" 3 > "$OUT/pmc_$pass.log" 2>&1
 done

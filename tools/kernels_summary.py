@@ -62,13 +62,20 @@ try:
 except OSError:
     pass
 
+
+def cases_of(name):
+    return [cs for cs in cases if name.startswith(cs["kernel"])] or [cs for cs in cases if cs["kernel"] in name + "("]
+
 out = []
 for key in sorted(rec):
     name, grid = key
     r = rec[key]
     us = r["us"]
+    reps = sum(cs.get("reps", 0) for cs in cases_of(name))
+    if reps and len(us) > reps:          # the timed launches come last; what precedes them is warm-up / clock settling
+        us = us[-reps:]
     ent = {"kernel": name, "grid_threads": grid, "workgroup": r["workgroup"], "vgpr": r["vgpr"], "agpr": r["agpr"], "lds_bytes": r["lds"],
-           "scratch": r["scratch"], "dispatches": len(us), "avg_us": round(statistics.mean(us), 2), "min_us": round(min(us), 2),
+           "scratch": r["scratch"], "dispatches": len(r["us"]), "timed_dispatches": len(us), "avg_us": round(statistics.mean(us), 2), "min_us": round(min(us), 2),
            "median_us": round(statistics.median(us), 2)}
     c = counters.get(key, {})
     if "FETCH_SIZE" in c:
@@ -90,7 +97,7 @@ for key in sorted(rec):
         sq["wait_any_fraction_of_wave_cycles"] = round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3)
         sq["wait_inst_any_fraction_of_wave_cycles"] = round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 3)
         ent["sq"] = sq
-    match = [cs for cs in cases if name.startswith(cs["kernel"])] or [cs for cs in cases if cs["kernel"] in name + "("]
+    match = cases_of(name)
     if len(match) == 1 or (match and len({cs["algorithmic_bytes_per_launch"] for cs in match}) == 1):
         alg = match[0]["algorithmic_bytes_per_launch"]
         ent["case"] = match[0]["case"]

@@ -18,14 +18,26 @@ from pypbr_amd import _native as N, blending as B, functional as F  # noqa: E402
 
 REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 ONLY = sys.argv[2] if len(sys.argv) > 2 else ""
+WARM_MS = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0      # settle the clocks before timing: launch for this long first
 DEV = torch.device("cuda", 0)
 S = 4096
 PX = S * S
 
 
 def timed(fn, reps=REPS, warm=3):
+    """`warm` launches, then -- if WARM_MS -- launches until that much time has passed (after an idle moment the GPU runs
+    ~20 launches at boost clocks and the next ~100 up to 25 % slower: tools/transient_probe.py), then `reps` timed ones.
+    kernels_summary.py looks at the LAST `reps` dispatches of each kernel only."""
+    import time
     for _ in range(warm):
         fn()
+    if WARM_MS:
+        torch.cuda.synchronize()
+        t_end = time.perf_counter() + WARM_MS * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -36,7 +48,7 @@ def timed(fn, reps=REPS, warm=3):
 
 
 def report(case, kernel, alg_bytes, us, **extra):
-    line = {"case": case, "kernel": kernel, "algorithmic_bytes_per_launch": int(alg_bytes), "us_per_launch_hip_events": round(us, 1),
+    line = {"case": case, "kernel": kernel, "reps": extra.pop("reps", REPS), "algorithmic_bytes_per_launch": int(alg_bytes), "us_per_launch_hip_events": round(us, 1),
             "GBps_algorithmic": round(alg_bytes / us / 1e3, 1), "frac_of_8TBps": round(alg_bytes / us / 1e3 / 8000.0, 4)}
     line.update(extra)
     print(json.dumps(line), flush=True)
@@ -59,7 +71,7 @@ if want("fwd_f32"):
     a, n, r, m, out = F.pack_maps(*synth_material(S, DEV, 1), reserve_output=True)
     p = F.plan_cook_torrance(a, n, r, m, out=out.unsqueeze(0), **PT)
     report("fwd_f32: 1 x 4096^2 point metallic fp32 (bench.py workload)", "cook_torrance_kernel<1, 0, float, float, 4, false, true>",
-           p.bytes_per_pixel * PX, timed(lambda: p.launch(stream), reps=max(REPS, 50), warm=20))
+           p.bytes_per_pixel * PX, timed(lambda: p.launch(stream), reps=max(REPS, 50), warm=20), reps=max(REPS, 50))
     del a, n, r, m, out, p
 if want("fwd_f16"):
     h = batch(4, S, torch.float16, 10)
@@ -71,9 +83,9 @@ if want("fwd_f16"):
            p2.bytes_per_pixel * 4 * PX, timed(lambda: p2.launch(stream)))
     lights = [[math.cos(t), math.sin(t), 1.0] for t in [2 * math.pi * i / 16 for i in range(16)]]
     p16 = F.plan_cook_torrance(*h, view_dir=[0, 0, 1], light=lights, light_intensity=[[1.0 / 16] * 3] * 16, light_type="point", light_size=1.0)
-    us = timed(lambda: p16.launch(stream), reps=20, warm=60)     # steady state: the first ~50 launches run 7 % slower
+    us = timed(lambda: p16.launch(stream), reps=min(REPS, 20), warm=60)     # steady state: the first ~50 launches run 7 % slower
     report("fwd_16_lights: 4 x 4096^2, 16 point lights, fp16 maps -> fp32 (config 5 share)", "cook_torrance_batch_kernel<1, 0, __half, float, 2, 4, true>",
-           p16.bytes_per_pixel * 4 * PX, us, Gpixels_per_s=round(4 * PX / us / 1e3, 1))
+           p16.bytes_per_pixel * 4 * PX, us, Gpixels_per_s=round(4 * PX / us / 1e3, 1), reps=min(REPS, 20))
     del h, p, p2, p16
 if want("bwd"):
     for dtype, tag, kern in ((torch.float32, "bwd_f32", "cook_torrance_backward_kernel<1, 0, 4, false, float, false>"),

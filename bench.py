@@ -150,10 +150,14 @@ def recorded_traffic(kernel_name):
         return None, None
 
 
+SHARE_GPU = os.environ.get("PBR_BENCH_SHARE_GPU") == "1"     # test hook: N ranks on fewer GPUs (rank r on device r mod count), the
+                                                              # small collectives over gloo -- exercises the N > 1 code path on a 1-GPU box
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N`, N > 1, typed as it stands: this process has not touched the GPU (and never will);
     the N ranks run under torch.distributed.run as a CHILD process, and its exit code becomes ours."""
-    if torch.cuda.device_count() < n:          # counting devices does not initialise HIP
+    if torch.cuda.device_count() < n and not SHARE_GPU:          # counting devices does not initialise HIP
         raise SystemExit(f"bench.py --gpus {n}: only {torch.cuda.device_count()} ROCm device(s) visible")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -213,15 +217,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device; pypbr_amd has no CPU path")
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank % torch.cuda.device_count() if SHARE_GPU else local_rank)
     torch.cuda.set_device(device)
+    coll = device                                  # where the small collectives' buffers live
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if SHARE_GPU:                              # RCCL refuses two ranks on one device
+            dist.init_process_group("gloo")
+            coll = torch.device("cpu")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     def barrier():
         if distributed:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier() if SHARE_GPU else dist.barrier(device_ids=[local_rank])
 
     # light/view parameters: owned by rank 0, broadcast over RCCL/xGMI (404 B, once per change)
     params = dict(view_dir=VIEW, light=[LIGHT], light_intensity=[INTENSITY], light_size=LIGHT_SIZE)
@@ -264,11 +273,11 @@ def main():
 
     per_rank_us = [kernel_ms * 1e3]
     if distributed:
-        t = torch.tensor([elapsed, cold_s], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed, cold_s], device=coll, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, cold_s = float(t[0].item()), float(t[1].item())
-        gathered = [torch.zeros(1, device=device, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor([kernel_ms * 1e3], device=device, dtype=torch.float64))
+        gathered = [torch.zeros(1, device=coll, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(gathered, torch.tensor([kernel_ms * 1e3], device=coll, dtype=torch.float64))
         per_rank_us = [float(g.item()) for g in gathered]
 
     assert bool(torch.isfinite(plans[0].result).all())
@@ -288,7 +297,7 @@ def main():
             "config": {"workload": f"Batch=1 {args.size}x{args.size} BasecolorMetallicMaterial per GPU, point light, "
                                    f"fused HIP kernel, fp32 maps, sRGB in/out (BASELINE.json configs[1])",
                        "kernel": kernel, "pixels_per_launch": pixels, "bytes_per_pixel": bpp,
-                       "parallelism": f"material-sharded x{world}",
+                       "parallelism": f"material-sharded x{world}" + (" (TEST HOOK: ranks share GPUs, collectives over gloo)" if SHARE_GPU else ""),
                        "timing": f"value/ms_per_step: {args.steps} steps after {args.warmup} warm-up + {args.steps} cold-timed + "
                                  f"{args.settle} clock-settle launches (sustained rate); value_cold/ms_per_step_cold: the "
                                  f"{args.steps} steps right after the {args.warmup} warm-up launches",
@@ -310,7 +319,7 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_passes)
         print(json.dumps(line), flush=True)
     if distributed:
-        dist.barrier(device_ids=[local_rank])
+        barrier()
         dist.destroy_process_group()
 
 

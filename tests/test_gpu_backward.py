@@ -302,3 +302,30 @@ def test_gradient_of_a_light_position_only_and_host_tensors():
     out2 = F.cook_torrance(a.cuda(), n.cuda(), r.cuda(), m.cuda(), view_dir=view, light=L2, light_intensity=inten, light_type="point", light_size=1.0)
     (out2 * wt.cuda()).sum().backward()
     assert torch.equal(L2.grad, L.grad)
+
+
+def test_light_gradients_with_fused_tile_and_fp16_maps():
+    """The light / view adjoints compose with the fused tile() (wrap-around addressing: every output pixel contributes,
+    whatever texel it reads) and with fp16 map storage.  Ground truth: float64 oracle autograd on the materialised repeat
+    / on the exact fp32 up-casts of the fp16 maps."""
+    import torch_oracle as O
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(17)
+    h, w = 12, 20
+    a, n = torch.rand(3, h, w, generator=g), torch.cat([(torch.rand(2, h, w, generator=g) - 0.5), torch.ones(1, h, w)], 0)
+    r, m = torch.rand(1, h, w, generator=g) * 0.7 + 0.3, torch.rand(1, h, w, generator=g)
+    wt = torch.rand(3, 2 * h, 2 * w, generator=g) - 0.4
+    light, view = torch.tensor([0.3, 0.2, 0.8]), torch.tensor([0.0, 0.1, 1.0])
+    for half in (False, True):
+        src = [t.half() for t in (a, n, r, m)] if half else [a, n, r, m]
+        L64, V64 = light.double().requires_grad_(True), view.double().requires_grad_(True)
+        ref = O.cook_torrance(*[t.float().double().repeat(1, 2, 2) for t in src], None, view=V64, light=L64,
+                              intensity=torch.ones(3, dtype=torch.float64), light_type="point", light_size=2.0)
+        (ref * wt.double()).sum().backward()
+        L, V = light.clone().cuda().requires_grad_(True), view.clone().requires_grad_(True)
+        out = F.cook_torrance(*[t.cuda() for t in src], tile=2, view_dir=V, light=L, light_intensity=[1, 1, 1], light_type="point", light_size=2.0)
+        assert out.shape == (3, 2 * h, 2 * w) and (out.detach().cpu() - ref.detach().float()).abs().max().item() <= 1e-5
+        (out * wt.cuda()).sum().backward()
+        for name, got, want in (("light", L.grad.cpu(), L64.grad), ("view", V.grad, V64.grad)):
+            err = (got.double() - want).abs()
+            assert (err <= 2e-5 * (1.0 + want.abs().max())).all(), (half, name, got, want)

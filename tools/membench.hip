@@ -103,6 +103,22 @@ void oneshot_w3(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size
     st<NT>(out + i, r0); st<NT>(out + plane + i, r1); st<NT>(out + 2 * plane + i, r2);
 }
 
+// two 1 KiB pieces per plane and wave (lane l: pieces l and l + 64 of a 2 KiB run): 16 loads in flight per lane, every
+// instruction still covers a contiguous 1 KiB.  WPE waves per SIMD.
+template <bool NT, int FMAS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void oneshot_x2(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size_t plane) {
+    const size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (i + 64 >= nv) return;
+    f4 v[8], w[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { v[c] = ld<NT>(in + c * plane + i); w[c] = ld<NT>(in + c * plane + i + 64); }
+    f4 r0 = work<FMAS>(v[0] + v[3] + v[6], v[6], v[7]), r1 = work<FMAS>(v[1] + v[4] + v[7], v[6], v[7]), r2 = work<FMAS>(v[2] + v[5], v[6], v[7]);
+    f4 q0 = work<FMAS>(w[0] + w[3] + w[6], w[6], w[7]), q1 = work<FMAS>(w[1] + w[4] + w[7], w[6], w[7]), q2 = work<FMAS>(w[2] + w[5], w[6], w[7]);
+    st<NT>(out + i, r0); st<NT>(out + plane + i, r1); st<NT>(out + 2 * plane + i, r2);
+    st<NT>(out + i + 64, q0); st<NT>(out + plane + i + 64, q1); st<NT>(out + 2 * plane + i + 64, q2);
+}
+
 // read-only and write-only ceilings
 template <bool NT> __global__ __launch_bounds__(256) void readonly(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size_t plane) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -173,6 +189,12 @@ int main(int argc, char **argv) {
     W3(oneshot_w3, true, 0); W3(oneshot_ldsdma, true, 0); W3(oneshot_ldsdma, false, 0);
     W3(oneshot_w3, true, 60); W3(oneshot_ldsdma, true, 60);
     W3(oneshot_w3, true, 0); W3(oneshot_ldsdma, true, 0);
+#define X2(WPE, F, LDS) report("oneshot_x2 valu/px=" #F " waves/SIMD=" #WPE " lds=" #LDS, time_us([&](int i) { hipLaunchKernelGGL((oneshot_x2<true, F, WPE>), dim3((nv + 127) / 128), dim3(64), LDS, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
+#define W3L(F, LDS) report("oneshot_w3 valu/px=" #F " lds=" #LDS, time_us([&](int i) { hipLaunchKernelGGL((oneshot_w3<true, F>), dim3((nv + 63) / 64), dim3(64), LDS, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
+    W3L(0, 14848); W3L(60, 14848); W3L(160, 14848);
+    X2(1, 0, 0); X2(2, 0, 0); X2(2, 0, 24576); X2(2, 0, 32768); X2(3, 0, 0);
+    X2(1, 60, 0); X2(2, 60, 0); X2(2, 60, 24576); X2(2, 60, 32768); X2(2, 160, 0); X2(2, 160, 24576);
+    W3L(0, 14848); X2(2, 0, 24576);
 #define PERSIST(NT, F, B, G) report("persistent nt=" #NT " valu/px=" #F " block=" #B " grid=" #G, time_us([&](int i) { hipLaunchKernelGGL((persistent<NT, F, B>), dim3(G), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
     PERSIST(true, 0, 256, 1024); PERSIST(true, 0, 256, 2048);
     PERSIST(true, 60, 256, 2048);

@@ -36,6 +36,7 @@ int g_lds_bytes = -1;
 int g_xcd_log2 = -1;
 int g_bwd_vec = 4;
 int g_batch_inner = -1;
+int g_interleave = 0;
 
 struct KernelEntry { KernelFn fn; const char *name; };
 
@@ -186,6 +187,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_XCD_LOG2: slot = &pbr::g_xcd_log2; break;
         case PBR_TUNE_BWD_VEC: slot = &pbr::g_bwd_vec; break;
         case PBR_TUNE_BATCH_INNER: slot = &pbr::g_batch_inner; break;
+        case PBR_TUNE_INTERLEAVE: slot = &pbr::g_interleave; break;
         default: return -1;
     }
     const int old = *slot;

@@ -61,6 +61,7 @@ struct KArgs {
     int32_t n_tiles;         // tiles_x * ceil(rows / tile rows)
     int32_t xcd_log2;        // workgroup -> tile remap: each XCD takes runs of (1 << xcd_log2) consecutive tiles (0 = identity)
     int32_t xcd_tiles;       // tiles covered by the remap: n_tiles rounded down to a multiple of 8 << xcd_log2
+    int32_t ilv_b, ilv_tiles;// experiment (PBR_TUNE_INTERLEAVE): consecutive workgroups walk ilv_b materials round-robin, ilv_tiles tiles each
     int32_t xpose;           // 8-pixel lanes, fp32 result: exchange the lanes' 16-byte pieces through LDS before storing
     FastDiv div_h;           // row / H
     FastDiv div_tx;          // tile / tiles_x
@@ -189,6 +190,10 @@ __device__ __forceinline__ float linspace_at(float a, float b, float step, int n
 // [x << c, (x + 1) << c) of every block of 8 << c tiles, i.e. (1 KiB << c)-contiguous runs per XCD, while the chip-wide
 // front stays one compact window.  Scalar arithmetic only.
 __device__ __forceinline__ uint32_t tile_of_workgroup(const KArgs &a, uint32_t wg) {
+    if (a.ilv_b > 1) {
+        const uint32_t t = wg / (uint32_t)a.ilv_b, b = wg - t * (uint32_t)a.ilv_b;
+        return b * (uint32_t)a.ilv_tiles + t;
+    }
     if (a.xcd_log2 == 0 || wg >= (uint32_t)a.xcd_tiles) return wg;
     const uint32_t c = (uint32_t)a.xcd_log2, xcd = wg & 7u, slot = wg >> 3;
     return ((slot >> c) << (c + 3)) + (xcd << c) + (slot & ((1u << c) - 1u));

@@ -26,6 +26,7 @@ extern int g_f16_vec;              // pixels per lane for fp16 maps with one lig
 // kernels with no cap.  -1 = that rule; >= 0 = this many bytes for every launch (A/B runs).
 extern int g_lds_bytes;
 extern int g_batch_inner;          // materials per lane of the several-lights kernels: -1 = rule (4 | 2 | off), 0 = off, 2 | 4 = forced
+extern int g_interleave;           // experiment knob: materials of a batch interleaved workgroup by workgroup
 extern int g_bwd_vec;              // pixels per lane of the backward kernels: 4, or 2 (A/B knob)
 extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
 constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
@@ -115,9 +116,10 @@ inline int schedule_xcd_log2(const pbr_render_desc *d, int vec) {
     // Plane strides that are a multiple of 8 MiB put the same offset of all 11 planes of a material onto the same HBM
     // channel group; under the linear order every XCD then works on that group at once.  Runs hand each XCD its own
     // 64 KiB pieces.  Measured (round 2, tools/order_sweep.sh + tune.py, runs vs linear): 8 MiB planes +0.5 %, 16 MiB
-    // +8..10 %, 24 MiB -0.9 %, 32 MiB +4 %, 64 MiB +-0.5 %; other strides prefer the linear order: 4 MiB -3.8 %,
-    // 9 MiB -3.7 %, 36 MiB -1.6 %.
-    if (plane_bytes % (8ll << 20) == 0) return 6;
+    // +8..10 %, 24 MiB -0.9 %, 32 MiB +4 %; other strides prefer the linear order: 4 MiB -3.8 %, 9 MiB -3.7 %,
+    // 36 MiB -1.6 %.  From 64 MiB on (4096^2 planes) the two orders are level for one material (+-0.5 % on four boxes)
+    // and the linear one is 2 % ahead for a batch (4 x 4096^2: 451.9 vs 462.1 us), so the rule stops below that.
+    if (plane_bytes % (8ll << 20) == 0 && plane_bytes < (64ll << 20)) return 6;
     return 0;
 }
 
@@ -143,6 +145,7 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     k.n_tiles = tiles > INT32_MAX ? -1 : (int32_t)tiles;      // -1: more tiles than a 1-D grid holds, rejected by the callers
     k.xcd_log2 = schedule_xcd_log2(d, vec);
     k.xcd_tiles = k.n_tiles < 0 ? 0 : (k.n_tiles >> (k.xcd_log2 + 3)) << (k.xcd_log2 + 3);
+    if (g_interleave && by == 1 && d->batch > 1 && k.n_tiles > 0) { k.ilv_b = d->batch; k.ilv_tiles = k.n_tiles / d->batch; }
     // 8-pixel lanes with an fp32 result swap 16-byte pieces between the lanes of a row before storing (ct_kernel.hpp):
     // only when every row of every tile is full, so that the lane a piece comes from always exists
     k.xpose = vec == 8 && d->out_dtype == PBR_F32 && k.wv % bx == 0;

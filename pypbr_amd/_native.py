@@ -15,7 +15,7 @@ MAX_LIGHTS = 16
 F32, F16 = 0, 1
 LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 WORKFLOW_METALLIC, WORKFLOW_SPECULAR, WORKFLOW_CONVERTED = 0, 1, 2
-TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, TUNE_XCD_LOG2, TUNE_BWD_VEC, TUNE_BATCH_INNER = 0, 1, 2, 3, 4, 5, 6
+TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, TUNE_XCD_LOG2, TUNE_BWD_VEC, TUNE_BATCH_INNER, TUNE_INTERLEAVE = 0, 1, 2, 3, 4, 5, 6, 7
 
 OK = 0
 ERR_NULL_MAP, ERR_WORKFLOW, ERR_LIGHT_TYPE, ERR_SHAPE, ERR_DTYPE, ERR_CHANNELS, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7

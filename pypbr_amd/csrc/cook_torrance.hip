@@ -34,7 +34,7 @@ int g_block_log2 = 6;
 int g_f16_vec = 8;
 int g_lds_bytes = -1;
 int g_xcd_log2 = -1;
-int g_bwd_vec = 4;
+int g_bwd_vec = 0;
 int g_batch_inner = -1;
 int g_interleave = 0;
 

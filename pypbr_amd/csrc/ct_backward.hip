@@ -48,16 +48,19 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
                           (const void *)g_metallic, (const void *)g_specular})
         if (g && (reinterpret_cast<uintptr_t>(g) & 15u)) vec = 1;
     if (vec == 8) vec = 4;
-    // Two pixels per lane where the four-pixel body does not fit two waves per SIMD: with the light / view adjoints
-    // (PGRAD) it needs 256 VGPRs + 40 AGPRs = one wave per SIMD, the two-pixel body 155 = three.  (g_bwd_vec: A/B knob.)
-    if (vec == 4 && (g_bwd_vec == 2 || g_params)) vec = 2;
+    // Two pixels per lane (one packed pair): (a) with the light / view adjoints (PGRAD) the four-pixel body needs 256 VGPRs +
+    // 40 AGPRs = one wave per SIMD, the two-pixel body 155 = three; (b) with fp16 maps and one light the launch is VALU-bound
+    // and the two-pixel body (125 VGPRs, 4 waves per SIMD) runs 155.6 us against 162.6 us on a 4096^2 material (steady state,
+    // tools/bwd_ab.sh); with fp32 maps the four-pixel body wins (209 vs 218 us).  g_bwd_vec: A/B knob (2 | 4 force).
+    const bool f16_one_light = d->map_dtype == PBR_F16 && d->n_lights == 1;
+    if (vec == 4 && (g_bwd_vec == 2 || g_params || (f16_one_light && g_bwd_vec != 4))) vec = 2;
     KArgs k;
     fill_args(d, vec, k);
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
     k.o_cs = (int64_t)d->height * d->width; k.o_bs = 3 * k.o_cs;     // grad_out and the g_* are contiguous, whatever `out` was
     const BArgs b = {grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, static_cast<float *>(workspace)};
-    const BwdFn fn = g_params ? pick_bwd<true>(d, vec) : pick_bwd<false>(d, vec);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const BwdFn fn = g_params ? pick_bwd<true>(d, vec) : pick_bwd<false>(d, vec);
     hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0, st, k, b);
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return 1000 + (int)err;

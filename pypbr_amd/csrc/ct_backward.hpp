@@ -185,44 +185,14 @@ __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const Li
     }
 }
 
-//   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_*    VEC: 4 | 1    TM: storage type of the maps AND of their gradients
-//   (float | __half; arithmetic and the upstream gradient are fp32)
-//   PGRAD: also the adjoints of view / light / intensity, summed over the workgroup's pixels into b.g_param_partials
-//   (one row per workgroup; param_grad_finish_kernel adds the rows up).  In these instantiations no lane leaves early:
-//   lanes outside the map shade a clamped (valid) position with a zero upstream gradient, so that every lane takes
-//   part in the wave reductions.
-template <int LIGHT, int WF, int VEC, bool MULTI, typename TM = float, bool PGRAD = false>
-__global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
-    // Packed two-pixel arithmetic for fp16 maps and for several lights, as in the forward kernels: A/B on 4096^2 maps --
-    // fp16 maps 182 us packed vs 194 us scalar; 4 lights fp32 423 us vs 491 us; one light fp32 221 us packed vs 206 us
-    // scalar (that launch is bound by the memory system, and there the shorter arithmetic phases only make its 19
-    // streams burstier).
+// Everything after the loads: forward re-evaluation, chain rule, stores.  `t` holds the lane's texels (as floats), `go` the
+// upstream gradient.  s_param / n_param: the PGRAD instantiations' LDS accumulators.
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD>
+__device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, const LanePos &p, Texels<VEC> &t, float (&go)[3][VEC],
+                                              float *s_param, int n_param) {
     constexpr bool kPacked = sizeof(TM) == 2 || MULTI;
     using R = typename RealOf<VEC, kPacked>::type;
     constexpr int NG = RealOf<VEC, kPacked>::N;
-    const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
-    const int ty = (int)a.div_tx.div(tile);
-    const LanePos p = lane_pos<VEC, PGRAD>(a, (int)tile - ty * a.tiles_x, ty);
-    if (!PGRAD && !p.valid) return;
-    constexpr int kParamSlots = 3 + 6 * PBR_MAX_LIGHTS;
-    __shared__ float s_param[PGRAD ? kParamSlots : 1];
-    const int n_param = 3 + 6 * a.n_lights;
-    if constexpr (PGRAD) {
-        for (int i = threadIdx.x; i < n_param; i += blockDim.x) s_param[i] = 0.0f;
-        __syncthreads();
-    }
-    Texels<VEC> t;
-    load_texels<WF, TM, VEC, true>(a, a.has_normal != 0, p, t);
-    float go[3][VEC];
-    const int64_t opix = p.b * a.o_bs + p.pix;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) Ld<float, VEC>::template load<true>(b.gout, opix + c * a.o_cs, go[c]);
-    if (PGRAD && !p.valid) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) go[c][j] = 0.0f;
-    }
     float accV[3] = {0.0f, 0.0f, 0.0f}, accL[3] = {0.0f, 0.0f, 0.0f}, accI[3] = {0.0f, 0.0f, 0.0f};   // one-light PGRAD
     if (!a.has_normal) {
 #pragma unroll
@@ -384,6 +354,44 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
 #pragma unroll
         for (int c = 0; c < 3; ++c) Ld<TM, VEC>::template store<true>(b.g_spec, gp3 + c * a.o_cs, gs[c]);
     }
+}
+
+//   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_*    VEC: 4 | 2 | 1    TM: storage type of the maps AND of their gradients
+//   (float | __half; arithmetic and the upstream gradient are fp32)
+//   PGRAD: also the adjoints of view / light / intensity, summed over the workgroup's pixels into b.g_param_partials
+//   (one row per workgroup; param_grad_finish_kernel adds the rows up).  In these instantiations no lane leaves early:
+//   lanes outside the map shade a clamped (valid) position with a zero upstream gradient, so that every lane takes
+//   part in the wave reductions.
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM = float, bool PGRAD = false>
+__global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
+    // Packed two-pixel arithmetic for fp16 maps and for several lights, as in the forward kernels: A/B on 4096^2 maps --
+    // fp16 maps 182 us packed vs 194 us scalar; 4 lights fp32 423 us vs 491 us; one light fp32 221 us packed vs 206 us
+    // scalar (that launch is bound by the memory system, and there the shorter arithmetic phases only make its 19
+    // streams burstier).
+    const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
+    const int ty = (int)a.div_tx.div(tile);
+    const LanePos p = lane_pos<VEC, PGRAD>(a, (int)tile - ty * a.tiles_x, ty);
+    if (!PGRAD && !p.valid) return;
+    constexpr int kParamSlots = 3 + 6 * PBR_MAX_LIGHTS;
+    __shared__ float s_param[PGRAD ? kParamSlots : 1];
+    const int n_param = 3 + 6 * a.n_lights;
+    if constexpr (PGRAD) {
+        for (int i = threadIdx.x; i < n_param; i += blockDim.x) s_param[i] = 0.0f;
+        __syncthreads();
+    }
+    Texels<VEC> t;
+    load_texels<WF, TM, VEC, true>(a, a.has_normal != 0, p, t);
+    float go[3][VEC];
+    const int64_t opix = p.b * a.o_bs + p.pix;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Ld<float, VEC>::template load<true>(b.gout, opix + c * a.o_cs, go[c]);
+    if (PGRAD && !p.valid) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) go[c][j] = 0.0f;
+    }
+    backward_body<LIGHT, WF, VEC, MULTI, TM, PGRAD>(a, b, p, t, go, s_param, n_param);
 }
 
 // Adds up the per-workgroup rows of the PGRAD kernels (fp64 sums, fixed order: deterministic) and applies the part of

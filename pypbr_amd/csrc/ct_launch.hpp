@@ -27,7 +27,7 @@ extern int g_f16_vec;              // pixels per lane for fp16 maps with one lig
 extern int g_lds_bytes;
 extern int g_batch_inner;          // materials per lane of the several-lights kernels: -1 = rule (4 | 2 | off), 0 = off, 2 | 4 = forced
 extern int g_interleave;           // experiment knob: materials of a batch interleaved workgroup by workgroup
-extern int g_bwd_vec;              // pixels per lane of the backward kernels: 4, or 2 (A/B knob)
+extern int g_bwd_vec;              // pixels per lane of the backward kernels: 0 = rule (ct_backward.hip), 2 | 4 = forced (A/B)
 extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
 constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
 

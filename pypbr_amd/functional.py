@@ -339,9 +339,12 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
     view_dir, light, light_intensity (required), light_type="point", light_size=None,
     albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True,
     convert_to_diffuse_specular=False, y_offset=0, height_total=None, out_dtype=None, out=None,
-    schedule=0, autotune=False, tile=1, rows=None (see `plan_cook_torrance`).
+    schedule=0, autotune=False, tile=1, rows=None, blend=None, blend_flags=None (see `plan_cook_torrance`).
     Returns [3,H,W] or [B,3,H,W] (float32 unless `out_dtype`), on the same device,
-    enqueued on the current stream without synchronising.
+    enqueued on the current stream without synchronising.  Differentiable with respect to the maps and to
+    view_dir / light / light_intensity when those are tensors that require grad (backward kernels); the plain
+    evaluation goes through `torch.ops.pbr_hip.cook_torrance` when that extension is built, through the ctypes
+    binding of the same C ABI otherwise (and for out= / schedule= / autotune= / blend=).
     """
     if kwargs.get("blend") is not None and torch.is_grad_enabled() and any(
             isinstance(t, torch.Tensor) and t.requires_grad

@@ -89,7 +89,7 @@ if want("fwd_f16"):
     del h, p, p2, p16
 if want("bwd"):
     for dtype, tag, kern in ((torch.float32, "bwd_f32", "cook_torrance_backward_kernel<1, 0, 4, false, float, false>"),
-                             (torch.float16, "bwd_f16", "cook_torrance_backward_kernel<1, 0, 4, false, __half, false>")):
+                             (torch.float16, "bwd_f16", "cook_torrance_backward_kernel<1, 0, 2, false, __half, false>")):
         maps = [t.to(dtype) for t in synth_material(S, DEV, 7)]
         plan = F.plan_cook_torrance(*maps, **PT)
         gout = torch.rand(1, 3, S, S, device=DEV)

@@ -426,3 +426,29 @@ def test_torch_ops_are_registered_with_fake_kernels():
         assert d.shape == s.shape == a.shape
     with pytest.raises(NotImplementedError):          # no CPU kernels: the product has no CPU path
         torch.ops.pbr_hip.srgb_to_linear(torch.rand(3, 4, 4))
+
+
+def test_pack_maps_layouts_on_the_host():
+    """pack_maps is pure data movement, so its layouts are checkable without a GPU: values preserved, every map 256-byte
+    aligned inside ONE allocation, rows dense; the optional plane skew (off by default) only changes the plane pitch."""
+    g = torch.Generator().manual_seed(0)
+    a, r = torch.rand(2, 3, 8, 16, generator=g), torch.rand(2, 1, 8, 16, generator=g)
+    pa, pn, pr, out = F.pack_maps(a, None, r, reserve_output=True)
+    assert pn is None and torch.equal(pa, a) and torch.equal(pr, r) and out.shape == (2, 3, 8, 16) and out.dtype == torch.float32
+    base = pa.untyped_storage().data_ptr()
+    assert pr.untyped_storage().data_ptr() == base == out.untyped_storage().data_ptr()
+    assert all(t.data_ptr() % 256 == 0 and t.stride(-1) == 1 and t.stride(-2) == 16 for t in (pa, pr, out)) and pa.is_contiguous()
+    big = torch.rand(3, 2048, 1024, generator=g)                      # 8 MiB planes: the size the skew option applies to
+    old = F.PLANE_SKEW_BYTES
+    try:
+        F.PLANE_SKEW_BYTES = 4352
+        (skewed,) = F.pack_maps(big)
+        assert torch.equal(skewed, big) and skewed.stride() == (2048 * 1024 + 1088, 1024, 1) and not skewed.is_contiguous()
+        (small,) = F.pack_maps(a)                                       # other plane sizes stay dense
+        assert small.is_contiguous()
+    finally:
+        F.PLANE_SKEW_BYTES = old
+    (dense,) = F.pack_maps(big)
+    assert dense.is_contiguous() and torch.equal(dense, big)
+    pm = F.pack_maps(a, None, r, reserve_output=True, material_major=True)
+    assert torch.equal(pm[0], a) and torch.equal(pm[2], r) and pm[0].stride(0) == pm[2].stride(0) == pm[3].stride(0)

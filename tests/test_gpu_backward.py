@@ -329,3 +329,30 @@ def test_light_gradients_with_fused_tile_and_fp16_maps():
         for name, got, want in (("light", L.grad.cpu(), L64.grad), ("view", V.grad, V64.grad)):
             err = (got.double() - want).abs()
             assert (err <= 2e-5 * (1.0 + want.abs().max())).all(), (half, name, got, want)
+
+
+@pytest.mark.parametrize("quirk", [True, False])
+@pytest.mark.parametrize("light_type,light,size", [("point", [0.1, 0.1, 1.0], 1.0), ("directional", [0.3, -0.2, 1.0], None)])
+def test_gradients_through_the_fused_conversion_and_without_a_normal_map(quirk, light_type, light, size):
+    """CONVERTED workflow (to_diffuse_specular_material fused in front, metallic.py:98-108, both settings of the upstream
+    specular_is_srgb quirk) and the +Z default normal (cooktorrance.py:147-152): gradients w.r.t. the metallic-workflow maps
+    against float64 autograd through the oracle's composition of the same reference steps."""
+    import torch_oracle as O
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(23)
+    H, W = 20, 36
+    a, r, m = torch.rand(3, H, W, generator=g), torch.rand(1, H, W, generator=g) * 0.7 + 0.3, torch.rand(1, H, W, generator=g)
+    wt = torch.rand(3, H, W, generator=g) - 0.4
+    okw = dict(view=torch.tensor([0.0, 0.1, 1.0], dtype=torch.float64), light=torch.tensor(light, dtype=torch.float64),
+               intensity=torch.tensor([0.9, 0.8, 0.7], dtype=torch.float64), light_type=light_type, light_size=size)
+    leaves64 = [t.double().requires_grad_(True) for t in (a, r, m)]
+    ref = O.cook_torrance_converted(leaves64[0], None, leaves64[1], leaves64[2], quirk_specular_srgb=quirk, **okw)
+    (ref * wt.double()).sum().backward()
+    leaves = [t.clone().cuda().requires_grad_(True) for t in (a, r, m)]
+    out = F.cook_torrance(leaves[0], None, leaves[1], leaves[2], view_dir=[0.0, 0.1, 1.0], light=light, light_intensity=[0.9, 0.8, 0.7],
+                          light_type=light_type, light_size=size, convert_to_diffuse_specular=True, specular_is_srgb=quirk)
+    assert (out.detach().cpu() - ref.detach().float()).abs().max().item() <= 1e-5
+    (out * wt.cuda()).sum().backward()
+    for name, x, y in zip(("albedo", "roughness", "metallic"), leaves, leaves64):
+        err = (x.grad.cpu().double() - y.grad).abs()
+        assert (err <= 2e-5 * (1 + y.grad.abs())).all(), (name, float(err.max()))

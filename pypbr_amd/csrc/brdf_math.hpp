@@ -56,6 +56,7 @@ __device__ __forceinline__ float select_(bool m, float a, float b) { return m ? 
 __device__ __forceinline__ bool gt_(float a, float b) { return a > b; }
 __device__ __forceinline__ bool le_(float a, float b) { return a <= b; }
 __device__ __forceinline__ bool ge_(float a, float b) { return a >= b; }
+__device__ __forceinline__ bool eq_(float a, float b) { return a == b; }
 __device__ __forceinline__ bool and_(bool a, bool b) { return a && b; }
 
 // ---- two pixels per lane: +, -, * on f32x2 compile to v_pk_add/mul_f32, fma to v_pk_fma_f32
@@ -92,6 +93,7 @@ __device__ __forceinline__ f32x2 select_(i32x2 m, f32x2 a, f32x2 b) { return m ?
 __device__ __forceinline__ i32x2 gt_(f32x2 a, f32x2 b) { return a > b; }
 __device__ __forceinline__ i32x2 le_(f32x2 a, f32x2 b) { return a <= b; }
 __device__ __forceinline__ i32x2 ge_(f32x2 a, f32x2 b) { return a >= b; }
+__device__ __forceinline__ i32x2 eq_(f32x2 a, f32x2 b) { return a == b; }
 __device__ __forceinline__ i32x2 and_(i32x2 a, i32x2 b) { return a & b; }
 
 template <class R> __device__ __forceinline__ R splat(float v);

@@ -48,6 +48,8 @@ template <class R> __device__ __forceinline__ MaskT<R> in_unit(R x) {
     return and_(ge_(x, splat<R>(0.0f)), le_(x, splat<R>(1.0f)));
 }
 template <class R> __device__ __forceinline__ R masked(MaskT<R> m, R x) { return select_(m, x, splat<R>(0.0f)); }
+// 0 <= x <= 1 given clamp01(x), which the forward terms already hold: one compare per value instead of two.
+template <class R> __device__ __forceinline__ MaskT<R> in_unit(R x, R clamped) { return eq_(clamped, x); }
 
 // d/dx of utils.srgb_to_linear (functions.py:31-47): clamp (closed interval), branch, clamp.
 template <class R> __device__ __forceinline__ R srgb_to_linear_grad(R x) {
@@ -63,7 +65,7 @@ template <class R> __device__ __forceinline__ void srgb_to_linear_and_grad(R x, 
     const R e = exp2_hw(fma_(splat<R>(1.4f), log2_hw(u), splat<R>(-0.10814020f) /* 1.4*log2(1.055) */));
     const MaskT<R> low = le_(t, splat<R>(0.04045f));
     value = select_(low, t * (1.0f / 12.92f), (e * u) * (1.0f / 1.055f));
-    slope = masked(in_unit(x), select_(low, splat<R>(1.0f / 12.92f), e * 2.2748815f /* 2.4/1.055 */));
+    slope = masked(in_unit(x, t), select_(low, splat<R>(1.0f / 12.92f), e * 2.2748815f /* 2.4/1.055 */));
 }
 
 // d/dc of utils.linear_to_srgb (functions.py:50-66) for c already in [0,1].
@@ -76,7 +78,7 @@ template <class R> __device__ __forceinline__ R linear_to_srgb_grad_unit(R c) {
 template <class R> struct LightEvalT {
     R ndl_raw, ndl, c, s2, den, dl, dD, ds, q, dg, rad;
     MaskT<R> nh_pos;
-    R F[3], u[3];
+    R F[3], u[3], uc[3];      // uc = clamp01(u): the light's clamped contribution, also the test of the clamp's sub-gradient
 };
 
 template <class R>
@@ -96,6 +98,7 @@ __device__ __forceinline__ void eval_light(const PixelTermsT<R> &t, const LightG
     for (int ch = 0; ch < 3; ++ch) {
         e.F[ch] = fma_(t.f0[ch], g.om5, g.p5);
         e.u[ch] = fma_(e.F[ch], e.dg - t.kb[ch], t.kb[ch]) * (e.rad * inten[ch]);
+        e.uc[ch] = clamp01(e.u[ch]);
     }
 }
 
@@ -115,7 +118,7 @@ __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const Li
     R g_dg = splat<R>(0.0f), g_rad = splat<R>(0.0f), g_p5 = splat<R>(0.0f);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const R gu = masked(in_unit(e.u[ch]), g_col[ch]);                    // clamp :177
+        const R gu = masked(in_unit(e.u[ch], e.uc[ch]), g_col[ch]);          // clamp :177
         const R S = fma_(e.F[ch], e.dg - t.kb[ch], t.kb[ch]);                // F dg + (1 - F) kb
         const R gS = gu * (e.rad * inten[ch]);
         g_rad = fma_(gu * S, splat<R>(inten[ch]), g_rad);
@@ -153,7 +156,7 @@ __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const Li
     g_ndl = fma_(g_ds, t.ndv * 4.0f, g_ndl);
     adj.g_ndv = adj.g_ndv + g_ndv;                                           // N.V does not depend on the light
     // dots -> unit normal (clamps pass on the closed interval); c = N . h / |h|
-    const R gl = masked(in_unit(e.ndl_raw), g_ndl);
+    const R gl = masked(in_unit(e.ndl_raw, e.ndl), g_ndl);
     const R gch = g_c * sqrt_hw(g.rhh);
     adj.g_n.x = fma_(gl, g.L.x, fma_(gch, g.h.x, adj.g_n.x));
     adj.g_n.y = fma_(gl, g.L.y, fma_(gch, g.h.y, adj.g_n.y));
@@ -251,7 +254,7 @@ __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, co
                 LightEvalT<R> e;
                 eval_light(pt, light_geom<LIGHT, R>(lu, V, xs, ys), lu.inten, e);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) sum[c] = sum[c] + clamp01(e.u[c]);
+                for (int c = 0; c < 3; ++c) sum[c] = sum[c] + e.uc[c];
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -272,7 +275,7 @@ __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, co
             if (!MULTI) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(clamp01(e.u[c])) : gout_c[c];
+                    g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
             }
             LightParamAdjT<R> pa;
             backprop_light<LIGHT, PGRAD>(pt, lg, lu.inten, e, g_col, adj, V, pa);
@@ -313,7 +316,7 @@ __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, co
         scatter(gm, g, g_m);
         scatter(gr, g, fma_(adj.g_k, (rough + 1.0f) * 0.25f, adj.g_a2 * (rough * 2.0f)));   // k = (r+1)^2/8, a2 = r^2
         // N.V clamp, then F.normalize: g_n = (g - n (n.g)) / |n|
-        const R gv = masked(in_unit(pt.ndv_raw), adj.g_ndv);
+        const R gv = masked(in_unit(pt.ndv_raw, pt.ndv), adj.g_ndv);
         if constexpr (PGRAD) {                                                // N.V (:163): the direct share of V
             accV[0] += hsum(gv * pt.n.x); accV[1] += hsum(gv * pt.n.y); accV[2] += hsum(gv * pt.n.z);
         }

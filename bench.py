@@ -180,6 +180,8 @@ def timed_region(plans, steps, stream, barrier, offset=0):
     for i in range(steps):
         plans[(offset + i) % N_BUFFER_SETS].launch(stream)
     ev1.record()
+    while not ev1.query():                         # spin on the end event: a blocking wait adds tens of microseconds of wake-up
+        pass                                       # latency, which is 1-2 % of a 20-step region
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0             # this rank's K steps; MAX over ranks by the caller
     barrier()

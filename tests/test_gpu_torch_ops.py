@@ -127,3 +127,34 @@ def test_traces_through_aot_autograd():
     assert torch.equal(got, eager)
     for t, w in zip((a, n, r, m), want):
         assert torch.equal(t.grad, w)
+
+
+def test_operator_errors_match_the_reference_shaped_exceptions():
+    """Same exception types through the operator as through the ctypes plan (and as the reference raises where it has the
+    check): ValueError for a missing workflow map / bad shapes / bad light type, TypeError for mixed dtypes, RuntimeError
+    for maps that are not on a device."""
+    from pypbr_amd import functional as F
+    a, n, r, m, _ = _maps(1, 16, 24, 31)
+    kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1])
+    with pytest.raises(ValueError, match="either 'metallic' or 'specular'"):
+        F.cook_torrance(a, n, r, None, None, **kw)
+    with pytest.raises(ValueError, match="Unsupported light_type"):
+        F.cook_torrance(a, n, r, m, light_type="spot", **kw)
+    with pytest.raises(ValueError):
+        F.cook_torrance(a, n, r[..., :8], m, **kw)
+    with pytest.raises(TypeError):
+        F.cook_torrance(a, n.half(), r, m, **kw)
+    with pytest.raises(ValueError):
+        F.cook_torrance(a, n, r, m, view_dir=[0, 0, 1], light=[[0, 0, 1]] * 17, light_intensity=[1, 1, 1])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        F.cook_torrance(a.cpu(), n.cpu(), r.cpu(), m.cpu(), **kw)
+    with pytest.raises(TypeError):
+        F.cook_torrance(a, n, r, m, bogus_keyword=1, **kw)
+    # directly at the operator: the same checks live in C++ (TORCH_CHECK_VALUE / _TYPE)
+    v, l, i = torch.tensor([0.0, 0.0, 1.0]), torch.tensor([[0.1, 0.1, 1.0]]), torch.ones(1, 3)
+    with pytest.raises(ValueError):
+        torch.ops.pbr_hip.cook_torrance(a, n, r, None, None, v, l, i, 1.0, 1, True, True, False, True)
+    with pytest.raises(ValueError):
+        torch.ops.pbr_hip.cook_torrance(a, n, r, m, None, v, l, i, 1.0, 7, True, True, False, True)
+    with pytest.raises(TypeError):
+        torch.ops.pbr_hip.cook_torrance(a, n, r.double(), m, None, v, l, i, 1.0, 1, True, True, False, True)

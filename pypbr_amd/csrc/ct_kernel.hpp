@@ -457,6 +457,8 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
             f32x4 (*xp)[3][144] = reinterpret_cast<f32x4 (*)[3][144]>(xp_all);   // [wave of the workgroup][plane][64 + 8 pad + 64 + 8]
             const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
             const int bx = 1 << a.bx_log2, col = lane & (bx - 1), row0 = lane - col;
+            // lanes of this row that exist (the last tile of a row may be partial): its 2 nvt pieces are dealt to them
+            const int nvt = min(bx, a.wv - (p.x / VEC - col));
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float o[VEC];
@@ -473,9 +475,9 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
             for (int c = 0; c < 3; ++c) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const int q = s2 * bx + col;                              // piece index inside the row
+                    const int q = s2 * nvt + col;                             // piece index inside the row
                     const f32x4 v = xp[wave][c][(q & 1) * 72 + row0 + (q >> 1)];
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + base + c * a.o_cs + 4 * s2 * bx);
+                    f32x4 *dst = reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + base + c * a.o_cs + 4 * s2 * nvt);
                     if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
                 }
             }

@@ -146,9 +146,8 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     k.xcd_log2 = schedule_xcd_log2(d, vec);
     k.xcd_tiles = k.n_tiles < 0 ? 0 : (k.n_tiles >> (k.xcd_log2 + 3)) << (k.xcd_log2 + 3);
     if (g_interleave && by == 1 && d->batch > 1 && k.n_tiles > 0) { k.ilv_b = d->batch; k.ilv_tiles = k.n_tiles / d->batch; }
-    // 8-pixel lanes with an fp32 result swap 16-byte pieces between the lanes of a row before storing (ct_kernel.hpp):
-    // only when every row of every tile is full, so that the lane a piece comes from always exists
-    k.xpose = vec == 8 && d->out_dtype == PBR_F32 && k.wv % bx == 0;
+    // 8-pixel lanes with an fp32 result swap 16-byte pieces between the lanes of a row before storing (ct_kernel.hpp)
+    k.xpose = vec == 8 && d->out_dtype == PBR_F32;
     k.div_h.init((uint32_t)d->height);
     k.div_tx.init((uint32_t)k.tiles_x);
     k.tiled = is_tiled(d);

@@ -452,3 +452,15 @@ def test_pack_maps_layouts_on_the_host():
     assert dense.is_contiguous() and torch.equal(dense, big)
     pm = F.pack_maps(a, None, r, reserve_output=True, material_major=True)
     assert torch.equal(pm[0], a) and torch.equal(pm[2], r) and pm[0].stride(0) == pm[2].stride(0) == pm[3].stride(0)
+
+
+def test_bench_parent_process_refuses_more_ranks_than_devices_without_touching_the_gpu():
+    """`python bench.py --gpus N` (N > 1) starts its own ranks; with fewer devices than ranks the PARENT says so and exits
+    (it only counts devices, which does not initialise HIP) instead of printing a usage message for torchrun."""
+    if torch.cuda.device_count() >= 4:
+        pytest.skip("box has 4+ devices")
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PBR_BENCH_SHARE_GPU")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode != 0 and "only %d ROCm device(s) visible" % torch.cuda.device_count() in (run.stderr + run.stdout)

@@ -323,6 +323,33 @@ def grad_set(manifest):
     manifest["sets"]["grad"] = {k: _entry(v) for k, v in d.items()}
 
 
+def grad_param_set(manifest):
+    """Gradients of the REAL reference w.r.t. view_dir / light_dir_or_position / light_intensity (its forward is plain torch
+    ops on them, cooktorrance.py:95-96, :126-140): loss = sum(out * W), fp32 and float64 runs, the maps of grad.npz."""
+    z = dict(np.load(os.path.join(GOLDEN, "grad.npz")))
+    T = torch.from_numpy
+    a, n, r, m, s, wt = (T(z["in_" + k]) for k in ("albedo", "normal", "roughness", "metallic", "specular", "weight"))
+    view, inten = [0.05, 0.1, 0.9], [0.9, 0.8, 0.7]               # not unit length, not grey
+    d = {"in_view": np.array(view, np.float32), "in_intensity": np.array(inten, np.float32)}
+    for kind in ("metallic", "specular"):
+        for lk in ("pt1", "dir"):
+            ltype, lvec, lsize = LIGHTS[lk]
+            for dtype, pre in ((torch.float32, "grad"), (torch.float64, "g64")):
+                mat = make_material(kind, a, n, r, m, s, dtype=torch.float64) if dtype == torch.float64 else make_material(kind, a, n, r, m, s)
+                V = torch.tensor(view, dtype=dtype, requires_grad=True)
+                L = torch.tensor(lvec, dtype=dtype, requires_grad=True)
+                I = torch.tensor(inten, dtype=dtype, requires_grad=True)
+                out = CookTorranceBRDF(light_type=ltype)(mat, V, L, I, lsize, return_srgb=True)
+                assert out.dtype == dtype
+                (out * wt.to(dtype)).sum().backward()
+                if dtype == torch.float32:
+                    d[f"out_{kind}_{lk}"] = out.detach().numpy()
+                for name, leaf in (("view", V), ("light", L), ("intensity", I)):
+                    d[f"{pre}_{kind}_{lk}_{name}"] = leaf.grad.numpy()
+    np.savez(os.path.join(GOLDEN, "grad_params.npz"), **d)
+    manifest["sets"]["grad_params"] = {k: _entry(v) for k, v in d.items()}
+
+
 def example_blend_set(manifest):
     """examples/example_blend.py, literally: load `tiles` and `rocks` (PNG data fixtures under tests/golden/), HeightBlend(0.1,
     -0.5), resize((512,512)), tile(2), point-light render.  Only the maps the metallic workflow loads are copied for `rocks`."""
@@ -391,6 +418,20 @@ def blend_set(manifest):
     manifest["sets"]["blend"] = {k: _entry(v) for k, v in d.items()}
 
 
+def only_grad_params():
+    """`python oracle/gen_golden.py --only grad_params`: adds tests/golden/grad_params.npz and its MANIFEST entries without
+    touching the other fixtures (they are byte-for-byte what earlier rounds committed)."""
+    path = os.path.join(GOLDEN, "MANIFEST.json")
+    with open(path) as f:
+        manifest = json.load(f)
+    assert manifest["torch"] == torch.__version__, "regenerate everything on a new torch build"
+    torch.set_num_threads(manifest["aten_threads"])
+    grad_param_set(manifest)
+    with open(path, "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("grad_params.npz written:", sorted(manifest["sets"]["grad_params"])[:6], "...")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -432,4 +473,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:3] == ["--only", "grad_params"]:
+        only_grad_params()
+    else:
+        main()

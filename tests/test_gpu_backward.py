@@ -356,3 +356,30 @@ def test_gradients_through_the_fused_conversion_and_without_a_normal_map(quirk, 
     for name, x, y in zip(("albedo", "roughness", "metallic"), leaves, leaves64):
         err = (x.grad.cpu().double() - y.grad).abs()
         assert (err <= 2e-5 * (1 + y.grad.abs())).all(), (name, float(err.max()))
+
+
+@pytest.mark.parametrize("kind", ["metallic", "specular"])
+@pytest.mark.parametrize("lk", ["pt1", "dir"])
+def test_light_view_intensity_gradients_match_the_reference_autograd(kind, lk, golden):
+    """tests/golden/grad_params.npz: the REAL reference's autograd gradients w.r.t. view_dir / light_dir_or_position /
+    light_intensity on the maps of grad.npz (oracle/gen_golden.py --only grad_params)."""
+    from pypbr_amd import functional as F
+    z, zg = golden("grad_params"), golden("grad")
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    a, n, r = dev(zg["in_albedo"]), dev(zg["in_normal"]), dev(zg["in_roughness"])
+    m = dev(zg["in_metallic"]) if kind == "metallic" else None
+    s = dev(zg["in_specular"]) if kind == "specular" else None
+    ltype, lvec, lsize = LIGHTS[lk]
+    V = torch.tensor([0.05, 0.1, 0.9], requires_grad=True)
+    L = torch.tensor(lvec, device="cuda", requires_grad=True)
+    I = torch.tensor([0.9, 0.8, 0.7], requires_grad=True)
+    out = F.cook_torrance(a, n, r, m, s, view_dir=V, light=L, light_intensity=I, light_type=ltype, light_size=lsize)
+    assert (out.detach().cpu().numpy() - z[f"out_{kind}_{lk}"]).__abs__().max() <= 1e-5
+    (out * dev(zg["in_weight"])).sum().backward()
+    for name, leaf in (("view", V), ("light", L), ("intensity", I)):
+        g = leaf.grad.cpu().double().numpy()
+        ref32, ref64 = z[f"grad_{kind}_{lk}_{name}"].astype(np.float64), z[f"g64_{kind}_{lk}_{name}"]
+        band = 2e-5 * (1.0 + np.abs(ref64).max())
+        assert (np.abs(g - ref64) <= band).all(), (name, g, ref64)
+        # never further from the float64 gradient than the reference's own fp32 gradient is, plus the band
+        assert (np.abs(g - ref32) <= np.abs(ref32 - ref64) + band).all(), (name, g, ref32)

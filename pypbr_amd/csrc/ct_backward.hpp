@@ -42,6 +42,27 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Sums EIGHT values over the wave with 10 exchanges instead of 48: three halving steps (lanes whose bit 5 / 4 / 3 is set keep
+// the upper half of the values and send the lower one, the others the opposite), then a 3-step butterfly on the one value
+// left.  Lane l ends up with the wave total of value number (l >> 3) & 7, the same in all 8 lanes that share those bits.
+template <int C, int M>
+__device__ __forceinline__ void wave_halve(float (&v)[8], bool up) {     // C values -> C / 2: exchange across lane bit M
+#pragma unroll
+    for (int j = 0; j < C / 2; ++j) {
+        const float keep = up ? v[j + C / 2] : v[j], send = up ? v[j] : v[j + C / 2];
+        v[j] = keep + __shfl_xor(send, M, 64);
+    }
+}
+__device__ __forceinline__ float wave_sum8(float (&v)[8]) {
+    const int lane = threadIdx.x & 63;
+    wave_halve<8, 32>(v, (lane & 32) != 0);
+    wave_halve<4, 16>(v, (lane & 16) != 0);
+    wave_halve<2, 8>(v, (lane & 8) != 0);
+    float t = v[0];
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    return t;
+}
 
 template <class R> using MaskT = typename MaskOf<R>::type;
 template <class R> __device__ __forceinline__ MaskT<R> in_unit(R x) {
@@ -282,12 +303,11 @@ __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, co
             if constexpr (PGRAD) {
                 accV[0] += hsum(pa.g_V.x); accV[1] += hsum(pa.g_V.y); accV[2] += hsum(pa.g_V.z);
                 if constexpr (MULTI) {        // per-light sums leave the lane here: the light loop is a run-time loop
-                    const float v6[6] = {hsum(pa.g_L.x), hsum(pa.g_L.y), hsum(pa.g_L.z), hsum(pa.g_I[0]), hsum(pa.g_I[1]), hsum(pa.g_I[2])};
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        const float w = wave_sum(v6[j]);
-                        if ((threadIdx.x & 63) == 0) atomicAdd(&s_param[j < 3 ? 3 + 3 * l + j : 3 + 3 * a.n_lights + 3 * l + (j - 3)], w);
-                    }
+                    float v8[8] = {hsum(pa.g_L.x), hsum(pa.g_L.y), hsum(pa.g_L.z), hsum(pa.g_I[0]), hsum(pa.g_I[1]), hsum(pa.g_I[2]), 0.0f, 0.0f};
+                    const float w = wave_sum8(v8);
+                    const int j = (threadIdx.x >> 3) & 7;                    // the value this lane holds the wave total of
+                    if ((threadIdx.x & 7) == 0 && j < 6)
+                        atomicAdd(&s_param[j < 3 ? 3 + 3 * l + j : 3 + 3 * a.n_lights + 3 * l + (j - 3)], w);
                 } else {
                     accL[0] += hsum(pa.g_L.x); accL[1] += hsum(pa.g_L.y); accL[2] += hsum(pa.g_L.z);
                     accI[0] += hsum(pa.g_I[0]); accI[1] += hsum(pa.g_I[1]); accI[2] += hsum(pa.g_I[2]);
@@ -328,13 +348,15 @@ __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, co
         scatter(gn[2], g, (gnh.z - pt.n.z * radial) * rn);
     }
     if constexpr (PGRAD) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float wv = wave_sum(accV[j]);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&s_param[j], wv);
+        {   // slots 0..2 = V; one light: 3..5 = L, 6..8 = I (n_param = 9), so values 0..7 of the first batch map to slots 0..7
+            float v8[8] = {accV[0], accV[1], accV[2], MULTI ? 0.0f : accL[0], MULTI ? 0.0f : accL[1], MULTI ? 0.0f : accL[2],
+                           MULTI ? 0.0f : accI[0], MULTI ? 0.0f : accI[1]};
+            const float w = wave_sum8(v8);
+            const int j = (threadIdx.x >> 3) & 7;
+            if ((threadIdx.x & 7) == 0 && j < (MULTI ? 3 : 8)) atomicAdd(&s_param[j], w);
             if constexpr (!MULTI) {
-                const float wl = wave_sum(accL[j]), wi = wave_sum(accI[j]);
-                if ((threadIdx.x & 63) == 0) { atomicAdd(&s_param[3 + j], wl); atomicAdd(&s_param[6 + j], wi); }
+                const float wi = wave_sum(accI[2]);
+                if ((threadIdx.x & 63) == 0) atomicAdd(&s_param[8], wi);
             }
         }
         __syncthreads();

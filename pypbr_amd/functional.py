@@ -683,7 +683,7 @@ def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool =
         return padded(n_planes * pitch_of(shape, esz))
     sizes = [0 if t is None else extent(t.shape, t.element_size()) for t in maps]
     out_bytes = extent(out_shape, 4) if reserve_output else 0
-    arena = torch.empty(sum(sizes) + out_bytes, dtype=torch.uint8, device=dev)
+    arena = _aligned_arena(sum(sizes) + out_bytes, dev)
 
     def view(off, shape, dtype, esz):
         pitch = pitch_of(shape, esz) // esz
@@ -693,7 +693,8 @@ def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool =
             strides.append(step)
             step *= d
         strides = tuple(reversed(strides))            # (..., planes, rows, 1): dense rows, `pitch` elements between planes
-        return arena.view(dtype).as_strided(tuple(shape), strides, off // esz)
+        typed = arena.view(dtype)
+        return typed.as_strided(tuple(shape), strides, typed.storage_offset() + off // esz)
     views, off = [], 0
     for t, nbytes in zip(maps, sizes):
         if t is None:
@@ -714,6 +715,14 @@ def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool =
 PLANE_SKEW_BYTES = int(os.environ.get("PBR_PLANE_SKEW_BYTES", "0"))
 
 
+def _aligned_arena(nbytes, dev):
+    """`nbytes` of uint8 whose first byte is 256-byte aligned IN MEMORY, whatever the allocator hands out (the device
+    allocator already aligns to 512; the host allocator only to 64)."""
+    raw = torch.empty(nbytes + 255, dtype=torch.uint8, device=dev)
+    skip = -raw.data_ptr() % 256
+    return raw[skip:skip + nbytes]
+
+
 def _pack_material_major(maps, batch, dev, reserve_output, padded):
     """Batched maps [B,C,H,W]: material b's planes (and its result) next to each other, materials one pitch apart.
     The views keep their [B,C,H,W] shapes; only the batch stride differs from a free-standing tensor, which the C ABI
@@ -726,7 +735,7 @@ def _pack_material_major(maps, batch, dev, reserve_output, padded):
     out_bytes = padded(3 * h * w * 4) if reserve_output else 0
     pitch += out_bytes
     shared_bytes = sum(padded(t.numel() * t.element_size()) for t in maps if t is not None and t.shape[0] == 1)
-    arena = torch.empty(batch * pitch + shared_bytes, dtype=torch.uint8, device=dev)
+    arena = _aligned_arena(batch * pitch + shared_bytes, dev)
     views, off, shared_off = [], 0, batch * pitch
     for t in maps:
         if t is None:
@@ -735,15 +744,16 @@ def _pack_material_major(maps, batch, dev, reserve_output, padded):
         es, plane = t.element_size(), t.shape[-2] * t.shape[-1]
         typed = arena.view(t.dtype)
         if t.shape[0] == 1:
-            v = typed.as_strided(tuple(t.shape), (t[0].numel(), plane, t.shape[-1], 1), shared_off // es)
+            v = typed.as_strided(tuple(t.shape), (t[0].numel(), plane, t.shape[-1], 1), typed.storage_offset() + shared_off // es)
             shared_off += padded(t.numel() * es)
         else:
-            v = typed.as_strided(tuple(t.shape), (pitch // es, plane, t.shape[-1], 1), off // es)
+            v = typed.as_strided(tuple(t.shape), (pitch // es, plane, t.shape[-1], 1), typed.storage_offset() + off // es)
             off += padded(t[0].numel() * es)
         v.copy_(t)
         views.append(v)
     if reserve_output:
-        views.append(arena.view(torch.float32).as_strided((batch, 3, h, w), (pitch // 4, h * w, w, 1), off // 4))
+        typed = arena.view(torch.float32)
+        views.append(typed.as_strided((batch, 3, h, w), (pitch // 4, h * w, w, 1), typed.storage_offset() + off // 4))
     return tuple(views)
 
 

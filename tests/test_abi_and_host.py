@@ -371,7 +371,7 @@ def test_pack_maps_layout_on_the_host():
     assert out.shape == (3, 7, 9) and out.dtype == torch.float32 and out.is_contiguous()
     base = pa.untyped_storage().data_ptr()
     assert all(t.untyped_storage().data_ptr() == base for t in (pr, pm, out))            # ONE allocation
-    assert all((t.data_ptr() - base) % 256 == 0 for t in (pa, pr, pm, out))
+    assert all(t.data_ptr() % 256 == 0 for t in (pa, pr, pm, out))                       # in memory, whatever the allocator's base
     assert pa.data_ptr() < pr.data_ptr() < pm.data_ptr() < out.data_ptr()
     b = torch.rand(2, 3, 4, 8, generator=g)
     pb, ob = F.pack_maps(b, reserve_output=True)

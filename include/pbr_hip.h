@@ -205,12 +205,6 @@ int pbr_metallic_to_specular(const void *albedo, const void *metallic, void *dif
  */
 int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *basecolor, void *metallic,
                              size_t n, int albedo_is_srgb, int dtype, void *stream);
-/*
- * MaterialBase._process_normal_map, base.py:191-242.  channels = 2 or 3, planar
- * [channels][pixels] -> [3][pixels].  3 channels: kept as-is when any value is
- * negative, else x*2-1 and unit length.  `workspace` = 4 bytes of device memory
- * (the min<0 flag; zeroed by the call).
- */
 /* Gradient of pbr_decode_normal w.r.t. the stored map (what autograd computes through base.py:191-242 when a predicted
  * normal map is assigned to a material in a rendering loss): fp32, `workspace` = the flag pbr_decode_normal left. */
 int pbr_decode_normal_backward(const void *src, const void *grad_out, void *grad_in, int32_t channels, int64_t pixels,
@@ -223,6 +217,15 @@ int pbr_decode_normal_backward(const void *src, const void *grad_out, void *grad
 int pbr_fold_gradient(const void *src, void *dst, int32_t batch, int32_t channels, int32_t h, int32_t w, int32_t ny,
                       int32_t nx, int fold_batch, void *stream);
 
+/*
+ * MaterialBase._process_normal_map, base.py:191-242.  channels = 2 or 3, planar
+ * [channels][pixels] -> [3][pixels].  3 channels: kept as-is when any value is
+ * negative, else x*2-1 and unit length.  `workspace` = 4 bytes of device memory
+ * (the min<0 flag; written by the call: 1 when the map was kept as it is).
+ * Source and destination disjoint: the map is read once (twice when it is kept
+ * as it is only because of a negative value the 4096-sample probe missed).
+ * `dst == src` is allowed: flag pass first, then the transform.
+ */
 int pbr_decode_normal(const void *src, void *dst, int32_t channels, int64_t pixels, int dtype,
                       void *workspace, void *stream);
 

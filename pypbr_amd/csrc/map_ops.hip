@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void specular_to_metallic_kernel(const void *d
 }
 
 // ---- normal decode (base.py:191-242) ---------------------------------------------
-// Read-only pass: 16-byte loads, four in flight per lane (a lone dword load per iteration left it at 3.7 TB/s).
+// Read-only pass (in-place calls only; see the one-pass path below): 16-byte loads, four in flight per lane (a lone dword
+// load per iteration left it at 3.7 TB/s); every wave leaves as soon as the flag is set.
 template <typename T>
 __global__ __launch_bounds__(256) void any_negative_kernel(const void *src, size_t n, int *flag, int vec_ok) {
     const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(256) void any_negative_kernel(const void *src, size
     const size_t nq = vec_ok ? n / 4 : 0;
     size_t q = tid;
     for (; q + 3 * stride < nq; q += 4 * stride) {
+        if (__atomic_load_n(flag, __ATOMIC_RELAXED) != 0) return;   // settled by the probe or by another wave
         float v[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) Quad<T>::ld(src, q + u * stride, v[u]);
@@ -205,6 +207,55 @@ __global__ __launch_bounds__(256) void decode_normal_kernel(const void *src, voi
         }
         Elem<T>::st(dst, p, x); Elem<T>::st(dst, (size_t)P + p, y); Elem<T>::st(dst, 2 * (size_t)P + p, z);
     }
+}
+
+// 3-channel maps in ONE pass over the data when source and destination do not overlap.  Three launches, no host decision:
+//  1. normal_probe_kernel looks at 4096 values spread over the map and WRITES the flag (a signed map -- a predicted or a
+//     blended normal -- has a negative value among them practically always; an encoded PNG map never);
+//  2. decode_normal_speculative_kernel returns at once when the flag is already set; otherwise it decodes as if no value
+//     were negative and records exactly whether one was;
+//  3. keep_normal_kernel returns at once unless the flag is set, in which case the result is the map as it is
+//     (base.py:212-213) -- also after a speculative decode that met a negative value late (rare, costs the second pass).
+// The flag is exact in every case: the probe only ever sets it on a negative value it has seen.
+template <typename T>
+__global__ __launch_bounds__(256) void normal_probe_kernel(const void *src, size_t n, int *flag) {
+    const size_t step = n / 4096 > 0 ? n / 4096 : 1;
+    bool neg = false;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const size_t i = ((size_t)k * 256 + threadIdx.x) * step;
+        if (i < n) neg |= Elem<T>::ld(src, i) < 0.0f;
+    }
+    const int any = __syncthreads_or(neg);
+    if (threadIdx.x == 0) *flag = any ? 1 : 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void decode_normal_speculative_kernel(const void *src, void *dst, int64_t P, int *flag) {
+    if (*flag != 0) return;                                        // the probe met a negative value: kept as it is
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    bool neg = false;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < (size_t)P; p += stride) {
+        float x = Elem<T>::ld(src, p), y = Elem<T>::ld(src, (size_t)P + p), z = Elem<T>::ld(src, 2 * (size_t)P + p);
+        neg |= (x < 0.0f) | (y < 0.0f) | (z < 0.0f);
+        x = fmaf(x, 2.0f, -1.0f); y = fmaf(y, 2.0f, -1.0f); z = fmaf(z, 2.0f, -1.0f);
+        const float r = rsq(fmaxf(fmaf(z, z, fmaf(y, y, x * x)), 1e-24f));       // F.normalize
+        Elem<T>::st(dst, p, x * r); Elem<T>::st(dst, (size_t)P + p, y * r); Elem<T>::st(dst, 2 * (size_t)P + p, z * r);
+    }
+    if (__ballot(neg) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void keep_normal_kernel(const void *src, void *dst, size_t n, const int *flag, int vec_ok) {
+    if (*flag == 0) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nq = vec_ok ? n / 4 : 0;
+    for (size_t q = tid; q < nq; q += stride) {
+        float v[4];
+        Quad<T>::ld(src, q, v);
+        Quad<T>::st(dst, q, v);
+    }
+    for (size_t i = nq * 4 + tid; i < n; i += stride) Elem<T>::st(dst, i, Elem<T>::ld(src, i));
 }
 
 // Gradient folding (autograd plumbing of the backward kernel): the backward kernel writes one gradient per OUTPUT
@@ -358,8 +409,28 @@ int pbr_decode_normal(const void *src, void *dst, int32_t channels, int64_t pixe
     if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     int *flag = static_cast<int *>(workspace);
-    if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) return hip_status();
     const unsigned grid = stream_grid((size_t)pixels);
+    const size_t esz = dtype == PBR_F32 ? 4 : 2, n = (size_t)pixels * 3;
+    if (channels == 2) {
+        if (hipMemsetAsync(flag, 0, sizeof(int), s) != hipSuccess) return hip_status();
+    } else if (dtype == PBR_F32) {                                          // the probe writes the flag, 0 or 1
+        hipLaunchKernelGGL((normal_probe_kernel<float>), dim3(1), dim3(256), 0, s, src, n, flag);
+    } else {
+        hipLaunchKernelGGL((normal_probe_kernel<__half>), dim3(1), dim3(256), 0, s, src, n, flag);
+    }
+    const char *s0 = static_cast<const char *>(src), *d0 = static_cast<const char *>(dst);
+    if (channels == 3 && (d0 + n * esz <= s0 || s0 + n * esz <= d0)) {      // disjoint: one pass (+ a conditional fix-up)
+        const int vec_ok = is_aligned(src, 4 * esz) && is_aligned(dst, 4 * esz);
+        const unsigned fix_grid = stream_grid(n / 16 + 1);
+        if (dtype == PBR_F32) {
+            hipLaunchKernelGGL((decode_normal_speculative_kernel<float>), dim3(grid), dim3(256), 0, s, src, dst, pixels, flag);
+            hipLaunchKernelGGL((keep_normal_kernel<float>), dim3(fix_grid), dim3(256), 0, s, src, dst, n, flag, vec_ok);
+        } else {
+            hipLaunchKernelGGL((decode_normal_speculative_kernel<__half>), dim3(grid), dim3(256), 0, s, src, dst, pixels, flag);
+            hipLaunchKernelGGL((keep_normal_kernel<__half>), dim3(fix_grid), dim3(256), 0, s, src, dst, n, flag, vec_ok);
+        }
+        return hip_status();
+    }
     if (dtype == PBR_F32) {
         if (channels == 3) {
             hipLaunchKernelGGL((any_negative_kernel<float>), dim3(stream_grid((size_t)pixels * 3 / 16)), dim3(256), 0, s, src, (size_t)pixels * 3, flag, (int)is_aligned(src, 16));

@@ -128,6 +128,40 @@ def test_known_answer_means(golden, manifest):
         assert abs(float(got.astype(np.float64).mean()) - mean) < 2e-7, key
 
 
+def test_decode_normal_one_pass_equals_two_pass():
+    """pbr_decode_normal reads a 3-channel map ONCE when source and destination are disjoint (a 4096-sample probe, then a
+    speculative decode that records negatives exactly, then a fix-up that only runs if one turned up); in place it keeps
+    the flag pass first.  Both must give the same bits: for encoded maps, for maps whose only negative value is one the
+    probe does not look at (the last element; index 1 of a large map), for signed maps, and for odd sizes / fp16."""
+    from pypbr_amd import _native as N, functional as F
+    lib = N.lib()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for dtype in (torch.float32, torch.float16):
+        for h, w in ((64, 64), (37, 53), (1, 1), (513, 1027)):
+            for case in ("encoded", "last_negative", "second_negative", "first_negative", "signed"):
+                x = torch.rand(3, h, w, device="cuda", generator=g).to(dtype)
+                if case == "last_negative":
+                    x[2, -1, -1] = -0.25
+                elif case == "second_negative":
+                    x.view(-1)[min(1, x.numel() - 1)] = -0.25
+                elif case == "first_negative":
+                    x[0, 0, 0] = -0.25
+                elif case == "signed":
+                    x = x * 2 - 1
+                    x[0, 0, 0] = -0.5                                           # 1 x 1 maps too
+                one_pass = F.decode_normal(x)
+                two_pass, flag = x.clone(), torch.empty(1, dtype=torch.int32, device="cuda")
+                N.check(lib.pbr_decode_normal(two_pass.data_ptr(), two_pass.data_ptr(), 3, h * w, F._DTYPES[dtype], flag.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream))
+                assert torch.equal(one_pass, two_pass), (dtype, h, w, case)
+                if case == "encoded":
+                    assert flag.item() == 0 and not torch.equal(one_pass, x)
+                    n = one_pass.float().norm(dim=0)
+                    assert (n - 1).abs().max().item() <= (2e-6 if dtype == torch.float32 else 2e-3)
+                else:
+                    assert flag.item() == 1 and torch.equal(one_pass, x)          # kept as it is (base.py:212-213)
+
+
 def test_conversions_and_colour(golden):
     from pypbr_amd import functional as F
     z = golden("misc")

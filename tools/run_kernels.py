@@ -130,8 +130,18 @@ if want("map_ops"):
            timed(lambda: lib.pbr_metallic_to_specular(a.data_ptr(), m.data_ptr(), o3.data_ptr(), o3b.data_ptr(), 1, PX, 1, N.F32, stream)))
     report("map_ops diffuse/specular -> basecolor/metallic 4096^2 (6 planes in, 6 out)", "specular_to_metallic_kernel", 48 * PX,
            timed(lambda: lib.pbr_specular_to_metallic(a.data_ptr(), n.data_ptr(), o3.data_ptr(), o3b.data_ptr(), a.numel(), 0, N.F32, stream)))
-    report("map_ops decode_normal 3 ch [0,1]-encoded 4096^2: the transform kernel (3 planes in, 3 out; the any-negative flag pass before it reads the 3 planes once more)", "decode_normal_kernel", 24 * PX,
+    report("map_ops decode_normal 3 ch [0,1]-encoded 4096^2, one pass: probe, decode + record any negative (3 planes in, 3 out), fix-up kernel that returns at once", "decode_normal_speculative_kernel", 24 * PX,
            timed(lambda: lib.pbr_decode_normal(n.data_ptr(), o3.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
+    n_signed = n * 2 - 1
+    report("map_ops decode_normal 3 ch already signed 4096^2, one pass: the probe sees a negative value, the decode returns at once, the map is copied as it is (3 planes in, 3 out)", "keep_normal_kernel", 24 * PX,
+           timed(lambda: lib.pbr_decode_normal(n_signed.data_ptr(), o3.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
+    n_inplace = n.clone()
+    n_late = n.clone()
+    n_late.view(-1)[-1] = -1.0
+    report("map_ops decode_normal 3 ch, the only negative value is one the probe does not see: full decode, then the copy (6 planes in, 6 out)", "decode_normal_speculative_kernel", 48 * PX,
+           timed(lambda: lib.pbr_decode_normal(n_late.data_ptr(), o3.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
+    report("map_ops decode_normal in place (flag pass + transform; the map is a fixed point after the first call: 6 planes in, 3 out)", "decode_normal_kernel", 36 * PX,
+           timed(lambda: lib.pbr_decode_normal(n_inplace.data_ptr(), n_inplace.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
     report("blend_maps 3 ch 4096^2 (7 planes in, 3 out)", "blend_kernel<false>", 40 * PX,
            timed(lambda: lib.pbr_blend_maps(a.data_ptr(), n.data_ptr(), m.data_ptr(), o3.data_ptr(), 3, PX, 0, stream)))
     report("blend_maps normals 4096^2 (7 planes in, 3 out)", "blend_kernel<true>", 40 * PX,

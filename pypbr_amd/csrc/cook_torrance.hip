@@ -37,6 +37,7 @@ int g_xcd_log2 = -1;
 int g_bwd_vec = 0;
 int g_batch_inner = -1;
 int g_interleave = 0;
+int g_scalar_base = 1;
 
 struct KernelEntry { KernelFn fn; const char *name; };
 
@@ -107,6 +108,7 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
         pbr_render_desc g = *d;
         g.batch = d->batch / nb;
         fill_args(&g, 2, k);
+        if (g_scalar_base != 2) k.sbase = 0;      // a group of materials is a batch (ct_launch.hpp: the rule is single materials)
     } else {
         fill_args(d, vec, k);
     }
@@ -188,6 +190,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_BWD_VEC: slot = &pbr::g_bwd_vec; break;
         case PBR_TUNE_BATCH_INNER: slot = &pbr::g_batch_inner; break;
         case PBR_TUNE_INTERLEAVE: slot = &pbr::g_interleave; break;
+        case PBR_TUNE_SCALAR_BASE: slot = &pbr::g_scalar_base; break;
         default: return -1;
     }
     const int old = *slot;

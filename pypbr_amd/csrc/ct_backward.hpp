@@ -363,21 +363,25 @@ __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, co
         for (int i = threadIdx.x; i < n_param; i += blockDim.x) b.g_param_partials[(int64_t)blockIdx.x * n_param + i] = s_param[i];
         if (!p.valid) return;
     }
-    const int64_t gp3 = (int64_t)p.b * 3 * a.o_cs + p.pix, gp1 = (int64_t)p.b * a.o_cs + p.pix;
+    // gradient planes are dense: [B][C][H*W] with the result's channel stride
+    auto put = [&](void *plane, int channels, int c, const float *v) {
+        if (p.sb) Ld<TM, VEC>::template store<true>(plane_at<TM>(plane, ((int64_t)p.b0 * channels + c) * a.o_cs, (uint32_t)p.pix), 0, v);
+        else Ld<TM, VEC>::template store<true>(plane, ((int64_t)p.b * channels + c) * a.o_cs + p.pix, v);
+    };
     if (b.g_albedo) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Ld<TM, VEC>::template store<true>(b.g_albedo, gp3 + c * a.o_cs, ga[c]);
+        for (int c = 0; c < 3; ++c) put(b.g_albedo, 3, c, ga[c]);
     }
     if (b.g_normal && a.has_normal) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Ld<TM, VEC>::template store<true>(b.g_normal, gp3 + c * a.o_cs, gn[c]);
+        for (int c = 0; c < 3; ++c) put(b.g_normal, 3, c, gn[c]);
     }
-    if (b.g_rough) Ld<TM, VEC>::template store<true>(b.g_rough, gp1, gr);
+    if (b.g_rough) put(b.g_rough, 1, 0, gr);
     if (WF != PBR_WORKFLOW_SPECULAR) {
-        if (b.g_metal) Ld<TM, VEC>::template store<true>(b.g_metal, gp1, gm);
+        if (b.g_metal) put(b.g_metal, 1, 0, gm);
     } else if (b.g_spec) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Ld<TM, VEC>::template store<true>(b.g_spec, gp3 + c * a.o_cs, gs[c]);
+        for (int c = 0; c < 3; ++c) put(b.g_spec, 3, c, gs[c]);
     }
 }
 
@@ -387,8 +391,16 @@ __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, co
 //   (one row per workgroup; param_grad_finish_kernel adds the rows up).  In these instantiations no lane leaves early:
 //   lanes outside the map shade a clamped (valid) position with a zero upstream gradient, so that every lane takes
 //   part in the wave reductions.
+#ifndef PBR_BWD_F16_WAVES
+#define PBR_BWD_F16_WAVES 4
+#endif
+// Two-pixel lanes, one light, fp16 maps: the allocator lands on 129 VGPRs = 3 waves per SIMD, one register past 4 waves.
+template <int VEC, bool MULTI, typename TM, bool PGRAD>
+constexpr int bwd_min_waves() { return VEC == 2 && !MULTI && !PGRAD && sizeof(TM) == 2 ? PBR_BWD_F16_WAVES : 1; }
+
 template <int LIGHT, int WF, int VEC, bool MULTI, typename TM = float, bool PGRAD = false>
-__global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bwd_min_waves<VEC, MULTI, TM, PGRAD>())))
+void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
     // Packed two-pixel arithmetic for fp16 maps and for several lights, as in the forward kernels: A/B on 4096^2 maps --
     // fp16 maps 182 us packed vs 194 us scalar; 4 lights fp32 423 us vs 491 us; one light fp32 221 us packed vs 206 us
     // scalar (that launch is bound by the memory system, and there the shorter arithmetic phases only make its 19
@@ -409,7 +421,10 @@ __global__ __launch_bounds__(256) void cook_torrance_backward_kernel(const KArgs
     float go[3][VEC];
     const int64_t opix = p.b * a.o_bs + p.pix;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) Ld<float, VEC>::template load<true>(b.gout, opix + c * a.o_cs, go[c]);
+    for (int c = 0; c < 3; ++c) {
+        if (p.sb) Ld<float, VEC>::template load<true>(plane_at<float>(b.gout, p.b0 * a.o_bs + c * a.o_cs, (uint32_t)p.pix), 0, go[c]);
+        else Ld<float, VEC>::template load<true>(b.gout, opix + c * a.o_cs, go[c]);
+    }
     if (PGRAD && !p.valid) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)

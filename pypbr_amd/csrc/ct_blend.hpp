@@ -75,8 +75,9 @@ void cook_torrance_blend_kernel(const KArgs a, const KBlend b) {
     float w[VEC];
     load_texels<WF, float, VEC, true>(a, true, p, t);
     load_texels<WF, float, VEC, true>(b, true, p, u);
-    Ld<float, VEC>::template load<true>(b.mask, p.b * b.k_bs + p.src, w);
-    const bool keep_signed = b.normal_signed[p.b] != 0;
+    if (p.sb) Ld<float, VEC>::template load<true>(plane_at<float>(b.mask, p.b0 * b.k_bs, (uint32_t)p.src), 0, w);
+    else Ld<float, VEC>::template load<true>(b.mask, p.b * b.k_bs + p.src, w);
+    const bool keep_signed = b.normal_signed[p.sb ? p.b0 : p.b] != 0;
     blend_texels<WF, VEC>(t, u, w, keep_signed);
     shade_and_store<LIGHT, WF, float, VEC, MULTI, true, MULTI>(a, p, t);
 }

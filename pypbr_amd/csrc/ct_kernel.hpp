@@ -63,6 +63,7 @@ struct KArgs {
     int32_t xcd_tiles;       // tiles covered by the remap: n_tiles rounded down to a multiple of 8 << xcd_log2
     int32_t ilv_b, ilv_tiles;// experiment (PBR_TUNE_INTERLEAVE): consecutive workgroups walk ilv_b materials round-robin, ilv_tiles tiles each
     int32_t xpose;           // 8-pixel lanes, fp32 result: exchange the lanes' 16-byte pieces through LDS before storing
+    int32_t sbase;           // every tile lies inside one material and every plane is < 4 GiB: scalar plane addresses (plane_at)
     FastDiv div_h;           // row / H
     FastDiv div_tx;          // tile / tiles_x
     int32_t tiled;           // maps are (map_h, map_w) and repeat over the (H_total, W) output (MaterialBase.tile)
@@ -178,6 +179,21 @@ template <> struct Ld<float, 8> {
     }
 };
 
+// Scalar plane addressing (KArgs::sbase).  The general form of an access is map + b * batch_stride + c * channel_stride +
+// lane offset with a per-lane material index b: a 64-bit multiply-add and a 64-bit add per plane in vector registers
+// (19 planes in the backward kernel: 9 % of its VALU instructions and two address registers per plane).  When the
+// whole workgroup works on one material, everything but the lane offset is uniform: the plane's address is formed
+// with scalar instructions and the access becomes `global_load ... v_offset, s[base:base+1]` -- no vector address
+// arithmetic at all, and ONE 32-bit offset register shared by all planes of the same element size.  The empty asm keeps
+// the compiler from folding the lane offset back into a 64-bit vector address.
+typedef __attribute__((address_space(1))) char *global_ptr;
+template <typename T>
+__device__ __forceinline__ void *plane_at(const void *plane, int64_t uniform_elems, uint32_t lane_elems) {
+    uint64_t base = reinterpret_cast<uint64_t>(plane) + (uint64_t)uniform_elems * sizeof(T);
+    asm("" : "+s"(base));
+    return (void *)(reinterpret_cast<global_ptr>(base) + lane_elems * (uint32_t)sizeof(T));
+}
+
 // torch.linspace two-ended evaluation (what ATen's device kernel computes), branch-free:
 // i < n/2 ? a + step*i : b - step*(n-1-i).
 __device__ __forceinline__ float linspace_at(float a, float b, float step, int n, int i) {
@@ -207,6 +223,8 @@ struct LanePos {
     int64_t pix;          // y * W + x: where the result goes
     int64_t src;          // where the texels come from: pix, or the wrapped position inside the (map_h, map_w) maps
     bool valid;
+    bool sb;              // KArgs::sbase: b == b0 for every lane of the workgroup, pix and src fit 30 bits
+    int b0;               // material of the tile's first row (scalar)
 };
 
 // CLAMP: lanes outside the map get the nearest position inside it (valid = false): they may load, must not store.
@@ -218,7 +236,9 @@ __device__ __forceinline__ LanePos lane_pos(const KArgs &a, int tile_x, int tile
     LanePos p;
     p.valid = xv < a.wv && row < a.rows;
     if (CLAMP) { xv = xv < a.wv ? xv : a.wv - 1; row = row < a.rows ? row : a.rows - 1; }
-    p.b = (int)a.div_h.div((uint32_t)row);
+    p.sb = a.sbase != 0;
+    p.b0 = (int)a.div_h.div((uint32_t)(tile_y << (a.bt_log2 - a.bx_log2)));
+    p.b = p.sb ? p.b0 : (int)a.div_h.div((uint32_t)row);
     p.y = row - p.b * a.H;
     p.x = xv * VEC;
     p.pix = (int64_t)p.y * a.W + p.x;
@@ -237,7 +257,24 @@ template <int VEC> struct Texels { float al[3][VEC], nm[3][VEC], ro[VEC], me[VEC
 // Issues every load of the lane's texels; nothing here waits on memory.
 // `Src` is KArgs, or KBlend (the second material of a fused blend): same member names.
 template <int WF, typename TI, int VEC, bool NT, class Src>
-__device__ __forceinline__ void load_texels(const Src &a, bool has_normal, const LanePos &p, Texels<VEC> &t) {
+__device__ __forceinline__ void load_texels(const Src &a, bool has_normal, const LanePos &p, Texels<VEC> &t, int material = -1) {
+    if (p.sb) {                                         // scalar plane addresses, one lane offset for all planes
+        const int b = material < 0 ? p.b0 : material;
+        const uint32_t src = (uint32_t)p.src;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(plane_at<TI>(a.albedo, b * a.a_bs + c * a.a_cs, src), 0, t.al[c]);
+        if (has_normal) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(plane_at<TI>(a.normal, b * a.n_bs + c * a.n_cs, src), 0, t.nm[c]);
+        }
+        Ld<TI, VEC>::template load<NT>(plane_at<TI>(a.rough, b * a.r_bs, src), 0, t.ro);
+        if (WF != PBR_WORKFLOW_SPECULAR) Ld<TI, VEC>::template load<NT>(plane_at<TI>(a.metal, b * a.m_bs, src), 0, t.me);
+        if (WF == PBR_WORKFLOW_SPECULAR) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(plane_at<TI>(a.spec, b * a.s_bs + c * a.s_cs, src), 0, t.sp[c]);
+        }
+        return;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) Ld<TI, VEC>::template load<NT>(a.albedo, p.b * a.a_bs + c * a.a_cs + p.src, t.al[c]);
     if (has_normal) {
@@ -477,7 +514,8 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const int q = s2 * nvt + col;                             // piece index inside the row
                     const f32x4 v = xp[wave][c][(q & 1) * 72 + row0 + (q >> 1)];
-                    f32x4 *dst = reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + base + c * a.o_cs + 4 * s2 * nvt);
+                    f32x4 *dst = p.sb ? static_cast<f32x4 *>(plane_at<float>(a.out, p.b0 * a.o_bs + c * a.o_cs, (uint32_t)p.pix - 4 * col + 4 * s2 * nvt))
+                                      : reinterpret_cast<f32x4 *>(static_cast<float *>(a.out) + base + c * a.o_cs + 4 * s2 * nvt);
                     if (NT) __builtin_nontemporal_store(v, dst); else *dst = v;
                 }
             }
@@ -489,7 +527,8 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
         float o[VEC];
 #pragma unroll
         for (int g = 0; g < NG; ++g) scatter(o, g, res[c][g]);
-        Ld<TO, VEC>::template store<NT>(a.out, p.b * a.o_bs + c * a.o_cs + p.pix, o);
+        if (p.sb) Ld<TO, VEC>::template store<NT>(plane_at<TO>(a.out, p.b0 * a.o_bs + c * a.o_cs, (uint32_t)p.pix), 0, o);
+        else Ld<TO, VEC>::template store<NT>(a.out, p.b * a.o_bs + c * a.o_cs + p.pix, o);
     }
 }
 
@@ -545,7 +584,7 @@ void cook_torrance_batch_kernel(const KArgs a) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         pj[j] = p; pj[j].b = p.b * NB + j;
-        load_texels<WF, TI, VEC, NT>(a, a.has_normal != 0, pj[j], t[j]);
+        load_texels<WF, TI, VEC, NT>(a, a.has_normal != 0, pj[j], t[j], p.b0 * NB + j);
     }
     const Vec3 V = {a.V[0], a.V[1], a.V[2]};
     PixelTermsT<R> pt[NB][NG];
@@ -599,7 +638,8 @@ void cook_torrance_batch_kernel(const KArgs a) {
                 if (a.out_srgb) v = linear_to_srgb_unit(v);                     // :179-180
                 scatter(o, g, v);
             }
-            Ld<TO, VEC>::template store<NT>(a.out, pj[j].b * a.o_bs + c * a.o_cs + p.pix, o);
+            if (p.sb) Ld<TO, VEC>::template store<NT>(plane_at<TO>(a.out, (p.b0 * NB + j) * a.o_bs + c * a.o_cs, (uint32_t)p.pix), 0, o);
+            else Ld<TO, VEC>::template store<NT>(a.out, pj[j].b * a.o_bs + c * a.o_cs + p.pix, o);
         }
     }
 }

@@ -26,6 +26,7 @@ extern int g_f16_vec;              // pixels per lane for fp16 maps with one lig
 // kernels with no cap.  -1 = that rule; >= 0 = this many bytes for every launch (A/B runs).
 extern int g_lds_bytes;
 extern int g_batch_inner;          // materials per lane of the several-lights kernels: -1 = rule (4 | 2 | off), 0 = off, 2 | 4 = forced
+extern int g_scalar_base;          // scalar plane addresses (KArgs::sbase): 0 never, 1 = rule (single materials), 2 = whenever the launch allows them
 extern int g_interleave;           // experiment knob: materials of a batch interleaved workgroup by workgroup
 extern int g_bwd_vec;              // pixels per lane of the backward kernels: 0 = rule (ct_backward.hip), 2 | 4 = forced (A/B)
 extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
@@ -148,6 +149,16 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     if (g_interleave && by == 1 && d->batch > 1 && k.n_tiles > 0) { k.ilv_b = d->batch; k.ilv_tiles = k.n_tiles / d->batch; }
     // 8-pixel lanes with an fp32 result swap 16-byte pieces between the lanes of a row before storing (ct_kernel.hpp)
     k.xpose = vec == 8 && d->out_dtype == PBR_F32;
+    // Scalar plane addresses (ct_kernel.hpp, plane_at) need every workgroup inside one material -- tile rows divide the
+    // band height, or there is one material -- and 32-bit byte offsets inside a plane (< 2^30 elements).  Used for
+    // single materials only: in-process A/B (tools/tune.py, knob "sb") 4096^2 fp32 115.5 vs 116.4 us, fused tile(2)
+    // 80.9 vs 84.3, backward fp32 212.2 vs 217.6, fp16 -> fp16 291.8 vs 297.4; batches run 0.5-2 % SLOWER with it
+    // (4 x 4096^2 fp16 334.2 vs 328.2, 16 x 2048^2 fp32 481.7 vs 474.7, 16 lights 1148 vs 1141) -- g_scalar_base = 2
+    // turns it on for those too.
+    const int64_t plane_px = (int64_t)d->height * d->width;
+    const int64_t map_px = is_tiled(d) ? (int64_t)d->map_height * d->map_width : plane_px;
+    const bool sb_allowed = (d->batch == 1 || d->height % by == 0) && plane_px < (1ll << 30) && map_px < (1ll << 30) && !k.ilv_b;
+    k.sbase = sb_allowed && (g_scalar_base == 2 || (g_scalar_base == 1 && d->batch == 1));
     k.div_h.init((uint32_t)d->height);
     k.div_tx.init((uint32_t)k.tiles_x);
     k.tiled = is_tiled(d);

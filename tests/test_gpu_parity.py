@@ -511,6 +511,51 @@ def test_example_brdf_script_path(golden):
         sys.modules.update(saved)
 
 
+def test_scalar_plane_addresses_are_bit_identical():
+    """KArgs::sbase (ct_kernel.hpp, plane_at): plane addresses formed with scalar instructions when a workgroup stays inside
+    one material.  Same loads, same arithmetic, same stores -- so knob 0 (never), 1 (rule: single materials) and 2
+    (whenever the launch allows it) must agree bit for bit, forward and backward, for single materials, batches whose
+    height the tile rows divide, batches where they do not (the general path whatever the knob), fp16, several lights,
+    tiled maps and strided (packed) maps."""
+    from pypbr_amd import _native as N, functional as F
+    lib = N.lib()
+    g = torch.Generator(device="cuda").manual_seed(11)
+
+    def maps(b, h, w, dtype=torch.float32):
+        a = torch.rand(b, 3, h, w, device="cuda", generator=g)
+        n = torch.nn.functional.normalize(torch.rand(b, 3, h, w, device="cuda", generator=g) * 2 - 1, dim=1)
+        r = torch.rand(b, 1, h, w, device="cuda", generator=g) * 0.9 + 0.1
+        m = torch.rand(b, 1, h, w, device="cuda", generator=g)
+        return [t.to(dtype) for t in (a, n, r, m)]
+    point = dict(view_dir=[0.1, -0.2, 1.0], light=[0.1, 0.1, 1.0], light_intensity=[1.0, 0.9, 0.8], light_type="point", light_size=1.0)
+    ring = dict(view_dir=[0, 0, 1], light=[[1, 0, 1], [0, 1, 1], [-1, 0, 1], [0, -1, 1]], light_intensity=[[0.25] * 3] * 4, light_type="point")
+    cases = [("single", maps(1, 64, 256), point, {}), ("batch, rows divide", maps(4, 32, 64), point, {}),
+             ("batch, ragged", maps(3, 37, 52), point, {}), ("fp16 x8", maps(2, 16, 512, torch.float16), point, {}),
+             ("fp16 -> fp16", maps(1, 16, 512, torch.float16), point, dict(out_dtype=torch.float16)),
+             ("4 lights, batch-inner", maps(4, 16, 128, torch.float16), ring, {}), ("4 lights, single", maps(1, 16, 128), ring, {})]
+    try:
+        for name, mp, light, extra in cases:
+            outs, grads = [], []
+            for knob in (0, 1, 2):
+                lib.pbr_set_tuning(N.TUNE_SCALAR_BASE, knob)
+                outs.append(F.cook_torrance(*mp, **light, **extra).clone())
+                if mp[0].dtype == torch.float32:
+                    leaves = [t.clone().requires_grad_() for t in mp]
+                    F.cook_torrance(*leaves, **light).square().sum().backward()
+                    grads.append([t.grad.clone() for t in leaves])
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), name
+            for ga, gb, gc in zip(*grads) if grads else ():
+                assert torch.equal(ga, gb) and torch.equal(ga, gc), name
+        a, n, r, m = (t[0] for t in maps(1, 32, 64))                              # fused tile(2): (32, 64) maps, (64, 128) image
+        tiled = []
+        for knob in (0, 1, 2):
+            lib.pbr_set_tuning(N.TUNE_SCALAR_BASE, knob)
+            tiled.append(F.cook_torrance(a, n, r, m, **point, tile=(2, 2)).clone())
+        assert torch.equal(tiled[0], tiled[1]) and torch.equal(tiled[0], tiled[2])
+    finally:
+        lib.pbr_set_tuning(N.TUNE_SCALAR_BASE, 1)
+
+
 def test_schedules_are_bit_identical_and_autotune_picks_one():
     """The workgroup -> tile order (descriptor field `schedule`) only changes WHERE a tile runs: every order must
     write bit-identical results, on shapes whose tile count is not a multiple of the run length too."""

@@ -30,7 +30,7 @@ namespace pbr {
 
 // tuning knobs (declared in ct_launch.hpp, set through pbr_set_tuning)
 int g_nontemporal = 1;
-int g_block_log2 = 6;
+int g_block_log2 = 0;
 int g_f16_vec = 8;
 int g_lds_bytes = -1;
 int g_xcd_log2 = -1;
@@ -38,6 +38,7 @@ int g_bwd_vec = 0;
 int g_batch_inner = -1;
 int g_interleave = 0;
 int g_scalar_base = 1;
+int g_max_vec = 8;
 
 struct KernelEntry { KernelFn fn; const char *name; };
 
@@ -191,6 +192,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_BATCH_INNER: slot = &pbr::g_batch_inner; break;
         case PBR_TUNE_INTERLEAVE: slot = &pbr::g_interleave; break;
         case PBR_TUNE_SCALAR_BASE: slot = &pbr::g_scalar_base; break;
+        case PBR_TUNE_MAX_VEC: slot = &pbr::g_max_vec; break;
         default: return -1;
     }
     const int old = *slot;

@@ -29,11 +29,15 @@ static BwdFn pick_bwd(const pbr_render_desc *d, int vec) {
 #undef PBR_BWD
 }
 
-// Tiles of the 1-pixel-per-lane decomposition: the most any launch of this descriptor can have.
+// Tiles of the decomposition with the smallest tiles -- one pixel per lane, 64-lane workgroups: the most any launch of
+// this descriptor can have whatever the tuning knobs say (more pixels per lane or larger workgroups only merge tiles).
+// Same geometry as fill_args: bx = lanes along x (a power of two covering the row, at most 64), 64 / bx rows per tile.
 static int64_t max_tiles(const pbr_render_desc *d) {
-    KArgs k;
-    fill_args(d, 1, k);
-    return k.n_tiles;
+    int lg = 0;
+    while ((1 << lg) < d->width && lg < 6) ++lg;
+    const int64_t bx = 1ll << lg, by = 64 >> lg, rows = (int64_t)d->batch * d->height;
+    const int64_t tiles = ((d->width + bx - 1) / bx) * ((rows + by - 1) / by);
+    return tiles > INT32_MAX ? -1 : tiles;
 }
 
 static int launch_backward(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal, void *g_roughness,
@@ -43,10 +47,7 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
     if (!grad_out) return PBR_ERR_NULL_MAP;
     if (g_params && !workspace) return PBR_ERR_NULL_MAP;
     if (d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;        // the upstream gradient is fp32; maps (and their gradients) fp32 | fp16
-    int vec = pick_vec(d);
-    for (const void *g : {grad_out, (const void *)g_albedo, (const void *)g_normal, (const void *)g_roughness,
-                          (const void *)g_metallic, (const void *)g_specular})
-        if (g && (reinterpret_cast<uintptr_t>(g) & 15u)) vec = 1;
+    int vec = pick_vec(d);                                    // grad_out and the g_* only need element alignment (f32x4_e)
     if (vec == 8) vec = 4;
     // Two pixels per lane (one packed pair): (a) with the light / view adjoints (PGRAD) the four-pixel body needs 256 VGPRs +
     // 40 AGPRs = one wave per SIMD, the two-pixel body 155 = three; (b) with fp16 maps and one light the launch is VALU-bound
@@ -54,9 +55,15 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
     // tools/bwd_ab.sh); with fp32 maps the four-pixel body wins (209 vs 218 us).  g_bwd_vec: A/B knob (2 | 4 force).
     const bool f16_one_light = d->map_dtype == PBR_F16 && d->n_lights == 1;
     if (vec == 4 && (g_bwd_vec == 2 || g_params || (f16_one_light && g_bwd_vec != 4))) vec = 2;
+    // The light / view adjoints are sums over pixels: the overlapping last lane of a ragged row (lane_pos: dup) would
+    // count its shared pixels twice, so odd widths take the one-pixel body there.
+    if (g_params && (d->width & 1)) vec = 1;
     KArgs k;
-    fill_args(d, vec, k);
+    // Light / view adjoints: a workgroup adds its waves' sums into LDS with atomics -- with ONE wave per workgroup the
+    // order of additions is fixed and the result deterministic run to run (the rows are added in fp64 in a fixed order).
+    fill_args(d, vec, k, g_params ? 6 : 0);
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+    if (g_params && k.n_tiles > max_tiles(d)) return PBR_ERR_SHAPE;   // one workspace row per workgroup: never past what the size query promised
     k.o_cs = (int64_t)d->height * d->width; k.o_bs = 3 * k.o_cs;     // grad_out and the g_* are contiguous, whatever `out` was
     const BArgs b = {grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, static_cast<float *>(workspace)};
     hipStream_t st = static_cast<hipStream_t>(stream);

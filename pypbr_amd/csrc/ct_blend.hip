@@ -49,9 +49,8 @@ int pbr_cook_torrance_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, 
     // "Is the blended normal already signed?" is a property of the WHOLE map (base.py:212).  A row band of an untiled map
     // only holds its own rows, so its flags must come from the caller (pbr_blend_normal_sign over every band, combined).
     if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE && !is_tiled(d) && d->height != d->height_total) return PBR_ERR_UNSUPPORTED;
-    int vec = pick_vec(d);
-    for (const pbr_map *m : {&bl->albedo, &bl->normal, &bl->roughness, &bl->metallic, &bl->specular, &bl->mask})
-        if (m->data && ((reinterpret_cast<uintptr_t>(m->data) & 15u) || m->batch_stride % 4 || m->channel_stride % 4)) vec = 1;
+    int vec = pick_vec(d);                                    // the second material and the mask only need element alignment
+    if (vec == 8) vec = 4;
     KArgs k;
     fill_args(d, vec, k);
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;

@@ -82,17 +82,22 @@ struct KArgs {
 // ------------------------------------------------------------------ typed vector I/O
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// The same vectors with ELEMENT alignment: what a lane's 4 (2) pixels have when the row pitch or a view's origin is not
+// a multiple of 16 (8) bytes.  The instruction is the same global_load_dwordx4 / dwordx2 (gfx950 runs in unaligned
+// access mode); a misaligned wave touches one more 128-byte line per plane.  Aligned data loses nothing.
+typedef f32x4 f32x4_e __attribute__((aligned(4)));
+typedef f16x4 f16x4_e __attribute__((aligned(2)));
 
 template <typename T, int VEC> struct Ld;
 template <> struct Ld<float, 4> {
     template <bool NT> static __device__ __forceinline__ void load(const void *p, int64_t i, float v[4]) {
-        const f32x4 *q = reinterpret_cast<const f32x4 *>(static_cast<const float *>(p) + i);
+        const f32x4_e *q = reinterpret_cast<const f32x4_e *>(static_cast<const float *>(p) + i);
         const f32x4 t = NT ? __builtin_nontemporal_load(q) : *q;
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
     template <bool NT> static __device__ __forceinline__ void store(void *p, int64_t i, const float v[4]) {
         const f32x4 t = {v[0], v[1], v[2], v[3]};
-        f32x4 *q = reinterpret_cast<f32x4 *>(static_cast<float *>(p) + i);
+        f32x4_e *q = reinterpret_cast<f32x4_e *>(static_cast<float *>(p) + i);
         if (NT) __builtin_nontemporal_store(t, q); else *q = t;
     }
 };
@@ -106,13 +111,13 @@ template <> struct Ld<float, 1> {
 };
 template <> struct Ld<__half, 4> {
     template <bool NT> static __device__ __forceinline__ void load(const void *p, int64_t i, float v[4]) {
-        const f16x4 *q = reinterpret_cast<const f16x4 *>(static_cast<const _Float16 *>(p) + i);
+        const f16x4_e *q = reinterpret_cast<const f16x4_e *>(static_cast<const _Float16 *>(p) + i);
         const f16x4 t = NT ? __builtin_nontemporal_load(q) : *q;
         v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
     }
     template <bool NT> static __device__ __forceinline__ void store(void *p, int64_t i, const float v[4]) {
         const f16x4 t = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-        f16x4 *q = reinterpret_cast<f16x4 *>(static_cast<_Float16 *>(p) + i);
+        f16x4_e *q = reinterpret_cast<f16x4_e *>(static_cast<_Float16 *>(p) + i);
         if (NT) __builtin_nontemporal_store(t, q); else *q = t;
     }
 };
@@ -126,8 +131,8 @@ template <> struct Ld<__half, 1> {
 };
 
 // 2 pixels per lane (one packed pair): the register-light form of the backward kernel for fp16 maps
-typedef float f32x2v __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2), aligned(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2), aligned(2)));
 template <> struct Ld<float, 2> {
     template <bool NT> static __device__ __forceinline__ void load(const void *p, int64_t i, float v[2]) {
         const f32x2v *q = reinterpret_cast<const f32x2v *>(static_cast<const float *>(p) + i);
@@ -225,6 +230,7 @@ struct LanePos {
     bool valid;
     bool sb;              // KArgs::sbase: b == b0 for every lane of the workgroup, pix and src fit 30 bits
     int b0;               // material of the tile's first row (scalar)
+    int dup;              // ragged rows: this many of the lane's first pixels are also the previous lane's last ones
 };
 
 // CLAMP: lanes outside the map get the nearest position inside it (valid = false): they may load, must not store.
@@ -240,7 +246,12 @@ __device__ __forceinline__ LanePos lane_pos(const KArgs &a, int tile_x, int tile
     p.b0 = (int)a.div_h.div((uint32_t)(tile_y << (a.bt_log2 - a.bx_log2)));
     p.b = p.sb ? p.b0 : (int)a.div_h.div((uint32_t)row);
     p.y = row - p.b * a.H;
+    // Widths that VEC does not divide: the last lane of a row moves back so that it ends with the row, overlapping its
+    // neighbour by `dup` pixels.  Both lanes compute the same values for those pixels and store them twice -- every
+    // access stays a full vector, and there is no tail code.  (Reductions over pixels must skip the duplicates.)
     p.x = xv * VEC;
+    p.dup = 0;
+    if (VEC > 1 && p.x > a.W - VEC) { p.dup = p.x - (a.W - VEC); p.x = a.W - VEC; }
     p.pix = (int64_t)p.y * a.W + p.x;
     p.src = p.pix;
     if (a.tiled) {        // MaterialBase.tile (base.py:524-537) as wrap-around addressing: texel (y mod h, x mod w)

@@ -17,7 +17,7 @@ namespace pbr {
 // Measured A/B on MI355X, 4096x4096 point/metallic (tools/tune.py, DESIGN.md "Schedule experiments"):
 // nt hint on: -5 % time; one-wave workgroups: -2 % vs 256 lanes (no LDS/barrier, so nothing is lost).
 extern int g_nontemporal;
-extern int g_block_log2;           // workgroup size: 64 (6), 128 (7) or 256 (8) lanes
+extern int g_block_log2;           // workgroup size: 64 (6), 128 (7) or 256 (8) lanes; 0 = rule (64; 256 for the one-pixel kernels)
 extern int g_f16_vec;              // pixels per lane for fp16 maps with one light: 8 (16-byte loads) or 4
 // Dynamic LDS per one-wave workgroup, unused by the kernel: an occupancy governor finer than whole waves per
 // SIMD (160 KiB / value = waves per CU).  amdgpu_waves_per_eu(3,3) on the kernel allows 12 waves per CU; the
@@ -27,6 +27,7 @@ extern int g_f16_vec;              // pixels per lane for fp16 maps with one lig
 extern int g_lds_bytes;
 extern int g_batch_inner;          // materials per lane of the several-lights kernels: -1 = rule (4 | 2 | off), 0 = off, 2 | 4 = forced
 extern int g_scalar_base;          // scalar plane addresses (KArgs::sbase): 0 never, 1 = rule (single materials), 2 = whenever the launch allows them
+extern int g_max_vec;              // A/B and test knob: at most this many pixels per lane (1 = the one-pixel kernels everywhere)
 extern int g_interleave;           // experiment knob: materials of a batch interleaved workgroup by workgroup
 extern int g_bwd_vec;              // pixels per lane of the backward kernels: 0 = rule (ct_backward.hip), 2 | 4 = forced (A/B)
 extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
@@ -65,34 +66,26 @@ inline bool is_tiled(const pbr_render_desc *d) {
     return d->map_height > 0 && (d->map_height != d->height_total || d->map_width != d->width);
 }
 
-// 16-byte path: every plane start and every row start must be 16-byte (fp16: 8-byte) aligned.
+// Pixels per lane.  4 whenever a row holds 4 pixels: the vector accesses only need element alignment (ct_kernel.hpp,
+// f32x4_e), and a width that 4 does not divide is covered by overlapping the last two lanes of a row (lane_pos) --
+// measured on 4090^2 fp32: 5.6 TB/s against 3.5 (3.9 with 256-lane workgroups) for the one-pixel-per-lane kernels, which
+// remain for rows shorter than 4 pixels and for tiled maps whose width 4 does not divide (a lane must not straddle a
+// seam).  8 (fp16 maps, one light: 16-byte loads, and the fp32 result's piece exchange) keeps its alignment demands.
 inline int pick_vec(const pbr_render_desc *d) {
-    const int esz_in = d->map_dtype == PBR_F32 ? 4 : 2, esz_out = d->out_dtype == PBR_F32 ? 4 : 2;
-    if (d->width % 4) return 1;
+    if (g_max_vec == 1 || d->width < 4) return 1;
     const bool tiled = is_tiled(d);
     if (tiled && d->map_width % 4) return 1;          // a lane's pixels must not straddle a seam
-    auto ok = [&](const pbr_map &m, int esz, bool three) {
-        if (!m.data) return true;
-        const uintptr_t align = esz == 4 ? 15u : 7u;
-        if (reinterpret_cast<uintptr_t>(m.data) & align) return false;
-        if (m.batch_stride % 4) return false;
-        if (three && (m.channel_stride % 4)) return false;
-        return true;
-    };
-    if (!ok(d->albedo, esz_in, true) || !ok(d->normal, esz_in, true) || !ok(d->roughness, esz_in, false) ||
-        !ok(d->metallic, esz_in, false) || !ok(d->specular, esz_in, true))
-        return 1;
-    if (reinterpret_cast<uintptr_t>(d->out) & (esz_out == 4 ? 15u : 7u)) return 1;
-    if (d->out_batch_stride % 8 || d->out_channel_stride % 8) return 1;      // 0 (contiguous) passes
     // fp16 maps, ONE light (HBM-bound): 8 pixels per lane keep the loads 16 bytes wide.  With several
     // lights the kernel is VALU-bound and the 4-pixel body's lower register count wins.
-    if (esz_in == 2 && d->width % 8 == 0 && (!tiled || d->map_width % 8 == 0) && d->n_lights == 1 && g_f16_vec == 8) {
+    if (d->map_dtype == PBR_F16 && d->width % 8 == 0 && (!tiled || d->map_width % 8 == 0) && d->n_lights == 1 && g_f16_vec == 8 &&
+        g_max_vec >= 8) {
         auto ok16 = [&](const pbr_map &m, bool three) {
             return !m.data || ((reinterpret_cast<uintptr_t>(m.data) & 15u) == 0 && m.batch_stride % 8 == 0 &&
                                (!three || m.channel_stride % 8 == 0));
         };
         if (ok16(d->albedo, true) && ok16(d->normal, true) && ok16(d->roughness, false) && ok16(d->metallic, false) &&
-            ok16(d->specular, true) && (reinterpret_cast<uintptr_t>(d->out) & 15u) == 0)
+            ok16(d->specular, true) && (reinterpret_cast<uintptr_t>(d->out) & 15u) == 0 && d->out_batch_stride % 8 == 0 &&
+            d->out_channel_stride % 8 == 0)
             return 8;
     }
     return 4;
@@ -124,7 +117,7 @@ inline int schedule_xcd_log2(const pbr_render_desc *d, int vec) {
     return 0;
 }
 
-inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
+inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log2 = 0) {
     std::memset(&k, 0, sizeof(k));
     k.albedo = d->albedo.data; k.normal = d->normal.data; k.rough = d->roughness.data;
     k.metal = d->metallic.data; k.spec = d->specular.data; k.out = d->out;
@@ -135,8 +128,12 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k) {
     k.o_cs = d->out_channel_stride ? d->out_channel_stride : (int64_t)d->height * d->width;
     k.o_bs = d->out_batch_stride ? d->out_batch_stride : 3 * k.o_cs;
     k.rows = d->batch * d->height; k.H = d->height; k.W = d->width;
-    k.wv = d->width / vec;
-    k.bt_log2 = g_block_log2 < 6 ? 6 : (g_block_log2 > 8 ? 8 : g_block_log2);
+    k.wv = (d->width + vec - 1) / vec;             // ragged widths: the last lane of a row overlaps its neighbour (lane_pos)
+    // One wave per workgroup; the one-pixel kernels cover only 256 bytes of a plane per wave and run 14 % faster in
+    // four-wave workgroups (4090^2: 186 against 213 us).
+    // `block_log2`: the caller's demand (the light-gradient kernels need one-wave workgroups, see ct_backward.hip).
+    const int want = block_log2 ? block_log2 : g_block_log2;
+    k.bt_log2 = want == 0 ? (vec == 1 ? 8 : 6) : (want < 6 ? 6 : (want > 8 ? 8 : want));
     int lg = 0;
     while ((1 << lg) < k.wv && lg < k.bt_log2) ++lg;
     k.bx_log2 = lg;

@@ -152,14 +152,23 @@ def test_validation_codes_without_a_device():
         N.check(N.ERR_DTYPE)
 
 
-def test_ragged_and_unaligned_maps_select_the_scalar_kernel():
+def test_kernel_selection_for_ragged_and_narrow_maps():
+    """Widths that 4 does not divide still take the 4-pixel kernels (the last two lanes of a row overlap, ct_kernel.hpp
+    lane_pos); rows shorter than 4 pixels, and the PBR_TUNE_MAX_VEC = 1 test knob, select the one-pixel kernels."""
     lib = N.lib()
-    a, n, r, m = torch.rand(1, 3, 5, 13), torch.rand(1, 3, 5, 13), torch.rand(1, 1, 5, 13), torch.rand(1, 1, 5, 13)
     kw = dict(view_dir=[0, 0, 1], light=[0, 0, 1], light_intensity=[1, 1, 1], light_type="point", light_size=1.0,
               albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True, convert_to_diffuse_specular=False,
               y_offset=0, height_total=None)
-    d = F.build_descriptor(a, n, r, m, None, torch.empty(1, 3, 5, 13), **kw)
-    assert lib.pbr_kernel_name(ctypes.byref(d)).endswith(b"_v1")
+
+    def name(w):
+        a, n, r, m = torch.rand(1, 3, 5, w), torch.rand(1, 3, 5, w), torch.rand(1, 1, 5, w), torch.rand(1, 1, 5, w)
+        return lib.pbr_kernel_name(ctypes.byref(F.build_descriptor(a, n, r, m, None, torch.empty(1, 3, 5, w), **kw)))
+    assert name(13).endswith(b"_v4") and name(16).endswith(b"_v4") and name(4).endswith(b"_v4") and name(3).endswith(b"_v1")
+    assert lib.pbr_set_tuning(N.TUNE_MAX_VEC, 1) == 8
+    try:
+        assert name(13).endswith(b"_v1") and name(16).endswith(b"_v1")
+    finally:
+        lib.pbr_set_tuning(N.TUNE_MAX_VEC, 8)
     big = torch.rand(1, 3, 5, 20)
     view = big[:, :, :, 2:18]                                     # width 16 but rows start 8 bytes off alignment
     view_c = F._as_batched(view, (3,), "albedo")

@@ -511,6 +511,67 @@ def test_example_brdf_script_path(golden):
         sys.modules.update(saved)
 
 
+def test_ragged_rows_take_the_vector_kernels_and_match_the_one_pixel_kernels():
+    """Widths that 4 does not divide, and maps that start off a 16-byte boundary, run on the 4-pixel (2-pixel) kernels:
+    element-aligned vector accesses, the last two lanes of a row overlapping (ct_kernel.hpp lane_pos).  The one-pixel
+    kernels (PBR_TUNE_MAX_VEC = 1) evaluate the same functions per pixel, so everything must agree bit for bit: forward,
+    map gradients, light gradients (odd widths fall back to one pixel there), fp16, several lights (batch-inner, two
+    pixels per lane), fused blend."""
+    from pypbr_amd import _native as N, functional as F
+    import pypbr_amd.blending as B
+    lib = N.lib()
+    g = torch.Generator(device="cuda").manual_seed(21)
+
+    def off16(t, k=1):
+        """the same values in a tensor whose storage starts k elements past a 16-byte boundary"""
+        flat = torch.empty(t.numel() + 8, dtype=t.dtype, device=t.device)
+        v = flat[k:k + t.numel()].view(t.shape)
+        v.copy_(t)
+        assert v.data_ptr() % 16 != 0 and v.is_contiguous()
+        return v
+
+    def maps(b, h, w, dtype=torch.float32, shift=False):
+        a = torch.rand(b, 3, h, w, device="cuda", generator=g)
+        n = torch.nn.functional.normalize(torch.rand(b, 3, h, w, device="cuda", generator=g) * 2 - 1, dim=1)
+        r = torch.rand(b, 1, h, w, device="cuda", generator=g) * 0.9 + 0.1
+        m = torch.rand(b, 1, h, w, device="cuda", generator=g)
+        out = [t.to(dtype) for t in (a, n, r, m)]
+        return [off16(t) for t in out] if shift else out
+    point = dict(view_dir=[0.1, -0.2, 1.0], light=[0.1, 0.1, 1.0], light_intensity=[1.0, 0.9, 0.8], light_type="point", light_size=1.0)
+    ring = dict(view_dir=[0, 0, 1], light=[[1, 0, 1], [0, 1, 1], [-1, 0, 1], [0, -1, 1]], light_intensity=[[0.25] * 3] * 4, light_type="point")
+    cases = [("w % 4 = 1", maps(1, 9, 53), point), ("w % 4 = 2, batch", maps(3, 7, 130), point), ("w % 4 = 3", maps(2, 5, 7), point),
+             ("w = 4", maps(1, 3, 4), point), ("w = 5", maps(1, 3, 5), point), ("aligned width, shifted storage", maps(2, 6, 64, shift=True), point),
+             ("ragged and shifted", maps(1, 6, 67, shift=True), point), ("fp16 ragged", maps(2, 5, 37, torch.float16), point),
+             ("fp16 shifted", maps(1, 4, 64, torch.float16, shift=True), point),
+             ("4 lights, batch-inner, odd width", maps(4, 6, 45, torch.float16), ring), ("4 lights, single, ragged", maps(1, 6, 46), ring)]
+    try:
+        for name, mp, light in cases:
+            outs, grads, lgrads = [], [], []
+            for max_vec in (8, 1):
+                lib.pbr_set_tuning(N.TUNE_MAX_VEC, max_vec)
+                outs.append(F.cook_torrance(*mp, **light).clone())
+                if mp[0].dtype == torch.float32:
+                    leaves = [t.clone().requires_grad_() for t in mp]
+                    lt = torch.tensor(light["light"], dtype=torch.float32, device="cuda", requires_grad=True)
+                    F.cook_torrance(*leaves, **{**light, "light": lt}).square().sum().backward()
+                    grads.append([t.grad.clone() for t in leaves])
+                    lgrads.append(lt.grad.clone())
+            assert torch.equal(outs[0], outs[1]), name
+            for ga, gb in zip(*grads) if grads else ():
+                assert torch.equal(ga, gb), name
+            if lgrads:                                            # sums over pixels: same values, another order of addition
+                assert torch.allclose(lgrads[0], lgrads[1], rtol=2e-5, atol=1e-7), (name, lgrads)
+        m1, m2 = maps(1, 9, 53), maps(1, 9, 53)
+        mask = torch.rand(1, 1, 9, 53, device="cuda", generator=g)
+        fused = []
+        for max_vec in (8, 1):
+            lib.pbr_set_tuning(N.TUNE_MAX_VEC, max_vec)
+            fused.append(F.cook_torrance(*m1, **point, blend=(*m2, None, mask)).clone())
+        assert torch.equal(fused[0], fused[1])
+    finally:
+        lib.pbr_set_tuning(N.TUNE_MAX_VEC, 8)
+
+
 def test_scalar_plane_addresses_are_bit_identical():
     """KArgs::sbase (ct_kernel.hpp, plane_at): plane addresses formed with scalar instructions when a workgroup stays inside
     one material.  Same loads, same arithmetic, same stores -- so knob 0 (never), 1 (rule: single materials) and 2

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Soak run: random shapes / storage types / light counts / tiles / bands / workgroup orders for N seconds.  Every
 configuration is evaluated twice with different workgroup orders and must give bit-identical, finite results; one in
-eight also runs the backward kernel and the fused blend.  python tools/soak.py [seconds]"""
+three also on the one-pixel kernels and with the other plane-addressing mode (bit-identical); one in eight also runs
+the backward kernel and the fused blend.  python tools/soak.py [seconds]"""
 import os
 import random
 import sys
@@ -21,7 +22,7 @@ n_cfg = n_bwd = n_blend = 0
 while time.time() < t_end:
     B = rng.choice([1, 1, 2, 3, 4, 5, 8])
     h = rng.choice([1, 2, 7, 16, 33, 64, 100, 257, 512])
-    w = rng.choice([1, 3, 4, 8, 12, 20, 64, 100, 256, 1000, 1024])
+    w = rng.choice([1, 3, 4, 5, 8, 12, 13, 20, 37, 64, 100, 256, 1000, 1001, 1024])
     dtype = rng.choice([torch.float32, torch.float32, torch.float16])
     lights = rng.choice([1, 1, 1, 2, 5, 16])
     ny, nx = rng.choice([(1, 1), (1, 1), (2, 2), (1, 3), (3, 1)])
@@ -54,6 +55,15 @@ while time.time() < t_end:
         out4 = F.cook_torrance(a, n, r, m, s, schedule=N.SCHEDULE_LINEAR, **kw)
         lib.pbr_set_tuning(N.TUNE_F16_VEC, 8)
         assert torch.equal(out4, out1), ("f16 vec", B, h, w, lights, ny, nx, wf, ltype)
+    if n_cfg % 3 == 0:       # the one-pixel kernels == the vector kernels (ragged rows overlap their last two lanes); scalar plane bases
+        lib = N.lib()
+        lib.pbr_set_tuning(N.TUNE_MAX_VEC, 1)
+        out_1px = F.cook_torrance(a, n, r, m, s, schedule=N.SCHEDULE_LINEAR, **kw)
+        lib.pbr_set_tuning(N.TUNE_MAX_VEC, 8)
+        lib.pbr_set_tuning(N.TUNE_SCALAR_BASE, rng.choice([0, 2]))
+        out_sb = F.cook_torrance(a, n, r, m, s, schedule=N.SCHEDULE_LINEAR, **kw)
+        lib.pbr_set_tuning(N.TUNE_SCALAR_BASE, 1)
+        assert torch.equal(out_1px, out1) and torch.equal(out_sb, out1), ("max_vec / scalar base", B, h, w, dtype, lights, ny, nx, wf, ltype)
     n_cfg += 1
     if n_cfg % 8 == 0 and (ny, nx) == (1, 1) and r.shape[0] == B:
         leaves = [None if t is None else t.clone().requires_grad_(True) for t in (a, n, r, m, s)]

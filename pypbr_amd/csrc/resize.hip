@@ -18,7 +18,12 @@
 // with the tap weights normalised once per tile (as ATen does) instead of per output.  Against the two-pass form (kept
 // for extreme down-scales whose windows do not fit) this saves the write and the re-read of the width-pass result:
 // 4096^2 -> 2048^2, 3 planes, antialiased: 450 MB of HBM traffic -> 252 MB.  Measured (profiles/, rocprofv3 SQ / LDS
-// counters): the kernel is bound by the LDS pipe (65 % busy; VALUs 40 %), not by HBM (2.8 TB/s of algorithmic bytes).
+// counters): the kernel is bound by the LDS pipe (65-80 % busy: SQ_LDS_IDX_ACTIVE 145 k of 170-218 k cycles per CU, 13.5 cycles
+// per LDS instruction, ~28 bytes per clock: dword reads two floats apart are 2-way bank conflicts), VALUs 40 %, not by HBM
+// (3.1 TB/s of algorithmic bytes).  Tried on top and measured level or worse, hence not here: persistent workgroups with the
+// next tile's window prefetched through registers (86 us against 81.5), unmasked tap loops for interior tiles (81.0).
+// Phase elimination (4096^2 -> 2048^2, 81.5 us): without global loads 80.1, without the width pass 59.5, without the height
+// pass 60.5, without both 46.2, tables + LDS writes only 25.2.
 #include <hip/hip_runtime.h>
 
 #include <climits>
@@ -214,31 +219,29 @@ __global__ __launch_bounds__(256) void resize_tile_kernel(const float *__restric
         for (int k = 32; k > 0; k >>= 1) m = max(m, __shfl_xor(m, k, 64));
         if (o == 0) tap_max[1] = m;
     }
-    // ---- phase 1: raw window -> LDS.  A wave takes a row at a time, lanes along x: no index arithmetic beyond an add
+    // ---- phase 1: raw window -> LDS
     const float *sp = src + ((int64_t)plane * fh.n_in + ylo) * w_in + xbase;
     if (tg.vec_ok) {
-        // lanes along x (a power of two >= the 16-byte pieces of a row), the rest of the workgroup along rows; four rows of
-        // loads in flight per lane before the first LDS store
-        const int c4n = (in_cols + 3) >> 2;
-        int lg = 2;
-        while ((1 << lg) < c4n && lg < 8) ++lg;
-        const int c4 = tid & ((1 << lg) - 1), rstep = 256 >> lg;
-        const bool inside = c4 < c4n && xbase + 4 * c4 < w_in;                             // w_in % 4 == 0
-        for (int cc = c4; cc < c4n; cc += 256) {                                           // one pass unless a row has > 256 pieces
-            for (int r0 = tid >> lg; r0 < in_rows; r0 += 4 * rstep) {
-                float4 v[4];
+        // The window's 16-byte pieces dealt to the lanes in linear order (piece e = row e / c4n, column e % c4n: every lane
+        // busy whatever the row length), ALL of a lane's loads -- up to 8 -- in flight before the first LDS store: one
+        // memory round trip per workgroup instead of one per four rows.  The division is a float multiply: (e + 0.5) / c4n is
+        // at least 0.5 / c4n away from an integer, far more than the rounding error for e < 2^16, c4n <= 256.
+        const int c4n = (in_cols + 3) >> 2, total = in_rows * c4n;
+        const float inv = 1.0f / (float)c4n;
+        for (int e0 = tid; e0 < total; e0 += 8 * 256) {
+            float4 v[8];
+            int at[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = r0 + u * rstep;
-                    v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                    if (inside && r < in_rows) v[u] = *reinterpret_cast<const float4 *>(sp + (int64_t)r * w_in + 4 * cc);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = r0 + u * rstep;
-                    if (r < in_rows) *reinterpret_cast<float4 *>(raw + r * tg.pitch + 4 * cc) = v[u];
-                }
+            for (int u = 0; u < 8; ++u) {
+                const int e = e0 + u * 256;
+                const int r = (int)(((float)e + 0.5f) * inv), c = e - r * c4n;
+                v[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                at[u] = e < total ? r * tg.pitch + 4 * c : -1;
+                if (e < total && xbase + 4 * c < w_in) v[u] = *reinterpret_cast<const float4 *>(sp + (int64_t)r * w_in + 4 * c);   // w_in % 4 == 0
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (at[u] >= 0) *reinterpret_cast<float4 *>(raw + at[u]) = v[u];
         }
     } else {
         for (int c = tid & 63; c < in_cols; c += 64)

@@ -193,6 +193,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_INTERLEAVE: slot = &pbr::g_interleave; break;
         case PBR_TUNE_SCALAR_BASE: slot = &pbr::g_scalar_base; break;
         case PBR_TUNE_MAX_VEC: slot = &pbr::g_max_vec; break;
+        case PBR_TUNE_RESIZE_ROWS: slot = &pbr::g_resize_rows; break;
         default: return -1;
     }
     const int old = *slot;

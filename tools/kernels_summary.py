@@ -35,7 +35,8 @@ for path in glob.glob(f"{root}/trace/**/*kernel_trace.csv", recursive=True):
             continue
         key = (short(row["Kernel_Name"]), grid_of(row))
         r = rec.setdefault(key, {"us": [], "vgpr": int(row["VGPR_Count"]), "agpr": int(row["Accum_VGPR_Count"]), "lds": int(row["LDS_Block_Size"]),
-                                 "scratch": int(row["Scratch_Size"]), "workgroup": int(row["Workgroup_Size_X"])})
+                                 "scratch": int(row["Scratch_Size"]), "workgroup": int(row["Workgroup_Size_X"]),
+                                 "first": int(row["Start_Timestamp"])})
         r["us"].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-3)
 
 counters = {}
@@ -66,12 +67,21 @@ except OSError:
 def cases_of(name):
     return [cs for cs in cases if name.startswith(cs["kernel"])] or [cs for cs in cases if cs["kernel"] in name + "("]
 
+# one kernel, several cases, each with its own grid (the resize shapes): the n-th grid to appear belongs to the n-th case
+by_order = {}
+for name in {k[0] for k in rec}:
+    keys = sorted((k for k in rec if k[0] == name), key=lambda k: rec[k]["first"])
+    match = cases_of(name)
+    if len(match) > 1 and len(match) == len(keys):
+        for k, cs in zip(keys, match):
+            by_order[k] = [cs]
+
 out = []
 for key in sorted(rec):
     name, grid = key
     r = rec[key]
     us = r["us"]
-    reps = sum(cs.get("reps", 0) for cs in cases_of(name))
+    reps = sum(cs.get("reps", 0) for cs in by_order.get(key, cases_of(name)))
     if reps and len(us) > reps:          # the timed launches come last; what precedes them is warm-up / clock settling
         us = us[-reps:]
     ent = {"kernel": name, "grid_threads": grid, "workgroup": r["workgroup"], "vgpr": r["vgpr"], "agpr": r["agpr"], "lds_bytes": r["lds"],
@@ -97,7 +107,7 @@ for key in sorted(rec):
         sq["wait_any_fraction_of_wave_cycles"] = round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3)
         sq["wait_inst_any_fraction_of_wave_cycles"] = round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 3)
         ent["sq"] = sq
-    match = cases_of(name)
+    match = by_order.get(key, cases_of(name))
     if len(match) == 1 or (match and len({cs["algorithmic_bytes_per_launch"] for cs in match}) == 1):
         alg = match[0]["algorithmic_bytes_per_launch"]
         ent["case"] = match[0]["case"]

@@ -140,7 +140,7 @@ if want("map_ops"):
     n_late.view(-1)[-1] = -1.0
     report("map_ops decode_normal 3 ch, the only negative value is one the probe does not see: full decode, then the copy (6 planes in, 6 out)", "decode_normal_speculative_kernel", 48 * PX,
            timed(lambda: lib.pbr_decode_normal(n_late.data_ptr(), o3.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
-    report("map_ops decode_normal in place (flag pass + transform; the map is a fixed point after the first call: 6 planes in, 3 out)", "decode_normal_kernel", 36 * PX,
+    report("map_ops decode_normal in place (the map is signed after the first call: the probe settles the flag, the flag pass leaves at once, the transform copies 3 planes in, 3 out)", "decode_normal_kernel", 24 * PX,
            timed(lambda: lib.pbr_decode_normal(n_inplace.data_ptr(), n_inplace.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
     report("blend_maps 3 ch 4096^2 (7 planes in, 3 out)", "blend_kernel<false>", 40 * PX,
            timed(lambda: lib.pbr_blend_maps(a.data_ptr(), n.data_ptr(), m.data_ptr(), o3.data_ptr(), 3, PX, 0, stream)))
@@ -155,6 +155,6 @@ if want("resize"):
     for (ho, wo), aa in (((S // 2, S // 2), True), ((S // 4, S // 4), True), ((S * 3 // 2, S * 3 // 2), False)):
         out = torch.empty(3, ho, wo, device=DEV)
         ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, S, wo) // 4), device=DEV)
-        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", "resize_", 12 * (PX + ho * wo),
+        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", "resize_strip_kernel", 12 * (PX + ho * wo),
                timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), 3, S, S, ho, wo, int(aa), ws.data_ptr(), stream)))
         del out, ws

@@ -263,6 +263,39 @@ __global__ __launch_bounds__(256) void keep_normal_kernel(const void *src, void 
 // Gradient folding (autograd plumbing of the backward kernel): the backward kernel writes one gradient per OUTPUT
 // pixel and material; a map that is shared by the whole batch, or repeated ny x nx times by a fused tile(), owns the
 // sum of those.  dst[bo][c][y][x] = sum_{b in group} sum_{ty,tx} src[b][c][ty*h + y][tx*w + x], fixed order.
+// Four consecutive columns per lane (w % 4 == 0, 16-byte aligned planes): the terms of a sum are independent 16-byte
+// loads, four of them in flight at a time; added in the same fixed order as the one-column form below.
+__global__ __launch_bounds__(256) void fold_gradient_quad_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                                 int batch, int channels, int h, int w, int ny, int nx, int fold_batch) {
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const int wq = w >> 2;
+    const int64_t plane_q = (int64_t)h * wq, total = (int64_t)(fold_batch ? 1 : batch) * channels * plane_q;
+    const int64_t W = (int64_t)nx * w, src_plane = (int64_t)ny * h * W;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int reps = ny * nx, terms = (fold_batch ? batch : 1) * reps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t pq = i % plane_q, t = i / plane_q;
+        const int c = (int)(t % channels), bo = (int)(t / channels);
+        const int y = (int)(pq / wq), x = (int)(pq - (int64_t)y * wq) * 4;
+        const float *p0 = src + ((int64_t)(fold_batch ? 0 : bo) * channels + c) * src_plane + (int64_t)y * W + x;
+        auto term = [&](int k) {                         // k = (b, ty, tx) in the order of the sum
+            const int b = k / reps, r = k - b * reps, ty = r / nx, tx = r - ty * nx;
+            return p0 + (int64_t)b * channels * src_plane + (int64_t)ty * h * W + (int64_t)tx * w;
+        };
+        v4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        int k = 0;
+        for (; k + 4 <= terms; k += 4) {
+            v4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(term(k + u)));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc += v[u];
+        }
+        for (; k < terms; ++k) acc += __builtin_nontemporal_load(reinterpret_cast<const v4 *>(term(k)));
+        __builtin_nontemporal_store(acc, reinterpret_cast<v4 *>(dst) + i);
+    }
+}
+
 __global__ __launch_bounds__(256) void fold_gradient_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                             int batch, int channels, int h, int w, int ny, int nx, int fold_batch) {
     const int64_t plane = (int64_t)h * w, total = (int64_t)(fold_batch ? 1 : batch) * channels * plane;
@@ -396,6 +429,12 @@ int pbr_fold_gradient(const void *src, void *dst, int32_t batch, int32_t channel
     if (!src || !dst) return PBR_ERR_NULL_MAP;
     if (batch < 1 || channels < 1 || h < 1 || w < 1 || ny < 1 || nx < 1) return PBR_ERR_SHAPE;
     const size_t items = (size_t)(fold_batch ? 1 : batch) * channels * h * w;
+    if (w % 4 == 0 && is_aligned(src, 16) && is_aligned(dst, 16)) {
+        hipLaunchKernelGGL(fold_gradient_quad_kernel, dim3(stream_grid(items / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           static_cast<const float *>(src), static_cast<float *>(dst), (int)batch, (int)channels, (int)h, (int)w,
+                           (int)ny, (int)nx, fold_batch);
+        return hip_status();
+    }
     hipLaunchKernelGGL(fold_gradient_kernel, dim3(stream_grid(items)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float *>(src), static_cast<float *>(dst), (int)batch, (int)channels, (int)h, (int)w,
                        (int)ny, (int)nx, fold_batch);

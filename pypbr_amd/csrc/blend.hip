@@ -73,47 +73,87 @@ __global__ __launch_bounds__(256) void blend_kernel(const float *__restrict__ m1
     }
 }
 
+// V floats of one plane: V = 4 -> one 16-byte streaming access, V = 1 -> a dword.
+template <int V> struct Run;
+template <> struct Run<4> {
+    static __device__ __forceinline__ void ld(const float *p, int64_t i, float v[4]) {
+        const bf4 t = __builtin_nontemporal_load(reinterpret_cast<const bf4 *>(p + i));
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void st(float *p, int64_t i, const float v[4]) {
+        __builtin_nontemporal_store(bf4{v[0], v[1], v[2], v[3]}, reinterpret_cast<bf4 *>(p + i));
+    }
+};
+template <> struct Run<1> {
+    static __device__ __forceinline__ void ld(const float *p, int64_t i, float v[1]) { v[0] = p[i]; }
+    static __device__ __forceinline__ void st(float *p, int64_t i, const float v[1]) { p[i] = v[0]; }
+};
+
 // Gradient of blend_kernel (what autograd derives from functional.py:103-110 / :119-145): g1, g2 [C][P] (NULL = not wanted),
 // gmask [P] (NULL = not wanted; `accumulate`: added to what is there -- the mask is shared by every map of a material).
-template <bool NORMAL>
+// V pixels per lane (4: P % 4 == 0 and 16-byte aligned planes; 4096^2, 3 channels: 241 -> 207 us = 5.5 TB/s).
+template <bool NORMAL, int V>
 __global__ __launch_bounds__(256) void blend_backward_kernel(const float *__restrict__ m1, const float *__restrict__ m2,
                                                              const float *__restrict__ mask, const float *__restrict__ gout,
                                                              float *__restrict__ g1, float *__restrict__ g2, float *__restrict__ gmask,
                                                              int channels, int64_t P, int accumulate) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += stride) {
-        const float w = mask[p], iw = 1.0f - w;
-        float gw = 0.0f;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * V;
+    for (int64_t p = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * V; p < P; p += stride) {
+        float w[V], gw[V];
+        Run<V>::ld(mask, p, w);
+#pragma unroll
+        for (int j = 0; j < V; ++j) gw[j] = 0.0f;
         if (NORMAL) {
-            const Vec3 a = {m1[p], m1[P + p], m1[2 * P + p]}, b = {m2[p], m2[P + p], m2[2 * P + p]};
-            const Vec3 g = {gout[p], gout[P + p], gout[2 * P + p]};
-            const float ra = rsq(fmaxf(dot(a, a), 1e-24f)), rb = rsq(fmaxf(dot(b, b), 1e-24f));
-            const Vec3 ah = {a.x * ra, a.y * ra, a.z * ra}, bh = {b.x * rb, b.y * rb, b.z * rb};
-            const Vec3 c = {fmaf(w, ah.x, iw * bh.x), fmaf(w, ah.y, iw * bh.y), fmaf(w, ah.z, iw * bh.z)};
-            const float rc = rsq(fmaxf(dot(c, c), 1e-24f));
-            const Vec3 o = {c.x * rc, c.y * rc, c.z * rc};
-            const float og = dot(o, g);                                  // F.normalize: (g - o (o.g)) / |c|
-            const Vec3 gc = {(g.x - o.x * og) * rc, (g.y - o.y * og) * rc, (g.z - o.z * og) * rc};
-            gw = gc.x * (ah.x - bh.x) + gc.y * (ah.y - bh.y) + gc.z * (ah.z - bh.z);
-            if (g1) {
-                const Vec3 ga = {w * gc.x, w * gc.y, w * gc.z};
-                const float d = dot(ah, ga);
-                g1[p] = (ga.x - ah.x * d) * ra; g1[P + p] = (ga.y - ah.y * d) * ra; g1[2 * P + p] = (ga.z - ah.z * d) * ra;
-            }
-            if (g2) {
+            float av[3][V], bv[3][V], gv[3][V], o1[3][V], o2[3][V];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { Run<V>::ld(m1, c * P + p, av[c]); Run<V>::ld(m2, c * P + p, bv[c]); Run<V>::ld(gout, c * P + p, gv[c]); }
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float iw = 1.0f - w[j];
+                const Vec3 a = {av[0][j], av[1][j], av[2][j]}, b = {bv[0][j], bv[1][j], bv[2][j]}, g = {gv[0][j], gv[1][j], gv[2][j]};
+                const float ra = rsq(fmaxf(dot(a, a), 1e-24f)), rb = rsq(fmaxf(dot(b, b), 1e-24f));
+                const Vec3 ah = {a.x * ra, a.y * ra, a.z * ra}, bh = {b.x * rb, b.y * rb, b.z * rb};
+                const Vec3 c = {fmaf(w[j], ah.x, iw * bh.x), fmaf(w[j], ah.y, iw * bh.y), fmaf(w[j], ah.z, iw * bh.z)};
+                const float rc = rsq(fmaxf(dot(c, c), 1e-24f));
+                const Vec3 o = {c.x * rc, c.y * rc, c.z * rc};
+                const float og = dot(o, g);                                  // F.normalize: (g - o (o.g)) / |c|
+                const Vec3 gc = {(g.x - o.x * og) * rc, (g.y - o.y * og) * rc, (g.z - o.z * og) * rc};
+                gw[j] = gc.x * (ah.x - bh.x) + gc.y * (ah.y - bh.y) + gc.z * (ah.z - bh.z);
+                const Vec3 ga = {w[j] * gc.x, w[j] * gc.y, w[j] * gc.z};
+                const float da = dot(ah, ga);
+                o1[0][j] = (ga.x - ah.x * da) * ra; o1[1][j] = (ga.y - ah.y * da) * ra; o1[2][j] = (ga.z - ah.z * da) * ra;
                 const Vec3 gb = {iw * gc.x, iw * gc.y, iw * gc.z};
-                const float d = dot(bh, gb);
-                g2[p] = (gb.x - bh.x * d) * rb; g2[P + p] = (gb.y - bh.y * d) * rb; g2[2 * P + p] = (gb.z - bh.z * d) * rb;
+                const float db = dot(bh, gb);
+                o2[0][j] = (gb.x - bh.x * db) * rb; o2[1][j] = (gb.y - bh.y * db) * rb; o2[2][j] = (gb.z - bh.z * db) * rb;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (g1) Run<V>::st(g1, c * P + p, o1[c]);
+                if (g2) Run<V>::st(g2, c * P + p, o2[c]);
             }
         } else {
             for (int ch = 0; ch < channels; ++ch) {
-                const float g = gout[ch * P + p];
-                if (g1) g1[ch * P + p] = w * g;
-                if (g2) g2[ch * P + p] = iw * g;
-                gw = fmaf(g, m1[ch * P + p] - m2[ch * P + p], gw);
+                float g[V], a[V], b[V], o1[V], o2[V];
+                Run<V>::ld(gout, ch * P + p, g); Run<V>::ld(m1, ch * P + p, a); Run<V>::ld(m2, ch * P + p, b);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    o1[j] = w[j] * g[j];
+                    o2[j] = (1.0f - w[j]) * g[j];
+                    gw[j] = fmaf(g[j], a[j] - b[j], gw[j]);
+                }
+                if (g1) Run<V>::st(g1, ch * P + p, o1);
+                if (g2) Run<V>::st(g2, ch * P + p, o2);
             }
         }
-        if (gmask) gmask[p] = accumulate ? gmask[p] + gw : gw;
+        if (gmask) {
+            if (accumulate) {
+                float old[V];
+                Run<V>::ld(gmask, p, old);
+#pragma unroll
+                for (int j = 0; j < V; ++j) gw[j] += old[j];
+            }
+            Run<V>::st(gmask, p, gw);
+        }
     }
 }
 
@@ -201,8 +241,19 @@ int pbr_blend_maps_backward(const void *map1, const void *map2, const void *mask
     const float *a = static_cast<const float *>(map1), *b = static_cast<const float *>(map2), *k = static_cast<const float *>(mask);
     const float *g = static_cast<const float *>(grad_out);
     float *ga = static_cast<float *>(g_map1), *gb = static_cast<float *>(g_map2), *gk = static_cast<float *>(g_mask);
-    if (is_normal) hipLaunchKernelGGL(blend_backward_kernel<true>, grid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
-    else hipLaunchKernelGGL(blend_backward_kernel<false>, grid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
+    bool vec = pixels % 4 == 0;
+    for (const void *p : {map1, map2, mask, grad_out, (const void *)g_map1, (const void *)g_map2, (const void *)g_mask})
+        if (p && (reinterpret_cast<uintptr_t>(p) & 15u)) vec = false;
+    if (vec) {
+        const int64_t vblocks = (pixels / 4 + 255) / 256;
+        const dim3 vgrid((unsigned)(vblocks > 256 * 8 ? 256 * 8 : vblocks));
+        if (is_normal) hipLaunchKernelGGL((blend_backward_kernel<true, 4>), vgrid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
+        else hipLaunchKernelGGL((blend_backward_kernel<false, 4>), vgrid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
+    } else if (is_normal) {
+        hipLaunchKernelGGL((blend_backward_kernel<true, 1>), grid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
+    } else {
+        hipLaunchKernelGGL((blend_backward_kernel<false, 1>), grid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? PBR_OK : 1000 + (int)e;
 }

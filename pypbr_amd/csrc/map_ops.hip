@@ -319,28 +319,48 @@ __global__ __launch_bounds__(256) void fold_gradient_kernel(const float *__restr
 // Gradient of decode_normal_kernel (MaterialBase._process_normal_map, base.py:191-242) w.r.t. the stored map, with
 // torch's conventions: a map that was kept as is passes the gradient through; x*2-1 contributes a factor 2;
 // F.normalize projects out the radial component; clamp(1 - x^2 - y^2, min=1e-6) passes where it did not clamp.
-template <int CH>
+template <int CH, int V>
 __global__ __launch_bounds__(256) void decode_normal_backward_kernel(const float *__restrict__ src, const float *__restrict__ gout,
                                                                      float *__restrict__ gin, int64_t P, const int *flag) {
     const bool keep = CH == 3 && *flag != 0;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < (size_t)P; p += stride) {
-        const float gx = gout[p], gy = gout[(size_t)P + p], gz = gout[2 * (size_t)P + p];
-        if (keep) { gin[p] = gx; gin[(size_t)P + p] = gy; gin[2 * (size_t)P + p] = gz; continue; }
-        const float x = fmaf(src[p], 2.0f, -1.0f), y = fmaf(src[(size_t)P + p], 2.0f, -1.0f);
-        float z, q = 0.0f;
-        if (CH == 3) z = fmaf(src[2 * (size_t)P + p], 2.0f, -1.0f);
-        else { q = 1.0f - (x * x + y * y); z = sqrt_hw(fmaxf(q, 1e-6f)); }
-        const float r = rsq(fmaxf(fmaf(z, z, fmaf(y, y, x * x)), 1e-24f));
-        const float nx = x * r, ny = y * r, nz = z * r;
-        const float radial = fmaf(nz, gz, fmaf(ny, gy, nx * gx));
-        const float px = (gx - nx * radial) * r, py = (gy - ny * radial) * r, pz = (gz - nz * radial) * r;
-        if (CH == 3) {
-            gin[p] = 2.0f * px; gin[(size_t)P + p] = 2.0f * py; gin[2 * (size_t)P + p] = 2.0f * pz;
-        } else {                                                         // z = sqrt(clamp(q)), dz/dx = -x / z where q >= 1e-6
-            const float dz = q >= 1e-6f ? -pz * rcp(z) : 0.0f;
-            gin[p] = 2.0f * fmaf(dz, x, px); gin[(size_t)P + p] = 2.0f * fmaf(dz, y, py);
+    const size_t stride = (size_t)gridDim.x * blockDim.x * V, Ps = (size_t)P;
+    auto ld = [](const float *p, size_t i, float v[V]) {          // V = 4: one 16-byte streaming load (P % 4 == 0, aligned planes)
+        if constexpr (V == 4) Quad<float>::ld(p, i / 4, v); else v[0] = p[i];
+    };
+    auto st = [](float *p, size_t i, const float v[V]) {
+        if constexpr (V == 4) Quad<float>::st(p, i / 4, v); else p[i] = v[0];
+    };
+    for (size_t p = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * V; p < Ps; p += stride) {
+        float g[3][V], s[3][V], o[3][V];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ld(gout, c * Ps + p, g[c]);
+        if (keep) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) st(gin, c * Ps + p, g[c]);
+            continue;
         }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) ld(src, c * Ps + p, s[c]);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            const float gx = g[0][k], gy = g[1][k], gz = g[2][k];
+            const float x = fmaf(s[0][k], 2.0f, -1.0f), y = fmaf(s[1][k], 2.0f, -1.0f);
+            float z, q = 0.0f;
+            if (CH == 3) z = fmaf(s[2][k], 2.0f, -1.0f);
+            else { q = 1.0f - (x * x + y * y); z = sqrt_hw(fmaxf(q, 1e-6f)); }
+            const float r = rsq(fmaxf(fmaf(z, z, fmaf(y, y, x * x)), 1e-24f));
+            const float nx = x * r, ny = y * r, nz = z * r;
+            const float radial = fmaf(nz, gz, fmaf(ny, gy, nx * gx));
+            const float px = (gx - nx * radial) * r, py = (gy - ny * radial) * r, pz = (gz - nz * radial) * r;
+            if (CH == 3) {
+                o[0][k] = 2.0f * px; o[1][k] = 2.0f * py; o[2][k] = 2.0f * pz;
+            } else {                                                     // z = sqrt(clamp(q)), dz/dx = -x / z where q >= 1e-6
+                const float dz = q >= 1e-6f ? -pz * rcp(z) : 0.0f;
+                o[0][k] = 2.0f * fmaf(dz, x, px); o[1][k] = 2.0f * fmaf(dz, y, py);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) st(gin, c * Ps + p, o[c]);
     }
 }
 
@@ -499,8 +519,17 @@ int pbr_decode_normal_backward(const void *src, const void *grad_out, void *grad
     hipStream_t s = static_cast<hipStream_t>(stream);
     const unsigned grid = stream_grid((size_t)pixels);
     auto a = static_cast<const float *>(src), g = static_cast<const float *>(grad_out);
-    if (channels == 3) hipLaunchKernelGGL((decode_normal_backward_kernel<3>), dim3(grid), dim3(256), 0, s, a, g, static_cast<float *>(grad_in), pixels, static_cast<const int *>(workspace));
-    else hipLaunchKernelGGL((decode_normal_backward_kernel<2>), dim3(grid), dim3(256), 0, s, a, g, static_cast<float *>(grad_in), pixels, static_cast<const int *>(workspace));
+    float *gi = static_cast<float *>(grad_in);
+    const int *flag = static_cast<const int *>(workspace);
+    if (pixels % 4 == 0 && is_aligned(src, 16) && is_aligned(grad_out, 16) && is_aligned(grad_in, 16)) {
+        const unsigned vgrid = stream_grid((size_t)pixels / 4);
+        if (channels == 3) hipLaunchKernelGGL((decode_normal_backward_kernel<3, 4>), dim3(vgrid), dim3(256), 0, s, a, g, gi, pixels, flag);
+        else hipLaunchKernelGGL((decode_normal_backward_kernel<2, 4>), dim3(vgrid), dim3(256), 0, s, a, g, gi, pixels, flag);
+    } else if (channels == 3) {
+        hipLaunchKernelGGL((decode_normal_backward_kernel<3, 1>), dim3(grid), dim3(256), 0, s, a, g, gi, pixels, flag);
+    } else {
+        hipLaunchKernelGGL((decode_normal_backward_kernel<2, 1>), dim3(grid), dim3(256), 0, s, a, g, gi, pixels, flag);
+    }
     return hip_status();
 }
 

@@ -40,6 +40,12 @@ static int64_t max_tiles(const pbr_render_desc *d) {
     return tiles > INT32_MAX ? -1 : tiles;
 }
 
+// Workspace of the light / view gradients: max_tiles rows of partial sums (fp32), then kParamStageRows rows of stage sums (fp64).
+static size_t stage_offset_bytes(const pbr_render_desc *d) {
+    const size_t rows = (size_t)max_tiles(d) * (size_t)(3 + 6 * d->n_lights) * sizeof(float);
+    return (rows + 7) & ~(size_t)7;
+}
+
 static int launch_backward(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal, void *g_roughness,
                            void *g_metallic, void *g_specular, void *g_params, void *workspace, void *stream) {
     const int rc = validate(d);
@@ -74,8 +80,12 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
     if (g_params) {
         ParamFinishArgs f;
         std::memset(&f, 0, sizeof(f));
-        f.partials = static_cast<const float *>(workspace); f.out = static_cast<float *>(g_params);
-        f.n_rows = k.n_tiles; f.n_lights = d->n_lights; f.light_type = d->light_type;
+        const int n_param = 3 + 6 * d->n_lights;
+        double *stage = reinterpret_cast<double *>(static_cast<char *>(workspace) + stage_offset_bytes(d));
+        hipLaunchKernelGGL(param_grad_stage_kernel, dim3(kParamStageRows), dim3(256), 0, st, static_cast<const float *>(workspace), stage,
+                           (int)k.n_tiles, n_param);
+        f.stage = stage; f.out = static_cast<float *>(g_params);
+        f.n_rows = kParamStageRows; f.n_lights = d->n_lights; f.light_type = d->light_type;
         for (int c = 0; c < 3; ++c) f.view[c] = d->view_dir[c];
         for (int i = 0; i < d->n_lights; ++i)
             for (int c = 0; c < 3; ++c) f.lights[i][c] = d->lights[i][c];
@@ -97,7 +107,7 @@ int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, v
 size_t pbr_param_grad_workspace_bytes(const pbr_render_desc *d) {
     if (pbr::validate(d) != PBR_OK) return 0;
     const int64_t tiles = pbr::max_tiles(d);
-    return tiles < 0 ? 0 : (size_t)tiles * (size_t)(3 + 6 * d->n_lights) * sizeof(float);
+    return tiles < 0 ? 0 : pbr::stage_offset_bytes(d) + (size_t)pbr::kParamStageRows * (size_t)(3 + 6 * d->n_lights) * sizeof(double);
 }
 
 int pbr_cook_torrance_backward_params(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal,

@@ -438,15 +438,40 @@ void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
 // the chain rule that sits in front of the kernel: view_dir and a directional light enter through F.normalize
 // (cooktorrance.py:95, :126), whose Jacobian is (I - v v^T) / max(|x|, 1e-12).  One workgroup per 3-vector:
 // vector 0 = view, 1..L = lights, L+1..2L = intensities.  out: [3 + 6 L] floats in that order.
+// Stage 1 of the row sum: kParamStageRows workgroups, each adds a contiguous block of rows.  The rows are read as one flat
+// array, lane t taking elements t, t + T, t + 2 T ... with T the largest multiple of n_param <= 256, so a lane always
+// meets the same parameter and the loads are coalesced; fp64, fixed order.  (One workgroup per 3-vector walking all
+// 131 072 rows of a 4096^2 launch by itself took 155 us -- as long as the kernel that produced them.)
+constexpr int kParamStageRows = 256;
+__global__ __launch_bounds__(256) void param_grad_stage_kernel(const float *__restrict__ partials, double *__restrict__ stage,
+                                                               int n_rows, int n_param) {
+    const int T = (256 / n_param) * n_param, per = (n_rows + kParamStageRows - 1) / kParamStageRows;
+    const int r0 = blockIdx.x * per, r1 = min(n_rows, r0 + per);
+    __shared__ double part[256];
+    double s = 0.0;
+    if ((int)threadIdx.x < T && r0 < r1) {
+        const float *p = partials + (int64_t)r0 * n_param;
+        const int64_t n = (int64_t)(r1 - r0) * n_param;
+        for (int64_t e = threadIdx.x; e < n; e += T) s += p[e];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if ((int)threadIdx.x < n_param) {
+        double t = 0.0;
+        for (int k = threadIdx.x; k < T; k += n_param) t += part[k];
+        stage[(int64_t)blockIdx.x * n_param + threadIdx.x] = t;
+    }
+}
+
 struct ParamFinishArgs {
-    const float *partials; float *out; int32_t n_rows, n_lights, light_type;
+    const double *stage; float *out; int32_t n_rows, n_lights, light_type;      // n_rows = kParamStageRows rows of stage sums
     float view[3]; float lights[PBR_MAX_LIGHTS][3];
 };
 __global__ __launch_bounds__(256) void param_grad_finish_kernel(const ParamFinishArgs a) {
     const int vec = blockIdx.x, n_param = 3 + 6 * a.n_lights;
     double s[3] = {0.0, 0.0, 0.0};
     for (int r = threadIdx.x; r < a.n_rows; r += 256) {
-        const float *row = a.partials + (int64_t)r * n_param + 3 * vec;
+        const double *row = a.stage + (int64_t)r * n_param + 3 * vec;
         s[0] += row[0]; s[1] += row[1]; s[2] += row[2];
     }
     __shared__ double red[3][256];

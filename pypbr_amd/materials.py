@@ -14,7 +14,12 @@ ATen/CPU arithmetic in this package.
 Differences from the reference, all supersets:
   * maps may be any floating torch.Tensor on any device (the reference only files
     CPU float32 `torch.FloatTensor`s into `_maps`) and may carry a
-    leading batch dimension [B,C,H,W] (F2);
+    leading batch dimension [B,C,H,W] (F2).  A ROCm-resident tensor assigned to a material
+    that still sits on its default device (cpu) pulls the MATERIAL onto the tensor's
+    device instead of being copied to the host -- the rendering-loss loop of
+    docs/source/tutorials/06_advanced.rst builds a material from predicted device tensors
+    every step, and a silent device -> host -> device round trip of every map cost 9.8 ms
+    per step at 2048^2 against 0.2 ms of kernels (tools/flow_trace.py);
   * `to_diffuse_specular_material(specular_is_srgb=...)` exposes the flag the upstream
     conversion forgets to set (F6); the default keeps upstream behaviour.
 """
@@ -83,7 +88,7 @@ class MaterialBase:
     def __init__(self, albedo=None, albedo_is_srgb: bool = True, normal=None, roughness=None,
                  normal_convention: NormalConvention = NormalConvention.OPENGL,
                  device: torch.device = torch.device("cpu"), **kwargs):
-        self.device = device
+        self.device = device if isinstance(device, torch.device) else torch.device(device)
         self.normal_convention = normal_convention
         self._maps = {}
         self.albedo_is_srgb = albedo_is_srgb
@@ -141,6 +146,8 @@ class MaterialBase:
         if value is None:
             return None
         if isinstance(value, torch.Tensor):
+            if value.is_cuda and self.device.type == "cpu":
+                self.device = value.device           # a device tensor pulls the material onto its device (module docstring)
             t = value.to(self.device)
         elif isinstance(value, np.ndarray):
             t = torch.from_numpy(value).float().to(self.device)

@@ -160,3 +160,30 @@ def test_device_resident_light_tensors_sync_once():
     other = torch.tensor([0.5, 0.5, 0.5], device="cuda")
     del light
     assert F._host_vec3(other) == pytest.approx([0.5, 0.5, 0.5])
+
+
+def test_device_tensors_pull_a_default_material_onto_their_device():
+    """The rendering-loss loop (06_advanced.rst:73-107) builds a material from predicted DEVICE tensors every step.  The
+    reference's type gate would drop them; here they are maps, and a material still on its default device
+    moves to theirs instead of copying every map to the host and back: no host copy, gradients reach the leaf, and
+    to(device) afterwards is a no-op."""
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    from pypbr_amd.models import CookTorranceBRDF
+    g = torch.Generator(device="cuda").manual_seed(3)
+    albedo = torch.rand(3, 32, 48, device="cuda", generator=g, requires_grad=True)
+    normal = torch.nn.functional.normalize(torch.rand(3, 32, 48, device="cuda", generator=g) * 2 - 1, dim=0)
+    rough, metal = torch.rand(1, 32, 48, device="cuda", generator=g), torch.rand(1, 32, 48, device="cuda", generator=g)
+    mat = BasecolorMetallicMaterial(albedo=albedo, normal=normal, roughness=rough, metallic=metal)
+    assert mat.device.type == "cuda" and all(t.is_cuda for t in mat._maps.values())
+    assert mat._maps["roughness"].data_ptr() == rough.data_ptr()                 # not copied anywhere
+    ptrs = {k: t.data_ptr() for k, t in mat._maps.items()}
+    mat.to("cuda")
+    assert {k: t.data_ptr() for k, t in mat._maps.items()} == ptrs
+    out = CookTorranceBRDF("point")(mat, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0]), 1.0)
+    assert out.is_cuda
+    out.mean().backward()
+    assert albedo.grad is not None and albedo.grad.abs().sum().item() > 0
+    cpu_mat = BasecolorMetallicMaterial(albedo=albedo.detach().cpu(), roughness=rough.cpu(), metallic=metal.cpu())
+    assert cpu_mat.device.type == "cpu" and not cpu_mat._maps["albedo"].is_cuda   # host tensors leave the material where it is
+    explicit = BasecolorMetallicMaterial(albedo=albedo.detach().cpu(), roughness=rough, metallic=metal, device=torch.device("cuda"))
+    assert all(t.is_cuda for t in explicit._maps.values())

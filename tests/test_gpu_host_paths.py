@@ -187,3 +187,28 @@ def test_device_tensors_pull_a_default_material_onto_their_device():
     assert cpu_mat.device.type == "cpu" and not cpu_mat._maps["albedo"].is_cuda   # host tensors leave the material where it is
     explicit = BasecolorMetallicMaterial(albedo=albedo.detach().cpu(), roughness=rough, metallic=metal, device=torch.device("cuda"))
     assert all(t.is_cuda for t in explicit._maps.values())
+
+
+def test_reassigning_a_signed_normal_map_returns_the_tensor_itself():
+    """base.py:212-213: a normal map with a negative value is kept as it is -- the reference returns the very tensor.  The
+    first assignment of a tensor decodes on the device (no host decision); the second assignment of the same unchanged
+    tensor reads the 4-byte verdict once and hands a signed map back untouched, an encoded one is decoded afresh; an
+    in-place change of the tensor (version counter) starts over."""
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    g = torch.Generator(device="cuda").manual_seed(9)
+    signed = torch.nn.functional.normalize(torch.rand(3, 16, 24, device="cuda", generator=g) * 2 - 1, dim=0)
+    encoded = torch.rand(3, 16, 24, device="cuda", generator=g)
+    rough = torch.rand(1, 16, 24, device="cuda", generator=g)
+
+    def normal_of(t):
+        return BasecolorMetallicMaterial(albedo=torch.rand(3, 16, 24, device="cuda"), normal=t, roughness=rough, metallic=rough)._maps["normal"]
+    first = normal_of(signed)
+    assert first.data_ptr() != signed.data_ptr() and torch.equal(first, signed)          # device path: a copy, same values
+    assert normal_of(signed) is signed and normal_of(signed) is signed                    # from the second time on: the tensor itself
+    e1, e2, e3 = normal_of(encoded), normal_of(encoded), normal_of(encoded)
+    assert e2 is not encoded and e3 is not e2 and torch.equal(e1, e2) and torch.equal(e2, e3)   # encoded maps: a fresh decode each time
+    assert (e1.norm(dim=0) - 1).abs().max().item() < 1e-5
+    signed.abs_()                                                                         # now all >= 0: decoded like an encoded map
+    again = normal_of(signed)
+    assert again is not signed and not torch.equal(again, signed)
+    assert torch.allclose(again, torch.nn.functional.normalize(signed * 2 - 1, dim=0), atol=2e-6)

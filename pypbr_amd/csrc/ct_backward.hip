@@ -29,6 +29,37 @@ static BwdFn pick_bwd(const pbr_render_desc *d, int vec) {
 #undef PBR_BWD
 }
 
+using BwdStreamFn = void (*)(const KArgs, const BArgs, int, int);
+static BwdStreamFn pick_bwd_stream(const pbr_render_desc *d, bool full) {
+    const bool point = d->light_type == PBR_LIGHT_POINT;
+#define PBR_BWDS(L, W) return full ? cook_torrance_backward_stream_kernel<L, W, true> : cook_torrance_backward_stream_kernel<L, W, false>
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: PBR_BWDS(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC);
+        case 1: PBR_BWDS(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR);
+        case 2: PBR_BWDS(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED);
+        case 3: PBR_BWDS(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC);
+        case 4: PBR_BWDS(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR);
+        default: PBR_BWDS(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED);
+    }
+#undef PBR_BWDS
+}
+
+// Rounds of the streamed backward kernel (ct_backward.hpp: its grid is rounds x the waves the chip holds at once), or 0 when
+// the launch does not qualify: fp16 maps, one light, untiled, rows a whole number of 128-pixel tiles, 4-byte aligned planes
+// with even strides (its loads and stores move two fp16 values per lane).  g_bwd_run: -1 = rule, 0 = never, N = N rounds (A/B).
+static int stream_run(const pbr_render_desc *d, const void *grad_out, void *const g[5]) {
+    if (g_bwd_run == 0 || d->map_dtype != PBR_F16 || d->n_lights != 1 || is_tiled(d) || d->width % 128) return 0;
+    if ((int64_t)d->height * d->width >= (1ll << 30) || d->batch > 65535) return 0;
+    auto ok = [](const pbr_map &m) {
+        return !m.data || ((reinterpret_cast<uintptr_t>(m.data) & 3u) == 0 && m.batch_stride % 2 == 0 && m.channel_stride % 2 == 0);
+    };
+    if (!ok(d->albedo) || !ok(d->normal) || !ok(d->roughness) || !ok(d->metallic) || !ok(d->specular)) return 0;
+    if (reinterpret_cast<uintptr_t>(grad_out) & 3u) return 0;
+    for (int i = 0; i < 5; ++i)
+        if (reinterpret_cast<uintptr_t>(g[i]) & 3u) return 0;
+    return g_bwd_run > 0 ? g_bwd_run : 1;
+}
+
 // Tiles of the decomposition with the smallest tiles -- one pixel per lane, 64-lane workgroups: the most any launch of
 // this descriptor can have whatever the tuning knobs say (more pixels per lane or larger workgroups only merge tiles).
 // Same geometry as fill_args: bx = lanes along x (a power of two covering the row, at most 64), 64 / bx rows per tile.
@@ -65,6 +96,30 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
     // count its shared pixels twice, so odd widths take the one-pixel body there.
     if (g_params && (d->width & 1)) vec = 1;
     KArgs k;
+    void *const gs[5] = {g_albedo, g_normal, g_roughness, g_metallic, g_specular};
+    if (const int rounds = g_params ? 0 : stream_run(d, grad_out, gs)) {
+        fill_args(d, 2, k, 6);
+        k.o_cs = (int64_t)d->height * d->width; k.o_bs = 3 * k.o_cs;
+        const BArgs b = {grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, nullptr};
+        const int tiles = (int)(k.o_cs / 128);
+        const bool spec = d->workflow == PBR_WORKFLOW_SPECULAR;
+        const int n_stores = (g_albedo ? 3 : 0) + (g_normal && d->normal.data ? 3 : 0) + (g_roughness ? 1 : 0) +
+                             (spec ? (g_specular ? 3 : 0) : (g_metallic ? 1 : 0));
+        // every run-time flag on and every gradient wanted: the instantiation without flag branches
+        const bool full = d->albedo_is_srgb && d->return_srgb && d->normal.data && g_albedo && g_normal && g_roughness &&
+                          (spec ? (g_specular && d->specular_is_srgb) : (g_metallic && (d->workflow == PBR_WORKFLOW_METALLIC || d->specular_is_srgb)));
+        // one-wave workgroups, kStreamWavesPerSimd of them per SIMD: the grid covers the chip `rounds` times, split over the materials
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        const int64_t slots = (int64_t)cus * 4 * kStreamWavesPerSimd * rounds;
+        int64_t per_material = (slots + d->batch - 1) / d->batch;
+        if (per_material > tiles) per_material = tiles;
+        if (per_material < 1) per_material = 1;
+        hipLaunchKernelGGL(pick_bwd_stream(d, full), dim3((unsigned)per_material, (unsigned)d->batch, 1), dim3(64, 1, 1), 0,
+                           static_cast<hipStream_t>(stream), k, b, tiles, n_stores);
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+    }
     // Light / view adjoints: a workgroup adds its waves' sums into LDS with atomics -- with ONE wave per workgroup the
     // order of additions is fixed and the result deterministic run to run (the rows are added in fp64 in a fixed order).
     fill_args(d, vec, k, g_params ? 6 : 0);

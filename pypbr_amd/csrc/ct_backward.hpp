@@ -434,6 +434,131 @@ void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
     backward_body<LIGHT, WF, VEC, MULTI, TM, PGRAD>(a, b, p, t, go, s_param, n_param);
 }
 
+// ------------------------------------------------------------------ streamed form (fp16 maps, one light)
+// With fp16 maps the backward pass moves 44 B per pixel and is bound by instruction issue, not by HBM: a one-tile wave
+// spends about as long being dispatched, forming its 19 plane addresses and waiting for its first loads as it spends
+// computing, and at 4 waves per SIMD (125 VGPRs) that leaves the VALUs idle a third of the time.  Here the grid is as many
+// waves as the chip holds at once (or a small multiple), and wave w of a material walks its 128-pixel tiles w, w + G,
+// w + 2 G ... (G = waves per material): at any moment the chip works on one compact window of every plane, as with
+// one-tile waves, every wave does the same amount of work (no tail round), and the texels and the upstream gradient of the NEXT tile travel global ->
+// LDS (global_load_lds_dword: no VGPR destination, so the prefetch costs no registers and the kernel keeps its 4 waves
+// per SIMD) while the current tile is differentiated from registers.  Per tile: 8 (10) map planes x 256 B + 3 gradient
+// planes x 512 B = 3.5 (4) KiB of LDS per wave, ONE buffer -- a tile's values are copied to registers (11 ds_reads)
+// before the next tile's loads are issued into the same buffer.  Plane addresses, the material index and the light block
+// are formed once per wave; a tile costs a scalar row / column split and the lane-constant offset.  Same backward_body as
+// cook_torrance_backward_kernel<.., 2, false, __half, false>: bit-identical gradients.
+//   Requires (checked by the launcher): one light, untiled maps, W % 128 == 0, planes below 2^30 pixels, every plane
+//   4-byte aligned with even strides, no light / view adjoints.
+#ifndef PBR_BWD_STREAM_WAVES
+#define PBR_BWD_STREAM_WAVES 3
+#endif
+constexpr int kStreamWavesPerSimd = PBR_BWD_STREAM_WAVES;
+constexpr int kStreamMapPlanes = 10;                                 // albedo 3, normal 3, roughness, metallic | specular 3
+constexpr int kStreamLdsWords = kStreamMapPlanes * 64 + 3 * 128;
+typedef __attribute__((address_space(3))) void *lds_ptr;
+
+template <typename T>
+__device__ __forceinline__ void dma_dword(const void *plane, int64_t uniform_elems, uint32_t lane_elems, uint32_t *lds, bool second_half = false) {
+    const __attribute__((address_space(1))) void *g = (const __attribute__((address_space(1))) void *)plane_at<T>(plane, uniform_elems, lane_elems);
+    if (second_half) __builtin_amdgcn_global_load_lds(g, (lds_ptr)lds, 4, 256, 2);      // + 256 B on both sides
+    else __builtin_amdgcn_global_load_lds(g, (lds_ptr)lds, 4, 0, 2);
+}
+
+template <int LIGHT, int WF, bool FULL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PBR_BWD_STREAM_WAVES)))
+void cook_torrance_backward_stream_kernel(const KArgs a, const BArgs b, const int tiles_per_material, const int n_stores) {
+    __shared__ uint32_t buf[kStreamLdsWords];
+    const int lane = threadIdx.x, mat = blockIdx.y;
+    const int t0 = blockIdx.x, t1 = tiles_per_material, step = gridDim.x;      // tiles t0, t0 + step, ... of material `mat`
+    if (FULL) {      // the usual rendering-loss launch: sRGB in and out, a normal map, every gradient wanted -- no flag branches
+        __builtin_assume(a.albedo_srgb != 0); __builtin_assume(a.out_srgb != 0); __builtin_assume(a.has_normal != 0);
+        __builtin_assume(a.spec_srgb != 0);
+        __builtin_assume(b.g_albedo != nullptr); __builtin_assume(b.g_normal != nullptr); __builtin_assume(b.g_rough != nullptr);
+        __builtin_assume(b.g_metal != nullptr); __builtin_assume(b.g_spec != nullptr);
+    }
+    const bool has_normal = FULL || a.has_normal != 0;
+    auto issue = [&](int t) {
+        const uint32_t l2 = (uint32_t)t * 128u + 2u * lane, l1 = (uint32_t)t * 128u + lane;   // lane offsets in pixels: pairs | singles
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dma_dword<__half>(a.albedo, mat * a.a_bs + c * a.a_cs, l2, &buf[c * 64]);
+        if (has_normal) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dma_dword<__half>(a.normal, mat * a.n_bs + c * a.n_cs, l2, &buf[(3 + c) * 64]);
+        }
+        dma_dword<__half>(a.rough, mat * a.r_bs, l2, &buf[6 * 64]);
+        if (WF != PBR_WORKFLOW_SPECULAR) {
+            dma_dword<__half>(a.metal, mat * a.m_bs, l2, &buf[7 * 64]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) dma_dword<__half>(a.spec, mat * a.s_bs + c * a.s_cs, l2, &buf[(7 + c) * 64]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint32_t *dst = &buf[kStreamMapPlanes * 64 + c * 128];
+            dma_dword<float>(b.gout, mat * a.o_bs + c * a.o_cs, l1, dst);
+            dma_dword<float>(b.gout, mat * a.o_bs + c * a.o_cs, l1, dst, true);
+        }
+    };
+    // The tile's values leave LDS through hand-written ds_reads: for an LDS read the compiler can see it waits until EVERY
+    // vector-memory operation in flight has finished (it knows the buffer is the target of LDS-DMA loads, not which of
+    // them) -- that includes the previous tile's stores, a full write round trip per tile.
+    const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr)buf;
+    const uint32_t at4 = lds0 + 4u * lane, at8 = lds0 + kStreamMapPlanes * 256u + 8u * lane;
+    issue(t0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = t0; t < t1; t += step) {
+        // the tile's loads were issued BEFORE the previous tile's stores (vmcnt counts both, in order): when at most the
+        // stores are still in flight, the loads have landed
+        if (FULL && WF != PBR_WORKFLOW_SPECULAR) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (FULL) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (n_stores == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n_stores == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t w[kStreamMapPlanes];
+        float2 g2[3];
+#pragma unroll
+        for (int q = 0; q < kStreamMapPlanes; ++q) {
+            w[q] = 0u;
+            const bool used = q < 3 || (q < 6 && has_normal) || q == 6 || q == 7 || (q > 7 && WF == PBR_WORKFLOW_SPECULAR);
+            if (used) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[q]) : "v"(at4), "i"(q * 256) : "memory");
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(g2[c]) : "v"(at8), "i"(c * 512) : "memory");
+        // the values are in registers: the buffer may be overwritten (every later use of them depends on this wait)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]),
+                       "+v"(g2[0]), "+v"(g2[1]), "+v"(g2[2]) :: "memory");
+        Texels<2> tx;
+        float go[3][2];
+        auto halves = [&](int plane, float v[2]) {
+            const f16x2 h = __builtin_bit_cast(f16x2, w[plane]);
+            v[0] = (float)h.x; v[1] = (float)h.y;
+        };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) halves(c, tx.al[c]);
+        if (has_normal) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) halves(3 + c, tx.nm[c]);
+        }
+        halves(6, tx.ro);
+        if (WF != PBR_WORKFLOW_SPECULAR) {
+            halves(7, tx.me);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) halves(7 + c, tx.sp[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { go[c][0] = g2[c].x; go[c][1] = g2[c].y; }
+        if (t + step < t1) issue(t + step);
+        const int ty = (int)a.div_tx.div((uint32_t)t);          // row of the material; tiles_x = W / 128 tiles per row
+        LanePos p;
+        p.b = p.b0 = mat; p.y = ty; p.x = (t - ty * a.tiles_x) * 128 + 2 * lane;
+        p.pix = p.src = (int64_t)t * 128 + 2 * lane;
+        p.valid = true; p.sb = true; p.dup = 0;
+        backward_body<LIGHT, WF, 2, false, __half, false>(a, b, p, tx, go, nullptr, 0);
+    }
+}
+
 // Adds up the per-workgroup rows of the PGRAD kernels (fp64 sums, fixed order: deterministic) and applies the part of
 // the chain rule that sits in front of the kernel: view_dir and a directional light enter through F.normalize
 // (cooktorrance.py:95, :126), whose Jacobian is (I - v v^T) / max(|x|, 1e-12).  One workgroup per 3-vector:

@@ -383,3 +383,57 @@ def test_light_view_intensity_gradients_match_the_reference_autograd(kind, lk, g
         assert (np.abs(g - ref64) <= band).all(), (name, g, ref64)
         # never further from the float64 gradient than the reference's own fp32 gradient is, plus the band
         assert (np.abs(g - ref32) <= np.abs(ref32 - ref64) + band).all(), (name, g, ref32)
+
+
+@pytest.mark.gpu
+def test_streamed_backward_is_bit_identical_to_the_one_tile_kernels():
+    """fp16 maps with one light and rows that are a whole number of 128-pixel tiles take the streamed backward kernel
+    (ct_backward.hpp: a wave walks a run of tiles, the next tile's texels travel global -> LDS while the current one is
+    differentiated).  Same backward_body as the one-tile kernel, so every gradient must agree bit for bit -- for runs
+    that do not divide the tile count, batches, every workflow, both light types, a missing normal map, sRGB off, and
+    only some of the gradients wanted."""
+    from pypbr_amd import _native as N, functional as F
+    lib = N.lib()
+    g = torch.Generator(device="cuda").manual_seed(77)
+
+    def maps(b, h, w, spec=False):
+        a = torch.rand(b, 3, h, w, device="cuda", generator=g)
+        n = torch.nn.functional.normalize(torch.rand(b, 3, h, w, device="cuda", generator=g) * 2 - 1, dim=1)
+        r = torch.rand(b, 1, h, w, device="cuda", generator=g) * 0.9 + 0.1
+        m = torch.rand(b, 3 if spec else 1, h, w, device="cuda", generator=g)
+        return [t.half() for t in (a, n, r, m)]
+    point = dict(view_dir=[0.1, -0.2, 1.0], light=[0.1, 0.1, 1.0], light_intensity=[1.0, 0.9, 0.8], light_type="point", light_size=1.0)
+    sun = dict(view_dir=[0, 0.1, 1.0], light=[0.3, -0.2, 1.0], light_intensity=[0.8, 0.7, 0.6], light_type="directional")
+
+    def grads(mp, kw, run, wanted=(True, True, True, True), spec=False, no_normal=False):
+        lib.pbr_set_tuning(N.TUNE_BWD_RUN, run)
+        leaves = [t.clone().requires_grad_(w) for t, w in zip(mp, wanted)]
+        a, n, r, m = leaves
+        args = dict(kw)
+        if spec:
+            out = F.cook_torrance(a, None if no_normal else n, r, None, specular=m, **args)
+        else:
+            out = F.cook_torrance(a, None if no_normal else n, r, m, **args)
+        wt = torch.rand(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) - 0.3
+        (out * wt).sum().backward()
+        return [t.grad.clone() if t.grad is not None else None for t in leaves]
+    cases = [("single 5 x 384", maps(1, 5, 384), point, {}),
+             ("batch 3 x 7 x 128", maps(3, 7, 128), point, {}),
+             ("directional", maps(2, 9, 256), sun, {}),
+             ("linear in and out", maps(1, 6, 256), dict(point, albedo_is_srgb=False, return_srgb=False), {}),
+             ("specular", maps(2, 5, 256, spec=True), point, dict(spec=True)),
+             ("converted", maps(2, 5, 256), dict(sun, convert_to_diffuse_specular=True), {}),
+             ("no normal map", maps(1, 11, 128), point, dict(no_normal=True)),
+             ("albedo and roughness only", maps(1, 8, 256), sun, dict(wanted=(True, False, True, False))),
+             ("full rows 64 x 1024", maps(1, 64, 1024), point, {})]
+    try:
+        for name, mp, kw, extra in cases:
+            want = grads(mp, kw, 0, **extra)                  # the one-tile kernels
+            for run in (1, 2, 7, 1000):          # rounds: grid = run x the waves the chip holds; 1000 = one tile per wave
+                got = grads(mp, kw, run, **extra)
+                for x, y in zip(want, got):
+                    assert (x is None) == (y is None), (name, run)
+                    if x is not None:
+                        assert torch.equal(x, y), (name, run, float((x.float() - y.float()).abs().max()))
+    finally:
+        lib.pbr_set_tuning(N.TUNE_BWD_RUN, -1)

@@ -57,7 +57,7 @@ static int stream_run(const pbr_render_desc *d, const void *grad_out, void *cons
     if (reinterpret_cast<uintptr_t>(grad_out) & 3u) return 0;
     for (int i = 0; i < 5; ++i)
         if (reinterpret_cast<uintptr_t>(g[i]) & 3u) return 0;
-    return g_bwd_run > 0 ? g_bwd_run : 1;
+    return g_bwd_run > 0 ? g_bwd_run : 4;          // 4096^2: 1 round 144-146 us, 2: 140-141, 4: 137-139, 6: 138, 8: 139-140 (tools/bwd_stream_ab.sh)
 }
 
 // Tiles of the decomposition with the smallest tiles -- one pixel per lane, 64-lane workgroups: the most any launch of

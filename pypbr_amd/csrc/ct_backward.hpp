@@ -457,11 +457,15 @@ constexpr int kStreamMapPlanes = 10;                                 // albedo 3
 constexpr int kStreamLdsWords = kStreamMapPlanes * 64 + 3 * 128;
 typedef __attribute__((address_space(3))) void *lds_ptr;
 
-template <typename T>
-__device__ __forceinline__ void dma_dword(const void *plane, int64_t uniform_elems, uint32_t lane_elems, uint32_t *lds, bool second_half = false) {
-    const __attribute__((address_space(1))) void *g = (const __attribute__((address_space(1))) void *)plane_at<T>(plane, uniform_elems, lane_elems);
-    if (second_half) __builtin_amdgcn_global_load_lds(g, (lds_ptr)lds, 4, 256, 2);      // + 256 B on both sides
-    else __builtin_amdgcn_global_load_lds(g, (lds_ptr)lds, 4, 0, 2);
+// One LDS-DMA load: lane l's dword goes to LDS byte OFF + 4 l of the tile buffer.  M0 (the LDS base of the instruction) is
+// the buffer for EVERY load of the kernel -- the plane's place inside it travels in the instruction's offset field, which
+// the hardware adds to the global address too, so the plane's (scalar) base is biased by -OFF: no s_mov m0 + wait state
+// per load (14 loads per tile).
+template <typename T, int OFF>
+__device__ __forceinline__ void dma_dword(const void *plane, int64_t uniform_elems, uint32_t lane_elems, uint32_t *buf) {
+    const uint64_t base = reinterpret_cast<uint64_t>(plane) + (uint64_t)uniform_elems * sizeof(T) - (uint64_t)OFF;
+    const __attribute__((address_space(1))) void *g = (const __attribute__((address_space(1))) void *)(reinterpret_cast<global_ptr>(base) + lane_elems * (uint32_t)sizeof(T));
+    __builtin_amdgcn_global_load_lds(g, (lds_ptr)buf, 4, OFF, 2);
 }
 
 template <int LIGHT, int WF, bool FULL>
@@ -479,25 +483,29 @@ void cook_torrance_backward_stream_kernel(const KArgs a, const BArgs b, const in
     const bool has_normal = FULL || a.has_normal != 0;
     auto issue = [&](int t) {
         const uint32_t l2 = (uint32_t)t * 128u + 2u * lane, l1 = (uint32_t)t * 128u + lane;   // lane offsets in pixels: pairs | singles
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dma_dword<__half>(a.albedo, mat * a.a_bs + c * a.a_cs, l2, &buf[c * 64]);
+        dma_dword<__half, 0 * 256>(a.albedo, mat * a.a_bs, l2, buf);
+        dma_dword<__half, 1 * 256>(a.albedo, mat * a.a_bs + a.a_cs, l2, buf);
+        dma_dword<__half, 2 * 256>(a.albedo, mat * a.a_bs + 2 * a.a_cs, l2, buf);
         if (has_normal) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dma_dword<__half>(a.normal, mat * a.n_bs + c * a.n_cs, l2, &buf[(3 + c) * 64]);
+            dma_dword<__half, 3 * 256>(a.normal, mat * a.n_bs, l2, buf);
+            dma_dword<__half, 4 * 256>(a.normal, mat * a.n_bs + a.n_cs, l2, buf);
+            dma_dword<__half, 5 * 256>(a.normal, mat * a.n_bs + 2 * a.n_cs, l2, buf);
         }
-        dma_dword<__half>(a.rough, mat * a.r_bs, l2, &buf[6 * 64]);
+        dma_dword<__half, 6 * 256>(a.rough, mat * a.r_bs, l2, buf);
         if (WF != PBR_WORKFLOW_SPECULAR) {
-            dma_dword<__half>(a.metal, mat * a.m_bs, l2, &buf[7 * 64]);
+            dma_dword<__half, 7 * 256>(a.metal, mat * a.m_bs, l2, buf);
         } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dma_dword<__half>(a.spec, mat * a.s_bs + c * a.s_cs, l2, &buf[(7 + c) * 64]);
+            dma_dword<__half, 7 * 256>(a.spec, mat * a.s_bs, l2, buf);
+            dma_dword<__half, 8 * 256>(a.spec, mat * a.s_bs + a.s_cs, l2, buf);
+            dma_dword<__half, 9 * 256>(a.spec, mat * a.s_bs + 2 * a.s_cs, l2, buf);
         }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            uint32_t *dst = &buf[kStreamMapPlanes * 64 + c * 128];
-            dma_dword<float>(b.gout, mat * a.o_bs + c * a.o_cs, l1, dst);
-            dma_dword<float>(b.gout, mat * a.o_bs + c * a.o_cs, l1, dst, true);
-        }
+        constexpr int G = kStreamMapPlanes * 256;                // the upstream gradient: 128 floats per plane, two loads each
+        dma_dword<float, G + 0>(b.gout, mat * a.o_bs, l1, buf);
+        dma_dword<float, G + 256>(b.gout, mat * a.o_bs + 64, l1, buf);
+        dma_dword<float, G + 512>(b.gout, mat * a.o_bs + a.o_cs, l1, buf);
+        dma_dword<float, G + 768>(b.gout, mat * a.o_bs + a.o_cs + 64, l1, buf);
+        dma_dword<float, G + 1024>(b.gout, mat * a.o_bs + 2 * a.o_cs, l1, buf);
+        dma_dword<float, G + 1280>(b.gout, mat * a.o_bs + 2 * a.o_cs + 64, l1, buf);
     };
     // The tile's values leave LDS through hand-written ds_reads: for an LDS read the compiler can see it waits until EVERY
     // vector-memory operation in flight has finished (it knows the buffer is the target of LDS-DMA loads, not which of

@@ -166,3 +166,43 @@ def test_offsets_beyond_2_to_31_elements():
     # the tail of the last plane was written, and nothing is left unwritten in between (an empty() buffer would show garbage / NaN)
     assert bool(torch.isfinite(out[B - 1, 2, H - 1]).all()) and float(out[B - 1].min()) >= 0.0 and float(out[B - 1].max()) <= 1.0
     print(f"\n[12 x 8192^2 fp16 maps, offsets > 2^31 elements] max|hip-ref64| {worst:.2e}")
+
+
+def test_streamed_backward_full_shape_2x4096_fp16():
+    """The streamed backward kernel (fp16 maps, one light) at a full shape: 2 x 4096^2, i.e. 262 144 tiles over a grid of
+    a few thousand waves, both materials -- every gradient plane bit-equal to the one-tile kernels', whatever the number of
+    rounds; and a crop against the float64 autograd of the ATen restatement (the criterion of tests/test_gpu_backward.py)."""
+    from pypbr_amd import _native as N, functional as F
+    lib = N.lib()
+    B, H, W = 2, 4096, 4096
+    maps = _maps(B, H, W, 31, torch.float16)
+    maps[2] = maps[2].clamp(min=0.3)                   # gradients come back in fp16: keep the specular peak inside its range
+    kw = dict(view_dir=[0.0, 0.1, 1.0], light=[0.1, 0.1, 1.0], light_intensity=[1.0, 0.9, 0.8], light_type="point", light_size=1.0)
+    wt = torch.rand(B, 3, H, W, device="cuda", generator=torch.Generator(device="cuda").manual_seed(32)) - 0.3
+
+    def grads(rounds):
+        lib.pbr_set_tuning(N.TUNE_BWD_RUN, rounds)
+        leaves = [t.clone().requires_grad_() for t in maps]
+        (F.cook_torrance(*leaves, **kw) * wt).sum().backward()
+        return [t.grad for t in leaves]
+    try:
+        want = grads(0)
+        for rounds in (-1, 1, 3):
+            got = grads(rounds)
+            for name, x, y in zip(("albedo", "normal", "roughness", "metallic"), want, got):
+                assert torch.equal(x, y), (rounds, name)
+            del got
+    finally:
+        lib.pbr_set_tuning(N.TUNE_BWD_RUN, -1)
+    assert all(bool(torch.isfinite(x).all()) for x in want)
+    # last rows of the last material against float64 autograd of the oracle
+    b, y0, h = B - 1, H - 8, 8
+    crop = [t[b, :, y0:].float().cpu().double().requires_grad_() for t in maps]
+    ref = O.cook_torrance(*crop, None, view=torch.tensor(kw["view_dir"], dtype=torch.float64), light=torch.tensor(kw["light"], dtype=torch.float64),
+                          intensity=torch.tensor(kw["light_intensity"], dtype=torch.float64), light_type="point", light_size=1.0,
+                          y_offset=y0, H_total=H)
+    (ref * wt[b, :, y0:].cpu().double()).sum().backward()
+    for name, x, leaf in zip(("albedo", "normal", "roughness", "metallic"), want, crop):
+        g64 = leaf.grad
+        err = (x[b, :, y0:].float().cpu().double() - g64).abs()
+        assert bool((err <= 1e-3 * (1e-3 + g64.abs()) + 2e-5 * (1 + g64.abs())).all()), (name, float(err.max()))      # fp16 gradient storage

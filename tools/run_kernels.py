@@ -89,7 +89,7 @@ if want("fwd_f16"):
     del h, p, p2, p16
 if want("bwd"):
     for dtype, tag, kern in ((torch.float32, "bwd_f32", "cook_torrance_backward_kernel<1, 0, 4, false, float, false>"),
-                             (torch.float16, "bwd_f16", "cook_torrance_backward_kernel<1, 0, 2, false, __half, false>")):
+                             (torch.float16, "bwd_f16", "cook_torrance_backward_stream_kernel<1, 0, true>")):      # PBR_TUNE_BWD_RUN=0: the one-tile kernel <1, 0, 2, false, __half, false>
         maps = [t.to(dtype) for t in synth_material(S, DEV, 7)]
         plan = F.plan_cook_torrance(*maps, **PT)
         gout = torch.rand(1, 3, S, S, device=DEV)
@@ -102,6 +102,17 @@ if want("bwd"):
         report(f"{tag}: backward 1 x 4096^2 point metallic ({dtype}) maps 8 planes + grad_out 3 fp32 in, 8 gradient planes out", kern,
                (8 * es + 12 + 8 * es) * PX, timed(bwd))
         del maps, plan, gout, grads
+if want("bwd_dir"):
+    maps = [t.half() for t in synth_material(S, DEV, 7)]
+    plan = F.plan_cook_torrance(*maps, view_dir=[0, 0, 1], light=[0.3, -0.2, 1.0], light_intensity=[1, 1, 1], light_type="directional")
+    gout = torch.rand(1, 3, S, S, device=DEV)
+    grads = [torch.empty_like(t) for t in maps]
+
+    def bwd_dir():
+        N.check(lib.pbr_cook_torrance_backward(ctypes.byref(plan.desc), gout.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(),
+                                               grads[2].data_ptr(), grads[3].data_ptr(), None, stream))
+    report("bwd_dir_f16: backward 1 x 4096^2 directional metallic fp16 maps", "cook_torrance_backward_stream_kernel<0, 0, true>", 44 * PX, timed(bwd_dir))
+    del maps, plan, gout, grads
 if want("blend_fused"):
     m1, m2 = synth_material(S, DEV, 21), synth_material(S, DEV, 22)
     mask = torch.rand(1, S, S, device=DEV)

@@ -613,15 +613,6 @@ template <int LIGHT, int WF, typename TI, typename TO, int VEC, bool MULTI, bool
 __global__ __launch_bounds__(256)
 __attribute__((amdgpu_waves_per_eu(MULTI ? 4 : PBR_WAVES_PER_EU, MULTI ? 8 : PBR_WAVES_PER_EU)))
 void cook_torrance_kernel(const KArgs a) {
-#ifdef PBR_PRELOAD_ARGS
-    // experiment: every argument the ADDRESSES depend on in one batch of scalar loads (one round trip before the vector loads
-    // instead of four); the shading parameters are read after the vector loads have been issued
-    asm volatile("" :: "s"(a.xcd_log2), "s"(a.xcd_tiles), "s"(a.ilv_b), "s"(a.div_tx.mul), "s"(a.div_tx.sh1), "s"(a.div_tx.sh2), "s"(a.tiles_x),
-                 "s"(a.bx_log2), "s"(a.bt_log2), "s"(a.wv), "s"(a.rows), "s"(a.sbase), "s"(a.div_h.mul), "s"(a.div_h.sh1), "s"(a.div_h.sh2),
-                 "s"(a.H), "s"(a.W), "s"(a.tiled), "s"(a.has_normal));
-    asm volatile("" :: "s"(a.albedo), "s"(a.normal), "s"(a.rough), "s"(a.metal), "s"(a.spec), "s"(a.a_bs), "s"(a.a_cs), "s"(a.n_bs), "s"(a.n_cs),
-                 "s"(a.r_bs), "s"(a.m_bs));
-#endif
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
     const int ty = (int)a.div_tx.div(tile);
     const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);

@@ -196,6 +196,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_MAX_VEC: slot = &pbr::g_max_vec; break;
         case PBR_TUNE_RESIZE_ROWS: slot = &pbr::g_resize_rows; break;
         case PBR_TUNE_BWD_RUN: slot = &pbr::g_bwd_run; break;
+        case PBR_TUNE_RESIZE_XCD: slot = &pbr::g_resize_xcd; break;
         default: return -1;
     }
     const int old = *slot;

@@ -15,6 +15,8 @@ S = 4096
 a = torch.rand(3, S, S, device=dev)
 cases = [(2048, True), (1024, True), (3000, True), (1365, True), (6144, False), (8192, False), (5000, True)]
 rows = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,4,8,16,32,64").split(",")]
+if len(sys.argv) > 2:                     # second argument: tile order, 1 = XCD-contiguous (default), 0 = identity
+    lib.pbr_set_tuning(N.TUNE_RESIZE_XCD, int(sys.argv[2]))
 for ho, aa in cases:
     out = torch.empty(3, ho, ho, device=dev)
     ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, S, ho) // 4), device=dev)

@@ -35,7 +35,7 @@
 
 namespace pbr {
 
-int g_resize_xcd = 1;              // XCD-contiguous tile order of the strip kernel: 1 = rule (not for up-scales beyond ~1.3x), 0 = identity, 2 = always (A/B knob PBR_TUNE_RESIZE_XCD)
+int g_resize_xcd = 1;              // XCD-contiguous tile order of the strip kernel: 1 = chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many tiles (A/B knob PBR_TUNE_RESIZE_XCD)
 int g_resize_rows = 0;             // output rows per tile of the strip form: 0 = rule, else forced (A/B knob PBR_TUNE_RESIZE_ROWS)
 
 struct AxisFilter {
@@ -111,7 +111,7 @@ constexpr int kTileW = 64;
 // Only taps inside a window are ever used (0 x inf must not become NaN).  The sums are formed height-first, ATen's
 // width-first: the same products added in another order, a few ulp apart (tests: <= 2e-6 from ATen).
 // LDS: wx[K][64] wy[K][toh] | xo[64] xn[64] yo[toh] yn[toh] | mid[toh][pitch] + 16 floats of slack.
-struct StripGeom { int toh, tiles_x, tiles_y, kx, ky, pitch, vec_ok, xcd_chunk; };     // xcd_chunk: tiles per XCD of the XCD-contiguous order (0 = identity)
+struct StripGeom { int toh, tiles_x, tiles_y, kx, ky, pitch, vec_ok, xcd_chunk, xcd_tiles; };     // XCD-contiguous order: tiles per chunk (0 = identity), tiles covered by whole blocks of 8 chunks
 
 template <int K, bool VEC>
 __device__ __forceinline__ void height_from_global(const float *__restrict__ sp, float *mid, const float *wy, const int *yo, const int *yn,
@@ -195,10 +195,14 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
     __shared__ int tap_max[2];
     // Workgroups are dealt to the 8 XCDs round-robin; each XCD has its own L2.  With the identity order the left / right / upper /
     // lower neighbours of a tile -- which share its halo rows and the 128-byte lines its window starts and ends in -- run on
-    // OTHER XCDs, and every shared line leaves HBM once per XCD that touches it (PMC: 1.3-1.4 x the algorithmic bytes).  Here
-    // XCD x works through the x-th eighth of the tiles in order, so neighbours meet in one L2.
+    // OTHER XCDs, and every shared line leaves HBM once per XCD that touches it (PMC: 1.3-1.4 x the algorithmic bytes, 2 x the input
+    // when up-scaling).  Here XCD x takes the x-th CHUNK of consecutive tiles out of every block of 8 chunks, so the left / right
+    // neighbours (and, with chunks of two tile rows, half of the upper / lower ones) meet in one L2.
     int tile = blockIdx.x;
-    if (tg.xcd_chunk > 0 && tile < 8 * tg.xcd_chunk) tile = (tile & 7) * tg.xcd_chunk + (tile >> 3);
+    if (tg.xcd_chunk > 0 && tile < tg.xcd_tiles) {          // blocks of 8 chunks: XCD x takes chunk x of every block
+        const int span = 8 * tg.xcd_chunk, blk = tile / span, r = tile - blk * span;
+        tile = blk * span + (r & 7) * tg.xcd_chunk + (r >> 3);
+    }
     const int per_plane = tg.tiles_x * tg.tiles_y;
     const int plane = tile / per_plane, t2 = tile - plane * per_plane;
     const int ty = t2 / tg.tiles_x, tx = t2 - ty * tg.tiles_x;
@@ -317,10 +321,14 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
             const int64_t tx = (w_out + kTileW - 1) / kTileW, tyy = (h_out + toh - 1) / toh;
             if (lds <= 64 * 1024 && planes * tx * tyy <= INT32_MAX) {
                 const int64_t n_tiles = planes * tx * tyy;
-                // XCD-contiguous order (resize_strip_kernel): 3 x 4096^2 -> 2048^2 56.0 -> 50.0 us, -> 1024^2 44.4 -> 36.5, -> 1365^2 46.3 -> 40.6,
-                // -> 5000^2 132.5 -> 119.0; level at 3000^2; up-scales beyond ~1.3x run 1-4 % slower with it (6144^2 164 -> 165.5, 8192^2 270 -> 280)
-                const bool xcd_order = g_resize_xcd == 2 || (g_resize_xcd == 1 && fw.scale >= 0.75f && fh.scale >= 0.75f);
-                const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, xcd_order ? (int)(n_tiles / 8) : 0};
+                // XCD-contiguous order (resize_strip_kernel) in chunks of 64 tiles.  Identity order -> chunks of 64, 3 x 4096^2 (us):
+                // -> 2048^2 55.1 -> 48.0, -> 1024^2 44.4 -> 36.8, -> 1365^2 46.3 -> 41.0, -> 3000^2 74.7 -> 72.7, -> 5000^2 127.6 -> 114.3,
+                // -> 6144^2 163.5 -> 158.1, -> 8192^2 269.1 -> 271.5; HBM reads 301.5 -> 201.7 MB for the 2x down-scale (the input is
+                // 201.3 MB), 399.7 -> 201.7 MB for the 1.5x up-scale.  One chunk per XCD (an eighth of all tiles each) is as good for
+                // down-scales but 4 % slower for large up-scales (eight write fronts far apart); 32 ... 1024 tiles are within 2 %.
+                int64_t chunk = g_resize_xcd == 0 ? 0 : (g_resize_xcd >= 8 ? g_resize_xcd : (g_resize_xcd == 2 ? n_tiles / 8 : 64));
+                if (chunk > n_tiles / 8) chunk = n_tiles / 8;
+                const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0)};
                 hipLaunchKernelGGL(resize_strip_kernel, dim3((unsigned)(planes * tx * tyy)), dim3(256), lds, s,
                                    static_cast<const float *>(src), static_cast<float *>(dst), (int)h_out, (int)w_out, (int)w_in, tg, fw, fh);
                 const hipError_t e = hipGetLastError();

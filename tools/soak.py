@@ -18,7 +18,7 @@ rng = random.Random(12345)
 g = torch.Generator(device="cuda").manual_seed(1)
 dev = torch.device("cuda", 0)
 t_end = time.time() + seconds
-n_cfg = n_bwd = n_blend = 0
+n_cfg = n_bwd = n_blend = n_stream = 0
 while time.time() < t_end:
     B = rng.choice([1, 1, 2, 3, 4, 5, 8])
     h = rng.choice([1, 2, 7, 16, 33, 64, 100, 257, 512])
@@ -77,5 +77,17 @@ while time.time() < t_end:
             ob = F.cook_torrance(a, n, r, m, s, blend=second, **kw)
             assert bool(torch.isfinite(ob).all()), ("blend", B, h, w, lights, wf, ltype)
             n_blend += 1
+    if dtype == torch.float16 and lights == 1 and w % 128 == 0 and (ny, nx) == (1, 1) and r.shape[0] == B:
+        # the streamed backward kernel (rounds 1 ... 4) == the one-tile kernels, bit for bit
+        lib = N.lib()
+        grads = []
+        for knob in (0, rng.choice([-1, 1, 2, 3])):
+            lib.pbr_set_tuning(N.TUNE_BWD_RUN, knob)
+            leaves = [None if t is None else t.clone().requires_grad_(True) for t in (a, n, r, m, s)]
+            F.cook_torrance(*leaves, **kw).square().sum().backward()
+            grads.append([None if t is None else t.grad for t in leaves])
+        lib.pbr_set_tuning(N.TUNE_BWD_RUN, -1)
+        assert all(x is None or torch.equal(x, y) for x, y in zip(*grads)), ("streamed backward", B, h, w, wf, ltype)
+        n_stream += 1
 torch.cuda.synchronize()
-print(f"soak ok: {n_cfg} configurations x 2 orders, {n_bwd} backward passes, {n_blend} fused blends in {seconds:.0f} s")
+print(f"soak ok: {n_cfg} configurations x 2 orders, {n_bwd} backward passes, {n_blend} fused blends, {n_stream} streamed backward passes in {seconds:.0f} s")

@@ -165,6 +165,8 @@ int pbr_cook_torrance_blend(const pbr_render_desc *desc, const pbr_blend_desc *b
  * ([B][3|1][H][W]); NULL skips it.  Same sub-gradient conventions as torch (clamp passes on the
  * closed interval).  With tiled maps (map_height/map_width) the g_* are OUTPUT-sized: one value per
  * output pixel; the gradient of a texel is the sum over its repeats, which is left to the caller.
+ * fp16 maps with one light, rows of a whole number of 128 pixels and 4-byte-aligned planes take a streamed kernel (persistent
+ * waves, the next tile prefetched global -> LDS); every other launch the one-tile kernels -- same values either way.
  */
 int pbr_cook_torrance_backward(const pbr_render_desc *desc, const void *grad_out, void *g_albedo,
                                void *g_normal, void *g_roughness, void *g_metallic, void *g_specular,

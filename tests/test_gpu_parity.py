@@ -878,3 +878,27 @@ def test_resize_guard_bands_and_random_shapes():
         # the source coordinate scale * (i + 0.5) of a large map carries ~1e-5 of fp32 rounding (ulp of 100 is 7.6e-6), and
         # ATen and this kernel round it at different points: weights, hence values in [0,1], agree to ~1e-5, not to the ulp
         assert (got - ref).abs().max().item() <= 1e-5, (trial, c, hi, wi, ho, wo, aa, float((got - ref).abs().max()))
+
+
+def test_resize_tile_orders_are_bit_identical():
+    """pbr_resize_bilinear walks its tiles in XCD-contiguous chunks (every XCD takes its own chunk of each block of 8 chunks, so
+    the tiles that share halo rows and boundary lines meet in one L2).  The order only changes WHERE a tile runs: identity order,
+    chunks of 64 (default), one chunk per XCD and chunks of 8 tiles must agree bit for bit -- on tile counts that are not a
+    multiple of a block, down- and up-scaling -- and with ATen."""
+    from pypbr_amd import _native as N, functional as F
+    lib = N.lib()
+    g = torch.Generator().manual_seed(77)
+    try:
+        for shape, size, aa in (((3, 1000, 1400), (700, 900), True), ((2, 520, 1096), (1210, 1500), False), ((5, 777, 640), (300, 333), True)):
+            x = torch.rand(*shape, generator=g)
+            ref = torch.nn.functional.interpolate(x[None], size=size, mode="bilinear", align_corners=False, antialias=aa)[0]
+            outs = []
+            for knob in (0, 1, 2, 8):
+                lib.pbr_set_tuning(N.TUNE_RESIZE_XCD, knob)
+                outs.append(F.resize(x.cuda(), size, antialias=aa))
+            for o in outs[1:]:
+                assert torch.equal(outs[0], o), (shape, size)
+            # source coordinates of a 1 500-pixel axis carry ~1e-5 of fp32 rounding, and ATen rounds them at other points (see the test above)
+            assert (outs[0].cpu() - ref).abs().max().item() <= 3e-5, (shape, size)
+    finally:
+        lib.pbr_set_tuning(N.TUNE_RESIZE_XCD, 1)

@@ -454,12 +454,12 @@ void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
 // ------------------------------------------------------------------ streamed form (fp16 maps, one light)
 // With fp16 maps the backward pass moves 44 B per pixel and is bound by instruction issue, not by HBM: a one-tile wave
 // spends about as long being dispatched, forming its 19 plane addresses and waiting for its first loads as it spends
-// computing, and at 4 waves per SIMD (125 VGPRs) that leaves the VALUs idle a third of the time.  Here the grid is as many
+// computing, and its 4 waves per SIMD (125 VGPRs) cannot cover that: the VALUs idle a third of the time.  Here the grid is as many
 // waves as the chip holds at once (or a small multiple), and wave w of a material walks its 128-pixel tiles w, w + G,
 // w + 2 G ... (G = waves per material): at any moment the chip works on one compact window of every plane, as with
 // one-tile waves, every wave does the same amount of work (no tail round), and the texels and the upstream gradient of the NEXT tile travel global ->
-// LDS (global_load_lds_dword: no VGPR destination, so the prefetch costs no registers and the kernel keeps its 4 waves
-// per SIMD) while the current tile is differentiated from registers.  Per tile: 8 (10) map planes x 256 B + 3 gradient
+// LDS (global_load_lds_dword: no VGPR destination, so the prefetch costs no registers) while the current tile is
+// differentiated from registers; 3 waves per SIMD (the loop needs 124-150 VGPRs; a fourth wave measured level).  Per tile: 8 (10) map planes x 256 B + 3 gradient
 // planes x 512 B = 3.5 (4) KiB of LDS per wave, ONE buffer -- a tile's values are copied to registers (11 ds_reads)
 // before the next tile's loads are issued into the same buffer.  Plane addresses, the material index and the light block
 // are formed once per wave; a tile costs a scalar row / column split and the lane-constant offset.  Same backward_body as
@@ -492,10 +492,12 @@ void cook_torrance_backward_stream_kernel(const KArgs a, const BArgs b, const in
     const int lane = threadIdx.x, mat = blockIdx.y;
     const int t0 = blockIdx.x, t1 = tiles_per_material, step = gridDim.x;      // tiles t0, t0 + step, ... of material `mat`
     if (FULL) {      // the usual rendering-loss launch: sRGB in and out, a normal map, every gradient wanted -- no flag branches
+        // exactly the facts the launcher has checked for this workflow (a false assumption would be undefined behaviour): the
+        // specular decode flag only where the workflow reads it, the metallic | specular gradient only where it is written
         __builtin_assume(a.albedo_srgb != 0); __builtin_assume(a.out_srgb != 0); __builtin_assume(a.has_normal != 0);
-        __builtin_assume(a.spec_srgb != 0);
         __builtin_assume(b.g_albedo != nullptr); __builtin_assume(b.g_normal != nullptr); __builtin_assume(b.g_rough != nullptr);
-        __builtin_assume(b.g_metal != nullptr); __builtin_assume(b.g_spec != nullptr);
+        if (WF != PBR_WORKFLOW_METALLIC) __builtin_assume(a.spec_srgb != 0);
+        if (WF == PBR_WORKFLOW_SPECULAR) __builtin_assume(b.g_spec != nullptr); else __builtin_assume(b.g_metal != nullptr);
     }
     const bool has_normal = FULL || a.has_normal != 0;
     auto issue = [&](int t) {

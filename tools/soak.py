@@ -19,7 +19,11 @@ g = torch.Generator(device="cuda").manual_seed(1)
 dev = torch.device("cuda", 0)
 t_end = time.time() + seconds
 n_cfg = n_bwd = n_blend = n_stream = 0
+t_note = time.time() + 60
 while time.time() < t_end:
+    if time.time() > t_note:                      # a line a minute: a silent GPU job is taken to be hung
+        print(f"  ... {n_cfg} configurations so far", flush=True)
+        t_note += 60
     B = rng.choice([1, 1, 2, 3, 4, 5, 8])
     h = rng.choice([1, 2, 7, 16, 33, 64, 100, 257, 512])
     w = rng.choice([1, 3, 4, 5, 8, 12, 13, 20, 37, 64, 100, 256, 1000, 1001, 1024])

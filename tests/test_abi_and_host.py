@@ -473,3 +473,20 @@ def test_bench_parent_process_refuses_more_ranks_than_devices_without_touching_t
     run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"],
                          capture_output=True, text=True, env=env, timeout=300)
     assert run.returncode != 0 and "only %d ROCm device(s) visible" % torch.cuda.device_count() in (run.stderr + run.stdout)
+
+
+def test_tuning_knob_numbers_match_the_header():
+    """The PBR_TUNE_* enumerators of include/pbr_hip.h, the TUNE_* constants of the ctypes binding and pbr_set_tuning agree:
+    every knob of the header is known to the binding under the same number, the library accepts it (and hands back the
+    previous value), and an unknown number is refused."""
+    import re
+    from pypbr_amd import _native as N
+    header = open(os.path.join(ROOT, "include", "pbr_hip.h")).read()
+    knobs = {m.group(1): int(m.group(2)) for m in re.finditer(r"PBR_TUNE_(\w+)\s*=\s*(\d+)", header)}
+    assert len(knobs) >= 13 and sorted(knobs.values()) == list(range(len(knobs)))
+    lib = N.lib()
+    for name, number in knobs.items():
+        assert getattr(N, "TUNE_" + name) == number, name
+        old = lib.pbr_set_tuning(number, 0)
+        assert lib.pbr_set_tuning(number, old) == 0, name              # the value just set comes back; the old one is restored
+    assert lib.pbr_set_tuning(len(knobs), 0) == -1

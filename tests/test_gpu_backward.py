@@ -425,6 +425,7 @@ def test_streamed_backward_is_bit_identical_to_the_one_tile_kernels():
              ("converted", maps(2, 5, 256), dict(sun, convert_to_diffuse_specular=True), {}),
              ("no normal map", maps(1, 11, 128), point, dict(no_normal=True)),
              ("albedo and roughness only", maps(1, 8, 256), sun, dict(wanted=(True, False, True, False))),
+             ("row band of a taller map", maps(2, 6, 256), dict(point, y_offset=5, height_total=32), {}),
              ("full rows 64 x 1024", maps(1, 64, 1024), point, {})]
     try:
         for name, mp, kw, extra in cases:

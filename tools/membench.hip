@@ -103,6 +103,23 @@ void oneshot_w3(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size
     st<NT>(out + i, r0); st<NT>(out + plane + i, r1); st<NT>(out + 2 * plane + i, r2);
 }
 
+// the BACKWARD kernel's pattern: 8 map planes + 3 upstream-gradient planes in, 8 gradient planes out (19 streams, 76 B per
+// pixel), one-wave groups at WPE waves per SIMD, optional arithmetic
+template <bool NT, int FMAS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void oneshot_bwd(const f4 *__restrict__ in, const f4 *__restrict__ gout, f4 *__restrict__ out, size_t nv, size_t plane) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= nv) return;
+    f4 v[11];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = ld<NT>(in + c * plane + i);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[8 + c] = ld<NT>(gout + c * plane + i);
+    const f4 r = work<FMAS>(v[0] + v[3] + v[6] + v[8], v[9], v[10]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) st<NT>(out + c * plane + i, r + v[c]);
+}
+
 // two 1 KiB pieces per plane and wave (lane l: pieces l and l + 64 of a 2 KiB run): 16 loads in flight per lane, every
 // instruction still covers a contiguous 1 KiB.  WPE waves per SIMD.
 template <bool NT, int FMAS, int WPE>
@@ -195,6 +212,13 @@ int main(int argc, char **argv) {
     X2(1, 0, 0); X2(2, 0, 0); X2(2, 0, 24576); X2(2, 0, 32768); X2(3, 0, 0);
     X2(1, 60, 0); X2(2, 60, 0); X2(2, 60, 24576); X2(2, 60, 32768); X2(2, 160, 0); X2(2, 160, 24576);
     W3L(0, 14848); X2(2, 0, 24576);
+    {   // backward pattern: 19 streams
+        f4 *bo = nullptr; CHECK(hipMalloc(&bo, 8 * px * 4));
+        const double bytes_b = 76.0 * px;
+#define BWD(WPE, F) report("backward pattern 11 in / 8 out, valu/px=" #F " waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_bwd<true, F, WPE>), dim3((nv + 63) / 64), dim3(64), 0, 0, in[i % NSETS], out[i % NSETS], bo, nv, plane); }, iters), bytes_b)
+        BWD(2, 0); BWD(3, 0); BWD(4, 0); BWD(2, 60); BWD(2, 160); BWD(3, 60); BWD(2, 0);
+        CHECK(hipFree(bo));
+    }
 #define PERSIST(NT, F, B, G) report("persistent nt=" #NT " valu/px=" #F " block=" #B " grid=" #G, time_us([&](int i) { hipLaunchKernelGGL((persistent<NT, F, B>), dim3(G), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
     PERSIST(true, 0, 256, 1024); PERSIST(true, 0, 256, 2048);
     PERSIST(true, 60, 256, 2048);

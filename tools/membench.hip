@@ -120,6 +120,35 @@ void oneshot_bwd(const f4 *__restrict__ in, const f4 *__restrict__ gout, f4 *__r
     for (int c = 0; c < 8; ++c) st<NT>(out + c * plane + i, r + v[c]);
 }
 
+// the backward kernel's pattern with fp16 maps (44 B per pixel: 8 fp16 planes + 3 fp32 gradient planes in, 8 fp16 planes out).
+// PX = pixels per lane: 2 = what the kernels do (4-byte map accesses, 8-byte gradient accesses), 8 = the same bytes through
+// 16-byte accesses.  One-wave groups, WPE waves per SIMD.
+template <int PX, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void oneshot_bwd16(const unsigned *__restrict__ in, const float *__restrict__ gout, unsigned *__restrict__ out, size_t npx, size_t plane_px) {
+    const size_t i = ((size_t)blockIdx.x * 64 + threadIdx.x) * PX;            // first pixel of the lane
+    if (i >= npx) return;
+    constexpr int W = PX / 2, G = PX;                                           // dwords per lane and plane: maps | gradient
+    unsigned v[8][W]; float g[3][G];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[c][k] = __builtin_nontemporal_load(in + (c * plane_px + i) / 2 + k);
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < G; ++k) g[c][k] = __builtin_nontemporal_load(gout + c * plane_px + i + k);
+    unsigned mix = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < G; ++k) mix ^= __float_as_uint(g[c][k]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int k = 0; k < W; ++k) __builtin_nontemporal_store(v[c][k] ^ mix, out + (c * plane_px + i) / 2 + k);
+}
+
 // two 1 KiB pieces per plane and wave (lane l: pieces l and l + 64 of a 2 KiB run): 16 loads in flight per lane, every
 // instruction still covers a contiguous 1 KiB.  WPE waves per SIMD.
 template <bool NT, int FMAS, int WPE>
@@ -218,6 +247,15 @@ int main(int argc, char **argv) {
 #define BWD(WPE, F) report("backward pattern 11 in / 8 out, valu/px=" #F " waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_bwd<true, F, WPE>), dim3((nv + 63) / 64), dim3(64), 0, 0, in[i % NSETS], out[i % NSETS], bo, nv, plane); }, iters), bytes_b)
         BWD(2, 0); BWD(3, 0); BWD(4, 0); BWD(2, 60); BWD(2, 160); BWD(3, 60); BWD(2, 0);
         CHECK(hipFree(bo));
+    }
+    {   // backward pattern with fp16 maps: 4-byte accesses (what the kernels do) against 16-byte accesses on the same bytes
+        unsigned *hi = nullptr, *ho = nullptr; float *hg = nullptr;
+        CHECK(hipMalloc(&hi, 8 * px * 2)); CHECK(hipMalloc(&ho, 8 * px * 2)); CHECK(hipMalloc(&hg, 3 * px * 4));
+        CHECK(hipMemset(hi, 0x3c, 8 * px * 2)); CHECK(hipMemset(hg, 0x3c, 3 * px * 4));
+        const double bytes_h = 44.0 * px;
+#define BWD16(PX, WPE) report("fp16 backward pattern, " #PX " px per lane, waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_bwd16<PX, WPE>), dim3((unsigned)((px / PX + 63) / 64)), dim3(64), 0, 0, hi, hg, ho, px, px); }, iters), bytes_h)
+        BWD16(2, 4); BWD16(2, 3); BWD16(2, 8); BWD16(4, 4); BWD16(8, 3); BWD16(8, 2); BWD16(2, 4); BWD16(8, 3);
+        CHECK(hipFree(hi)); CHECK(hipFree(ho)); CHECK(hipFree(hg));
     }
 #define PERSIST(NT, F, B, G) report("persistent nt=" #NT " valu/px=" #F " block=" #B " grid=" #G, time_us([&](int i) { hipLaunchKernelGGL((persistent<NT, F, B>), dim3(G), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
     PERSIST(true, 0, 256, 1024); PERSIST(true, 0, 256, 2048);

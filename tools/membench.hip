@@ -149,6 +149,24 @@ void oneshot_bwd16(const unsigned *__restrict__ in, const float *__restrict__ go
         for (int k = 0; k < W; ++k) __builtin_nontemporal_store(v[c][k] ^ mix, out + (c * plane_px + i) / 2 + k);
 }
 
+// the forward kernel's pattern with fp16 maps and an fp32 result (28 B per pixel), 8 pixels per lane: 16-byte loads, two
+// 16-byte stores per result plane (each covering 16 of every 32 bytes -- the kernel swaps pieces through LDS to fill them)
+template <int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void oneshot_fwd16(const f4 *__restrict__ in, f4 *__restrict__ out, size_t npx, size_t plane_px) {
+    const size_t i = ((size_t)blockIdx.x * 64 + threadIdx.x) * 8;
+    if (i >= npx) return;
+    f4 v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = __builtin_nontemporal_load(in + (c * plane_px + i) / 8);
+    const f4 r = v[0] + v[1] + v[2] + v[3] + v[4] + v[5] + v[6] + v[7];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        __builtin_nontemporal_store(r + v[c], out + (c * plane_px + i) / 4);
+        __builtin_nontemporal_store(r - v[c], out + (c * plane_px + i) / 4 + 1);
+    }
+}
+
 // two 1 KiB pieces per plane and wave (lane l: pieces l and l + 64 of a 2 KiB run): 16 loads in flight per lane, every
 // instruction still covers a contiguous 1 KiB.  WPE waves per SIMD.
 template <bool NT, int FMAS, int WPE>
@@ -256,6 +274,14 @@ int main(int argc, char **argv) {
 #define BWD16(PX, WPE) report("fp16 backward pattern, " #PX " px per lane, waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_bwd16<PX, WPE>), dim3((unsigned)((px / PX + 63) / 64)), dim3(64), 0, 0, hi, hg, ho, px, px); }, iters), bytes_h)
         BWD16(2, 4); BWD16(2, 3); BWD16(2, 8); BWD16(4, 4); BWD16(8, 3); BWD16(8, 2); BWD16(2, 4); BWD16(8, 3);
         CHECK(hipFree(hi)); CHECK(hipFree(ho)); CHECK(hipFree(hg));
+    }
+    {   // forward pattern with fp16 maps -> fp32 result, four materials (the config 5' probe shape)
+        const size_t p4 = 4 * px;
+        f4 *fi = nullptr, *fo = nullptr;
+        CHECK(hipMalloc(&fi, 8 * p4 * 2)); CHECK(hipMalloc(&fo, 3 * p4 * 4)); CHECK(hipMemset(fi, 0x3c, 8 * p4 * 2));
+#define FWD16(WPE) report("fp16 forward pattern 4 x S^2, 8 px per lane, waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_fwd16<WPE>), dim3((unsigned)((p4 / 8 + 63) / 64)), dim3(64), 0, 0, fi, fo, p4, p4); }, iters), 28.0 * p4)
+        FWD16(2); FWD16(3); FWD16(4); FWD16(3);
+        CHECK(hipFree(fi)); CHECK(hipFree(fo));
     }
 #define PERSIST(NT, F, B, G) report("persistent nt=" #NT " valu/px=" #F " block=" #B " grid=" #G, time_us([&](int i) { hipLaunchKernelGGL((persistent<NT, F, B>), dim3(G), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
     PERSIST(true, 0, 256, 1024); PERSIST(true, 0, 256, 2048);

@@ -167,6 +167,30 @@ void oneshot_fwd16(const f4 *__restrict__ in, f4 *__restrict__ out, size_t npx, 
     }
 }
 
+// BASELINE config 3's layout: B materials as five [B][C][S^2] tensors (albedo 3, normal 3, roughness 1, metallic 1 -> result 3),
+// 11 streams whose plane strides are all multiples of 16 MiB at S = 2048.  RUNS: XCD x takes runs of 64 consecutive tiles
+// (tile_of_workgroup's remap); else the identity order.  One-wave groups, 3 waves per SIMD, as the fused kernel.
+template <bool RUNS, int FMAS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void batch_w3(const f4 *__restrict__ al, const f4 *__restrict__ nm, const f4 *__restrict__ ro, const f4 *__restrict__ me, f4 *__restrict__ out,
+              unsigned tiles_per_mat, unsigned n_tiles, size_t plane) {
+    unsigned tile = blockIdx.x;
+    if (RUNS && tile < (n_tiles >> 9 << 9)) { const unsigned xcd = tile & 7u, slot = tile >> 3; tile = ((slot >> 6) << 9) + (xcd << 6) + (slot & 63u); }
+    const unsigned b = tile / tiles_per_mat;
+    const size_t i = (size_t)(tile - b * tiles_per_mat) * 64 + threadIdx.x;
+    f4 v[8];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = ld<true>(al + ((size_t)b * 3 + c) * plane + i);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[3 + c] = ld<true>(nm + ((size_t)b * 3 + c) * plane + i);
+    v[6] = ld<true>(ro + (size_t)b * plane + i);
+    v[7] = ld<true>(me + (size_t)b * plane + i);
+    f4 r0 = work<FMAS>(v[0] + v[3] + v[6], v[6], v[7]);
+    f4 r1 = work<FMAS>(v[1] + v[4] + v[7], v[6], v[7]);
+    f4 r2 = work<FMAS>(v[2] + v[5], v[6], v[7]);
+    st<true>(out + ((size_t)b * 3) * plane + i, r0); st<true>(out + ((size_t)b * 3 + 1) * plane + i, r1); st<true>(out + ((size_t)b * 3 + 2) * plane + i, r2);
+}
+
 // two 1 KiB pieces per plane and wave (lane l: pieces l and l + 64 of a 2 KiB run): 16 loads in flight per lane, every
 // instruction still covers a contiguous 1 KiB.  WPE waves per SIMD.
 template <bool NT, int FMAS, int WPE>
@@ -282,6 +306,20 @@ int main(int argc, char **argv) {
 #define FWD16(WPE) report("fp16 forward pattern 4 x S^2, 8 px per lane, waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_fwd16<WPE>), dim3((unsigned)((p4 / 8 + 63) / 64)), dim3(64), 0, 0, fi, fo, p4, p4); }, iters), 28.0 * p4)
         FWD16(2); FWD16(3); FWD16(4); FWD16(3);
         CHECK(hipFree(fi)); CHECK(hipFree(fo));
+    }
+    for (int cfg = 0; cfg < 2; ++cfg) {   // config 3 (64 x 2048^2) and config 4's share (64 x 1024^2): the batch layout's own ceiling, both orders
+        const size_t s = cfg == 0 ? 2048 : 1024, B = 64, pp = s * s / 4;          // plane in f4 units
+        f4 *al, *nm, *ro, *me, *ou;
+        CHECK(hipMalloc(&al, B * 3 * pp * 16)); CHECK(hipMalloc(&nm, B * 3 * pp * 16)); CHECK(hipMalloc(&ro, B * pp * 16)); CHECK(hipMalloc(&me, B * pp * 16));
+        CHECK(hipMalloc(&ou, B * 3 * pp * 16));
+        CHECK(hipMemset(al, 0x3c, B * 3 * pp * 16)); CHECK(hipMemset(nm, 0x3c, B * 3 * pp * 16)); CHECK(hipMemset(ro, 0x3c, B * pp * 16)); CHECK(hipMemset(me, 0x3c, B * pp * 16));
+        const unsigned tpm = (unsigned)(pp / 64), nt = (unsigned)(B * tpm);
+        const double bytes_b = 44.0 * B * s * s;
+        char nm2[96];
+#define BATCH(RUNS, F) snprintf(nm2, sizeof(nm2), "batch 64 x %zu^2, order=%s, valu/px=%d", s, RUNS ? "runs of 64" : "identity", F); \
+        report(nm2, time_us([&](int i) { hipLaunchKernelGGL((batch_w3<RUNS, F>), dim3(nt), dim3(64), 0, 0, al, nm, ro, me, ou, tpm, nt, pp); }, 10), bytes_b)
+        BATCH(false, 0); BATCH(true, 0); BATCH(false, 60); BATCH(true, 60); BATCH(false, 0); BATCH(true, 0);
+        CHECK(hipFree(al)); CHECK(hipFree(nm)); CHECK(hipFree(ro)); CHECK(hipFree(me)); CHECK(hipFree(ou));
     }
 #define PERSIST(NT, F, B, G) report("persistent nt=" #NT " valu/px=" #F " block=" #B " grid=" #G, time_us([&](int i) { hipLaunchKernelGGL((persistent<NT, F, B>), dim3(G), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)
     PERSIST(true, 0, 256, 1024); PERSIST(true, 0, 256, 2048);

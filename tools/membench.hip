@@ -191,6 +191,22 @@ void batch_w3(const f4 *__restrict__ al, const f4 *__restrict__ nm, const f4 *__
     st<true>(out + ((size_t)b * 3) * plane + i, r0); st<true>(out + ((size_t)b * 3 + 1) * plane + i, r1); st<true>(out + ((size_t)b * 3 + 2) * plane + i, r2);
 }
 
+// the fused blend + render pattern: two materials (8 planes each) and a mask in, 3 planes out (80 B per pixel, 20 streams)
+template <int WPE, int FMAS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void oneshot_blend(const f4 *__restrict__ a, const f4 *__restrict__ b, const f4 *__restrict__ mask, f4 *__restrict__ out, size_t nv, size_t plane) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= nv) return;
+    f4 v[17];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { v[c] = ld<true>(a + c * plane + i); v[8 + c] = ld<true>(b + c * plane + i); }
+    v[16] = ld<true>(mask + i);
+    f4 m0 = v[16], s0 = v[0] * m0 + v[8], s1 = v[1] * m0 + v[9], s2 = v[2] * m0 + v[10];
+#pragma unroll
+    for (int c = 3; c < 8; ++c) { s0 += v[c] * m0; s1 += v[8 + c]; s2 += v[c] - v[8 + c]; }
+    st<true>(out + i, work<FMAS>(s0, s1, s2)); st<true>(out + plane + i, work<FMAS>(s1, s2, s0)); st<true>(out + 2 * plane + i, work<FMAS>(s2, s0, s1));
+}
+
 // two 1 KiB pieces per plane and wave (lane l: pieces l and l + 64 of a 2 KiB run): 16 loads in flight per lane, every
 // instruction still covers a contiguous 1 KiB.  WPE waves per SIMD.
 template <bool NT, int FMAS, int WPE>
@@ -306,6 +322,12 @@ int main(int argc, char **argv) {
 #define FWD16(WPE) report("fp16 forward pattern 4 x S^2, 8 px per lane, waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_fwd16<WPE>), dim3((unsigned)((p4 / 8 + 63) / 64)), dim3(64), 0, 0, fi, fo, p4, p4); }, iters), 28.0 * p4)
         FWD16(2); FWD16(3); FWD16(4); FWD16(3);
         CHECK(hipFree(fi)); CHECK(hipFree(fo));
+    }
+    {   // fused blend + render pattern: 17 planes in, 3 out
+        f4 *mk = nullptr; CHECK(hipMalloc(&mk, px * 4)); CHECK(hipMemset(mk, 0x3c, px * 4));
+#define BLEND(WPE, F) report("blend+render pattern 17 in / 3 out, valu/px=" #F " waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_blend<WPE, F>), dim3((nv + 63) / 64), dim3(64), 0, 0, in[0], in[1], mk, out[i % NSETS], nv, plane); }, iters), 80.0 * px)
+        BLEND(2, 0); BLEND(3, 0); BLEND(2, 60); BLEND(3, 60); BLEND(2, 0);
+        CHECK(hipFree(mk));
     }
     for (int cfg = 0; cfg < 2; ++cfg) {   // config 3 (64 x 2048^2) and config 4's share (64 x 1024^2): the batch layout's own ceiling, both orders
         const size_t s = cfg == 0 ? 2048 : 1024, B = 64, pp = s * s / 4;          // plane in f4 units

@@ -341,6 +341,20 @@ int main(int argc, char **argv) {
 #define BATCH(RUNS, F) snprintf(nm2, sizeof(nm2), "batch 64 x %zu^2, order=%s, valu/px=%d", s, RUNS ? "runs of 64" : "identity", F); \
         report(nm2, time_us([&](int i) { hipLaunchKernelGGL((batch_w3<RUNS, F>), dim3(nt), dim3(64), 0, 0, al, nm, ro, me, ou, tpm, nt, pp); }, 10), bytes_b)
         BATCH(false, 0); BATCH(true, 0); BATCH(false, 60); BATCH(true, 60); BATCH(false, 0); BATCH(true, 0);
+        if (cfg == 0) {      // the same batch with every plane stride padded off the 16 MiB grid (one allocation per tensor, planes pp + pad apart)
+            for (size_t pad : {(size_t)272, (size_t)4112, (size_t)65552}) {          // f4 units: 4 352 B, 64.25 KiB, 1 MiB + 256 B
+                f4 *al2, *nm2b, *ro2, *me2, *ou2;
+                const size_t ps = pp + pad;
+                CHECK(hipMalloc(&al2, B * 3 * ps * 16)); CHECK(hipMalloc(&nm2b, B * 3 * ps * 16)); CHECK(hipMalloc(&ro2, B * ps * 16)); CHECK(hipMalloc(&me2, B * ps * 16));
+                CHECK(hipMalloc(&ou2, B * 3 * ps * 16));
+                CHECK(hipMemset(al2, 0x3c, B * 3 * ps * 16)); CHECK(hipMemset(nm2b, 0x3c, B * 3 * ps * 16)); CHECK(hipMemset(ro2, 0x3c, B * ps * 16)); CHECK(hipMemset(me2, 0x3c, B * ps * 16));
+                snprintf(nm2, sizeof(nm2), "batch 64 x 2048^2, plane stride +%zu B, identity", pad * 16);
+                report(nm2, time_us([&](int i) { hipLaunchKernelGGL((batch_w3<false, 0>), dim3(nt), dim3(64), 0, 0, al2, nm2b, ro2, me2, ou2, tpm, nt, ps); }, 10), bytes_b);
+                snprintf(nm2, sizeof(nm2), "batch 64 x 2048^2, plane stride +%zu B, runs of 64", pad * 16);
+                report(nm2, time_us([&](int i) { hipLaunchKernelGGL((batch_w3<true, 0>), dim3(nt), dim3(64), 0, 0, al2, nm2b, ro2, me2, ou2, tpm, nt, ps); }, 10), bytes_b);
+                CHECK(hipFree(al2)); CHECK(hipFree(nm2b)); CHECK(hipFree(ro2)); CHECK(hipFree(me2)); CHECK(hipFree(ou2));
+            }
+        }
         CHECK(hipFree(al)); CHECK(hipFree(nm)); CHECK(hipFree(ro)); CHECK(hipFree(me)); CHECK(hipFree(ou));
     }
 #define PERSIST(NT, F, B, G) report("persistent nt=" #NT " valu/px=" #F " block=" #B " grid=" #G, time_us([&](int i) { hipLaunchKernelGGL((persistent<NT, F, B>), dim3(G), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_rw)

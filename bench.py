@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of fused Cook-Torrance evaluation on MI355X.
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): one
-4096x4096 BasecolorMetallicMaterial per GPU (albedo sRGB, decoded normal, roughness,
-metallic; fp32 planar), point light, sRGB output.  A "step" is one pass of the hot
-path over that batch = ONE launch of the fused kernel through the C ABI
-(pbr_cook_torrance), inputs already resident in HBM.  With --gpus N every rank owns
-its own material (independent materials shard with no data-path collective, weak
-scaling); the light/view parameter block is broadcast once from rank 0 over RCCL.
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--size S] [--batch B] [--no-cpu-baseline]
+                  [--layout arena|separate] [--settle L] [--cpu-budget SECONDS]
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096] [--no-cpu-baseline] [--layout arena|separate] [--settle 300]
+`--config` selects the workload by SURVEY.md 8d's numbering (= BASELINE.json configs[config - 1]); a "step" is one pass of
+the hot path over this rank's batch = ONE launch of the fused kernel through the C ABI, inputs already resident in HBM:
+  2 (default, the configuration the metric is quoted on)  one 4096x4096 BasecolorMetallicMaterial PER GPU (albedo sRGB,
+     decoded normal, roughness, metallic; fp32 planar), point light, sRGB out.  WEAK scaling: every rank owns its own
+     material;
+  3  B=64 2048x2048 materials, directional light, sRGB -> linear and the metallic -> diffuse/specular conversion fused
+     in front of the specular-workflow evaluation (upstream's F6 flag setting timed, the other one beside it);
+  4  B=512 1024x1024 materials, point light;
+  5  B=32 4096x4096 materials, 16 point lights on a ring accumulated in-kernel, fp16 maps, fp32 accumulate and result.
+Configs 3-5 are STRONG-scaled: the job is the whole batch, rank r generates and owns the materials of
+pypbr_amd.distributed.partition(B, H, N, r) -- nobody ever holds the whole batch -- and evaluates them through
+pypbr_amd.distributed.cook_torrance_sharded(owned=...), which broadcasts the light / view block from rank 0 over RCCL
+(backend "nccl") before the plan is built.  The data path has no collective; results stay sharded.
 
 `python bench.py --gpus N` with N > 1 starts the N ranks itself: the parent process (which never touches a GPU)
 runs `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
@@ -19,20 +26,23 @@ environment), the script is a rank.
 Timing protocol.  Two timed regions, both K steps bracketed by barrier + synchronize, MAX over ranks:
   cold    W warm-up launches from whatever state the GPU was in, then K timed steps -- the literal
           "W warm-up, K steps" protocol -> `ms_per_step_cold`, `value_cold`;
-  steady  `--settle` (default 300) further untimed launches so that power management has settled the clocks
-          (tools/transient_probe.py), then K timed steps -> `ms_per_step`, `value`: the sustained rate.
+  steady  `--settle` further untimed launches (default: 300 for config 2, else what fills ~40 ms) so that power
+          management has settled the clocks (tools/transient_probe.py), then K timed steps -> `ms_per_step`, `value`:
+          the sustained rate.
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
-  roofline     -- achieved algorithmic HBM GB/s of the kernel (44 B/pixel x pixels per launch / average launch
-                  duration from HIP events on the launch stream over ALL 2K timed launches, cold + steady: the figure a
-                  rocprofv3 --kernel-trace average of the same command reproduces) vs 8 TB/s
-  per_rank     -- kernel_us of every rank (steady region) and the latency of the light-block broadcast
+  roofline     -- achieved algorithmic HBM GB/s of the kernel (bytes per pixel x this rank's pixels per launch / average
+                  launch duration from HIP events on the launch stream over ALL 2K timed launches, cold + steady: the figure a
+                  rocprofv3 --kernel-trace average of the same command reproduces) vs 8 TB/s; for N > 1 the slowest rank's
+  roofline_valu-- config 5 only: the launch is VALU-bound; vector instructions issued per second against the chip's issue rate
+  per_rank     -- kernel_us of every rank (steady region), its shard, and the latency of the light-block broadcast
   parity       -- bands of the timed output of this run against the float64 C oracle and the ATen restatement
-  cpu_baseline -- the ATen-level restatement of the reference's CPU path (oracle/torch_oracle.py,
-                  kind "port": bit-equal to the reference in the dev container) timed on this
-                  host's cores on a bounded sample, rank 0, N=1 only.
+  cpu_baseline -- the ATen-level restatement of the reference's CPU path (oracle/torch_oracle.py, kind "port": bit-equal to the
+                  reference in the dev container) timed on this host's cores, rank 0, N=1 only: 1 thread and all host
+                  cores at 256^2 / 1024^2 / 2048^2, CPU model stated.
 """
 import argparse
 import json
+import math
 import os
 import socket
 import subprocess
@@ -45,13 +55,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-N_BUFFER_SETS = 3              # rotate map sets: 704 MiB per step never re-hits the 256 MiB Infinity Cache anyway
-VIEW, LIGHT, INTENSITY, LIGHT_SIZE = [0.0, 0.0, 1.0], [0.1, 0.1, 1.0], [1.0, 1.0, 1.0], 1.0
+N_BUFFER_SETS = 3              # config 2 rotates map sets: 704 MiB per step never re-hits the 256 MiB Infinity Cache anyway
+VIEW = [0.0, 0.0, 1.0]
+RING16 = [[math.cos(2 * math.pi * i / 16), math.sin(2 * math.pi * i / 16), 1.0] for i in range(16)]
+
+# SURVEY.md 8d.  light/intensity are lists of lights; `flags` go to the evaluation as they are.
+CONFIGS = {
+    2: dict(batch=1, size=4096, scaling="weak", dtype=torch.float32, light_type="point", light=[[0.1, 0.1, 1.0]],
+            intensity=[[1.0, 1.0, 1.0]], light_size=1.0, flags={}, steps=500, warmup=50,
+            name="Batch=1 {S}x{S} BasecolorMetallicMaterial per GPU, point light, fused HIP kernel, fp32 maps, sRGB in/out "
+                 "(BASELINE.json configs[1])"),
+    3: dict(batch=64, size=2048, scaling="strong", dtype=torch.float32, light_type="directional", light=[[0.3, -0.2, 1.0]],
+            intensity=[[1.0, 1.0, 1.0]], light_size=None, flags=dict(convert_to_diffuse_specular=True, specular_is_srgb=True),
+            steps=40, warmup=5,
+            name="Batch={B} {S}x{S} materials, directional light, sRGB->linear + metallic->diffuse-specular conversion fused "
+                 "(specular_is_srgb=True: upstream's flag, SURVEY.md F6), fp32 (BASELINE.json configs[2])"),
+    4: dict(batch=512, size=1024, scaling="strong", dtype=torch.float32, light_type="point", light=[[0.1, 0.1, 1.0]],
+            intensity=[[1.0, 1.0, 1.0]], light_size=1.0, flags={}, steps=40, warmup=5,
+            name="Batch={B} {S}x{S} materials sharded over the ranks, point light, fp32 (BASELINE.json configs[3])"),
+    5: dict(batch=32, size=4096, scaling="strong", dtype=torch.float16, light_type="point", light=RING16,
+            intensity=[[1.0 / 16] * 3] * 16, light_size=1.0, flags={}, steps=20, warmup=3,
+            name="Batch={B} {S}x{S} materials, 16 point lights accumulated in-kernel, fp16 maps, fp32 accumulate and result "
+                 "(BASELINE.json configs[4])"),
+}
+# config 5 is VALU-bound.  Vector instructions per (pixel, light) of the batch-inner kernel, counted by rocprofv3
+# (SQ_INSTS_VALU x 64 / (pixels x lights), profiles/r02_kernels.json) -- the algorithmic figure its VALU roofline uses; the
+# chip issues at most one vector instruction per SIMD per 4 cycles for a wave of 64 (16 lanes per clock):
+VALU_INSTR_PER_PIXEL_LIGHT = 29.3
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4 * 64          # lane-instructions per ns: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles x 64 lanes
 
 
-def synth_material(size, device, seed):
+def synth_material(size, device, seed, dtype=torch.float32, rows=None):
     """SURVEY.md 8d config 2 recipe: U[0,1) albedo/metallic, roughness remapped to [0.05,1],
-    normal = normalize([U(-.5,.5), U(-.5,.5), 1]) stored decoded."""
+    normal = normalize([U(-.5,.5), U(-.5,.5), 1]) stored decoded.  `rows=(y0, y1)`: that band of the same material."""
     g = torch.Generator(device=device).manual_seed(seed)
     H = W = size
     albedo = torch.rand(3, H, W, device=device, generator=g)
@@ -60,7 +96,22 @@ def synth_material(size, device, seed):
     normal = normal / normal.norm(dim=0, keepdim=True)
     rough = torch.rand(1, H, W, device=device, generator=g) * 0.95 + 0.05
     metal = torch.rand(1, H, W, device=device, generator=g)
-    return albedo, normal, rough, metal
+    maps = [t.to(dtype) for t in (albedo, normal, rough, metal)]
+    if rows is not None:
+        maps = [t[:, rows[0]:rows[1]].contiguous() for t in maps]
+    return maps
+
+
+def synth_shard(cfg, shard, device, seed0):
+    """This rank's materials [batch_start, batch_stop) x rows [row_start, row_stop): material b is drawn from seed0 + b,
+    whoever owns it, so the job is the same however many ranks split it."""
+    nb, h, S = shard.batch_stop - shard.batch_start, shard.row_stop - shard.row_start, cfg["size"]
+    out = [torch.empty((nb, c, h, S), dtype=cfg["dtype"], device=device) for c in (3, 3, 1, 1)]
+    band = None if h == S else (shard.row_start, shard.row_stop)
+    for i, b in enumerate(range(shard.batch_start, shard.batch_stop)):
+        for dst, src in zip(out, synth_material(S, device, seed0 + b, cfg["dtype"], band)):
+            dst[i].copy_(src)
+    return out
 
 
 def _oracle_path():
@@ -69,69 +120,108 @@ def _oracle_path():
         sys.path.insert(0, p)
 
 
-def cpu_baseline(sample_size, passes):
-    """Times the ATen-level oracle (the reference's op sequence) on the host cores."""
+def _oracle_eval(cfg, maps, y_offset=0, H_total=None, dtype=None):
+    """The ATen restatement (oracle/torch_oracle.py) of this configuration on CPU maps [C,h,W] (fp32, or float64 twins)."""
+    import torch_oracle as O
+    dt = dtype or torch.float32
+    a, n, r, m = [t.to(dt) for t in maps]
+    kw = dict(view=torch.tensor(VIEW, dtype=dt), light_type=cfg["light_type"], light_size=cfg["light_size"],
+              y_offset=y_offset, H_total=H_total)
+    lights, inten = torch.tensor(cfg["light"], dtype=dt), torch.tensor(cfg["intensity"], dtype=dt)
+    if cfg["flags"].get("convert_to_diffuse_specular"):
+        return O.cook_torrance_converted(a, n, r, m, quirk_specular_srgb=cfg["flags"].get("specular_is_srgb", True),
+                                         light=lights[0], intensity=inten[0], **kw)
+    if len(cfg["light"]) > 1:
+        return O.cook_torrance_multi(a, n, r, m, None, lights=lights, intensities=inten, **kw)
+    return O.cook_torrance(a, n, r, m, None, light=lights[0], intensity=inten[0], **kw)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, budget_s=40.0):
+    """SURVEY.md 8d / BASELINE.md 4: the ATen restatement of the reference's CPU path with torch.set_num_threads(n) for
+    n = 1, n = 16 (a GPU box's CPU share per GPU) and n = all host cores, at 256^2 (the size BASELINE configs[0] names),
+    1024^2 and 2048^2 (several lights: 256^2, 512^2, 1024^2), this configuration's light and flags, CPU model stated.
+    Bounded: a leg that the previous (smaller) leg of its thread count predicts to overrun what is left of `budget_s`
+    is skipped, and the line says so.  `value` / `cores`: the fastest thread count at the largest size measured."""
     _oracle_path()
-    import torch_oracle
-    a, n, r, m = [t.cpu() for t in synth_material(sample_size, "cpu", 99)]
-    kw = dict(view=torch.tensor(VIEW), light=torch.tensor(LIGHT), intensity=torch.tensor(INTENSITY),
-              light_type="point", light_size=LIGHT_SIZE)
-    small = [t[:, :512, :512].contiguous() for t in (a, n, r, m)]
-    torch_oracle.cook_torrance(*small, None, **kw)                                  # warm-up (cold first call ~1 s)
-    # ATen's intra-op pool defaults to every host core; the reference's op mix scales badly past a few
-    # threads (SURVEY.md section 6), so give it its best thread count: probe on a 512x512 crop
-    best, best_t = torch.get_num_threads(), float("inf")
-    for nt in sorted({1, 4, 8, 16, 32, torch.get_num_threads()}):
-        if nt > (os.cpu_count() or 1):
-            continue
-        torch.set_num_threads(nt)
-        t0 = time.perf_counter()
-        torch_oracle.cook_torrance(*small, None, **kw)
-        dt = time.perf_counter() - t0
-        if dt < best_t:
-            best, best_t = nt, dt
-    torch.set_num_threads(best)
-    t0 = time.perf_counter()
-    for _ in range(passes):
-        torch_oracle.cook_torrance(a, n, r, m, None, **kw)
-    dt = time.perf_counter() - t0
-    return {"value": round(sample_size * sample_size * passes / dt / 1e6, 3), "unit": "Mpixels/s",
-            "cores": torch.get_num_threads(), "host_cores": os.cpu_count(), "kind": "port",
-            "sample": f"{passes} passes of one {sample_size}x{sample_size} material, same recipe and light as the GPU "
-                      f"workload, oracle/torch_oracle.py (ATen ops of the reference) at its fastest ATen thread count, {dt:.1f} s"}
+    host = os.cpu_count() or 1
+    saved = torch.get_num_threads()
+    t_start = time.perf_counter()
+    table, skipped = [], []
+    warm = synth_material(128, "cpu", 98)
+    legs = ((256, 5), (1024, 2), (2048, 1)) if len(cfg["light"]) == 1 else ((256, 2), (512, 1), (1024, 1))
+    for threads in sorted({1, min(16, host), host}):
+        torch.set_num_threads(threads)
+        _oracle_eval(cfg, warm)                                     # first call of a thread count: pool start-up
+        per_pixel = None
+        for size, passes in legs:
+            left = budget_s - (time.perf_counter() - t_start)
+            if left <= 0 or (per_pixel is not None and per_pixel * size * size * passes > left):
+                skipped.append(f"{size}^2 x {threads} threads")
+                continue
+            maps = synth_material(size, "cpu", 99)
+            t0 = time.perf_counter()
+            for _ in range(passes):
+                _oracle_eval(cfg, maps)
+            dt = (time.perf_counter() - t0) / passes
+            per_pixel = dt / (size * size)
+            table.append({"size": size, "threads": threads, "ms": round(dt * 1e3, 1), "Mpixels_per_s": round(size * size / dt / 1e6, 3)})
+    torch.set_num_threads(saved)
+    biggest = max(e["size"] for e in table)
+    best = max((e for e in table if e["size"] == biggest), key=lambda e: e["Mpixels_per_s"])
+    return {"value": best["Mpixels_per_s"], "unit": "Mpixels/s", "cores": best["threads"], "host_cores": host, "kind": "port",
+            "cpu_model": cpu_model(), "table": table,
+            "sample": f"oracle/torch_oracle.py (the reference's ATen ops, bit-equal to it in the dev container), this configuration's "
+                      f"light and flags, one material of " + " / ".join(f"{sz}^2 ({p} passes)" for sz, p in legs) +
+                      f" at 1, 16 and all {host} host threads, {time.perf_counter() - t_start:.1f} s in all; value = the fastest thread "
+                      f"count at {biggest}^2" + (f"; skipped for time: {skipped}" if skipped else "")}
 
 
-def parity_of_timed_output(plan, maps, size, band_rows=8):
-    """The checker's leg (like cpu_baseline: the only place bench.py touches oracle/): three row bands of the
-    output the timed launches wrote -- first rows, middle, LAST rows -- against the float64 C oracle
-    (oracle/ct_oracle.c) and the fp32 ATen restatement of the reference (oracle/torch_oracle.py)."""
+def parity_of_timed_output(cfg, out, maps, shard, band_rows):
+    """The checker's leg (like cpu_baseline: the only place bench.py touches oracle/): row bands of the output the timed
+    launches wrote -- first rows of the first material, middle, LAST rows of the last material this rank owns -- against
+    the float64 C oracle (oracle/ct_oracle.c) and the fp32 ATen restatement of the reference (oracle/torch_oracle.py)."""
     _oracle_path()
     import numpy as np
     import c_oracle
-    import torch_oracle
-    out = plan.result
-    a, n, r, m = maps
+    S, h = cfg["size"], shard.row_stop - shard.row_start
+    nb = shard.batch_stop - shard.batch_start
+    picks = sorted({(0, 0), (nb // 2, max(0, (h - band_rows) // 2)), (nb - 1, max(0, h - band_rows))})
     worst64 = worst32 = 0.0
     over = values = 0
-    bands = sorted({0, (size - band_rows) // 2, size - band_rows})
-    for y0 in bands:
-        sl = slice(y0, y0 + band_rows)
-        ca, cn, cr, cm = [t[:, sl, :].cpu() for t in (a, n, r, m)]
-        got = out[:, sl, :].cpu().numpy()
-        ref64 = c_oracle.render(ca.numpy(), cn.numpy(), cr.numpy(), cm.numpy(), view=VIEW, lights=LIGHT, intensities=INTENSITY,
-                                light_type="point", light_size=LIGHT_SIZE, y_offset=y0, H_total=size, dtype=np.float64)
-        ref32 = torch_oracle.cook_torrance(ca, cn, cr, cm, None, view=torch.tensor(VIEW), light=torch.tensor(LIGHT),
-                                           intensity=torch.tensor(INTENSITY), light_type="point", light_size=LIGHT_SIZE,
-                                           y_offset=y0, H_total=size).numpy()
+    fp16_out = out.dtype == torch.float16
+    for i, y0 in picks:
+        sl = slice(y0, min(h, y0 + band_rows))
+        crop = [t[i, :, sl, :].float().cpu() for t in maps]                       # fp16 maps: the oracle gets their exact up-casts
+        got = out[i, :, sl, :].float().cpu().numpy()
+        yg = shard.row_start + y0
+        converted = bool(cfg["flags"].get("convert_to_diffuse_specular"))
+        ref64 = c_oracle.render(*[t.numpy() for t in crop], None, view=VIEW, lights=cfg["light"], intensities=cfg["intensity"],
+                                light_type=cfg["light_type"], light_size=cfg["light_size"], y_offset=yg, H_total=S,
+                                workflow="converted" if converted else "metallic",
+                                specular_is_srgb=cfg["flags"].get("specular_is_srgb", True), dtype=np.float64)
+        ref32 = _oracle_eval(cfg, crop, y_offset=yg, H_total=S).numpy()
         worst64 = max(worst64, float(np.abs(got - ref64).max()))
         d32 = np.abs(got - ref32)
         worst32 = max(worst32, float(d32.max()))
         over += int((d32 > 1e-5).sum())
         values += got.size
     return {"max_abs_err_vs_fp64_oracle": worst64, "max_abs_err_vs_reference_fp32": worst32,
-            "values_over_1e-5_vs_reference_fp32": over, "values": values, "tolerance": 1e-5,
-            "sample": f"rows {[f'{y}..{y + band_rows - 1}' for y in bands]} (all {size} columns) of the output written by the "
-                      f"timed launches of map set 0; fp64: oracle/ct_oracle.c, fp32: oracle/torch_oracle.py (reference's ATen ops)"}
+            "values_over_1e-5_vs_reference_fp32": over, "values": values,
+            "tolerance": 4.9e-4 if fp16_out else 1e-5,
+            "sample": f"{len(picks)} bands of {band_rows} rows x {S} columns (local material, first row) = "
+                      f"{[(shard.batch_start + i, shard.row_start + y) for i, y in picks]} of the output written by rank 0's timed launches; "
+                      f"fp64: oracle/ct_oracle.c, fp32: oracle/torch_oracle.py (reference's ATen ops)"}
 
 
 def recorded_traffic(kernel_name):
@@ -178,7 +268,7 @@ def timed_region(plans, steps, stream, barrier, offset=0):
     t0 = time.perf_counter()
     ev0.record()                                   # same stream the kernels are launched on
     for i in range(steps):
-        plans[(offset + i) % N_BUFFER_SETS].launch(stream)
+        plans[(offset + i) % len(plans)].launch(stream)
     ev1.record()
     while not ev1.query():                         # spin on the end event: a blocking wait adds tens of microseconds of wake-up
         pass                                       # latency, which is 1-2 % of a 20-step region
@@ -191,16 +281,17 @@ def timed_region(plans, steps, stream, barrier, offset=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=500)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="workload, SURVEY.md 8d numbering (BASELINE.json configs[config-1])")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--size", type=int, default=None, help="override the configuration's map edge (tests)")
+    ap.add_argument("--batch", type=int, default=None, help="override the configuration's batch (tests; configs 3-5)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the checker's legs (cpu_baseline and parity)")
-    ap.add_argument("--settle", type=int, default=300, help="untimed clock-settle launches between the cold and the steady timed region")
+    ap.add_argument("--settle", type=int, default=None, help="untimed clock-settle launches between the cold and the steady timed region")
     ap.add_argument("--layout", choices=("separate", "arena"), default="arena",
-                    help="arena (default): the material's maps and result in one allocation, as Material.to(device) lays "
+                    help="config 2.  arena (default): the material's maps and result in one allocation, as Material.to(device) lays "
                          "them out (F.pack_maps); separate: five tensors as torch's allocator places them")
-    ap.add_argument("--cpu-sample", type=int, default=2048)
-    ap.add_argument("--cpu-passes", type=int, default=4)
+    ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds the cpu_baseline leg may take (legs predicted to overrun are skipped and named)")
     ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1")
     args = ap.parse_args()
 
@@ -214,8 +305,19 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    cfg = dict(CONFIGS[args.config])
+    if args.size:
+        cfg["size"] = args.size
+    if args.batch:
+        if args.config == 2:
+            raise SystemExit("--batch applies to configs 3-5 (config 2 is one material per GPU)")
+        cfg["batch"] = args.batch
+    steps = args.steps if args.steps is not None else cfg["steps"]
+    warmup = args.warmup if args.warmup is not None else cfg["warmup"]
+    S = cfg["size"]
+
     from pypbr_amd import functional as F
-    from pypbr_amd.distributed import broadcast_light_block
+    from pypbr_amd.distributed import Shard, broadcast_light_block, cook_torrance_sharded, partition
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device; pypbr_amd has no CPU path")
@@ -235,10 +337,9 @@ def main():
             dist.barrier() if SHARE_GPU else dist.barrier(device_ids=[local_rank])
 
     # light/view parameters: owned by rank 0, broadcast over RCCL/xGMI (404 B, once per change)
-    params = dict(view_dir=VIEW, light=[LIGHT], light_intensity=[INTENSITY], light_size=LIGHT_SIZE)
+    params = dict(view_dir=VIEW, light=cfg["light"], light_intensity=cfg["intensity"], light_size=cfg["light_size"])
     bcast_us = None
     if distributed:
-        params = broadcast_light_block(params if rank == 0 else None, device=device, src=0)
         lat = []
         for _ in range(20):                        # what one parameter change costs: pack, broadcast, unpack (D2H of 404 B)
             barrier()
@@ -248,77 +349,149 @@ def main():
         bcast_us = sorted(lat)[len(lat) // 2]
 
     plans, map_sets = [], []
-    for i in range(N_BUFFER_SETS):
-        a, n, r, m = synth_material(args.size, device, 1234 + rank * 16 + i)
-        out = None
-        if args.layout == "arena":      # the maps of a material and its result in ONE allocation (F.pack_maps)
-            a, n, r, m, out = F.pack_maps(a, n, r, m, reserve_output=True)
-            out = out.unsqueeze(0)
-        map_sets.append((a, n, r, m))
-        plans.append(F.plan_cook_torrance(a, n, r, m, view_dir=params["view_dir"], light=params["light"],
-                                          light_intensity=params["light_intensity"], light_type="point",
-                                          light_size=params["light_size"], out=out))
+    share_plan = None
+    if args.config == 2:
+        # weak scaling: every rank its own material; the block still comes from rank 0
+        if distributed:
+            params = broadcast_light_block(params if rank == 0 else None, device=device, src=0)
+        shard = Shard(0, 1, 0, S)
+        for i in range(N_BUFFER_SETS):
+            a, n, r, m = synth_material(S, device, 1234 + rank * 16 + i)
+            out = None
+            if args.layout == "arena":      # the maps of a material and its result in ONE allocation (F.pack_maps)
+                a, n, r, m, out = F.pack_maps(a, n, r, m, reserve_output=True)
+                out = out.unsqueeze(0)
+            map_sets.append([t.unsqueeze(0) for t in (a, n, r, m)])
+            plans.append(F.plan_cook_torrance(a, n, r, m, view_dir=params["view_dir"], light=params["light"],
+                                              light_intensity=params["light_intensity"], light_type=cfg["light_type"],
+                                              light_size=params["light_size"], out=out))
+        global_pixels = world * S * S
+    else:
+        # strong scaling: the job is the whole batch; this rank generates and owns partition(B, S, world, rank)
+        shard = partition(cfg["batch"], S, world, rank)
+        a, n, r, m = synth_shard(cfg, shard, device, 4000 * args.config)
+        maps = {"albedo": a, "normal": n, "roughness": r, "metallic": m}
+        if distributed:
+            _, plan = cook_torrance_sharded(maps, params if rank == 0 else None, light_type=cfg["light_type"], owned=shard,
+                                            global_shape=(cfg["batch"], S), plan=True, **cfg["flags"])
+        else:
+            plan = F.plan_cook_torrance(a, n, r, m, view_dir=VIEW, light=cfg["light"], light_intensity=cfg["intensity"],
+                                        light_type=cfg["light_type"], light_size=cfg["light_size"], y_offset=shard.row_start,
+                                        height_total=S, **cfg["flags"])
+        if plan is None:
+            raise SystemExit(f"rank {rank}: empty shard {tuple(shard)} -- more ranks than rows")
+        plans.append(plan)
+        map_sets.append([a, n, r, m])
+        global_pixels = cfg["batch"] * S * S
+        if world == 1 and cfg["batch"] % 8 == 0 and cfg["batch"] >= 16:
+            # beside the N = 1 point of the strong-scaling curve: the share one GPU of an 8-GPU node gets (its first B/8 materials)
+            k = cfg["batch"] // 8
+            share_plan = F.plan_cook_torrance(a[:k], n[:k], r[:k], m[:k], view_dir=VIEW, light=cfg["light"], light_intensity=cfg["intensity"],
+                                              light_type=cfg["light_type"], light_size=cfg["light_size"], out=plan.out[:k], **cfg["flags"])
     kernel = plans[0].kernel_name
     bpp = plans[0].bytes_per_pixel
-    pixels = args.size * args.size
+    local_pixels = (shard.batch_stop - shard.batch_start) * (shard.row_stop - shard.row_start) * S
     stream = torch.cuda.current_stream(device).cuda_stream
 
     # ---- cold: W warm-up launches, K timed steps (the literal protocol)
-    for i in range(args.warmup):
-        plans[i % N_BUFFER_SETS].launch(stream)
-    cold_s, cold_kernel_ms = timed_region(plans, args.steps, stream, barrier, offset=args.warmup)
+    for i in range(warmup):
+        plans[i % len(plans)].launch(stream)
+    cold_s, cold_kernel_ms = timed_region(plans, steps, stream, barrier, offset=warmup)
     # ---- steady: clock settle (from an idle GPU the first ~20 launches run at boost clocks, the next ~150 up to 25 %
-    # slower while power management reins them in, steady from launch ~300 on: tools/transient_probe.py), K timed steps
-    for i in range(args.settle):
-        plans[i % N_BUFFER_SETS].launch(stream)
-    elapsed, kernel_ms = timed_region(plans, args.steps, stream, barrier)
+    # slower while power management reins them in, steady from launch ~300 of the 0.115 ms kernel on: tools/transient_probe.py)
+    settle = args.settle if args.settle is not None else (300 if args.config == 2 else max(2, int(math.ceil(40.0 / max(cold_kernel_ms, 1e-3)))))
+    for i in range(settle):
+        plans[i % len(plans)].launch(stream)
+    elapsed, kernel_ms = timed_region(plans, steps, stream, barrier)
 
-    per_rank_us = [kernel_ms * 1e3]
+    extras = {}
+    if share_plan is not None:
+        _, share_ms = timed_region([share_plan], max(5, steps), stream, barrier)
+        k = cfg["batch"] // 8
+        extras["per_gpu_share_of_8"] = {"batch": k, "kernel_us": round(share_ms * 1e3, 2), "Mpixels_per_s": round(k * S * S / share_ms / 1e3, 1),
+                                        "hbm_GBps_algorithmic": round(bpp * k * S * S / share_ms / 1e6, 1),
+                                        "note": "the first B/8 materials of this very batch, same buffers: what one GPU of an 8-GPU node evaluates per step"}
+        plans[0].launch(stream)                    # the parity leg reads the full result: write it again
+    if args.config == 3:
+        # the other setting of upstream's F6 flag (specular decoded once), same maps, same protocol
+        alt = F.plan_cook_torrance(*map_sets[0], view_dir=params["view_dir"], light=params["light"], light_intensity=params["light_intensity"],
+                                   light_type=cfg["light_type"], light_size=params["light_size"], y_offset=shard.row_start, height_total=S,
+                                   out=plans[0].out, **dict(cfg["flags"], specular_is_srgb=False))
+        _, alt_ms = timed_region([alt], max(5, steps), stream, barrier)
+        extras["specular_is_srgb_false"] = {"kernel_us": round(alt_ms * 1e3, 2), "Mpixels_per_s": round(local_pixels / alt_ms / 1e3, 1),
+                                            "note": "this rank's shard with the flag a user sets by hand (decoded once); same kernel, same bytes"}
+        plans[0].launch(stream)
+
+    per_rank_us, per_rank_px = [kernel_ms * 1e3], [local_pixels]
+    per_rank_all = [0.5 * (kernel_ms + cold_kernel_ms) * 1e3]
+    shards = [tuple(shard)]
     if distributed:
         t = torch.tensor([elapsed, cold_s], device=coll, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, cold_s = float(t[0].item()), float(t[1].item())
-        gathered = [torch.zeros(1, device=coll, dtype=torch.float64) for _ in range(world)]
-        dist.all_gather(gathered, torch.tensor([kernel_ms * 1e3], device=coll, dtype=torch.float64))
-        per_rank_us = [float(g.item()) for g in gathered]
+        mine = torch.tensor([kernel_ms * 1e3, 0.5 * (kernel_ms + cold_kernel_ms) * 1e3, float(local_pixels)] + [float(v) for v in shard],
+                            device=coll, dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        per_rank_us = [float(g[0].item()) for g in gathered]
+        per_rank_all = [float(g[1].item()) for g in gathered]
+        per_rank_px = [int(g[2].item()) for g in gathered]
+        shards = [tuple(int(v.item()) for v in g[3:7]) for g in gathered]
 
     assert bool(torch.isfinite(plans[0].result).all())
 
     if rank == 0:
-        value = world * pixels * args.steps / elapsed / 1e6
-        kernel_all_ms = 0.5 * (kernel_ms + cold_kernel_ms)      # every timed launch of this run (K cold + K steady): what a
-        achieved = bpp * pixels / (kernel_all_ms * 1e-3) / 1e9   # rocprofv3 --kernel-trace average of the same command shows
-        traffic, traffic_run = recorded_traffic(kernel)
+        value = global_pixels * steps / elapsed / 1e6
+        slow = max(range(world), key=lambda i: per_rank_all[i])       # the rank every timed launch of which took longest:
+        kernel_all_ms = per_rank_all[slow] * 1e-3                     # K cold + K steady launches, what a rocprofv3 --kernel-trace
+        achieved = bpp * per_rank_px[slow] / (kernel_all_ms * 1e-3) / 1e9   # average of the same command shows
+        traffic, traffic_run = recorded_traffic(kernel) if args.config == 2 and S == 4096 else (None, None)
         line = {
-            "metric": "Mpixels/s Cook-Torrance eval, 4K maps",
-            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "metric": "Mpixels/s Cook-Torrance eval, 4K maps" if args.config == 2 else
+                      f"Mpixels/s Cook-Torrance eval, BASELINE.json configs[{args.config - 1}]",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": cfg["scaling"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "ms_per_step_cold": round(cold_s / args.steps * 1e3, 5),
-            "value_cold": round(world * pixels * args.steps / cold_s / 1e6, 1),
-            "config": {"workload": f"Batch=1 {args.size}x{args.size} BasecolorMetallicMaterial per GPU, point light, "
-                                   f"fused HIP kernel, fp32 maps, sRGB in/out (BASELINE.json configs[1])",
-                       "kernel": kernel, "pixels_per_launch": pixels, "bytes_per_pixel": bpp,
-                       "parallelism": f"material-sharded x{world}" + (" (TEST HOOK: ranks share GPUs, collectives over gloo)" if SHARE_GPU else ""),
-                       "timing": f"value/ms_per_step: {args.steps} steps after {args.warmup} warm-up + {args.steps} cold-timed + "
-                                 f"{args.settle} clock-settle launches (sustained rate); value_cold/ms_per_step_cold: the "
-                                 f"{args.steps} steps right after the {args.warmup} warm-up launches",
-                       "clock_settle_launches": args.settle,
-                       "layout": "arena: the 8 map planes of a material and its 3 result planes in one allocation "
-                                 "(pypbr_amd.functional.pack_maps, what Material.to(device) does)"
-                                 if args.layout == "arena" else "separate: albedo, normal, roughness, metallic and the result as "
-                                                                "five tensors wherever torch's allocator put them"},
+            "ms_per_step_cold": round(cold_s / steps * 1e3, 5),
+            "value_cold": round(global_pixels * steps / cold_s / 1e6, 1),
+            "config": {"workload": cfg["name"].format(S=S, B=cfg["batch"]), "config": args.config,
+                       "kernel": kernel, "global_batch": world if args.config == 2 else cfg["batch"], "map_size": [S, S],
+                       "pixels_per_step": global_pixels, "bytes_per_pixel": bpp, "lights": len(cfg["light"]),
+                       "map_dtype": "f16" if cfg["dtype"] == torch.float16 else "f32",
+                       "parallelism": (f"material-sharded x{world}: " + ("one material per rank (weak)" if args.config == 2 else
+                                       "pypbr_amd.distributed.partition over the batch, every rank generates and owns its slice (strong)"))
+                                      + (" (TEST HOOK: ranks share GPUs, collectives over gloo)" if SHARE_GPU else ""),
+                       "timing": f"value/ms_per_step: {steps} steps after {warmup} warm-up + {steps} cold-timed + "
+                                 f"{settle} clock-settle launches (sustained rate); value_cold/ms_per_step_cold: the "
+                                 f"{steps} steps right after the {warmup} warm-up launches",
+                       "clock_settle_launches": settle},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_run,
-                         "kernel_us": round(kernel_all_ms * 1e3, 2), "kernel_us_steady": round(kernel_ms * 1e3, 2),
-                         "kernel_us_cold": round(cold_kernel_ms * 1e3, 2)},
-            "per_rank": {"kernel_us": [round(u, 2) for u in per_rank_us],
+                         "kernel_us": round(kernel_all_ms * 1e3, 2), "kernel_us_steady": round(per_rank_us[slow], 2),
+                         "pixels_per_launch": per_rank_px[slow], "rank": slow},
+            "per_rank": {"kernel_us": [round(u, 2) for u in per_rank_us], "pixels_per_launch": per_rank_px,
+                         "shard_batch_rows": shards,
                          "light_block_broadcast_us": None if bcast_us is None else round(bcast_us, 1)},
         }
+        if args.config == 2:
+            line["config"]["layout"] = ("arena: the 8 map planes of a material and its 3 result planes in one allocation "
+                                        "(pypbr_amd.functional.pack_maps, what Material.to(device) does)" if args.layout == "arena" else
+                                        "separate: albedo, normal, roughness, metallic and the result as five tensors wherever torch's allocator put them")
+            line["roofline"]["kernel_us_cold"] = round(cold_kernel_ms * 1e3, 2)
+        if len(cfg["light"]) > 1:
+            L = len(cfg["light"])
+            ginstr = VALU_INSTR_PER_PIXEL_LIGHT * per_rank_px[slow] * L / (kernel_all_ms * 1e-3) / 1e9
+            line["roofline_valu"] = {"bound": "valu", "achieved": round(ginstr, 1), "peak": round(VALU_PEAK_GINSTR, 1), "unit": "G lane-instr/s",
+                                     "frac": round(ginstr / VALU_PEAK_GINSTR, 4),
+                                     "light_evals_per_s_G": round(per_rank_px[slow] * L / (kernel_all_ms * 1e-3) / 1e9, 1),
+                                     "basis": f"{VALU_INSTR_PER_PIXEL_LIGHT} vector instructions per (pixel, light) (rocprofv3 SQ_INSTS_VALU, "
+                                              "profiles/r02_kernels.json) against 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz; the "
+                                              "launch is VALU-bound, its HBM fraction is not the measure (SURVEY.md 8d)"}
+        line.update(extras)
         if not args.no_cpu_baseline:
-            line["parity"] = parity_of_timed_output(plans[0], map_sets[0], args.size)
+            line["parity"] = parity_of_timed_output(cfg, plans[0].out, map_sets[0], shard, 8 if S >= 2048 and len(cfg["light"]) == 1 else 4)
             if world == 1:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_passes)
+                line["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget)
         print(json.dumps(line), flush=True)
     if distributed:
         barrier()

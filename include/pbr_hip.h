@@ -96,7 +96,8 @@ typedef struct pbr_render_desc {
     void *out;                    /* [B][3][height][width]; contiguous unless out_*_stride (below) say otherwise */
 
     float view_dir[3];            /* un-normalised, as handed to forward (normalised like F.normalize, :95) */
-    float light_size;             /* point lights; <= 0 or NaN means "falsy": 1.0 (cooktorrance.py:130) */
+    float light_size;             /* point lights; `light_size or 1.0` (cooktorrance.py:130) is Python truthiness: 0 (None upstream)
+                                     means 1.0; a negative size mirrors the grid and NaN makes every result NaN, as upstream */
     float lights[PBR_MAX_LIGHTS][3];       /* direction (normalised here, :126) or position (:129) */
     float intensities[PBR_MAX_LIGHTS][3];  /* light_intensity per light (:96) */
 

@@ -418,6 +418,66 @@ def blend_set(manifest):
     manifest["sets"]["blend"] = {k: _entry(v) for k, v in d.items()}
 
 
+def edge_set(manifest):
+    """Round 3: the edges of the reference's argument handling, from the REAL reference.
+    (a) `light_size or 1.0` (cooktorrance.py:130) is Python truthiness: negative sizes are truthy and mirror the grid, 0.0 and
+        -0.0 mean 1.0, NaN is truthy (every value of the result is NaN);
+    (b) NaN texels: which output values the reference turns into NaN;
+    (c) BASELINE.json configs[0] at the size it names: `tiles` / `rocks` loaded from the PNG data fixtures, resize((256, 256)),
+        point light (SURVEY.md 8c anchors: means 0.492009 / 0.256256)."""
+    import warnings
+    a, n, r, m, s = draw_realistic(41, 33, 48)
+    d = {"in_albedo": a, "in_normal": n, "in_roughness": r, "in_metallic": m, "in_specular": s}
+    sizes = {"neg1": -1.0, "neg2p5": -2.5, "zero": 0.0, "negzero": -0.0, "nan": float("nan"), "none": None}
+    d["meta_sizes"] = np.array([[k, repr(v)] for k, v in sizes.items()])
+    for kind in ("metallic", "specular"):
+        mat = make_material(kind, a, n, r, m, s)
+        for tag, size in sizes.items():
+            for srgb in (True, False):
+                out = CookTorranceBRDF("point")(mat, torch.tensor(VIEW1), torch.tensor([0.1, 0.1, 1.0]), torch.tensor(INT1), size,
+                                                return_srgb=srgb)
+                d[f"out_{kind}_{tag}_{'srgb' if srgb else 'lin'}"] = out
+    assert torch.equal(d["out_metallic_zero_srgb"], d["out_metallic_none_srgb"]) and torch.equal(d["out_metallic_negzero_srgb"], d["out_metallic_none_srgb"])
+    assert bool(torch.isnan(d["out_metallic_nan_srgb"]).all()) and bool(torch.isnan(d["out_specular_nan_lin"]).all())
+    assert (d["out_metallic_neg1_srgb"] - d["out_metallic_none_srgb"]).abs().max() > 0.05
+    # (b) one NaN per map, at distinct pixels
+    an, nn, rn, mn = a.clone(), n.clone(), r.clone(), m.clone()
+    an[1, 3, 5] = float("nan"); nn[0, 7, 9] = float("nan"); rn[0, 11, 13] = float("nan"); mn[0, 15, 17] = float("nan")
+    matn = make_material("metallic", an, None, rn, mn, s)
+    matn._maps["normal"] = nn                      # past the decode: the NaN stays where it was put
+    for lk in ("pt1", "dir"):
+        d[f"out_nantexel_{lk}"] = render(matn, lk)
+    d.update({"in_nan_albedo": an, "in_nan_normal": nn, "in_nan_roughness": rn, "in_nan_metallic": mn})
+    # (c) configs[0]
+    for folder in ("tiles", "rocks"):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mat = load_material_from_folder(os.path.join(GOLDEN, folder), preferred_workflow="metallic")
+        mat.resize((256, 256))
+        out = CookTorranceBRDF(light_type="point")(mat, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]),
+                                                   torch.tensor([1.0, 1.0, 1.0]), 1.0)
+        d[f"out_{folder}256"] = out
+        d[f"mean_{folder}256"] = np.array(float(out.double().mean()))
+        print(folder, "256^2 point: mean %.6f min %.4f max %.4f" % (float(out.double().mean()), float(out.min()), float(out.max())))
+    d = {k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+    np.savez_compressed(os.path.join(GOLDEN, "edge.npz"), **d)
+    manifest["sets"]["edge"] = {k: _entry(v) for k, v in d.items() if v.dtype.kind == "f"}
+
+
+def only(name, fn):
+    """`python oracle/gen_golden.py --only <set>`: adds one fixture file and its MANIFEST entries without touching the others
+    (they are byte-for-byte what earlier rounds committed)."""
+    path = os.path.join(GOLDEN, "MANIFEST.json")
+    with open(path) as f:
+        manifest = json.load(f)
+    assert manifest["torch"] == torch.__version__, "regenerate everything on a new torch build"
+    torch.set_num_threads(manifest["aten_threads"])
+    fn(manifest)
+    with open(path, "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print(name + ".npz written:", len(manifest["sets"][name]), "entries")
+
+
 def only_grad_params():
     """`python oracle/gen_golden.py --only grad_params`: adds tests/golden/grad_params.npz and its MANIFEST entries without
     touching the other fixtures (they are byte-for-byte what earlier rounds committed)."""
@@ -463,6 +523,8 @@ def main():
     grad_set(manifest)
     blend_set(manifest)
     example_blend_set(manifest)
+    grad_param_set(manifest)
+    edge_set(manifest)
     with open(os.path.join(GOLDEN, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     tot = sum(os.path.getsize(os.path.join(GOLDEN, f)) for f in os.listdir(GOLDEN))
@@ -475,5 +537,7 @@ def main():
 if __name__ == "__main__":
     if sys.argv[1:3] == ["--only", "grad_params"]:
         only_grad_params()
+    elif sys.argv[1:3] == ["--only", "edge"]:
+        only("edge", edge_set)
     else:
         main()

@@ -103,6 +103,7 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     using namespace pbr;
     const int rc = validate(d);
     if (rc != PBR_OK) return rc;
+    if (nan_light_size(d)) return fill_result_nan(d, static_cast<hipStream_t>(stream));
     const int vec = pick_vec(d);
     KArgs k;
     const int nb = batch_group(d, vec);

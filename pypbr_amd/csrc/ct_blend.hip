@@ -49,6 +49,7 @@ int pbr_cook_torrance_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, 
     // "Is the blended normal already signed?" is a property of the WHOLE map (base.py:212).  A row band of an untiled map
     // only holds its own rows, so its flags must come from the caller (pbr_blend_normal_sign over every band, combined).
     if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE && !is_tiled(d) && d->height != d->height_total) return PBR_ERR_UNSUPPORTED;
+    if (nan_light_size(d)) return fill_result_nan(d, static_cast<hipStream_t>(stream));
     int vec = pick_vec(d);                                    // the second material and the mask only need element alignment
     if (vec == 8) vec = 4;
     KArgs k;

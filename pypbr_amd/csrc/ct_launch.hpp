@@ -165,8 +165,9 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log
     k.map_h = k.tiled ? d->map_height : d->height_total; k.map_w = k.tiled ? d->map_width : d->width;
     k.div_mh.init((uint32_t)k.map_h); k.div_mw.init((uint32_t)k.map_w);
     k.y_offset = d->y_offset; k.H_total = d->height_total;
-    // `light_size or 1.0` (:130): 0 / NaN / negative are treated as "not given".
-    const float size = (d->light_size > 0.0f) ? d->light_size : 1.0f;
+    // `light_size or 1.0` (:130) is Python truthiness: only None / 0 / 0.0 / -0.0 mean "not given"; a NEGATIVE size is truthy
+    // and mirrors the grid (linspace from +|s|/2 down to -|s|/2), NaN is truthy too (the launcher fills the result, below).
+    const float size = (d->light_size != 0.0f) ? d->light_size : 1.0f;
     const float lo = (float)(-(double)size / 2), hi = (float)((double)size / 2);
     k.x0 = lo; k.x1 = hi; k.xstep = d->width > 1 ? (hi - lo) / (float)(d->width - 1) : 0.0f;
     k.y0 = lo; k.y1 = hi; k.ystep = d->height_total > 1 ? (hi - lo) / (float)(d->height_total - 1) : 0.0f;
@@ -197,6 +198,23 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log
             for (int c = 0; c < 3; ++c) u.l[c] = d->lights[i][c];
         }
     }
+}
+
+// A NaN light_size is truthy (`nan or 1.0` is nan): the reference's point-light grid, hence every value of its result, is NaN
+// (torch.clamp and both colour transfers propagate it).  The kernels' clamps would flush it, so the launchers write that
+// answer directly: the result planes are filled with quiet NaNs.  Directional lights never read light_size (:125-127).
+inline bool nan_light_size(const pbr_render_desc *d) { return d->light_type == PBR_LIGHT_POINT && d->light_size != d->light_size; }
+inline int fill_result_nan(const pbr_render_desc *d, hipStream_t st) {
+    const int64_t plane = (int64_t)d->height * d->width;
+    const int64_t cs = d->out_channel_stride ? d->out_channel_stride : plane, bs = d->out_batch_stride ? d->out_batch_stride : 3 * cs;
+    for (int b = 0; b < d->batch; ++b)
+        for (int c = 0; c < 3; ++c) {
+            hipError_t e;
+            if (d->out_dtype == PBR_F32) e = hipMemsetD32Async((hipDeviceptr_t)(static_cast<float *>(d->out) + b * bs + c * cs), 0x7fc00000, (size_t)plane, st);
+            else e = hipMemsetD16Async((hipDeviceptr_t)(static_cast<uint16_t *>(d->out) + b * bs + c * cs), 0x7e00, (size_t)plane, st);
+            if (e != hipSuccess) return 1000 + (int)e;
+        }
+    return PBR_OK;
 }
 
 using KernelFn = void (*)(const KArgs);

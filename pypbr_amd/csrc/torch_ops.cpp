@@ -132,7 +132,7 @@ Prepared prepare(const Tensor &albedo, const OptTensor &normal, const Tensor &ro
     for (int c = 0; c < 3; ++c) d.view_dir[c] = v[c];
     for (size_t i = 0; i < L; ++i)
         for (int c = 0; c < 3; ++c) { d.lights[i][c] = l[3 * i + c]; d.intensities[i][c] = it[3 * i + c]; }
-    d.light_size = light_size > 0.0 ? (float)light_size : 0.0f;             // falsy -> 1.0 inside (cooktorrance.py:130)
+    d.light_size = (float)light_size;                                       // 0 = falsy -> 1.0 inside; negative / NaN pass through (cooktorrance.py:130)
     d.schedule = PBR_SCHEDULE_AUTO;
     p.B = B; p.H = d.height; p.W = d.width;
     return p;

@@ -13,7 +13,7 @@ Partitioning:
     that of the full map.
 The reference has no distributed code at all; this module is a build extension.
 """
-from typing import Dict, NamedTuple, Optional
+from typing import Dict, NamedTuple, Optional, Tuple
 
 import torch
 
@@ -76,7 +76,7 @@ def unpack_light_block(blk: torch.Tensor) -> Dict:
     size = float(blk[1].item())
     o = 5 + 3 * _MAX_LIGHTS
     return {"view_dir": blk[2:5].tolist(), "light": blk[5:5 + 3 * L].reshape(L, 3).tolist(),
-            "light_intensity": blk[o:o + 3 * L].reshape(L, 3).tolist(), "light_size": size if size > 0 else None}
+            "light_intensity": blk[o:o + 3 * L].reshape(L, 3).tolist(), "light_size": size if size != 0 else None}     # `light_size or 1.0`: only 0 is falsy; negative / NaN sizes travel as they are
 
 
 def broadcast_light_block(params: Optional[Dict], device: torch.device, src: int = 0, group=None) -> Dict:
@@ -111,10 +111,16 @@ def shard_maps(maps: Dict[str, Optional[torch.Tensor]], shard: Shard) -> Dict[st
 
 
 def cook_torrance_sharded(maps: Dict[str, Optional[torch.Tensor]], params: Optional[Dict], *, light_type: str,
-                          src: int = 0, group=None, render=None, **flags):
+                          src: int = 0, group=None, render=None, owned: Optional[Shard] = None,
+                          global_shape: Optional[Tuple[int, int]] = None, plan: bool = False, **flags):
     """Evaluates this rank's shard of `maps` ([B,C,H,W] tensors: albedo, normal, roughness,
     metallic | specular -- every rank holds, or can index, the full batch) with the
     parameters broadcast from `src`.  Returns (shard, output or None for an empty shard).
+    `owned=partition(...)` with `global_shape=(B, H)`: `maps` (and a blend's second material / mask) hold exactly THIS
+    rank's shard -- the materials [batch_start, batch_stop) and rows [row_start, row_stop) of a [B,C,H,W] job that no rank
+    holds as a whole (every rank generates or loads its own slice: BASELINE config 4, 512 materials over 8 GPUs); nothing
+    is cut.  `plan=True` returns (shard, RenderPlan or None) instead of launching: the caller launches it as often as it
+    likes (bench.py), parameters and blend flags already exchanged.
     `tile=` and `blend=` (see functional.plan_cook_torrance) shard too: with a fused tile the ranks split the rows of
     the tiled OUTPUT over whole source maps; a blend's second material and mask are sliced like the first.  A fused
     blend over ROW BANDS has the path's one real exchange step: whether the blended normal map counts as already
@@ -125,29 +131,47 @@ def cook_torrance_sharded(maps: Dict[str, Optional[torch.Tensor]], params: Optio
     from .functional import tile_counts
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     albedo = maps["albedo"]
-    B, _, H, _ = albedo.shape
     ny, nx = tile_counts(flags.pop("tile", 1))
     blend = flags.pop("blend", None)
-    p = broadcast_light_block(params, device=albedo.device, src=src, group=group)
-    shard = partition(B, H * ny, world, rank)          # rows of the OUTPUT: with a fused tile() that is ny * H
-    empty = shard.batch_stop <= shard.batch_start or shard.row_stop <= shard.row_start
     tiled = (ny, nx) != (1, 1)
+    if owned is not None:
+        if global_shape is None:
+            raise ValueError("owned= needs global_shape=(B, H): the extent of the whole job")
+        B, H = int(global_shape[0]), int(global_shape[1])
+        shard = Shard(*owned)
+        if shard != partition(B, H * ny, world, rank):
+            raise ValueError("owned=%s is not partition(%d, %d, %d, %d)" % (tuple(shard), B, H * ny, world, rank))
+        want_rows = H if tiled else shard.row_stop - shard.row_start
+        if albedo.shape[0] != shard.batch_stop - shard.batch_start or albedo.shape[-2] != want_rows:
+            raise ValueError("maps %s do not hold the shard %s" % (tuple(albedo.shape), tuple(shard)))
+    else:
+        B, _, H, _ = albedo.shape
+        shard = partition(B, H * ny, world, rank)          # rows of the OUTPUT: with a fused tile() that is ny * H
+    p = broadcast_light_block(params, device=albedo.device, src=src, group=group)
+    empty = shard.batch_stop <= shard.batch_start or shard.row_stop <= shard.row_start
     # untiled row bands of a fused blend: the one exchange step (every rank takes part, also one with an empty shard)
     exchange = blend is not None and not tiled and B < world and render is None
     if empty and not exchange:
         return shard, None
-    if tiled:      # the kernel wraps its texel addresses: every rank keeps whole source maps and evaluates a band of the output
+    if owned is not None:
+        cut = lambda t: t
+    elif tiled:    # the kernel wraps its texel addresses: every rank keeps whole source maps and evaluates a band of the output
         cut = lambda t: None if t is None else t[shard.batch_start:shard.batch_stop]
+    else:
+        cut = lambda t: None if t is None else t[shard.batch_start:shard.batch_stop, :, shard.row_start:shard.row_stop, :]
+    if tiled:
         flags.update(tile=(ny, nx), rows=shard.row_stop - shard.row_start)
         total = None
     else:
-        cut = lambda t: None if t is None else t[shard.batch_start:shard.batch_stop, :, shard.row_start:shard.row_stop, :]
         total = H
+    nb = shard.batch_stop - shard.batch_start
     if blend is not None:   # second material and mask are sharded exactly like the first ([B|1,C,H,W] tensors)
         def cut2(t):
             if t is None:
                 return None
             t = t if t.dim() == 4 else t.unsqueeze(0)
+            if owned is not None:
+                return t
             return cut(t if t.shape[0] > 1 else t.expand(B, *t.shape[1:]))
         flags["blend"] = tuple(cut2(t) for t in blend)
     kw = dict(view_dir=p["view_dir"], light=p["light"], light_intensity=p["light_intensity"], light_type=light_type,
@@ -157,18 +181,28 @@ def cook_torrance_sharded(maps: Dict[str, Optional[torch.Tensor]], params: Optio
         return shard, render(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"), **kw)
     from .functional import cook_torrance, plan_cook_torrance
     if not exchange:
+        if plan:
+            return shard, plan_cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"), **kw)
         return shard, cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"), **kw)
+    # The exchange path launches a plan directly: it is forward-only.  A tensor that requires grad must not come back
+    # without a grad_fn (training would silently see no gradient), so refuse instead of dropping it.
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad
+                                       for t in list(maps.values()) + list(blend) + [params.get(k) if params else None for k in ("view_dir", "light", "light_intensity")]):
+        raise NotImplementedError("gradients through a fused blend evaluated over row bands are not implemented: blend the maps "
+                                  "first (pypbr_amd.blending) and shard the blended material, or detach the inputs")
     signed = torch.zeros(B, dtype=torch.int32, device=albedo.device)       # one flag per material of the FULL batch
-    plan = None
+    rp = None
     if not empty:
-        plan = plan_cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"),
-                                  blend_flags=signed[shard.batch_start:shard.batch_stop], **kw)
-        signed[shard.batch_start:shard.batch_stop] = plan.blend_normal_sign()
+        rp = plan_cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"),
+                                blend_flags=signed[shard.batch_start:shard.batch_stop], **kw)
+        signed[shard.batch_start:shard.batch_stop] = rp.blend_normal_sign()
     where = _collective_device(albedo.device, group)
     combined = signed.to(where)
     dist.all_reduce(combined, op=dist.ReduceOp.MAX, group=group)
     if empty:
         return shard, None
-    plan.use_blend_flags(combined[shard.batch_start:shard.batch_stop])
-    with torch.cuda.device(plan.device):
-        return shard, plan.launch()
+    rp.use_blend_flags(combined[shard.batch_start:shard.batch_stop])
+    if plan:
+        return shard, rp
+    with torch.cuda.device(rp.device):
+        return shard, rp.launch()

@@ -385,8 +385,9 @@ class DiffuseSpecularMaterial(MaterialBase):
         albedo, specular = self._maps.get("albedo"), self._maps.get("specular")
         if albedo is None or specular is None:
             raise ValueError("Both albedo (diffuse) and specular maps are required for conversion.")
-        if specular.shape[-2:] != albedo.shape[-2:]:
-            raise NotImplementedError("specular map of a different size: resize it first")
+        if specular.shape[-2:] != albedo.shape[-2:]:       # diffuse.py:117-118: TF.resize(self.specular, diffuse.shape[1:], antialias=True)
+            size = tuple(albedo.shape[-2:])
+            specular = _through_device(specular, lambda t: F_.resize(t, size, antialias=True))
         srgb = self.albedo_is_srgb
         base, metallic = _through_device(
             albedo, lambda d: F_.diffuse_specular_to_basecolor_metallic(d, specular.to(d.device), albedo_is_srgb=srgb))

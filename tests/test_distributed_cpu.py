@@ -50,6 +50,11 @@ def test_light_block_roundtrip():
     assert torch.allclose(torch.tensor(q["light_intensity"]), torch.tensor(p["light_intensity"], dtype=torch.float32))
     assert torch.allclose(torch.tensor(q["view_dir"]), torch.tensor(p["view_dir"]))
     assert unpack_light_block(pack_light_block({**p, "light_size": None}))["light_size"] is None
+    # `light_size or 1.0` (cooktorrance.py:130): only 0 is falsy -- a negative size (mirrored grid) and NaN travel as they are
+    assert unpack_light_block(pack_light_block({**p, "light_size": -2.5}))["light_size"] == -2.5
+    assert unpack_light_block(pack_light_block({**p, "light_size": 0.0}))["light_size"] is None
+    nan = unpack_light_block(pack_light_block({**p, "light_size": float("nan")}))["light_size"]
+    assert nan is not None and nan != nan
     with pytest.raises(ValueError):
         pack_light_block({**p, "light": [[0, 0, 1]] * 17, "light_intensity": [[1, 1, 1]] * 17})
 
@@ -84,6 +89,20 @@ def _worker(rank, world, port, batch, tmpdir):
         if out is not None:
             assert calls[0]["height_total"] == H and calls[0]["y_offset"] == shard.row_start
             assert out.shape == (shard.batch_stop - shard.batch_start, 3, shard.row_stop - shard.row_start, W)
+        # a rank that OWNS only its shard (bench.py --config 4: 512 materials nobody holds as a whole) gets the same call
+        mine = partition(batch, H, world, rank)
+        local = {k: v[mine.batch_start:mine.batch_stop, :, mine.row_start:mine.row_stop].clone() for k, v in maps.items()}
+        calls.clear()
+        oshard, oout = cook_torrance_sharded(local, params if rank == 0 else None, light_type="point", render=render, owned=mine,
+                                             global_shape=(batch, H))
+        assert oshard == shard and (oout is None) == (out is None)
+        if out is not None:
+            assert torch.equal(oout, out) and calls[0]["y_offset"] == shard.row_start and calls[0]["height_total"] == H
+        with pytest.raises(ValueError):
+            cook_torrance_sharded(local, params if rank == 0 else None, light_type="point", render=render, owned=mine)
+        with pytest.raises(ValueError):
+            cook_torrance_sharded(local, params if rank == 0 else None, light_type="point", render=render,
+                                  owned=partition(batch, H, world, (rank + 1) % world), global_shape=(batch, H))
         # fused tile(2) + fused blend shard too: bands of the tiled OUTPUT over whole source maps; material 2 and the
         # mask cut like material 1 (a recorder stands in for the kernel: this checks the plumbing only)
         seen_kw = []

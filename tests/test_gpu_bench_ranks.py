@@ -34,3 +34,66 @@ def test_bench_starts_its_own_ranks_and_reports_the_whole_job():
     assert abs(line["value"] - 2 * 1024 * 1024 * 10 / (line["ms_per_step"] * 10 * 1e-3) / 1e6) <= 0.01 * line["value"]
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
     assert ("TEST HOOK" in line["config"]["parallelism"]) == shared
+
+
+def _bench(*flags, gpus=1, timeout=900):
+    env = dict(os.environ)
+    shared = torch.cuda.device_count() < gpus
+    if shared:
+        env["PBR_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + [str(f) for f in flags]
+    run = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, run.stdout
+    return json.loads(lines[0]), shared
+
+
+def test_config4_strong_scaled_over_two_ranks_at_reduced_size():
+    """`python bench.py --gpus 2 --config 4` (BASELINE.json configs[3]: B=512 1024^2 over the GPUs of a node) at a reduced
+    size: every rank generates and owns partition(B, H, 2, rank)'s materials, the light block comes from rank 0's broadcast
+    inside distributed.cook_torrance_sharded, the line reports the WHOLE job (strong scaling) and every rank's share."""
+    line, shared = _bench("--config", 4, "--batch", 10, "--size", 256, "--steps", 6, "--warmup", 2, "--settle", 4, gpus=2)
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["config"] == 4
+    assert line["config"]["global_batch"] == 10 and line["config"]["pixels_per_step"] == 10 * 256 * 256
+    assert line["per_rank"]["shard_batch_rows"] == [[0, 5, 0, 256], [5, 10, 0, 256]]
+    assert line["per_rank"]["pixels_per_launch"] == [5 * 256 * 256] * 2 and all(u > 0 for u in line["per_rank"]["kernel_us"])
+    assert line["per_rank"]["light_block_broadcast_us"] > 0
+    assert abs(line["value"] - 10 * 256 * 256 * 6 / (line["ms_per_step"] * 6 * 1e-3) / 1e6) <= 0.01 * line["value"]
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1 and line["config"]["bytes_per_pixel"] == 44
+    par = line["parity"]                                         # bands of rank 0's timed output against both oracles
+    assert par["max_abs_err_vs_fp64_oracle"] <= 2e-6 and par["values"] > 0
+    assert ("TEST HOOK" in line["config"]["parallelism"]) == shared
+
+
+def test_config4_row_bands_when_the_batch_is_smaller_than_the_world():
+    """One material over two ranks: the shard is a row band, generated as the band of the same seeded material."""
+    line, _ = _bench("--config", 4, "--batch", 1, "--size", 256, "--steps", 4, "--warmup", 1, "--settle", 2, gpus=2)
+    assert line["per_rank"]["shard_batch_rows"] == [[0, 1, 0, 128], [0, 1, 128, 256]]
+    assert line["parity"]["max_abs_err_vs_fp64_oracle"] <= 2e-6
+
+
+@pytest.mark.parametrize("config,flags,kernel,bpp", [
+    (3, ("--batch", 4, "--size", 512), "ct_directional_converted_f32_f32_v4", 44),
+    (5, ("--batch", 4, "--size", 512), "ctb_point_metallic_f16_f32_v2_b4", 28),
+    (4, ("--batch", 16, "--size", 256), "ct_point_metallic_f32_f32_v4", 44),
+])
+def test_named_configs_on_one_gpu_at_reduced_size(config, flags, kernel, bpp):
+    line, _ = _bench("--config", config, *flags, "--steps", 4, "--warmup", 1, "--settle", 2, "--no-cpu-baseline")
+    assert line["n_gpus"] == 1 and line["config"]["config"] == config and line["config"]["kernel"] == kernel
+    assert line["config"]["bytes_per_pixel"] == bpp and line["scaling"] == "strong"
+    if config == 3:
+        assert line["specular_is_srgb_false"]["kernel_us"] > 0
+    if config == 5:
+        assert line["roofline_valu"]["bound"] == "valu" and line["config"]["lights"] == 16 and line["config"]["map_dtype"] == "f16"
+    if config == 4:
+        assert line["per_gpu_share_of_8"]["batch"] == 2 and line["per_gpu_share_of_8"]["kernel_us"] > 0
+
+
+def test_named_config_parity_leg_at_reduced_size():
+    """The checker's legs of configs 3 and 5 (converted / 16 lights on fp16 maps): bands of the timed output against both oracles."""
+    for config, flags in ((3, ("--batch", 2, "--size", 256)), (5, ("--batch", 2, "--size", 256))):
+        line, _ = _bench("--config", config, *flags, "--steps", 3, "--warmup", 1, "--settle", 1, "--cpu-budget", 2)
+        assert line["parity"]["max_abs_err_vs_fp64_oracle"] <= 2e-6, (config, line["parity"])
+        cb = line["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cpu_model"] and {e["threads"] for e in cb["table"]} >= {1} and cb["value"] > 0

@@ -137,6 +137,26 @@ def test_conversion_resizes_a_metallic_map_of_another_size():
     assert (conv.specular.cpu() - (0.04 * (1 - m) + a * m)).abs().max().item() <= 2e-6
 
 
+def test_conversion_resizes_a_specular_map_of_another_size():
+    """diffuse.py:117-118: TF.resize(self.specular, diffuse.shape[1:], antialias=True), then the conversion on the RAW resized map."""
+    import torch_oracle as O
+    from pypbr_amd.materials import DiffuseSpecularMaterial
+    g = torch.Generator().manual_seed(18)
+    d, small = torch.rand(3, 64, 96, generator=g) * 0.9 + 0.08, torch.rand(3, 40, 30, generator=g)
+    mat = DiffuseSpecularMaterial(albedo=d, roughness=torch.rand(1, 64, 96, generator=g), specular=small, albedo_is_srgb=False).to("cuda")
+    back = mat.to_basecolor_metallic_material()
+    s = torch.nn.functional.interpolate(small[None], size=(64, 96), mode="bilinear", align_corners=False, antialias=True)[0]
+    base, met = O.diffuse_specular_to_basecolor_metallic(d, s)
+    assert back.albedo.shape == (3, 64, 96) and back.metallic.shape == (3, 64, 96)
+    # thresholded selects (den < 1e-6, metallic >= 0.95): compare away from the ties the resize's 2e-6 can flip
+    den = d - 0.04 + 1e-6
+    m_raw = (s - 0.04) / (den + 1e-6)
+    safe = (den.abs() > 0.05) & ((m_raw - 0.95).abs() > 1e-3)
+    assert (back.metallic.cpu() - met)[safe].abs().max().item() <= 1e-4          # the resize's 2e-6 over den >= 0.05
+    assert (back.albedo.cpu() - base)[safe & (met < 0.5)].abs().max().item() <= 5e-4
+    assert (back.metallic.cpu() - met)[safe].abs().median().item() <= 1e-6
+
+
 def test_blend_maps_broadcasts_a_single_channel_map():
     from pypbr_amd.blending import blend_maps
     g = torch.Generator().manual_seed(9)

@@ -36,29 +36,65 @@ def _stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+# ------------------------------------------------------------------ caches keyed on tensor identity + version counter
+# Three caches save repeated work on tensors that did not change between calls: the device copy of a CPU-resident material
+# (models.CookTorranceBRDF), the host copy of device-resident light / view tensors (below) and the "already signed?" verdict
+# of a normal map (materials).  They recognise "did not change" by object identity and `tensor._version` -- which is NOT
+# bumped by `t.data.add_()`, by edits of a numpy array that shares the tensor's memory (`torch.from_numpy(a).float()` shares
+# it for float32 arrays, and materials ingest arrays exactly so, as upstream does), or by kernels that write through raw
+# pointers (`out=`).  The reference re-reads its maps and parameters on every call, so all three are OFF by default and
+# opt-in: `set_caching(device_maps=True, parameters=True, decode_verdicts=True)`, or PBR_CACHE=maps,params,decode in the
+# environment, for loops that are known not to edit their tensors behind autograd's back.  Inference tensors
+# (torch.inference_mode) have no version counter at all and are never cached.
+CACHING = {"device_maps": False, "parameters": False, "decode_verdicts": False}
+for _tok, _key in (("maps", "device_maps"), ("params", "parameters"), ("decode", "decode_verdicts")):
+    if _tok in os.environ.get("PBR_CACHE", "").split(","):
+        CACHING[_key] = True
+
+
+def set_caching(device_maps: Optional[bool] = None, parameters: Optional[bool] = None, decode_verdicts: Optional[bool] = None) -> dict:
+    """Switches the identity + version keyed caches (see above) on or off; returns the previous settings."""
+    old = dict(CACHING)
+    for key, v in (("device_maps", device_maps), ("parameters", parameters), ("decode_verdicts", decode_verdicts)):
+        if v is not None:
+            CACHING[key] = bool(v)
+    return old
+
+
+def version_of(t: torch.Tensor):
+    """`t._version`, or None for tensors that do not track one (created under torch.inference_mode): those are not cached."""
+    try:
+        return None if t.is_inference() else t._version
+    except RuntimeError:
+        return None
+
+
 _HOST_COPIES = {}          # id(tensor) -> (weakref to it, its version, host copy) for device-resident parameter tensors
 _HOST_COPIES_MAX = 64
 
 
 def _host_vec3(v: TensorLike, rows: Optional[int] = None):
     """Light/view parameters travel in the kernel-argument segment, so they are host values.  A device tensor costs one
-    small blocking D2H copy -- once: the host values are remembered per tensor object and version counter, so a caller
+    small blocking D2H copy per call, as the reference's `.to(device)` / scalar reads do.  With
+    `set_caching(parameters=True)` the host values are remembered per tensor object and version counter, so a caller
     that keeps its light / view tensors on the GPU and passes the same unchanged tensors call after call (the
     reference's override_device usage) synchronises on the first call only.  Tensors that require grad are read
     detached; their gradient comes from the backward kernel (see _CookTorranceFn)."""
     if not isinstance(v, torch.Tensor):
         t = torch.as_tensor(v, dtype=torch.float32)
     elif v.is_cuda:
-        hit = _HOST_COPIES.get(id(v))
-        if hit is not None and hit[0]() is v and hit[1] == v._version:
+        ver = version_of(v) if CACHING["parameters"] else None
+        hit = _HOST_COPIES.get(id(v)) if ver is not None else None
+        if hit is not None and hit[0]() is v and hit[1] == ver:
             t = hit[2]
         else:
             t = v.detach().to("cpu", torch.float32)
-            for k in [k for k, e in _HOST_COPIES.items() if e[0]() is None]:
-                del _HOST_COPIES[k]
-            if len(_HOST_COPIES) >= _HOST_COPIES_MAX:
-                _HOST_COPIES.clear()
-            _HOST_COPIES[id(v)] = (weakref.ref(v), v._version, t)
+            if ver is not None:
+                for k in [k for k, e in _HOST_COPIES.items() if e[0]() is None]:
+                    del _HOST_COPIES[k]
+                if len(_HOST_COPIES) >= _HOST_COPIES_MAX:
+                    _HOST_COPIES.clear()
+                _HOST_COPIES[id(v)] = (weakref.ref(v), ver, t)
     else:
         t = v.detach().to(torch.float32)
     if rows is None:
@@ -371,6 +407,12 @@ def _blend_then_render_with_grad(albedo, normal, roughness, metallic, specular, 
     from .blending import blend_maps
     if kwargs.get("out") is not None or kwargs.get("tile", 1) not in (1, (1, 1)):
         raise NotImplementedError("gradients through the fused blend need out=None and untiled maps")
+    kwargs.pop("blend_flags", None)        # whole maps decide "already signed?" from their own values, as the reference does
+    if kwargs.get("height_total") not in (None, albedo.shape[-2]):
+        # a ROW BAND cannot take that decision from its own rows (base.py:212 looks at the whole map), and the unfused
+        # re-decode below has no way to be told the whole map's verdict
+        raise NotImplementedError("gradients through a fused blend need the whole map, not a row band: blend the maps first "
+                                  "(pypbr_amd.blending) and evaluate the blended material's bands")
     a2, n2, r2, m2, s2, mask = blend
     squeeze = albedo.dim() == 3
 
@@ -428,9 +470,9 @@ def _param_tensor(v, rows):
 def _cook_torrance_via_torch_op(albedo, normal, roughness, metallic=None, specular=None, *, view_dir, light, light_intensity,
                                 light_type="point", light_size=None, albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True,
                                 convert_to_diffuse_specular=False, y_offset=0, height_total=None, out_dtype=None, tile=1, rows=None,
-                                out=None, schedule=N.SCHEDULE_AUTO, autotune=False, blend=None):
+                                out=None, schedule=N.SCHEDULE_AUTO, autotune=False, blend=None, blend_flags=None):
     # (out / schedule / autotune / blend are at their defaults here -- _torch_op_can_take -- and named so that an unknown
-    # keyword raises TypeError exactly as on the plan path)
+    # keyword raises TypeError exactly as on the plan path; blend_flags without a blend means nothing on either path)
     lt = str(light_type).lower()
     if lt not in _LIGHT_TYPES:   # cooktorrance.py:62-65
         raise ValueError(f"Unsupported light_type: {lt}. Must be 'directional' or 'point'.")

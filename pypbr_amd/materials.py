@@ -85,16 +85,21 @@ def _through_device(t: torch.Tensor, fn):
 
 # "Already signed?" (base.py:212: `normal_map.min() < 0`) is a property of the tensor's VALUES, and for a signed map the
 # reference returns the very tensor it was given.  The rendering-loss loop wraps the same decoded normal map in a new
-# material every step; the first decode of a tensor leaves its verdict in a 4-byte device flag, the second assignment of
-# the same unchanged tensor (same object, same version counter) reads that flag once, and from then on a signed map is
-# handed back as it is -- no kernel, no copy, the reference's object identity -- while an encoded map is decoded afresh.
+# material every step; with functional.set_caching(decode_verdicts=True) the first decode of a tensor leaves its verdict
+# in a 4-byte device flag, the second assignment of the same unchanged tensor (same object, same version counter) reads
+# that flag once, and from then on a signed map is handed back as it is -- no kernel, no copy, the reference's object
+# identity -- while an encoded map is decoded afresh.  Off by default: the version counter does not see every edit
+# (functional.CACHING), and the reference looks at the values every time.
 _DECODE_VERDICTS = {}          # id(tensor) -> [weakref, version, device flag, host verdict or None]
 _DECODE_VERDICTS_MAX = 64
 
 
 def _decode_remembering(t: torch.Tensor) -> torch.Tensor:
+    ver = F_.version_of(t) if F_.CACHING["decode_verdicts"] else None
+    if ver is None:                 # the default (functional.set_caching): decide afresh, on the device, every assignment
+        return F_.decode_normal(t)
     hit = _DECODE_VERDICTS.get(id(t))
-    if hit is not None and hit[0]() is t and hit[1] == t._version:
+    if hit is not None and hit[0]() is t and hit[1] == ver:
         if hit[3] is None:
             hit[3] = bool(hit[2].item())       # the decode that wrote it ran an assignment ago: no wait in practice
         if hit[3]:
@@ -105,7 +110,7 @@ def _decode_remembering(t: torch.Tensor) -> torch.Tensor:
         del _DECODE_VERDICTS[k]
     if len(_DECODE_VERDICTS) >= _DECODE_VERDICTS_MAX:
         _DECODE_VERDICTS.clear()
-    _DECODE_VERDICTS[id(t)] = [weakref.ref(t), t._version, flag, None]
+    _DECODE_VERDICTS[id(t)] = [weakref.ref(t), ver, flag, None]
     return out
 
 
@@ -240,6 +245,17 @@ class MaterialBase:
     def as_dict(self):
         self.materialize_tile()
         return dict(self._maps)
+
+    def cache_on_device(self, enable: bool = True):
+        """Opt-in: CookTorranceBRDF keeps the device copy of this CPU-resident material between calls (one upload for a
+        loop over an unchanged material instead of one per call: 9.6 ms for a 4096^2 material).  The copy is recognised
+        as current by tensor identity and version counter, which do not see `.data` edits or edits of a numpy array that
+        shares a map's memory -- hence opt-in (functional.set_caching(device_maps=True) turns it on for every material).
+        All cached copies together are bounded (models.DEVICE_CACHE_CAP, least recently used evicted first)."""
+        object.__setattr__(self, "_cache_on_device", bool(enable))
+        if not enable:
+            self.drop_device_cache()
+        return self
 
     def drop_device_cache(self):
         """Frees the device copy CookTorranceBRDF keeps of a CPU-resident material between calls."""

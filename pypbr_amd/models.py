@@ -5,6 +5,9 @@ CookTorranceBRDF.__init__ :53-66, forward :68-182).  Same constructor, same
 forward arguments, same exceptions; the ~130 ATen ops of the reference's forward are
 replaced by a single call into libpbr_hip.so (pypbr_amd.functional.cook_torrance).
 """
+import collections
+import os
+import weakref
 from abc import ABC
 from typing import Optional
 
@@ -15,6 +18,31 @@ from torch import Tensor
 from . import _native
 from . import functional as F_
 from .materials import MaterialBase
+
+
+# Device copies kept by `material.cache_on_device()` (see CookTorranceBRDF._staged): id(material) -> (weakref, bytes), least
+# recently used first.  Together they stay below DEVICE_CACHE_CAP bytes (PBR_DEVICE_CACHE_CAP, default 4 GiB): a loop over a
+# dataset of CPU materials evicts the oldest copies instead of growing until the device is full.
+DEVICE_CACHE_CAP = int(os.environ.get("PBR_DEVICE_CACHE_CAP", str(4 << 30)))
+_DEVICE_CACHES = collections.OrderedDict()
+
+
+def _touch_device_cache(material):
+    if id(material) in _DEVICE_CACHES:
+        _DEVICE_CACHES.move_to_end(id(material))
+
+
+def _register_device_cache(material, nbytes):
+    _DEVICE_CACHES.pop(id(material), None)
+    for key in [k for k, (ref, _) in _DEVICE_CACHES.items() if ref() is None or "_device_cache" not in ref().__dict__]:
+        del _DEVICE_CACHES[key]
+    _DEVICE_CACHES[id(material)] = (weakref.ref(material), nbytes)
+    total = sum(n for _, n in _DEVICE_CACHES.values())
+    while total > DEVICE_CACHE_CAP and len(_DEVICE_CACHES) > 1:
+        _, (ref, n) = _DEVICE_CACHES.popitem(last=False)
+        if ref() is not None:
+            ref().__dict__.pop("_device_cache", None)
+        total -= n
 
 
 class BRDFModel(nn.Module, ABC):
@@ -41,23 +69,33 @@ class CookTorranceBRDF(BRDFModel):
     @staticmethod
     def _staged(material, maps, blend, compute):
         """Device copies of maps that live elsewhere (CPU-resident materials: the reference's default, e.g.
-        examples/example_brdf.py).  The copies land in ONE allocation (functional.pack_maps) and are kept on the
-        material, so a loop that evaluates an unchanged material again and again uploads it once (a 4096^2 material:
-        9.6 ms of PCIe per call otherwise).  The cache is keyed on the very tensor objects and their
-        version counters: assigning a new map, or modifying one in place, uploads afresh.  Maps that carry a gradient
-        are copied differentiably, uncached.  `material.drop_device_cache()` frees the device copy."""
+        examples/example_brdf.py), in ONE allocation (functional.pack_maps).  By default the maps are uploaded on every
+        call -- the reference re-reads its maps every call too.  Opt-in (`material.cache_on_device()`, or
+        functional.set_caching(device_maps=True) for every material): the copy is kept on the material, so a loop that
+        evaluates an unchanged material again and again uploads it once (a 4096^2 material: 9.6 ms of PCIe per call
+        otherwise).  The cache is keyed on the very tensor objects (held weakly) and their version counters:
+        assigning a new map, or modifying one in place, uploads afresh; tensors without a version counter
+        (torch.inference_mode) are never cached.  All cached copies together stay below DEVICE_CACHE_CAP bytes (least
+        recently used first out).  Maps that carry a gradient are copied differentiably, uncached.
+        `material.drop_device_cache()` frees the device copy."""
         tensors = tuple(maps) + tuple(blend or ())
         if any(t is not None and t.requires_grad for t in tensors):
             moved = tuple(None if t is None else t.to(compute) for t in tensors)
+            return moved[:5], (None if blend is None else moved[5:])
+        versions = tuple(None if t is None else F_.version_of(t) for t in tensors)
+        wanted = (F_.CACHING["device_maps"] or material.__dict__.get("_cache_on_device", False))
+        cacheable = wanted and all(v is not None for t, v in zip(tensors, versions) if t is not None)
+        hit = material.__dict__.get("_device_cache") if cacheable else None
+        if (hit is not None and hit[0] == compute and hit[1] == versions and len(hit[2]) == len(tensors)
+                and all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(hit[2], tensors))):
+            moved = hit[3]
+            _touch_device_cache(material)
         else:
-            versions = tuple(None if t is None else t._version for t in tensors)
-            hit = material.__dict__.get("_device_cache")
-            if (hit is not None and hit[0] == compute and hit[1] == versions and len(hit[2]) == len(tensors)
-                    and all(a is b for a, b in zip(hit[2], tensors))):
-                moved = hit[3]
-            else:
-                moved = F_.pack_maps(*tensors, device=compute)
-                material.__dict__["_device_cache"] = (compute, versions, tensors, moved)
+            moved = F_.pack_maps(*tensors, device=compute)
+            if cacheable:
+                refs = tuple(None if t is None else weakref.ref(t) for t in tensors)
+                material.__dict__["_device_cache"] = (compute, versions, refs, moved)
+                _register_device_cache(material, sum(t.numel() * t.element_size() for t in moved if t is not None))
         return moved[:5], (None if blend is None else moved[5:])
 
     def forward(self, material, view_dir: Tensor, light_dir_or_position: Tensor, light_intensity: Tensor,

@@ -24,16 +24,24 @@ _loaded = None
 
 
 def available() -> bool:
-    """Loads pypbr_amd/_pbr_torch_ops.so on first use; False when it has not been built (PBR_NO_TORCH_OPS=1 forces that)."""
+    """Loads pypbr_amd/_pbr_torch_ops.so on first use; False when it has not been built (PBR_NO_TORCH_OPS=1 forces that) or
+    does not load against this torch (another torch build, another C++ ABI): one warning, then every call takes the ctypes
+    binding of the same C ABI -- not an exception on the first call and a silent fallback afterwards."""
     global _loaded
     if _loaded is None:
         _loaded = False
         if os.environ.get("PBR_NO_TORCH_OPS") != "1" and os.path.exists(LIB_PATH):
             from . import _native
-            _native.lib()                       # libpbr_hip.so first: the extension links against it
-            torch.ops.load_library(LIB_PATH)
-            _register()
-            _loaded = True
+            _native.lib()                       # libpbr_hip.so first: the extension links against it (a missing one raises)
+            try:
+                torch.ops.load_library(LIB_PATH)
+                _register()
+                _loaded = True
+            except (OSError, RuntimeError) as e:
+                import warnings
+                warnings.warn("pypbr_amd: %s does not load against torch %s (%s); using the ctypes binding of libpbr_hip.so. "
+                              "Rebuild with `make -C pypbr_amd/csrc torch_ops`." % (LIB_PATH, torch.__version__, str(e).splitlines()[0]),
+                              RuntimeWarning, stacklevel=2)
     return _loaded
 
 

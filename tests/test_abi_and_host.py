@@ -271,7 +271,9 @@ def test_product_never_imports_the_oracle():
 # ---------------------------------------------------------------- N1: loader + alias (host side)
 def _write_png(path, arr, mode):
     from PIL import Image
-    Image.fromarray(arr, mode).save(path)
+    img = Image.fromarray(arr)               # mode inferred from dtype / shape ("mode=" goes away in Pillow 13)
+    assert img.mode == mode, (img.mode, mode)
+    img.save(path)
 
 
 def test_loader_workflow_selection_and_alias(tmp_path):

@@ -124,6 +124,15 @@ def _worker(rank, world, port, batch, tmpdir):
         if len(seen_kw) > (1 if tout is not None else 0):
             shape, kw = seen_kw[-1]
             assert kw["blend"][5].shape == (bshard.batch_stop - bshard.batch_start, 1, bshard.row_stop - bshard.row_start, W) == shape[:1] + (1,) + shape[2:]
+        if batch < world:
+            # the exchange path of a fused blend over row bands launches a plan directly (forward-only); inputs that
+            # require grad must be refused, not rendered into a result without a grad_fn
+            leaf = {k: (v.clone().requires_grad_(True) if k == "albedo" else v) for k, v in maps.items()}
+            with pytest.raises(NotImplementedError, match="row bands"):
+                cook_torrance_sharded(leaf, params if rank == 0 else None, light_type="point", blend=second)
+            with torch.no_grad():                                  # without grad mode there is nothing to lose: goes on to the kernel
+                with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
+                    cook_torrance_sharded(leaf, params if rank == 0 else None, light_type="point", blend=second)
         torch.save({"shard": tuple(shard), "out": out, "tshard": tuple(tshard)}, os.path.join(tmpdir, f"rank{rank}.pt"))
         dist.barrier()
         if rank == 0:

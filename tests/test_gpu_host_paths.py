@@ -63,10 +63,14 @@ def test_lazy_tile_is_seen_by_everything_but_the_brdf():
 
 
 def test_cpu_material_keeps_its_device_copy_between_calls():
+    """Opt-in (material.cache_on_device()): by default every call uploads the maps afresh, as the reference re-reads them."""
     from pypbr_amd import functional as F
     from pypbr_amd.models import CookTorranceBRDF
     brdf = CookTorranceBRDF("point")
-    mat = _material(seed=5)
+    plain = _material(seed=5)
+    brdf(plain, *ARGS); brdf(plain, *ARGS)
+    assert "_device_cache" not in plain.__dict__                      # default: nothing kept
+    mat = _material(seed=5).cache_on_device()
     calls = []
     real = F.pack_maps
 
@@ -168,18 +172,108 @@ def test_blend_maps_broadcasts_a_single_channel_map():
 
 
 def test_device_resident_light_tensors_sync_once():
+    """Opt-in (functional.set_caching(parameters=True)); by default the values are read from the device on every call."""
     from pypbr_amd import functional as F
     light = torch.tensor([0.1, 0.1, 1.0], device="cuda")
     F._HOST_COPIES.clear()
-    assert F._host_vec3(light) == pytest.approx([0.1, 0.1, 1.0])
-    assert len(F._HOST_COPIES) == 1
-    hit = F._HOST_COPIES[id(light)][2]
-    assert F._host_vec3(light) == pytest.approx([0.1, 0.1, 1.0]) and F._HOST_COPIES[id(light)][2] is hit
-    light.mul_(2.0)                                                   # in-place change: read again
-    assert F._host_vec3(light) == pytest.approx([0.2, 0.2, 2.0])
-    other = torch.tensor([0.5, 0.5, 0.5], device="cuda")
-    del light
-    assert F._host_vec3(other) == pytest.approx([0.5, 0.5, 0.5])
+    assert F._host_vec3(light) == pytest.approx([0.1, 0.1, 1.0]) and len(F._HOST_COPIES) == 0
+    old = F.set_caching(parameters=True)
+    try:
+        assert F._host_vec3(light) == pytest.approx([0.1, 0.1, 1.0])
+        assert len(F._HOST_COPIES) == 1
+        hit = F._HOST_COPIES[id(light)][2]
+        assert F._host_vec3(light) == pytest.approx([0.1, 0.1, 1.0]) and F._HOST_COPIES[id(light)][2] is hit
+        light.mul_(2.0)                                                   # in-place change: read again
+        assert F._host_vec3(light) == pytest.approx([0.2, 0.2, 2.0])
+        other = torch.tensor([0.5, 0.5, 0.5], device="cuda")
+        del light
+        assert F._host_vec3(other) == pytest.approx([0.5, 0.5, 0.5])
+    finally:
+        F.set_caching(**old)
+        F._HOST_COPIES.clear()
+
+
+def test_edits_the_version_counter_does_not_see_are_rendered(tmp_path):
+    """`tensor._version` is not bumped by `t.data.add_()`, by edits of a numpy array that shares a map's memory
+    (materials ingest float32 arrays without a copy, as upstream does) or by kernels writing through raw pointers, and
+    inference tensors have no version counter at all.  The reference re-reads maps and parameters on every call; with the
+    caches at their default (off) so does the build, and a material that opted in still never caches inference tensors."""
+    import numpy as np
+    from pypbr_amd import functional as F
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    from pypbr_amd.models import CookTorranceBRDF
+    assert F.CACHING == {"device_maps": False, "parameters": False, "decode_verdicts": False}
+    brdf = CookTorranceBRDF("point")
+    g = torch.Generator().manual_seed(15)
+    H, W = 32, 48
+    rough_np = (torch.rand(1, H, W, generator=g) * 0.5 + 0.4).numpy()
+    n = torch.nn.functional.normalize(torch.cat([torch.rand(2, H, W, generator=g) - 0.5, torch.ones(1, H, W)]), dim=0)
+    mat = BasecolorMetallicMaterial(albedo=torch.rand(3, H, W, generator=g), normal=None, roughness=rough_np, metallic=torch.rand(1, H, W, generator=g))
+    mat._maps["normal"] = n
+    assert mat._maps["roughness"].data_ptr() == rough_np.ctypes.data                     # shared memory, as upstream
+    o1 = brdf(mat, *ARGS)
+    rough_np *= 0.5                                                   # numpy edit: no version bump
+    v = mat._maps["roughness"]._version
+    o2 = brdf(mat, *ARGS)
+    assert mat._maps["roughness"]._version == v and not torch.equal(o1, o2)
+    mat._maps["albedo"].data.mul_(0.25)                               # .data edit: no version bump either
+    o3 = brdf(mat, *ARGS)
+    assert not torch.equal(o2, o3)
+    fresh = BasecolorMetallicMaterial(albedo=mat._maps["albedo"].clone(), normal=None, roughness=mat._maps["roughness"].clone(),
+                                      metallic=mat._maps["metallic"].clone())
+    fresh._maps["normal"] = n.clone()
+    assert torch.equal(o3, brdf(fresh, *ARGS))
+    # device-resident light tensor edited through .data
+    light = torch.tensor([0.1, 0.1, 1.0], device="cuda")
+    dev = fresh.clone().to("cuda")
+    a = brdf(dev, ARGS[0], light, ARGS[2], 1.0)
+    light.data.add_(0.3)
+    b = brdf(dev, ARGS[0], light, ARGS[2], 1.0)
+    assert not torch.equal(a, b) and torch.equal(b, brdf(dev, ARGS[0], light.clone(), ARGS[2], 1.0))
+    # inference mode: tensors without a version counter -- the reference's default flow -- also with every cache switched on
+    old = F.set_caching(device_maps=True, parameters=True, decode_verdicts=True)
+    try:
+        with torch.inference_mode():
+            gi = torch.Generator().manual_seed(16)
+            im = BasecolorMetallicMaterial(albedo=torch.rand(3, H, W, generator=gi), normal=torch.rand(3, H, W, generator=gi),
+                                           roughness=torch.rand(1, H, W, generator=gi) * 0.5 + 0.4, metallic=torch.rand(1, H, W, generator=gi))
+            assert im._maps["albedo"].is_inference()
+            i1 = brdf(im, *ARGS)
+            im._maps["albedo"].mul_(0.5)                              # in place, untracked
+            i2 = brdf(im, *ARGS)
+            assert not torch.equal(i1, i2) and "_device_cache" not in im.__dict__
+            lt = torch.tensor([0.1, 0.1, 1.0], device="cuda")
+            cm = im.clone().to("cuda")
+            cm.normal = torch.rand(3, H, W, device="cuda") * 2 - 1    # CUDA normal-map assignment under inference mode
+            c1 = brdf(cm, ARGS[0], lt, ARGS[2], 1.0)
+            lt.add_(0.2)
+            assert not torch.equal(c1, brdf(cm, ARGS[0], lt, ARGS[2], 1.0))
+    finally:
+        F.set_caching(**old)
+
+
+def test_device_cache_is_bounded_and_evicts_least_recently_used():
+    from pypbr_amd import models
+    from pypbr_amd.models import CookTorranceBRDF
+    brdf = CookTorranceBRDF("point")
+    mats = [_material(seed=20 + i).cache_on_device() for i in range(4)]
+    one = 4 * 48 * 64 * 8 + 4096                                      # 8 planes of 48 x 64 fp32 + alignment slack
+    old = models.DEVICE_CACHE_CAP
+    models.DEVICE_CACHE_CAP = 2 * one + 1024
+    models._DEVICE_CACHES.clear()
+    try:
+        for m in mats[:3]:
+            brdf(m, *ARGS)
+        assert [("_device_cache" in m.__dict__) for m in mats] == [False, True, True, False]
+        brdf(mats[1], *ARGS)                                          # a hit refreshes its place in the queue
+        brdf(mats[3], *ARGS)
+        assert [("_device_cache" in m.__dict__) for m in mats] == [False, True, False, True]
+        del mats[3]
+        brdf(mats[0], *ARGS)                                          # a collected material's entry is dropped, not counted
+        assert sum(n for _, n in models._DEVICE_CACHES.values()) <= models.DEVICE_CACHE_CAP
+    finally:
+        models.DEVICE_CACHE_CAP = old
+        models._DEVICE_CACHES.clear()
 
 
 def test_device_tensors_pull_a_default_material_onto_their_device():
@@ -214,6 +308,7 @@ def test_reassigning_a_signed_normal_map_returns_the_tensor_itself():
     first assignment of a tensor decodes on the device (no host decision); the second assignment of the same unchanged
     tensor reads the 4-byte verdict once and hands a signed map back untouched, an encoded one is decoded afresh; an
     in-place change of the tensor (version counter) starts over."""
+    from pypbr_amd import functional as F
     from pypbr_amd.materials import BasecolorMetallicMaterial
     g = torch.Generator(device="cuda").manual_seed(9)
     signed = torch.nn.functional.normalize(torch.rand(3, 16, 24, device="cuda", generator=g) * 2 - 1, dim=0)
@@ -222,6 +317,16 @@ def test_reassigning_a_signed_normal_map_returns_the_tensor_itself():
 
     def normal_of(t):
         return BasecolorMetallicMaterial(albedo=torch.rand(3, 16, 24, device="cuda"), normal=t, roughness=rough, metallic=rough)._maps["normal"]
+    d1, d2 = normal_of(signed), normal_of(signed)                     # default: decided on the device every time, a copy each time
+    assert d1 is not signed and d2 is not signed and torch.equal(d1, signed) and torch.equal(d2, signed)
+    old = F.set_caching(decode_verdicts=True)
+    try:
+        _remembered_verdicts(normal_of, signed, encoded)
+    finally:
+        F.set_caching(**old)
+
+
+def _remembered_verdicts(normal_of, signed, encoded):
     first = normal_of(signed)
     assert first.data_ptr() != signed.data_ptr() and torch.equal(first, signed)          # device path: a copy, same values
     assert normal_of(signed) is signed and normal_of(signed) is signed                    # from the second time on: the tensor itself

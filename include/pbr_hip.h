@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PBR_HIP_ABI_VERSION 3
+#define PBR_HIP_ABI_VERSION 4      /* 4: light_size follows Python truthiness (negative / NaN are not "absent"); gradients of the map ops */
 #define PBR_MAX_LIGHTS 16
 
 /* ---- status codes (negative = caller error, positive = HIP runtime error code + 1000) */
@@ -208,6 +208,24 @@ int pbr_metallic_to_specular(const void *albedo, const void *metallic, void *dif
  */
 int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *basecolor, void *metallic,
                              size_t n, int albedo_is_srgb, int dtype, void *stream);
+/*
+ * Gradients of the four conversions above w.r.t. their inputs -- what torch.autograd derives from the reference's plain torch
+ * ops, so that a rendering loss differentiates through material.to_linear() / to_srgb() (base.py:754-778), the lazy
+ * linear_albedo / linear_specular properties (base.py:262-277, diffuse.py:76-91), to_diffuse_specular_material (metallic.py:98-108)
+ * and to_basecolor_metallic_material (diffuse.py:128-147) exactly as upstream.  torch's sub-gradient conventions: clamp passes on
+ * the closed interval; masked assignment / torch.where route the gradient to the selected branch; the thresholded selects of
+ * diffuse.py:136-144 are re-taken with the forward's own arithmetic.  `src` / the maps are the FORWARD INPUTS; gradients have the
+ * maps' storage type and shape.  An upstream gradient that is NULL counts as zero (that output was not used); a result pointer
+ * that is NULL is not computed.
+ */
+int pbr_srgb_to_linear_backward(const void *src, const void *grad_out, void *grad_in, size_t n, int dtype, void *stream);
+int pbr_linear_to_srgb_backward(const void *src, const void *grad_out, void *grad_in, size_t n, int dtype, void *stream);
+int pbr_metallic_to_specular_backward(const void *albedo, const void *metallic, const void *g_diffuse, const void *g_specular,
+                                      void *g_albedo, void *g_metallic, int32_t batch, int64_t pixels, int albedo_is_srgb, int dtype,
+                                      void *stream);
+int pbr_specular_to_metallic_backward(const void *diffuse, const void *specular, const void *g_basecolor, const void *g_metallic,
+                                      void *g_diffuse, void *g_specular, size_t n, int albedo_is_srgb, int dtype, void *stream);
+
 /* Gradient of pbr_decode_normal w.r.t. the stored map (what autograd computes through base.py:191-242 when a predicted
  * normal map is assigned to a material in a rendering loss): fp32, `workspace` = the flag pbr_decode_normal left. */
 int pbr_decode_normal_backward(const void *src, const void *grad_out, void *grad_in, int32_t channels, int64_t pixels,
@@ -243,6 +261,15 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
                         int32_t h_out, int32_t w_out, int antialias, void *workspace, void *stream);
 
 /*
+ * Gradient of pbr_resize_bilinear w.r.t. its input (autograd through base.py:490-504 -> F.interpolate): the transposed tap
+ * matrices, g_in = Wy^T g_out Wx, gathered by input index in a fixed order (deterministic, no atomics).  grad_out
+ * [planes][h_out][w_out] -> grad_in [planes][h_in][w_in], fp32; `workspace`: pbr_resize_backward_workspace_bytes(...) bytes.
+ */
+size_t pbr_resize_backward_workspace_bytes(int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out, int32_t w_out);
+int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
+                                 int32_t w_out, int antialias, void *workspace, void *stream);
+
+/*
  * Material blending in front of the BRDF (examples/example_blend.py:14-16), fp32 planar maps.
  * pbr_blend_maps: blend_with_mask blending/functional.py:64-116 for ONE map, out = mask * map1 +
  * (1 - mask) * map2 over [channels][pixels] with a [pixels] mask; is_normal selects _blend_normals
@@ -261,6 +288,10 @@ int pbr_blend_maps_backward(const void *map1, const void *map2, const void *mask
                             int accumulate_mask, void *stream);
 int pbr_blend_sigmoid_mask(const void *prop1, const void *prop2, void *mask, int64_t n, float shift,
                            float blend_width, void *stream);
+/* Gradient of pbr_blend_sigmoid_mask w.r.t. both property maps (autograd through torch.sigmoid, functional.py:184-193), from the
+ * mask the forward call produced: g_prop1 = grad_out * mask (1 - mask) / (blend_width + 1e-6), g_prop2 = -g_prop1; NULL = not wanted. */
+int pbr_blend_sigmoid_mask_backward(const void *mask, const void *grad_out, void *g_prop1, void *g_prop2, int64_t n, float blend_width,
+                                    void *stream);
 int pbr_blend_gradient_mask(void *mask, int32_t height, int32_t width, int vertical, void *stream);
 
 /* ---- introspection / tuning (bench and tests only) --------------------------------- */

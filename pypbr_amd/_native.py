@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBR_HIP_LIB") or os.path.join(_HERE, "libpbr_hip.so")   # env override: A/B of two builds
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_LIGHTS = 16
 
 F32, F16 = 0, 1
@@ -30,6 +30,9 @@ EXPORTS = (
     "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask", "pbr_cook_torrance_autotune",
     "pbr_cook_torrance_blend", "pbr_fold_gradient", "pbr_decode_normal_backward",
     "pbr_blend_normal_sign", "pbr_blend_maps_backward", "pbr_param_grad_workspace_bytes", "pbr_cook_torrance_backward_params",
+    "pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
+    "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
+    "pbr_blend_sigmoid_mask_backward",
 )
 
 
@@ -114,6 +117,16 @@ def lib():
     L.pbr_linear_to_srgb.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     L.pbr_metallic_to_specular.argtypes = [vp, vp, vp, vp, i32, i64, ctypes.c_int, ctypes.c_int, vp]
     L.pbr_specular_to_metallic.argtypes = [vp, vp, vp, vp, sz, ctypes.c_int, ctypes.c_int, vp]
+    L.pbr_srgb_to_linear_backward.argtypes = [vp, vp, vp, sz, ctypes.c_int, vp]
+    L.pbr_linear_to_srgb_backward.argtypes = [vp, vp, vp, sz, ctypes.c_int, vp]
+    L.pbr_metallic_to_specular_backward.argtypes = [vp, vp, vp, vp, vp, vp, i32, i64, ctypes.c_int, ctypes.c_int, vp]
+    L.pbr_specular_to_metallic_backward.argtypes = [vp, vp, vp, vp, vp, vp, sz, ctypes.c_int, ctypes.c_int, vp]
+    L.pbr_resize_backward_workspace_bytes.argtypes = [i64, i32, i32, i32, i32]
+    L.pbr_resize_backward_workspace_bytes.restype = ctypes.c_size_t
+    L.pbr_resize_bilinear_backward.argtypes = [vp, vp, i64, i32, i32, i32, i32, ctypes.c_int, vp, vp]
+    for name in ("pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
+                 "pbr_specular_to_metallic_backward", "pbr_resize_bilinear_backward"):
+        getattr(L, name).restype = ctypes.c_int
     L.pbr_decode_normal.argtypes = [vp, vp, i32, i64, ctypes.c_int, vp, vp]
     L.pbr_decode_normal_backward.argtypes = [vp, vp, vp, i32, i64, vp, vp]
     L.pbr_decode_normal_backward.restype = ctypes.c_int
@@ -136,6 +149,8 @@ def lib():
     L.pbr_blend_maps_backward.restype = ctypes.c_int
     L.pbr_blend_sigmoid_mask.argtypes = [vp, vp, vp, i64, ctypes.c_float, ctypes.c_float, vp]
     L.pbr_blend_gradient_mask.argtypes = [vp, i32, i32, ctypes.c_int, vp]
+    L.pbr_blend_sigmoid_mask_backward.argtypes = [vp, vp, vp, vp, i64, ctypes.c_float, vp]
+    L.pbr_blend_sigmoid_mask_backward.restype = ctypes.c_int
     for name in ("pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask"):
         getattr(L, name).restype = ctypes.c_int
     L.pbr_render_desc_size.restype = ctypes.c_size_t

@@ -19,16 +19,7 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def _check_device_f32(t, what):
-    if not t.is_cuda:
-        raise RuntimeError("%s needs tensors on a ROCm device; there is no CPU path" % what)
-    if t.dtype != torch.float32:
-        raise TypeError("%s supports float32 maps, got %s" % (what, t.dtype))
-    return t.contiguous()
-
-
 def _check_f32(t, what):
-    F_.refuse_grad(t, what)
     if not t.is_cuda:
         raise RuntimeError("%s needs tensors on a ROCm device; there is no CPU path" % what)
     if t.dtype != torch.float32:
@@ -73,8 +64,7 @@ def blend_maps(map1: torch.Tensor, map2: torch.Tensor, mask: torch.Tensor, is_no
     """mask * map1 + (1 - mask) * map2 for one (C,H,W) map and a (1,H,W) mask; `is_normal`:
     normalise both, blend, re-normalise (functional.py:119-145).  Differentiable (its own backward kernel)."""
     wants_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (map1, map2, mask))
-    check = _check_device_f32 if wants_grad else _check_f32
-    a, b, m = check(map1, "blend_maps"), check(map2, "blend_maps"), check(mask, "blend_maps")
+    a, b, m = _check_f32(map1, "blend_maps"), _check_f32(map2, "blend_maps"), _check_f32(mask, "blend_maps")
     if a.dim() == 3 and b.dim() == 3 and a.shape[0] != b.shape[0] and 1 in (a.shape[0], b.shape[0]) and a.shape[1:] == b.shape[1:]:
         # `mask * map1 + (1 - mask) * map2` broadcasts a 1-channel map against a 3-channel one upstream (e.g. the
         # 3-channel metallic map to_basecolor_metallic_material returns, diffuse.py:147, against a 1-channel one)
@@ -87,16 +77,46 @@ def blend_maps(map1: torch.Tensor, map2: torch.Tensor, mask: torch.Tensor, is_no
     return _blend_maps_raw(a, b, m, is_normal)
 
 
-def sigmoid_mask(prop1: torch.Tensor, prop2: torch.Tensor, blend_width: float, shift: float = 0.0) -> torch.Tensor:
-    """sigmoid((prop1 + shift - prop2) / (blend_width + 1e-6)) (functional.py:184-193, :227-236)."""
-    a, b = _check_f32(prop1, "sigmoid_mask"), _check_f32(prop2, "sigmoid_mask")
-    if a.shape != b.shape:
-        raise ValueError("property maps %s / %s differ in shape" % (tuple(a.shape), tuple(b.shape)))
+def _sigmoid_mask_raw(a, b, blend_width, shift):
     out = torch.empty_like(a)
     with torch.cuda.device(a.device):
         _native.check(_native.lib().pbr_blend_sigmoid_mask(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(),
                                                            float(shift), float(blend_width), _stream(a)))
     return out
+
+
+class _SigmoidMaskFn(torch.autograd.Function):
+    """The height / property blend mask with its backward kernel: upstream it is torch.sigmoid of plain arithmetic on the two
+    property maps (functional.py:184-193), so a loss on the blended material reaches the height maps through the mask."""
+
+    @staticmethod
+    def forward(ctx, a, b, blend_width, shift):
+        out = _sigmoid_mask_raw(a.detach(), b.detach(), blend_width, shift)
+        ctx.save_for_backward(out)
+        ctx.blend_width = float(blend_width)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (mask,) = ctx.saved_tensors
+        g = grad_out.to(torch.float32).contiguous()
+        g1 = torch.empty_like(mask) if ctx.needs_input_grad[0] else None
+        g2 = torch.empty_like(mask) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(mask.device):
+            _native.check(_native.lib().pbr_blend_sigmoid_mask_backward(mask.data_ptr(), g.data_ptr(), None if g1 is None else g1.data_ptr(),
+                                                                        None if g2 is None else g2.data_ptr(), mask.numel(), ctx.blend_width,
+                                                                        _stream(mask)))
+        return g1, g2, None, None
+
+
+def sigmoid_mask(prop1: torch.Tensor, prop2: torch.Tensor, blend_width: float, shift: float = 0.0) -> torch.Tensor:
+    """sigmoid((prop1 + shift - prop2) / (blend_width + 1e-6)) (functional.py:184-193, :227-236).  Differentiable w.r.t. both maps."""
+    a, b = _check_f32(prop1, "sigmoid_mask"), _check_f32(prop2, "sigmoid_mask")
+    if a.shape != b.shape:
+        raise ValueError("property maps %s / %s differ in shape" % (tuple(a.shape), tuple(b.shape)))
+    if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+        return _SigmoidMaskFn.apply(a, b, float(blend_width), float(shift))
+    return _sigmoid_mask_raw(a, b, blend_width, shift)
 
 
 def gradient_mask(height: int, width: int, direction: str, device) -> torch.Tensor:

@@ -167,6 +167,17 @@ __global__ __launch_bounds__(256) void sigmoid_mask_kernel(const float *__restri
     }
 }
 
+// d/d(p1, p2) of the mask above, from the mask itself: sigma' = sigma (1 - sigma); g_p1 = g sigma' / (width + 1e-6), g_p2 = -g_p1
+__global__ __launch_bounds__(256) void sigmoid_mask_backward_kernel(const float *__restrict__ mask, const float *__restrict__ gout,
+                                                                    float *__restrict__ g1, float *__restrict__ g2, int64_t n, float inv_width) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float sg = mask[i], g = gout[i] * (sg * (1.0f - sg)) * inv_width;
+        if (g1) g1[i] = g;
+        if (g2) g2[i] = -g;
+    }
+}
+
 // torch.linspace(0, 1, n) along x (horizontal) or y (vertical), two-ended evaluation
 __global__ __launch_bounds__(256) void gradient_mask_kernel(float *__restrict__ mask, int H, int W, int vertical) {
     const int64_t total = (int64_t)H * W, stride = (int64_t)gridDim.x * blockDim.x;
@@ -217,6 +228,18 @@ int pbr_blend_sigmoid_mask(const void *prop1, const void *prop2, void *mask, int
     hipLaunchKernelGGL(sigmoid_mask_kernel, dim3(blend_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<const float *>(prop1), static_cast<const float *>(prop2), static_cast<float *>(mask), n,
                        shift, 1.0f / (blend_width + 1e-6f));
+    return blend_status();
+}
+
+int pbr_blend_sigmoid_mask_backward(const void *mask, const void *grad_out, void *g_prop1, void *g_prop2, int64_t n, float blend_width,
+                                    void *stream) {
+    using namespace pbr;
+    if (!mask || !grad_out) return PBR_ERR_NULL_MAP;
+    if (n < 1) return PBR_ERR_SHAPE;
+    if (!g_prop1 && !g_prop2) return PBR_OK;
+    hipLaunchKernelGGL(sigmoid_mask_backward_kernel, dim3(blend_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float *>(mask), static_cast<const float *>(grad_out), static_cast<float *>(g_prop1),
+                       static_cast<float *>(g_prop2), n, 1.0f / (blend_width + 1e-6f));
     return blend_status();
 }
 

@@ -364,6 +364,143 @@ __global__ __launch_bounds__(256) void decode_normal_backward_kernel(const float
     }
 }
 
+
+// ---- gradients of the colour transfers and of the workflow conversions ------------------------------------------------
+// What torch.autograd derives from the reference's plain torch ops (functions.py:31-66, metallic.py:98-108, diffuse.py:128-147),
+// so that a rendering loss differentiates through material.to_linear() / to_srgb() / to_diffuse_specular_material() /
+// to_basecolor_metallic_material() as it does upstream.  torch's sub-gradient conventions: clamp passes on the closed
+// interval, masked assignment / torch.where route the gradient to the selected branch only, pow differentiates as
+// e x^(e-1).  Gradients travel in the maps' storage type; arithmetic is fp32.  Same streaming form as the forward kernels.
+
+// d/dx srgb_to_linear(x) = [0 <= x <= 1] * (x <= 0.04045 ? 1/12.92 : 2.4/1.055 ((x + 0.055)/1.055)^1.4); the final clamp
+// always passes (its argument lies in [0,1]).
+__device__ __forceinline__ float srgb_to_linear_slope(float x) {
+    const float t = clamp01(x);
+    const float hi = exp2_hw(fmaf(1.4f, log2_hw(t + 0.055f), -0.10814020f /* 1.4 log2 1.055 */)) * 2.2748815f /* 2.4 / 1.055 */;
+    const float d = t <= 0.04045f ? 1.0f / 12.92f : hi;
+    return (x >= 0.0f && x <= 1.0f) ? d : 0.0f;
+}
+// d/dx linear_to_srgb(x) = [0 <= x <= 1] * (x <= 0.0031308 ? 12.92 : 1.055/2.4 x^(1/2.4 - 1))
+__device__ __forceinline__ float linear_to_srgb_slope(float x) {
+    const float c = clamp01(x);
+    const float hi = exp2_hw(log2_hw(c) * (1.0f / 2.4f - 1.0f)) * 0.43958333f /* 1.055 / 2.4 */;
+    const float d = c <= 0.0031308f ? 12.92f : hi;
+    return (x >= 0.0f && x <= 1.0f) ? d : 0.0f;
+}
+
+template <typename T, bool TO_LINEAR>
+__global__ __launch_bounds__(256) void colour_backward_kernel(const void *src, const void *gout, void *gin, size_t n, int vec_ok) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nq = vec_ok ? n / 4 : 0;
+    for (size_t q = tid; q < nq; q += stride) {
+        float x[4], g[4];
+        Quad<T>::ld(src, q, x);
+        Quad<T>::ld(gout, q, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) g[j] *= TO_LINEAR ? srgb_to_linear_slope(x[j]) : linear_to_srgb_slope(x[j]);
+        Quad<T>::st(gin, q, g);
+    }
+    for (size_t i = nq * 4 + tid; i < n; i += stride) {
+        const float x = Elem<T>::ld(src, i);
+        Elem<T>::st(gin, i, Elem<T>::ld(gout, i) * (TO_LINEAR ? srgb_to_linear_slope(x) : linear_to_srgb_slope(x)));
+    }
+}
+
+// metallic.py:98-108 backward: diffuse = lin (1 - m), specular = 0.04 (1 - m) + lin m, lin = srgb_to_linear(albedo) | albedo.
+//   g_lin = g_d (1 - m) + g_s m;  g_albedo = g_lin * slope;  g_m = sum_c (g_s (lin - 0.04) - g_d lin)
+// Either upstream gradient may be absent (NULL: that output was not used), either result may be unwanted (NULL).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void metallic_to_specular_backward_kernel(const void *albedo, const void *metallic, const void *g_diffuse,
+                                                                            const void *g_specular, void *g_albedo, void *g_metallic,
+                                                                            int batch, int64_t P, int albedo_srgb) {
+    constexpr int V = VEC ? 4 : 1;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t PV = (size_t)P / V, total = (size_t)batch * PV;
+    auto ld = [](const void *p, size_t i, float v[V]) { if constexpr (VEC) Quad<T>::ld(p, i, v); else v[0] = Elem<T>::ld(p, i); };
+    auto st = [](void *p, size_t i, const float v[V]) { if constexpr (VEC) Quad<T>::st(p, i, v); else Elem<T>::st(p, i, v[0]); };
+    for (size_t q = tid; q < total; q += stride) {
+        const size_t b = q / PV, pq = q - b * PV;
+        float m[V], gm[V];
+        ld(metallic, q, m);
+#pragma unroll
+        for (int j = 0; j < V; ++j) gm[j] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const size_t o = (b * 3 + c) * PV + pq;
+            float a[V], gd[V], gs[V], ga[V];
+            ld(albedo, o, a);
+#pragma unroll
+            for (int j = 0; j < V; ++j) { gd[j] = 0.0f; gs[j] = 0.0f; }
+            if (g_diffuse) ld(g_diffuse, o, gd);
+            if (g_specular) ld(g_specular, o, gs);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float lin = albedo_srgb ? srgb_to_linear(a[j]) : a[j];
+                const float slope = albedo_srgb ? srgb_to_linear_slope(a[j]) : 1.0f;
+                ga[j] = fmaf(gs[j] - gd[j], m[j], gd[j]) * slope;
+                gm[j] = fmaf(gs[j], lin - kDielectricF0, fmaf(-gd[j], lin, gm[j]));
+            }
+            if (g_albedo) st(g_albedo, o, ga);
+        }
+        if (g_metallic) st(g_metallic, q, gm);
+    }
+}
+
+// diffuse.py:128-147 backward (elementwise over all three channels; the metallic map it yields has three):
+//   num = s - 0.04, den = d - 0.04 + eps, q = num / (den + eps), m0 = clamp(q, 0, 1), m = den < eps ? 0 : m0,
+//   bc0 = d / (1 - m + eps), bc1 = m >= 0.95 ? s : bc0, bc = clamp(bc1, 0, 1);  d = srgb_to_linear(diffuse) | diffuse.
+// The selects are re-taken with the forward's own arithmetic (div_refined), so forward and backward agree on every branch.
+__device__ __forceinline__ void specular_to_metallic_backward_one(float draw, float s, float g_bc, float g_m, int albedo_srgb,
+                                                                   float &g_d, float &g_s) {
+    const float eps = 1e-6f;
+    const float d = albedo_srgb ? srgb_to_linear(draw) : draw;
+    const float num = s - kDielectricF0, den = d - kDielectricF0 + eps;
+    const float q = div_refined(num, den + eps);
+    float m = clamp01(q);
+    const bool dead = den < eps;
+    if (dead) m = 0.0f;
+    const float w = div_refined(1.0f, 1.0f - m + eps);
+    const bool metal = m >= 0.95f;
+    const float bc1 = metal ? s : d * w;
+    const float g_bc1 = (bc1 >= 0.0f && bc1 <= 1.0f) ? g_bc : 0.0f;
+    const float g_bc0 = metal ? 0.0f : g_bc1;
+    g_s = metal ? g_bc1 : 0.0f;
+    float gd = g_bc0 * w;
+    const float g_mt = fmaf(g_bc0 * d, w * w, g_m);
+    const float g_q = (!dead && q >= 0.0f && q <= 1.0f) ? g_mt : 0.0f;
+    const float r = div_refined(1.0f, den + eps);
+    g_s = fmaf(g_q, r, g_s);
+    gd = fmaf(-g_q * q, r, gd);
+    g_d = albedo_srgb ? gd * srgb_to_linear_slope(draw) : gd;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void specular_to_metallic_backward_kernel(const void *diffuse, const void *specular, const void *g_basecolor,
+                                                                            const void *g_metallic, void *g_diffuse, void *g_specular,
+                                                                            size_t n, int albedo_srgb, int vec_ok) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nq = vec_ok ? n / 4 : 0;
+    for (size_t q = tid; q < nq; q += stride) {
+        float d[4], sp[4], gb[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gm[4] = {0.0f, 0.0f, 0.0f, 0.0f}, gd[4], gs[4];
+        Quad<T>::ld(diffuse, q, d);
+        Quad<T>::ld(specular, q, sp);
+        if (g_basecolor) Quad<T>::ld(g_basecolor, q, gb);
+        if (g_metallic) Quad<T>::ld(g_metallic, q, gm);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) specular_to_metallic_backward_one(d[j], sp[j], gb[j], gm[j], albedo_srgb, gd[j], gs[j]);
+        if (g_diffuse) Quad<T>::st(g_diffuse, q, gd);
+        if (g_specular) Quad<T>::st(g_specular, q, gs);
+    }
+    for (size_t i = nq * 4 + tid; i < n; i += stride) {
+        float gd, gs;
+        specular_to_metallic_backward_one(Elem<T>::ld(diffuse, i), Elem<T>::ld(specular, i), g_basecolor ? Elem<T>::ld(g_basecolor, i) : 0.0f,
+                                          g_metallic ? Elem<T>::ld(g_metallic, i) : 0.0f, albedo_srgb, gd, gs);
+        if (g_diffuse) Elem<T>::st(g_diffuse, i, gd);
+        if (g_specular) Elem<T>::st(g_specular, i, gs);
+    }
+}
+
 static inline unsigned stream_grid(size_t work_items) {
     const size_t blocks = (work_items + 255) / 256;
     const size_t cap = 256 * 8;                                     // 256 CUs x 8 blocks, grid-stride beyond
@@ -440,6 +577,76 @@ int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *ba
         hipLaunchKernelGGL((specular_to_metallic_kernel<float>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb, vec_ok);
     else
         hipLaunchKernelGGL((specular_to_metallic_kernel<__half>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb, vec_ok);
+    return hip_status();
+}
+
+
+static int colour_backward_launch(const void *src, const void *gout, void *gin, size_t n, int dtype, void *stream, bool to_linear) {
+    using namespace pbr;
+    if (!src || !gout || !gin) return PBR_ERR_NULL_MAP;
+    if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
+    if (n == 0) return PBR_OK;
+    const size_t al = dtype == PBR_F32 ? 16 : 8;
+    const int vec_ok = is_aligned(src, al) && is_aligned(gout, al) && is_aligned(gin, al);
+    const unsigned grid = stream_grid(vec_ok ? (n + 3) / 4 : n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == PBR_F32) {
+        if (to_linear) hipLaunchKernelGGL((colour_backward_kernel<float, true>), dim3(grid), dim3(256), 0, s, src, gout, gin, n, vec_ok);
+        else hipLaunchKernelGGL((colour_backward_kernel<float, false>), dim3(grid), dim3(256), 0, s, src, gout, gin, n, vec_ok);
+    } else {
+        if (to_linear) hipLaunchKernelGGL((colour_backward_kernel<__half, true>), dim3(grid), dim3(256), 0, s, src, gout, gin, n, vec_ok);
+        else hipLaunchKernelGGL((colour_backward_kernel<__half, false>), dim3(grid), dim3(256), 0, s, src, gout, gin, n, vec_ok);
+    }
+    return hip_status();
+}
+
+int pbr_srgb_to_linear_backward(const void *src, const void *grad_out, void *grad_in, size_t n, int dtype, void *stream) {
+    return colour_backward_launch(src, grad_out, grad_in, n, dtype, stream, true);
+}
+
+int pbr_linear_to_srgb_backward(const void *src, const void *grad_out, void *grad_in, size_t n, int dtype, void *stream) {
+    return colour_backward_launch(src, grad_out, grad_in, n, dtype, stream, false);
+}
+
+int pbr_metallic_to_specular_backward(const void *albedo, const void *metallic, const void *g_diffuse, const void *g_specular,
+                                      void *g_albedo, void *g_metallic, int32_t batch, int64_t pixels, int albedo_is_srgb, int dtype,
+                                      void *stream) {
+    using namespace pbr;
+    if (!albedo || !metallic) return PBR_ERR_NULL_MAP;
+    if (batch < 1 || pixels < 1) return PBR_ERR_SHAPE;
+    if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
+    if (!g_albedo && !g_metallic) return PBR_OK;
+    const size_t al = dtype == PBR_F32 ? 16 : 8;
+    auto ok = [&](const void *p) { return !p || is_aligned(p, al); };
+    const bool vec = pixels % 4 == 0 && ok(albedo) && ok(metallic) && ok(g_diffuse) && ok(g_specular) && ok(g_albedo) && ok(g_metallic);
+    const size_t items = (size_t)batch * (size_t)pixels;
+    const unsigned grid = stream_grid(vec ? items / 4 : items);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+#define PBR_M2S_BWD(T, V) hipLaunchKernelGGL((metallic_to_specular_backward_kernel<T, V>), dim3(grid), dim3(256), 0, s, albedo, metallic, \
+                                             g_diffuse, g_specular, g_albedo, g_metallic, (int)batch, pixels, albedo_is_srgb)
+    if (dtype == PBR_F32) { if (vec) PBR_M2S_BWD(float, true); else PBR_M2S_BWD(float, false); }
+    else { if (vec) PBR_M2S_BWD(__half, true); else PBR_M2S_BWD(__half, false); }
+#undef PBR_M2S_BWD
+    return hip_status();
+}
+
+int pbr_specular_to_metallic_backward(const void *diffuse, const void *specular, const void *g_basecolor, const void *g_metallic,
+                                      void *g_diffuse, void *g_specular, size_t n, int albedo_is_srgb, int dtype, void *stream) {
+    using namespace pbr;
+    if (!diffuse || !specular) return PBR_ERR_NULL_MAP;
+    if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
+    if (n == 0 || (!g_diffuse && !g_specular)) return PBR_OK;
+    const size_t al = dtype == PBR_F32 ? 16 : 8;
+    auto ok = [&](const void *p) { return !p || is_aligned(p, al); };
+    const int vec_ok = ok(diffuse) && ok(specular) && ok(g_basecolor) && ok(g_metallic) && ok(g_diffuse) && ok(g_specular);
+    const unsigned grid = stream_grid(vec_ok ? (n + 3) / 4 : n);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == PBR_F32)
+        hipLaunchKernelGGL((specular_to_metallic_backward_kernel<float>), dim3(grid), dim3(256), 0, s, diffuse, specular, g_basecolor, g_metallic,
+                           g_diffuse, g_specular, n, albedo_is_srgb, vec_ok);
+    else
+        hipLaunchKernelGGL((specular_to_metallic_backward_kernel<__half>), dim3(grid), dim3(256), 0, s, diffuse, specular, g_basecolor, g_metallic,
+                           g_diffuse, g_specular, n, albedo_is_srgb, vec_ok);
     return hip_status();
 }
 

@@ -98,6 +98,71 @@ __global__ __launch_bounds__(256) void resize_height_kernel(const float *__restr
     }
 }
 
+
+// ---- gradient of the resize (what autograd derives from F.interpolate(mode="bilinear", antialias=...)) -------------------------
+// The forward is out = Wy in Wx^T with the banded tap matrices above; the gradient is g_in = Wy^T g_out Wx.  Two passes through a
+// workspace, each a GATHER by input index (no atomics, fixed summation order): tap windows are monotone in the output index, so the
+// outputs whose window holds input k are a contiguous range; it is bracketed from the window geometry and every candidate's exact
+// window is re-derived with the forward's own arithmetic (tap_window / tap_weight), the per-output normalisation 1 / sum_j w_j
+// coming from a small table computed first.
+__global__ __launch_bounds__(256) void resize_norm_kernel(float *__restrict__ inv, int n_out, AxisFilter f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    int xmin, n; float center, wsum = 0.0f;
+    tap_window(f, i, xmin, n, center);
+    for (int j = 0; j < n; ++j) wsum += tap_weight(f, j, xmin, center);
+    inv[i] = wsum != 0.0f ? 1.0f / wsum : 0.0f;
+}
+
+// first / last output index whose window can hold input k: |k + 0.5 - scale (i + 0.5)| <= support + 1, one more on each side
+__device__ __forceinline__ void candidates(const AxisFilter &f, int k, int n_out, int &lo, int &hi) {
+    const float inv = 1.0f / f.scale;
+    lo = max(0, (int)floorf(((float)k - f.support - 1.0f) * inv - 0.5f) - 1);
+    hi = min(n_out - 1, (int)ceilf(((float)k + f.support + 2.0f) * inv - 0.5f) + 1);
+}
+
+// pass A: tmp[plane][k][x] = sum_i Wy[i][k] g_out[plane][i][x]      (k over input rows, x over OUTPUT columns)
+__global__ __launch_bounds__(256) void resize_backward_rows_kernel(const float *__restrict__ gout, float *__restrict__ tmp, const float *__restrict__ inv,
+                                                                   int64_t planes, int n_out, int width, AxisFilter f) {
+    const int64_t total = planes * f.n_in * width, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int x = (int)(idx % width);
+        const int64_t t = idx / width;
+        const int k = (int)(t % f.n_in);
+        const int64_t plane = t / f.n_in;
+        int lo, hi;
+        candidates(f, k, n_out, lo, hi);
+        const float *g = gout + plane * n_out * width + x;
+        float acc = 0.0f;
+        for (int i = lo; i <= hi; ++i) {
+            int ymin, n; float center;
+            tap_window(f, i, ymin, n, center);
+            if (k >= ymin && k < ymin + n) acc = fmaf(tap_weight(f, k - ymin, ymin, center) * inv[i], g[(int64_t)i * width], acc);
+        }
+        tmp[idx] = acc;
+    }
+}
+
+// pass B: g_in[row][k] = sum_i Wx[i][k] tmp[row][i]                 (rows = planes * h_in, k over input columns)
+__global__ __launch_bounds__(256) void resize_backward_cols_kernel(const float *__restrict__ tmp, float *__restrict__ gin, const float *__restrict__ inv,
+                                                                   int64_t rows, int n_out, AxisFilter f) {
+    const int64_t total = rows * f.n_in, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t row = idx / f.n_in;
+        const int k = (int)(idx - row * f.n_in);
+        int lo, hi;
+        candidates(f, k, n_out, lo, hi);
+        const float *g = tmp + row * n_out;
+        float acc = 0.0f;
+        for (int i = lo; i <= hi; ++i) {
+            int xmin, n; float center;
+            tap_window(f, i, xmin, n, center);
+            if (k >= xmin && k < xmin + n) acc = fmaf(tap_weight(f, k - xmin, xmin, center) * inv[i], g[i], acc);
+        }
+        gin[idx] = acc;
+    }
+}
+
 constexpr int kTileW = 64;
 
 // A workgroup owns a toh x 64 tile of the output:
@@ -341,6 +406,31 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
                        static_cast<const float *>(src), tmp, planes * h_in, (int)w_out, fw);
     hipLaunchKernelGGL(resize_height_kernel, dim3(stream_grid(planes * h_out * w_out)), dim3(256), 0, s,
                        tmp, static_cast<float *>(dst), planes, (int)h_out, (int)w_out, fh);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+}
+
+size_t pbr_resize_backward_workspace_bytes(int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out, int32_t w_out) {
+    (void)w_in;
+    if (planes < 1 || h_in < 1 || h_out < 1 || w_out < 1) return 0;
+    return ((size_t)planes * (size_t)h_in * (size_t)w_out + (size_t)h_out + (size_t)w_out) * sizeof(float);
+}
+
+int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
+                                 int32_t w_out, int antialias, void *workspace, void *stream) {
+    using namespace pbr;
+    if (!grad_out || !grad_in || !workspace) return PBR_ERR_NULL_MAP;
+    if (planes < 1 || h_in < 1 || w_in < 1 || h_out < 1 || w_out < 1) return PBR_ERR_SHAPE;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const AxisFilter fw = make_filter(w_in, w_out, antialias != 0), fh = make_filter(h_in, h_out, antialias != 0);
+    float *tmp = static_cast<float *>(workspace);                    // [planes][h_in][w_out]
+    float *inv_y = tmp + (size_t)planes * h_in * w_out, *inv_x = inv_y + h_out;
+    hipLaunchKernelGGL(resize_norm_kernel, dim3((h_out + 255) / 256), dim3(256), 0, s, inv_y, (int)h_out, fh);
+    hipLaunchKernelGGL(resize_norm_kernel, dim3((w_out + 255) / 256), dim3(256), 0, s, inv_x, (int)w_out, fw);
+    hipLaunchKernelGGL(resize_backward_rows_kernel, dim3(stream_grid(planes * h_in * w_out)), dim3(256), 0, s,
+                       static_cast<const float *>(grad_out), tmp, inv_y, planes, (int)h_out, (int)w_out, fh);
+    hipLaunchKernelGGL(resize_backward_cols_kernel, dim3(stream_grid(planes * h_in * w_in)), dim3(256), 0, s,
+                       tmp, static_cast<float *>(grad_in), inv_x, planes * h_in, (int)w_out, fw);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? PBR_OK : 1000 + (int)e;
 }

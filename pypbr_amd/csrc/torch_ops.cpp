@@ -245,6 +245,81 @@ std::tuple<Tensor, Tensor> diffuse_specular_to_basecolor_metallic(const Tensor &
     return {base, met};
 }
 
+// ---- gradients of the map ops (pbr_*_backward): registered as operators of their own so that the autograd formulas
+// (pypbr_amd/torch_ops.py) stay traceable.  Gradients travel in the maps' storage type.
+Tensor colour_backward(const Tensor &x, const Tensor &grad_out, bool to_linear) {
+    TORCH_CHECK(x.is_cuda() && grad_out.is_cuda(), "pbr_hip colour transfer gradients need tensors on a ROCm device");
+    TORCH_CHECK_VALUE(x.sizes() == grad_out.sizes(), "texture and grad_out must have the same shape");
+    const Tensor t = x.contiguous(), g = grad_out.to(x.scalar_type()).contiguous();
+    const int dt = dtype_code(t, "texture");
+    const c10::DeviceGuard guard(t.device());
+    Tensor gin = at::empty_like(t);
+    const int rc = to_linear ? pbr_srgb_to_linear_backward(t.data_ptr(), g.data_ptr(), gin.data_ptr(), (size_t)t.numel(), dt, current_stream(t))
+                             : pbr_linear_to_srgb_backward(t.data_ptr(), g.data_ptr(), gin.data_ptr(), (size_t)t.numel(), dt, current_stream(t));
+    check_status(rc, "pbr_hip::colour_backward");
+    return gin;
+}
+
+std::tuple<Tensor, Tensor> metallic_to_diffuse_specular_backward(const Tensor &albedo, const Tensor &metallic, const OptTensor &g_diffuse,
+                                                                 const OptTensor &g_specular, bool albedo_is_srgb) {
+    const Tensor a = albedo.contiguous(), m = metallic.to(albedo.scalar_type()).contiguous();
+    const c10::DeviceGuard guard(a.device());
+    auto opt = [&](const OptTensor &t) { return t.has_value() && t->defined() ? t->to(a.scalar_type()).contiguous() : Tensor(); };
+    const Tensor gd = opt(g_diffuse), gs = opt(g_specular);
+    Tensor ga = at::empty_like(a), gm = at::empty_like(m);
+    const int64_t P = a.size(-1) * a.size(-2);
+    check_status(pbr_metallic_to_specular_backward(a.data_ptr(), m.data_ptr(), gd.defined() ? gd.data_ptr() : nullptr,
+                                                   gs.defined() ? gs.data_ptr() : nullptr, ga.data_ptr(), gm.data_ptr(),
+                                                   (int32_t)(a.numel() / (3 * P)), P, albedo_is_srgb, dtype_code(a, "albedo"), current_stream(a)),
+                 "pbr_hip::metallic_to_diffuse_specular_backward");
+    return {ga, gm};
+}
+
+std::tuple<Tensor, Tensor> diffuse_specular_to_basecolor_metallic_backward(const Tensor &diffuse, const Tensor &specular, const OptTensor &g_basecolor,
+                                                                           const OptTensor &g_metallic, bool albedo_is_srgb) {
+    const Tensor d = diffuse.contiguous(), s = specular.to(diffuse.scalar_type()).contiguous();
+    const c10::DeviceGuard guard(d.device());
+    auto opt = [&](const OptTensor &t) { return t.has_value() && t->defined() ? t->to(d.scalar_type()).contiguous() : Tensor(); };
+    const Tensor gb = opt(g_basecolor), gm = opt(g_metallic);
+    Tensor gd = at::empty_like(d), gs = at::empty_like(s);
+    check_status(pbr_specular_to_metallic_backward(d.data_ptr(), s.data_ptr(), gb.defined() ? gb.data_ptr() : nullptr,
+                                                   gm.defined() ? gm.data_ptr() : nullptr, gd.data_ptr(), gs.data_ptr(), (size_t)d.numel(),
+                                                   albedo_is_srgb, dtype_code(d, "diffuse"), current_stream(d)),
+                 "pbr_hip::diffuse_specular_to_basecolor_metallic_backward");
+    return {gd, gs};
+}
+
+// MaterialBase.resize for one map (base.py:490-504): [..., H, W] fp32 -> [..., h_out, w_out]
+Tensor resize(const Tensor &texture, int64_t h_out, int64_t w_out, bool antialias) {
+    TORCH_CHECK(texture.is_cuda(), "pbr_hip::resize needs a tensor on a ROCm device; there is no CPU path");
+    TORCH_CHECK_TYPE(texture.scalar_type() == at::kFloat, "pbr_hip::resize supports float32 maps, got ", texture.scalar_type());
+    TORCH_CHECK_VALUE(texture.dim() >= 2 && h_out >= 1 && w_out >= 1, "resize needs [..., H, W] and a positive size");
+    const Tensor t = texture.contiguous();
+    const c10::DeviceGuard guard(t.device());
+    const int64_t h = t.size(-2), w = t.size(-1), planes = t.numel() / (h * w);
+    std::vector<int64_t> shape(t.sizes().begin(), t.sizes().end());
+    shape[shape.size() - 2] = h_out; shape[shape.size() - 1] = w_out;
+    Tensor out = at::empty(shape, t.options());
+    Tensor ws = at::empty({(int64_t)(pbr_resize_workspace_bytes(planes, (int32_t)h, (int32_t)w_out) / 4 + 1)}, t.options());
+    check_status(pbr_resize_bilinear(t.data_ptr(), out.data_ptr(), planes, (int32_t)h, (int32_t)w, (int32_t)h_out, (int32_t)w_out, antialias,
+                                     ws.data_ptr(), current_stream(t)), "pbr_hip::resize");
+    return out;
+}
+
+Tensor resize_backward(const Tensor &grad_out, int64_t h_in, int64_t w_in, bool antialias) {
+    TORCH_CHECK(grad_out.is_cuda(), "pbr_hip::resize_backward needs a tensor on a ROCm device");
+    const Tensor g = grad_out.to(at::kFloat).contiguous();
+    const c10::DeviceGuard guard(g.device());
+    const int64_t ho = g.size(-2), wo = g.size(-1), planes = g.numel() / (ho * wo);
+    std::vector<int64_t> shape(g.sizes().begin(), g.sizes().end());
+    shape[shape.size() - 2] = h_in; shape[shape.size() - 1] = w_in;
+    Tensor gin = at::empty(shape, g.options());
+    Tensor ws = at::empty({(int64_t)(pbr_resize_backward_workspace_bytes(planes, (int32_t)h_in, (int32_t)w_in, (int32_t)ho, (int32_t)wo) / 4 + 1)}, g.options());
+    check_status(pbr_resize_bilinear_backward(g.data_ptr(), gin.data_ptr(), planes, (int32_t)h_in, (int32_t)w_in, (int32_t)ho, (int32_t)wo, antialias,
+                                              ws.data_ptr(), current_stream(g)), "pbr_hip::resize_backward");
+    return gin;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(pbr_hip, m) {
@@ -262,6 +337,13 @@ TORCH_LIBRARY(pbr_hip, m) {
     m.def("linear_to_srgb(Tensor texture) -> Tensor");
     m.def("metallic_to_diffuse_specular(Tensor albedo, Tensor metallic, bool albedo_is_srgb) -> (Tensor, Tensor)");
     m.def("diffuse_specular_to_basecolor_metallic(Tensor diffuse, Tensor specular, bool albedo_is_srgb) -> (Tensor, Tensor)");
+    m.def("colour_backward(Tensor texture, Tensor grad_out, bool to_linear) -> Tensor");
+    m.def("metallic_to_diffuse_specular_backward(Tensor albedo, Tensor metallic, Tensor? g_diffuse, Tensor? g_specular, bool albedo_is_srgb) "
+          "-> (Tensor, Tensor)");
+    m.def("diffuse_specular_to_basecolor_metallic_backward(Tensor diffuse, Tensor specular, Tensor? g_basecolor, Tensor? g_metallic, "
+          "bool albedo_is_srgb) -> (Tensor, Tensor)");
+    m.def("resize(Tensor texture, int h_out, int w_out, bool antialias) -> Tensor");
+    m.def("resize_backward(Tensor grad_out, int h_in, int w_in, bool antialias) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(pbr_hip, CUDA, m) {       // the CUDA dispatch key is the HIP device on a ROCm build of torch
@@ -272,4 +354,9 @@ TORCH_LIBRARY_IMPL(pbr_hip, CUDA, m) {       // the CUDA dispatch key is the HIP
     m.impl("linear_to_srgb", &linear_to_srgb);
     m.impl("metallic_to_diffuse_specular", &metallic_to_diffuse_specular);
     m.impl("diffuse_specular_to_basecolor_metallic", &diffuse_specular_to_basecolor_metallic);
+    m.impl("colour_backward", &colour_backward);
+    m.impl("metallic_to_diffuse_specular_backward", &metallic_to_diffuse_specular_backward);
+    m.impl("diffuse_specular_to_basecolor_metallic_backward", &diffuse_specular_to_basecolor_metallic_backward);
+    m.impl("resize", &resize);
+    m.impl("resize_backward", &resize_backward);
 }

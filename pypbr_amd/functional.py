@@ -622,16 +622,11 @@ def to_host(t: torch.Tensor, device=torch.device("cpu")) -> torch.Tensor:
     return host
 
 
-def refuse_grad(t: torch.Tensor, what: str):
-    """The map-level kernels (colour transfer, conversions, normal decode, resize, blends) have no backward: a tensor
-    that carries a gradient must not pass through them silently losing it (the reference's torch ops would keep it)."""
-    if t.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("%s is not differentiable in this build; only cook_torrance has a backward kernel "
-                                  "(detach the tensor, or run under torch.no_grad())" % what)
+def _needs_grad(*tensors) -> bool:
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
 
 
 def _device_tensor(t: torch.Tensor, what: str) -> torch.Tensor:
-    refuse_grad(t, what)
     if not t.is_cuda:
         raise RuntimeError("%s needs a tensor on a ROCm device; there is no CPU path" % what)
     if t.dtype not in _DTYPES:
@@ -639,31 +634,56 @@ def _device_tensor(t: torch.Tensor, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
-def srgb_to_linear(texture: torch.Tensor) -> torch.Tensor:
-    """utils.srgb_to_linear (pypbr/utils/functions.py:31-47) on the device."""
-    t = _device_tensor(texture, "srgb_to_linear")
+def _grad_like(g: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+    """The upstream gradient in the maps' storage type, contiguous (the backward kernels read it as the maps are stored)."""
+    return g.to(like.dtype).contiguous()
+
+
+def _colour_raw(t: torch.Tensor, to_linear: bool) -> torch.Tensor:
     out = torch.empty_like(t)
+    fn = N.lib().pbr_srgb_to_linear if to_linear else N.lib().pbr_linear_to_srgb
     with torch.cuda.device(t.device):
-        N.check(N.lib().pbr_srgb_to_linear(t.data_ptr(), out.data_ptr(), t.numel(), _DTYPES[t.dtype], _stream_ptr(t.device)))
+        N.check(fn(t.data_ptr(), out.data_ptr(), t.numel(), _DTYPES[t.dtype], _stream_ptr(t.device)))
     return out
+
+
+class _ColourFn(torch.autograd.Function):
+    """srgb_to_linear / linear_to_srgb with their backward kernels (pbr_*_backward): the reference's colour transfers are plain
+    torch ops (functions.py:31-66), so a rendering loss differentiates through material.to_linear() / linear_albedo."""
+
+    @staticmethod
+    def forward(ctx, texture, to_linear):
+        t = _device_tensor(texture.detach(), "srgb_to_linear" if to_linear else "linear_to_srgb")
+        ctx.save_for_backward(t)
+        ctx.to_linear = to_linear
+        return _colour_raw(t, to_linear)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (t,) = ctx.saved_tensors
+        g = _grad_like(grad_out, t)
+        gin = torch.empty_like(t)
+        fn = N.lib().pbr_srgb_to_linear_backward if ctx.to_linear else N.lib().pbr_linear_to_srgb_backward
+        with torch.cuda.device(t.device):
+            N.check(fn(t.data_ptr(), g.data_ptr(), gin.data_ptr(), t.numel(), _DTYPES[t.dtype], _stream_ptr(t.device)))
+        return gin, None
+
+
+def srgb_to_linear(texture: torch.Tensor) -> torch.Tensor:
+    """utils.srgb_to_linear (pypbr/utils/functions.py:31-47) on the device; differentiable (its own backward kernel)."""
+    if _needs_grad(texture):
+        return _ColourFn.apply(texture, True)
+    return _colour_raw(_device_tensor(texture, "srgb_to_linear"), True)
 
 
 def linear_to_srgb(texture: torch.Tensor) -> torch.Tensor:
-    """utils.linear_to_srgb (pypbr/utils/functions.py:50-66) on the device."""
-    t = _device_tensor(texture, "linear_to_srgb")
-    out = torch.empty_like(t)
-    with torch.cuda.device(t.device):
-        N.check(N.lib().pbr_linear_to_srgb(t.data_ptr(), out.data_ptr(), t.numel(), _DTYPES[t.dtype], _stream_ptr(t.device)))
-    return out
+    """utils.linear_to_srgb (pypbr/utils/functions.py:50-66) on the device; differentiable (its own backward kernel)."""
+    if _needs_grad(texture):
+        return _ColourFn.apply(texture, False)
+    return _colour_raw(_device_tensor(texture, "linear_to_srgb"), False)
 
 
-def metallic_to_diffuse_specular(albedo: torch.Tensor, metallic: torch.Tensor, albedo_is_srgb: bool = False):
-    """Arithmetic of to_diffuse_specular_material (metallic.py:98-108).  albedo [..,3,H,W],
-    metallic [..,1,H,W] -> (diffuse, specular) both [..,3,H,W] in linear space."""
-    a = _device_tensor(albedo, "metallic_to_diffuse_specular")
-    m = _device_tensor(metallic, "metallic_to_diffuse_specular")
-    if a.shape[-3] != 3 or m.shape[-3] != 1 or a.shape[-2:] != m.shape[-2:] or a.shape[:-3] != m.shape[:-3]:
-        raise ValueError("albedo [..,3,H,W] / metallic [..,1,H,W] expected, got %s / %s" % (tuple(a.shape), tuple(m.shape)))
+def _m2ds_raw(a, m, albedo_is_srgb):
     diffuse, spec = torch.empty_like(a), torch.empty_like(a)
     P = a.shape[-1] * a.shape[-2]
     with torch.cuda.device(a.device):
@@ -673,18 +693,91 @@ def metallic_to_diffuse_specular(albedo: torch.Tensor, metallic: torch.Tensor, a
     return diffuse, spec
 
 
-def diffuse_specular_to_basecolor_metallic(diffuse: torch.Tensor, specular: torch.Tensor, albedo_is_srgb: bool = False):
-    """Arithmetic of to_basecolor_metallic_material (diffuse.py:128-147): RAW specular in,
-    (basecolor, 3-channel metallic) out."""
-    d = _device_tensor(diffuse, "diffuse_specular_to_basecolor_metallic")
-    s = _device_tensor(specular, "diffuse_specular_to_basecolor_metallic")
-    if d.shape != s.shape:
-        raise ValueError("diffuse %s and specular %s must have the same shape" % (tuple(d.shape), tuple(s.shape)))
+class _MetallicToSpecularFn(torch.autograd.Function):
+    """to_diffuse_specular_material's arithmetic (metallic.py:98-108) with its backward kernel."""
+
+    @staticmethod
+    def forward(ctx, albedo, metallic, albedo_is_srgb):
+        a, m = albedo.detach(), metallic.detach()
+        ctx.save_for_backward(a, m)
+        ctx.srgb = bool(albedo_is_srgb)
+        return _m2ds_raw(a, m, albedo_is_srgb)
+
+    @staticmethod
+    def backward(ctx, g_diffuse, g_specular):
+        a, m = ctx.saved_tensors
+        gd = None if g_diffuse is None else _grad_like(g_diffuse, a)
+        gs = None if g_specular is None else _grad_like(g_specular, a)
+        ga = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        gm = torch.empty_like(m) if ctx.needs_input_grad[1] else None
+        P = a.shape[-1] * a.shape[-2]
+        ptr = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(a.device):
+            N.check(N.lib().pbr_metallic_to_specular_backward(a.data_ptr(), m.data_ptr(), ptr(gd), ptr(gs), ptr(ga), ptr(gm),
+                                                              a.numel() // (3 * P), P, int(ctx.srgb), _DTYPES[a.dtype],
+                                                              _stream_ptr(a.device)))
+        return ga, gm, None
+
+
+def metallic_to_diffuse_specular(albedo: torch.Tensor, metallic: torch.Tensor, albedo_is_srgb: bool = False):
+    """Arithmetic of to_diffuse_specular_material (metallic.py:98-108).  albedo [..,3,H,W],
+    metallic [..,1,H,W] -> (diffuse, specular) both [..,3,H,W] in linear space.  Differentiable w.r.t. both maps."""
+    a = _device_tensor(albedo, "metallic_to_diffuse_specular")
+    m = _device_tensor(metallic, "metallic_to_diffuse_specular")
+    if a.shape[-3] != 3 or m.shape[-3] != 1 or a.shape[-2:] != m.shape[-2:] or a.shape[:-3] != m.shape[:-3]:
+        raise ValueError("albedo [..,3,H,W] / metallic [..,1,H,W] expected, got %s / %s" % (tuple(a.shape), tuple(m.shape)))
+    if m.dtype != a.dtype:
+        m = m.to(a.dtype)
+    if _needs_grad(a, m):
+        return _MetallicToSpecularFn.apply(a, m, bool(albedo_is_srgb))
+    return _m2ds_raw(a, m, albedo_is_srgb)
+
+
+def _ds2bm_raw(d, s, albedo_is_srgb):
     base, met = torch.empty_like(d), torch.empty_like(d)
     with torch.cuda.device(d.device):
         N.check(N.lib().pbr_specular_to_metallic(d.data_ptr(), s.data_ptr(), base.data_ptr(), met.data_ptr(),
                                                  d.numel(), int(albedo_is_srgb), _DTYPES[d.dtype], _stream_ptr(d.device)))
     return base, met
+
+
+class _SpecularToMetallicFn(torch.autograd.Function):
+    """to_basecolor_metallic_material's arithmetic (diffuse.py:128-147) with its backward kernel (torch's sub-gradients through
+    clamp / where; the thresholded selects are re-taken with the forward's own arithmetic)."""
+
+    @staticmethod
+    def forward(ctx, diffuse, specular, albedo_is_srgb):
+        d, s = diffuse.detach(), specular.detach()
+        ctx.save_for_backward(d, s)
+        ctx.srgb = bool(albedo_is_srgb)
+        return _ds2bm_raw(d, s, albedo_is_srgb)
+
+    @staticmethod
+    def backward(ctx, g_basecolor, g_metallic):
+        d, s = ctx.saved_tensors
+        gb = None if g_basecolor is None else _grad_like(g_basecolor, d)
+        gm = None if g_metallic is None else _grad_like(g_metallic, d)
+        gd = torch.empty_like(d) if ctx.needs_input_grad[0] else None
+        gs = torch.empty_like(s) if ctx.needs_input_grad[1] else None
+        ptr = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(d.device):
+            N.check(N.lib().pbr_specular_to_metallic_backward(d.data_ptr(), s.data_ptr(), ptr(gb), ptr(gm), ptr(gd), ptr(gs), d.numel(),
+                                                              int(ctx.srgb), _DTYPES[d.dtype], _stream_ptr(d.device)))
+        return gd, gs, None
+
+
+def diffuse_specular_to_basecolor_metallic(diffuse: torch.Tensor, specular: torch.Tensor, albedo_is_srgb: bool = False):
+    """Arithmetic of to_basecolor_metallic_material (diffuse.py:128-147): RAW specular in,
+    (basecolor, 3-channel metallic) out.  Differentiable w.r.t. both maps."""
+    d = _device_tensor(diffuse, "diffuse_specular_to_basecolor_metallic")
+    s = _device_tensor(specular, "diffuse_specular_to_basecolor_metallic")
+    if d.shape != s.shape:
+        raise ValueError("diffuse %s and specular %s must have the same shape" % (tuple(d.shape), tuple(s.shape)))
+    if s.dtype != d.dtype:
+        s = s.to(d.dtype)
+    if _needs_grad(d, s):
+        return _SpecularToMetallicFn.apply(d, s, bool(albedo_is_srgb))
+    return _ds2bm_raw(d, s, albedo_is_srgb)
 
 
 def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool = False, material_major: bool = False):
@@ -799,13 +892,49 @@ def _pack_material_major(maps, batch, dev, reserve_output, padded):
     return tuple(views)
 
 
+def _resize_raw(t: torch.Tensor, ho: int, wo: int, antialias: bool) -> torch.Tensor:
+    h, w = t.shape[-2:]
+    planes = t.numel() // (h * w)
+    out = torch.empty(t.shape[:-2] + (ho, wo), dtype=t.dtype, device=t.device)
+    lib = N.lib()
+    ws = torch.empty(lib.pbr_resize_workspace_bytes(planes, h, wo) // 4, dtype=torch.float32, device=t.device)
+    with torch.cuda.device(t.device):
+        N.check(lib.pbr_resize_bilinear(t.data_ptr(), out.data_ptr(), planes, h, w, ho, wo, int(bool(antialias)),
+                                        ws.data_ptr(), _stream_ptr(t.device)))
+    return out
+
+
+class _ResizeFn(torch.autograd.Function):
+    """MaterialBase.resize for one map with its backward kernel (the transposed tap matrices: pbr_resize_bilinear_backward)."""
+
+    @staticmethod
+    def forward(ctx, texture, ho, wo, antialias):
+        t = texture.detach().contiguous()
+        ctx.geom = (tuple(t.shape), ho, wo, bool(antialias))
+        return _resize_raw(t, ho, wo, antialias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        shape, ho, wo, antialias = ctx.geom
+        h, w = shape[-2:]
+        g = grad_out.to(torch.float32).contiguous()
+        planes = g.numel() // (ho * wo)
+        gin = torch.empty(shape, dtype=torch.float32, device=g.device)
+        lib = N.lib()
+        ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(planes, h, w, ho, wo) // 4), dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            N.check(lib.pbr_resize_bilinear_backward(g.data_ptr(), gin.data_ptr(), planes, h, w, ho, wo, int(antialias), ws.data_ptr(),
+                                                     _stream_ptr(g.device)))
+        return gin, None, None, None
+
+
 def resize(texture: torch.Tensor, size, antialias: bool = True) -> torch.Tensor:
     """MaterialBase.resize for one map (base.py:490-504 -> torchvision resize of a float tensor):
     bilinear, align_corners=False, optional antialiasing.  `size` = (h, w), or an int that fixes the
-    SMALLER edge and keeps the aspect ratio (torchvision semantics).  [..., H, W] float32 on device."""
+    SMALLER edge and keeps the aspect ratio (torchvision semantics).  [..., H, W] float32 on device.
+    Differentiable (its own backward kernel), as F.interpolate is upstream."""
     if not texture.is_cuda:
         raise RuntimeError("resize needs a tensor on a ROCm device; there is no CPU path")
-    refuse_grad(texture, "resize")
     if texture.dtype != torch.float32:
         raise TypeError("resize supports float32 maps, got %s" % texture.dtype)
     h, w = texture.shape[-2:]
@@ -816,15 +945,9 @@ def resize(texture: torch.Tensor, size, antialias: bool = True) -> torch.Tensor:
         new_short, new_long = size, int(size * long / short)
         size = (new_long, new_short) if w <= h else (new_short, new_long)
     ho, wo = int(size[0]), int(size[1])
-    t = texture.contiguous()
-    planes = t.numel() // (h * w)
-    out = torch.empty(t.shape[:-2] + (ho, wo), dtype=t.dtype, device=t.device)
-    lib = N.lib()
-    ws = torch.empty(lib.pbr_resize_workspace_bytes(planes, h, wo) // 4, dtype=torch.float32, device=t.device)
-    with torch.cuda.device(t.device):
-        N.check(lib.pbr_resize_bilinear(t.data_ptr(), out.data_ptr(), planes, h, w, ho, wo, int(bool(antialias)),
-                                        ws.data_ptr(), _stream_ptr(t.device)))
-    return out
+    if _needs_grad(texture):
+        return _ResizeFn.apply(texture, ho, wo, bool(antialias))
+    return _resize_raw(texture.contiguous(), ho, wo, antialias)
 
 
 def _decode_normal_raw(t: torch.Tensor):

@@ -86,6 +86,49 @@ def _register():
     lib.register_fake("pbr_hip::diffuse_specular_to_basecolor_metallic")(
         lambda diffuse, specular, albedo_is_srgb: (torch.empty_like(diffuse), torch.empty_like(diffuse)))
 
+    lib.register_fake("pbr_hip::colour_backward")(lambda texture, grad_out, to_linear: torch.empty_like(texture))
+    lib.register_fake("pbr_hip::metallic_to_diffuse_specular_backward")(
+        lambda albedo, metallic, g_diffuse, g_specular, albedo_is_srgb: (torch.empty_like(albedo), torch.empty_like(metallic)))
+    lib.register_fake("pbr_hip::diffuse_specular_to_basecolor_metallic_backward")(
+        lambda diffuse, specular, g_basecolor, g_metallic, albedo_is_srgb: (torch.empty_like(diffuse), torch.empty_like(specular)))
+    lib.register_fake("pbr_hip::resize")(lambda texture, h_out, w_out, antialias: texture.new_empty(tuple(texture.shape[:-2]) + (h_out, w_out)))
+    lib.register_fake("pbr_hip::resize_backward")(
+        lambda grad_out, h_in, w_in, antialias: grad_out.new_empty(tuple(grad_out.shape[:-2]) + (h_in, w_in), dtype=torch.float32))
+
+    # autograd formulas of the map ops: one backward operator each (what the reference's autograd derives from its plain torch
+    # ops: functions.py:31-66, metallic.py:98-108, diffuse.py:128-147, base.py:490-504)
+    def colour_autograd(name, to_linear):
+        def setup(ctx, inputs, output):
+            ctx.save_for_backward(inputs[0])
+
+        def backward(ctx, grad_out):
+            (x,) = ctx.saved_tensors
+            return torch.ops.pbr_hip.colour_backward(x, grad_out, to_linear)
+        lib.register_autograd("pbr_hip::" + name, backward, setup_context=setup)
+    colour_autograd("srgb_to_linear", True)
+    colour_autograd("linear_to_srgb", False)
+
+    def pair_autograd(name):
+        def setup(ctx, inputs, output):
+            ctx.save_for_backward(inputs[0], inputs[1])
+            ctx.flag = inputs[2]
+
+        def backward(ctx, g0, g1):
+            x, y = ctx.saved_tensors
+            gx, gy = getattr(torch.ops.pbr_hip, name + "_backward")(x, y, g0, g1, ctx.flag)
+            return (gx if ctx.needs_input_grad[0] else None, gy.to(y.dtype) if ctx.needs_input_grad[1] else None, None)
+        lib.register_autograd("pbr_hip::" + name, backward, setup_context=setup)
+    pair_autograd("metallic_to_diffuse_specular")
+    pair_autograd("diffuse_specular_to_basecolor_metallic")
+
+    def resize_setup(ctx, inputs, output):
+        ctx.geom = (inputs[0].shape[-2], inputs[0].shape[-1], inputs[3])
+
+    def resize_backward(ctx, grad_out):
+        h, w, antialias = ctx.geom
+        return torch.ops.pbr_hip.resize_backward(grad_out, h, w, antialias), None, None, None
+    lib.register_autograd("pbr_hip::resize", resize_backward, setup_context=resize_setup)
+
     names = ("albedo", "normal", "roughness", "metallic", "specular", "view_dir", "lights", "intensities")
 
     def setup_context(ctx, inputs, output):

@@ -108,6 +108,15 @@ def test_opcheck():
     torch.library.opcheck(torch.ops.pbr_hip.metallic_to_diffuse_specular.default, (x, torch.rand(1, 16, 24, device="cuda"), True))
     torch.library.opcheck(torch.ops.pbr_hip.diffuse_specular_to_basecolor_metallic.default, (x, torch.rand(3, 16, 24, device="cuda"), False))
     torch.library.opcheck(torch.ops.pbr_hip.fold_gradient.default, (torch.rand(2, 3, 32, 48, device="cuda"), 16, 24, True))
+    # round 3: the map ops carry an autograd formula (their own backward operators), and resize is an operator too
+    xg = torch.rand(3, 16, 24, device="cuda", requires_grad=True)
+    for op in (torch.ops.pbr_hip.srgb_to_linear, torch.ops.pbr_hip.linear_to_srgb):
+        torch.library.opcheck(op.default, (xg,))
+    torch.library.opcheck(torch.ops.pbr_hip.metallic_to_diffuse_specular.default, (xg, torch.rand(1, 16, 24, device="cuda", requires_grad=True), True))
+    torch.library.opcheck(torch.ops.pbr_hip.diffuse_specular_to_basecolor_metallic.default, (xg, torch.rand(3, 16, 24, device="cuda", requires_grad=True), False))
+    torch.library.opcheck(torch.ops.pbr_hip.resize.default, (xg, 9, 31, True))
+    torch.library.opcheck(torch.ops.pbr_hip.colour_backward.default, (x, torch.rand(3, 16, 24, device="cuda"), True))
+    torch.library.opcheck(torch.ops.pbr_hip.resize_backward.default, (torch.rand(3, 9, 31, device="cuda"), 16, 24, True))
 
 
 def test_traces_through_aot_autograd():

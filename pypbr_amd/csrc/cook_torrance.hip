@@ -47,9 +47,8 @@ struct KernelEntry { KernelFn fn; const char *name; };
 template <int LIGHT, int WF, typename TI, typename TO>
 static KernelFn pick_variant(int vec, bool multi, bool nt) {
     if constexpr (sizeof(TI) == 2) {
-        if (vec == 8) {
-            if (multi) return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 8, true, true>
-                                 : cook_torrance_kernel<LIGHT, WF, TI, TO, 8, true, false>;
+        if (vec == 8 && !multi) {        // pick_vec hands out 8-pixel lanes for ONE light only (several lights are VALU-bound: 4-pixel lanes);
+                                         // the 8-pixel multi-light body would not fit 128 VGPRs (it spilled 220-304 bytes when it was instantiated)
             return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 8, false, true>
                       : cook_torrance_kernel<LIGHT, WF, TI, TO, 8, false, false>;
         }

@@ -492,3 +492,52 @@ def test_tuning_knob_numbers_match_the_header():
         old = lib.pbr_set_tuning(number, 0)
         assert lib.pbr_set_tuning(number, old) == 0, name              # the value just set comes back; the old one is restored
     assert lib.pbr_set_tuning(len(knobs), 0) == -1
+
+
+# ---------------------------------------------------------------- build-time ISA assertions
+def test_isa_assumptions_of_the_hand_scheduled_kernels_hold_and_the_checker_can_fail():
+    """tools/check_isa.py on the objects of this build: the streamed backward kernel's hand-counted `s_waitcnt vmcnt(N)` needs
+    exactly N stores per tile, the source's LDS-DMA loads and nothing else in vector memory, no scratch, no compiler-emitted
+    access to the DMA buffer; the fp16 forward's piece exchange needs its LDS writes before its reads.  And the checker is not
+    vacuous: doctored instruction streams (one spill, one extra store, an interleaved load, a compiler wait) are rejected."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_isa as C
+    for name in ("ct_backward", "cook_torrance"):
+        if not os.path.exists(os.path.join(C.CSRC, name + ".o")):
+            subprocess.check_call(["make", "-s", "-j4", "-C", C.CSRC])
+            break
+    report = C.check()
+    assert len(report) == 24 and sum("backward_stream" in r for r in report) == 12
+
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    co = C._code_object(os.path.join(C.CSRC, "ct_backward.o"), tmp)
+    fns, meta = C._functions(co), C._metadata(co)
+    sym = next(s for s in fns if "cook_torrance_backward_stream_kernelILi1ELi0ELb1E" in s)       # point, metallic, FULL
+    good = fns[sym]
+    assert C.check_stream_kernel(sym, good, meta[sym])[1] == []
+    first_store = next(i for i, (m, _) in enumerate(good) if m.startswith("global_store"))
+    first_loop_load = [i for i, (m, _) in enumerate(good) if m == "global_load_lds_dword"][14]
+    doctored = {
+        "spill": good[:first_store] + [("scratch_store_dword", "off, v1, s32")] + good[first_store:],
+        "extra store": good[:first_store] + [("global_store_dword", "v78, v1, s[2:3] nt")] + good[first_store:],
+        "plain load": good[:first_store] + [("global_load_dword", "v1, v78, s[2:3]")] + good[first_store:],
+        "interleaved": good[:first_loop_load + 3] + [("global_store_dword", "v78, v1, s[2:3] nt")] + good[first_loop_load + 3:first_store] + good[first_store + 1:],
+        "compiler wait": good[:first_store] + [("s_waitcnt", "vmcnt(3)")] + good[first_store:],
+        "compiler lds read": good[:first_store] + [("ds_read_b32", "v9, v2 offset:2048")] + good[first_store:],
+        "lds write": good[:first_store] + [("ds_write_b32", "v2, v9")] + good[first_store:],
+    }
+    for what, insts in doctored.items():
+        assert C.check_stream_kernel(sym, insts, meta[sym])[1], what
+    assert C.check_stream_kernel(sym, good, dict(meta[sym], private_segment_fixed_size=16))[1]
+    co = C._code_object(os.path.join(C.CSRC, "cook_torrance.o"), tmp)
+    fns, meta = C._functions(co), C._metadata(co)
+    sym = next(s for s in fns if "cook_torrance_kernelILi1ELi0E6__halffLi8ELb0ELb1E" in s)
+    good = fns[sym]
+    assert C.check_xpose_kernel(sym, good, meta[sym])[1] == []
+    w = [i for i, (m, _) in enumerate(good) if m == "ds_write_b128"]
+    r = [i for i, (m, _) in enumerate(good) if m == "ds_read_b128"]
+    swapped = list(good)
+    swapped[w[-1]], swapped[r[0]] = swapped[r[0]], swapped[w[-1]]
+    assert C.check_xpose_kernel(sym, swapped, meta[sym])[1]

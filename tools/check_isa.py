@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Build-time assertions on the gfx950 ISA of the hand-scheduled kernels (no GPU needed: reads the objects hipcc produced).
+
+Two kernels of this library are correct only if the compiler emits exactly the memory instructions their hand-counted waits
+assume ("What's weak" #7):
+
+* `cook_torrance_backward_stream_kernel<LIGHT, WF, FULL>` (csrc/ct_backward.hpp): the next tile's texels travel global -> LDS by
+  DMA (`global_load_lds_dword`), the tile's values leave LDS through hand-written `ds_read`s after a hand-counted
+  `s_waitcnt vmcnt(N)` -- N = the stores of one tile, because the tile's loads were issued before the previous tile's N stores
+  and vmcnt retires in order.  That holds only if: the kernel has NO other vector-memory traffic (no scratch, no buffer ops, no
+  plain global loads), exactly N stores per tile, exactly the DMA loads the source writes (once for the first tile, once in the
+  loop), loads and stores in two separate runs (not interleaved), no compiler-emitted LDS access to the DMA buffer (every
+  `ds_read` is one of the hand-written ones; nothing ever `ds_write`s), and no wait on vmcnt other than the hand-written ones.
+* the 16-byte piece exchange of `shade_and_store` (csrc/ct_kernel.hpp; 8-pixel lanes, fp32 result): every `ds_write_b128` of a
+  wave precedes every `ds_read_b128` (one wave only ever talks to itself, and a wave's LDS operations execute in order), nothing
+  spills.
+
+A ROCm bump that spills one register, or re-orders one access, fails the BUILD here instead of producing stale LDS reads on
+the GPU.  Run by __graft_entry__.build() and by tests/test_abi_and_host.py; `python tools/check_isa.py` prints the report.
+"""
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "pypbr_amd", "csrc")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+WF_NAMES = {0: "metallic", 1: "specular", 2: "converted"}
+
+
+class IsaError(AssertionError):
+    pass
+
+
+def _code_object(obj, tmp):
+    """The gfx950 code object bundled in a host object file."""
+    local = os.path.join(tmp, os.path.basename(obj))
+    shutil.copyfile(obj, local)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, capture_output=True, cwd=tmp)
+    hits = [f for f in os.listdir(tmp) if f.startswith(os.path.basename(obj) + ".") and "gfx950" in f]
+    if len(hits) != 1:
+        raise IsaError("no gfx950 code object in %s (found %s)" % (obj, hits))
+    return os.path.join(tmp, hits[0])
+
+
+def _functions(code_object):
+    """symbol -> list of (mnemonic, operand text) in layout order."""
+    text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", code_object], check=True,
+                          capture_output=True, text=True).stdout
+    out, cur = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:$", line)
+        if m:
+            cur = out.setdefault(m.group(1), [])
+            continue
+        m = re.match(r"^\s+([a-z_0-9]+)\s*(.*?)\s*(//.*)?$", line)
+        if m and cur is not None:
+            cur.append((m.group(1), m.group(2)))
+    return out
+
+
+def _metadata(code_object):
+    """symbol -> dict of the integer fields of its AMDGPU metadata entry (.private_segment_fixed_size, .vgpr_count ...)."""
+    notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", code_object], check=True, capture_output=True, text=True).stdout
+    out = {}
+    for block in re.split(r"\n\s+- \.agpr_count", notes)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        if not name:
+            continue
+        fields = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)\s*$", block, flags=re.M)}
+        out[name.group(1)] = fields
+    return out
+
+
+def _runs(insts, pred):
+    """Maximal runs of consecutive instructions (ignoring everything `pred` returns None for) sharing pred's value."""
+    runs, last = [], None
+    for m, ops in insts:
+        k = pred(m, ops)
+        if k is None:
+            continue
+        if k != last:
+            runs.append([k, 0])
+            last = k
+        runs[-1][1] += 1
+    return runs
+
+
+def check_stream_kernel(sym, insts, meta):
+    m = re.search(r"stream_kernelILi(\d)ELi(\d)ELb(\d)E", sym)
+    light, wf, full = int(m.group(1)), int(m.group(2)), m.group(3) == "1"
+    what = "backward_stream<%s,%s,%s>" % ("point" if light else "directional", WF_NAMES[wf], "FULL" if full else "flags")
+    n_maps = 10 if wf == 1 else 8                       # albedo 3 + normal 3 + roughness + (metallic | specular 3)
+    n_dma, n_stores = n_maps + 6, n_maps                # + the upstream gradient: 3 planes x 2 loads; one gradient plane per map plane
+    ops = [mn for mn, _ in insts]
+    fail = []
+    if meta.get("private_segment_fixed_size", -1) != 0:
+        fail.append("scratch: private_segment_fixed_size = %s" % meta.get("private_segment_fixed_size"))
+    for bad in ("scratch_", "buffer_", "flat_"):
+        n = sum(1 for o in ops if o.startswith(bad))
+        if n:
+            fail.append("%d %s* instructions" % (n, bad))
+    plain_loads = sum(1 for o in ops if o.startswith("global_load") and not o.startswith("global_load_lds"))
+    if plain_loads:
+        fail.append("%d plain global loads (everything must arrive by LDS-DMA)" % plain_loads)
+    n_ds_write = sum(1 for o in ops if o.startswith("ds_write") or o.startswith("ds_store"))
+    if n_ds_write:
+        fail.append("%d compiler-emitted LDS writes to the DMA buffer" % n_ds_write)
+    dma = [ops_txt for mn, ops_txt in insts if mn == "global_load_lds_dword"]
+    stores = sum(1 for o in ops if o.startswith("global_store"))
+    reads32 = [t for mn, t in insts if mn == "ds_read_b32"]
+    reads64 = [t for mn, t in insts if mn == "ds_read_b64"]
+    other_ds = sorted({o for o in ops if o.startswith("ds_") and o not in ("ds_read_b32", "ds_read_b64")})
+    if other_ds:
+        fail.append("unexpected LDS instructions %s" % other_ds)
+    waits = []
+    for mn, t in insts:
+        if mn == "s_waitcnt":
+            w = re.search(r"vmcnt\((\d+)\)", t)
+            if w:
+                waits.append(int(w.group(1)))
+
+    def offsets(texts):
+        return sorted(int(re.search(r"offset:(\d+)", t).group(1)) if "offset:" in t else 0 for t in texts)
+
+    if full:
+        if len(dma) != 2 * n_dma:
+            fail.append("%d global_load_lds_dword, expected 2 x %d (first tile + loop)" % (len(dma), n_dma))
+        want = sorted([256 * q for q in range(n_maps if wf == 1 else 8)] + [2560 + 256 * k for k in range(6)])
+        if offsets(dma) != sorted(want + want):
+            fail.append("DMA offsets %s, expected twice %s" % (offsets(dma), want))
+        if stores != n_stores:
+            fail.append("%d global stores per tile, the hand-counted wait assumes %d" % (stores, n_stores))
+        if sorted(waits) != [0, n_stores]:
+            fail.append("s_waitcnt vmcnt(...) values %s, expected exactly [0, %d] (a compiler-inserted wait?)" % (sorted(waits), n_stores))
+        if offsets(reads32) != [256 * q for q in range(n_maps)] or offsets(reads64) != [0, 512, 1024]:
+            fail.append("LDS reads b32 %s / b64 %s: not exactly the hand-written ones" % (offsets(reads32), offsets(reads64)))
+        # loads and stores in separate runs: [first tile's loads] ... then per loop body one run of stores and one of loads
+        runs = _runs(insts, lambda mn, t: "L" if mn == "global_load_lds_dword" else ("S" if mn.startswith("global_store") else None))
+        if sorted(r[1] for r in runs if r[0] == "L") != [n_dma, n_dma] or [r[1] for r in runs if r[0] == "S"] != [n_stores]:
+            fail.append("DMA loads and stores interleave: runs %s" % runs)
+        # the hand-written reads come right after the hand-counted wait, before anything else touches vector memory
+        idx = next((i for i, (mn, t) in enumerate(insts) if mn == "s_waitcnt" and "vmcnt(%d)" % n_stores in t), None)
+        if idx is not None:
+            nxt = [mn for mn, _ in insts[idx + 1: idx + 1 + n_maps + 3 + 8] if mn.startswith(("ds_", "global_", "s_waitcnt"))]
+            if nxt[:n_maps + 3] != ["ds_read_b32"] * n_maps + ["ds_read_b64"] * 3 and sorted(nxt[:n_maps + 3]) != sorted(["ds_read_b32"] * n_maps + ["ds_read_b64"] * 3):
+                fail.append("after s_waitcnt vmcnt(%d): %s" % (n_stores, nxt))
+    else:
+        if not set(waits) <= {0, 5, 8, 10}:
+            fail.append("s_waitcnt vmcnt(...) values %s outside the hand-written {0, 5, 8, 10}" % sorted(set(waits)))
+        if len(reads32) > n_maps or len(reads64) != 3:
+            fail.append("LDS reads: %d b32 / %d b64" % (len(reads32), len(reads64)))
+        if len(dma) > 2 * n_dma or len(dma) < n_dma:
+            fail.append("%d global_load_lds_dword" % len(dma))
+    summary = "%-48s vgpr %3d  scratch %d  dma %2d  stores %2d  ds_read %2d+%d  vmcnt waits %s" % (
+        what, meta.get("vgpr_count", -1), meta.get("private_segment_fixed_size", -1), len(dma), stores, len(reads32), len(reads64), sorted(waits))
+    return summary, ["%s: %s" % (what, f) for f in fail]
+
+
+def check_xpose_kernel(sym, insts, meta):
+    """cook_torrance_kernel<.., __half, float, 8, ..>: the piece exchange of shade_and_store."""
+    fail = []
+    if meta.get("private_segment_fixed_size", -1) != 0:
+        fail.append("scratch: private_segment_fixed_size = %s" % meta.get("private_segment_fixed_size"))
+    ops = [mn for mn, _ in insts]
+    w = [i for i, o in enumerate(ops) if o in ("ds_write_b128", "ds_store_b128")]
+    r = [i for i, o in enumerate(ops) if o in ("ds_read_b128", "ds_load_b128")]
+    if len(w) != 6 or len(r) != 6:
+        fail.append("%d ds_write_b128 / %d ds_read_b128, expected 6 / 6 (3 planes x 2 pieces)" % (len(w), len(r)))
+    elif max(w) > min(r):
+        fail.append("a ds_read_b128 precedes a ds_write_b128: the exchange reads pieces that are not written yet")
+    for bad in ("scratch_", "buffer_"):
+        if any(o.startswith(bad) for o in ops):
+            fail.append("%s* instructions" % bad)
+    short = re.sub(r"^_ZN3pbr20cook_torrance_kernelI", "ct<", sym).split("EEvNS")[0] + ">"
+    return "%-48s vgpr %3d  scratch %d  ds_write_b128 %d  ds_read_b128 %d" % (short, meta.get("vgpr_count", -1),
+                                                                               meta.get("private_segment_fixed_size", -1), len(w), len(r)), \
+           ["%s: %s" % (short, f) for f in fail]
+
+
+def check(verbose=False):
+    """Raises IsaError listing every violated assumption; returns the report lines."""
+    objs = {name: os.path.join(CSRC, name + ".o") for name in ("ct_backward", "cook_torrance")}
+    for path in objs.values():
+        if not os.path.exists(path):
+            raise IsaError("%s is missing: run `make -C pypbr_amd/csrc` first" % path)
+    report, failures = [], []
+    tmp = tempfile.mkdtemp(prefix="pbr_isa_")
+    try:
+        co = _code_object(objs["ct_backward"], tmp)
+        fns, meta = _functions(co), _metadata(co)
+        stream = sorted(s for s in fns if "cook_torrance_backward_stream_kernel" in s)
+        if len(stream) != 12:
+            failures.append("expected 12 instantiations of cook_torrance_backward_stream_kernel, found %d" % len(stream))
+        for s in stream:
+            line, bad = check_stream_kernel(s, fns[s], meta.get(s, {}))
+            report.append(line)
+            failures += bad
+        co = _code_object(objs["cook_torrance"], tmp)
+        fns, meta = _functions(co), _metadata(co)
+        # TI = __half ("6__half"), TO = float ("f"), VEC = 8, one light (the launcher never picks 8-pixel lanes for several)
+        xp = sorted(s for s in fns if re.search(r"cook_torrance_kernelILi\dELi\dE6__halffLi8ELb0E", s))
+        if len(xp) != 12:
+            failures.append("expected 12 instantiations of cook_torrance_kernel<.., __half, float, 8, false, ..>, found %d" % len(xp))
+        if any(re.search(r"cook_torrance_kernelILi\dELi\dE\S+Li8ELb1E", s) for s in fns):
+            failures.append("an 8-pixel multi-light instantiation exists again (it does not fit 128 VGPRs and is never launched)")
+        for s in xp:
+            line, bad = check_xpose_kernel(s, fns[s], meta.get(s, {}))
+            report.append(line)
+            failures += bad
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    if verbose:
+        print("\n".join(report))
+    if failures:
+        raise IsaError("ISA assumptions of the hand-scheduled kernels are violated:\n  " + "\n  ".join(failures))
+    return report
+
+
+if __name__ == "__main__":
+    try:
+        check(verbose=True)
+    except IsaError as e:
+        print(e, file=sys.stderr)
+        sys.exit(1)
+    print("ISA check ok")

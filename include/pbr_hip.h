@@ -157,6 +157,19 @@ int pbr_blend_normal_sign(const pbr_render_desc *desc, const pbr_blend_desc *ble
 int pbr_cook_torrance_blend(const pbr_render_desc *desc, const pbr_blend_desc *blend, void *workspace, void *stream);
 
 /*
+ * Gradient of pbr_cook_torrance_blend w.r.t. BOTH materials and the mask, in one pass (what autograd derives from
+ * examples/example_blend.py:14-32 inside a rendering loss: CookTorranceBRDF.forward, the re-assignment of the blended normal
+ * base.py:191-242, blend_with_mask blending/functional.py:64-145).  `desc` / `blend` / `workspace` exactly as for the forward
+ * call (PBR_BLEND_SIGN_COMPUTE recomputes the flags; row bands need PBR_BLEND_SIGN_GIVEN); `grad_out` [B][3][H][W] fp32
+ * contiguous.  Every non-NULL member of g_material1 / g_material2 and g_mask receives a contiguous fp32 gradient with one value
+ * per OUTPUT pixel and material ([B][3|1][H][W]; g_mask [B][1][H][W]); a map or mask that the batch shares (batch_stride 0) owns
+ * the sum over the batch, which is left to the caller (pbr_fold_gradient).  Untiled maps only (PBR_ERR_UNSUPPORTED otherwise).
+ */
+typedef struct pbr_map_grads { void *albedo, *normal, *roughness, *metallic, *specular; } pbr_map_grads;
+int pbr_cook_torrance_blend_backward(const pbr_render_desc *desc, const pbr_blend_desc *blend, void *workspace, const void *grad_out,
+                                     const pbr_map_grads *g_material1, const pbr_map_grads *g_material2, void *g_mask, void *stream);
+
+/*
  * Gradient of pbr_cook_torrance w.r.t. the maps (what torch.autograd computes through
  * cooktorrance.py:92-182 in the reference's rendering-loss use,
  * docs/source/tutorials/06_advanced.rst:73-107).  `desc` is the forward descriptor (its `out` is

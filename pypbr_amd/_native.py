@@ -32,7 +32,7 @@ EXPORTS = (
     "pbr_blend_normal_sign", "pbr_blend_maps_backward", "pbr_param_grad_workspace_bytes", "pbr_cook_torrance_backward_params",
     "pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
     "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
-    "pbr_blend_sigmoid_mask_backward",
+    "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward",
 )
 
 
@@ -61,6 +61,12 @@ class BlendDesc(ctypes.Structure):
     """pbr_blend_desc: material 2 of a fused blend + the weights of material 1."""
     _fields_ = [("albedo", PbrMap), ("normal", PbrMap), ("roughness", PbrMap), ("metallic", PbrMap), ("specular", PbrMap),
                 ("mask", PbrMap), ("sign_mode", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class MapGrads(ctypes.Structure):
+    """pbr_map_grads: where the gradients of one material's maps go (NULL = not wanted)."""
+    _fields_ = [("albedo", ctypes.c_void_p), ("normal", ctypes.c_void_p), ("roughness", ctypes.c_void_p), ("metallic", ctypes.c_void_p),
+                ("specular", ctypes.c_void_p)]
 
 
 BLEND_SIGN_COMPUTE, BLEND_SIGN_GIVEN = 0, 1
@@ -103,6 +109,9 @@ def lib():
     L.pbr_cook_torrance_autotune.restype = ctypes.c_int
     L.pbr_cook_torrance_blend.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(BlendDesc), vp, vp]
     L.pbr_cook_torrance_blend.restype = ctypes.c_int
+    L.pbr_cook_torrance_blend_backward.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(BlendDesc), vp, vp, ctypes.POINTER(MapGrads),
+                                                   ctypes.POINTER(MapGrads), vp, vp]
+    L.pbr_cook_torrance_blend_backward.restype = ctypes.c_int
     L.pbr_blend_normal_sign.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(BlendDesc), vp, vp]
     L.pbr_blend_normal_sign.restype = ctypes.c_int
     L.pbr_param_grad_workspace_bytes.argtypes = [ctypes.POINTER(RenderDesc)]

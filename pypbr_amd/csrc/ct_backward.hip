@@ -1,5 +1,6 @@
 // ct_backward.hip -- launchers of the backward kernels (C ABI: pbr_cook_torrance_backward, pbr_cook_torrance_backward_params);
 // device code in ct_backward.hpp.
+#define PBR_PARAM_GRAD_KERNELS
 #include "ct_backward.hpp"
 #include "ct_launch.hpp"
 

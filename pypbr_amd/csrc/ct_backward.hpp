@@ -211,9 +211,11 @@ __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const Li
 
 // Everything after the loads: forward re-evaluation, chain rule, stores.  `t` holds the lane's texels (as floats), `go` the
 // upstream gradient.  s_param / n_param: the PGRAD instantiations' LDS accumulators.
-template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD>
-__device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, const LanePos &p, Texels<VEC> &t, float (&go)[3][VEC],
-                                              float *s_param, int n_param) {
+//   `sink(ga, gn, gr, gm, gs)`: what happens to the lane's gradients w.r.t. the texels the shading read -- by default they are
+//   stored (backward_body below); the fused blend's backward (ct_blend_backward.hpp) carries them on through the blend.
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD, class Sink>
+__device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b, const LanePos &p, Texels<VEC> &t, float (&go)[3][VEC],
+                                                 float *s_param, int n_param, Sink &&sink) {
     constexpr bool kPacked = sizeof(TM) == 2 || MULTI;
     using R = typename RealOf<VEC, kPacked>::type;
     constexpr int NG = RealOf<VEC, kPacked>::N;
@@ -363,26 +365,35 @@ __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, co
         for (int i = threadIdx.x; i < n_param; i += blockDim.x) b.g_param_partials[(int64_t)blockIdx.x * n_param + i] = s_param[i];
         if (!p.valid) return;
     }
-    // gradient planes are dense: [B][C][H*W] with the result's channel stride
-    auto put = [&](void *plane, int channels, int c, const float *v) {
-        if (p.sb) Ld<TM, VEC>::template store<true>(plane_at<TM>(plane, ((int64_t)p.b0 * channels + c) * a.o_cs, (uint32_t)p.pix), 0, v);
-        else Ld<TM, VEC>::template store<true>(plane, ((int64_t)p.b * channels + c) * a.o_cs + p.pix, v);
-    };
-    if (b.g_albedo) {
+    sink(ga, gn, gr, gm, gs);
+}
+
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD>
+__device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, const LanePos &p, Texels<VEC> &t, float (&go)[3][VEC],
+                                              float *s_param, int n_param) {
+    backward_body_to<LIGHT, WF, VEC, MULTI, TM, PGRAD>(a, b, p, t, go, s_param, n_param,
+        [&](float (&ga)[3][VEC], float (&gn)[3][VEC], float (&gr)[VEC], float (&gm)[VEC], float (&gs)[3][VEC]) {
+            // gradient planes are dense: [B][C][H*W] with the result's channel stride
+            auto put = [&](void *plane, int channels, int c, const float *v) {
+                if (p.sb) Ld<TM, VEC>::template store<true>(plane_at<TM>(plane, ((int64_t)p.b0 * channels + c) * a.o_cs, (uint32_t)p.pix), 0, v);
+                else Ld<TM, VEC>::template store<true>(plane, ((int64_t)p.b * channels + c) * a.o_cs + p.pix, v);
+            };
+            if (b.g_albedo) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) put(b.g_albedo, 3, c, ga[c]);
-    }
-    if (b.g_normal && a.has_normal) {
+                for (int c = 0; c < 3; ++c) put(b.g_albedo, 3, c, ga[c]);
+            }
+            if (b.g_normal && a.has_normal) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) put(b.g_normal, 3, c, gn[c]);
-    }
-    if (b.g_rough) put(b.g_rough, 1, 0, gr);
-    if (WF != PBR_WORKFLOW_SPECULAR) {
-        if (b.g_metal) put(b.g_metal, 1, 0, gm);
-    } else if (b.g_spec) {
+                for (int c = 0; c < 3; ++c) put(b.g_normal, 3, c, gn[c]);
+            }
+            if (b.g_rough) put(b.g_rough, 1, 0, gr);
+            if (WF != PBR_WORKFLOW_SPECULAR) {
+                if (b.g_metal) put(b.g_metal, 1, 0, gm);
+            } else if (b.g_spec) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) put(b.g_spec, 3, c, gs[c]);
-    }
+                for (int c = 0; c < 3; ++c) put(b.g_spec, 3, c, gs[c]);
+            }
+        });
 }
 
 //   LIGHT: PBR_LIGHT_*    WF: PBR_WORKFLOW_*    VEC: 4 | 2 | 1    TM: storage type of the maps AND of their gradients
@@ -586,6 +597,7 @@ void cook_torrance_backward_stream_kernel(const KArgs a, const BArgs b, const in
     }
 }
 
+#ifdef PBR_PARAM_GRAD_KERNELS      // the two reduction kernels are not templates: defined in ct_backward.hip only (the header is shared)
 // Adds up the per-workgroup rows of the PGRAD kernels (fp64 sums, fixed order: deterministic) and applies the part of
 // the chain rule that sits in front of the kernel: view_dir and a directional light enter through F.normalize
 // (cooktorrance.py:95, :126), whose Jacobian is (I - v v^T) / max(|x|, 1e-12).  One workgroup per 3-vector:
@@ -653,5 +665,7 @@ __global__ __launch_bounds__(256) void param_grad_finish_kernel(const ParamFinis
     }
     for (int j = 0; j < 3; ++j) a.out[3 * vec + j] = (float)g[j];
 }
+
+#endif  // PBR_PARAM_GRAD_KERNELS
 
 }  // namespace pbr

@@ -1,5 +1,6 @@
 // ct_blend.hip -- launcher of the fused blend + evaluate kernels (C ABI: pbr_cook_torrance_blend); device code in ct_blend.hpp.
 #include "ct_blend.hpp"
+#include "ct_blend_backward.hpp"
 #include "ct_launch.hpp"
 
 namespace pbr {
@@ -31,9 +32,68 @@ static int launch_normal_sign(const pbr_render_desc *d, const pbr_blend_desc *bl
     return err == hipSuccess ? PBR_OK : 1000 + (int)err;
 }
 
+static void fill_blend(const pbr_blend_desc *bl, const void *workspace, KBlend &b) {
+    std::memset(&b, 0, sizeof(b));
+    b.albedo = bl->albedo.data; b.normal = bl->normal.data; b.rough = bl->roughness.data;
+    b.metal = bl->metallic.data; b.spec = bl->specular.data;
+    b.a_bs = bl->albedo.batch_stride; b.a_cs = bl->albedo.channel_stride;
+    b.n_bs = bl->normal.batch_stride; b.n_cs = bl->normal.channel_stride;
+    b.r_bs = bl->roughness.batch_stride; b.m_bs = bl->metallic.batch_stride;
+    b.s_bs = bl->specular.batch_stride; b.s_cs = bl->specular.channel_stride;
+    b.mask = static_cast<const float *>(bl->mask.data); b.k_bs = bl->mask.batch_stride;
+    b.normal_signed = static_cast<const int *>(workspace);
+}
+
 }  // namespace pbr
 
 extern "C" {
+
+int pbr_cook_torrance_blend_backward(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, const void *grad_out,
+                                     const pbr_map_grads *g_material1, const pbr_map_grads *g_material2, void *g_mask, void *stream) {
+    using namespace pbr;
+    const int rc = check_blend(d, bl, workspace);
+    if (rc != PBR_OK) return rc;
+    if (!grad_out || !g_material1 || !g_material2) return PBR_ERR_NULL_MAP;
+    if (is_tiled(d)) return PBR_ERR_UNSUPPORTED;              // a repeated texel owns a sum over its repeats: evaluate unfused
+    if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE && d->height != d->height_total) return PBR_ERR_UNSUPPORTED;
+    if (nan_light_size(d)) return PBR_ERR_UNSUPPORTED;
+    const int vec = d->width >= 2 && g_max_vec >= 2 ? 2 : 1;  // two pixels per lane: both materials' raw texels stay live through the chain rule
+    KArgs k;
+    fill_args(d, vec, k, 6);
+    if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+    k.o_cs = (int64_t)d->height * d->width; k.o_bs = 3 * k.o_cs;     // grad_out and every gradient plane are contiguous
+    k.sbase = 0;
+    KBlend b;
+    fill_blend(bl, workspace, b);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE) {            // the same map-global decision the forward launch took (base.py:212)
+        if (hipMemsetAsync(workspace, 0, sizeof(int) * (size_t)d->batch, st) != hipSuccess) return 1000 + (int)hipGetLastError();
+        const int src = launch_normal_sign(d, bl, workspace, st);
+        if (src != PBR_OK) return src;
+    }
+    const bool spec = d->workflow == PBR_WORKFLOW_SPECULAR;
+    const BArgs g1 = {grad_out, g_material1->albedo, g_material1->normal, g_material1->roughness, spec ? nullptr : g_material1->metallic,
+                      spec ? g_material1->specular : nullptr, nullptr};
+    const BBlend g2 = {g_material2->albedo, g_material2->normal, g_material2->roughness, spec ? nullptr : g_material2->metallic,
+                       spec ? g_material2->specular : nullptr, static_cast<float *>(g_mask)};
+    const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
+    void (*fn)(const KArgs, const KBlend, const BArgs, const BBlend) = nullptr;
+#define PBR_BLEND_BWD(L, W)                                                                                                              \
+    fn = vec == 2 ? (multi ? cook_torrance_blend_backward_kernel<L, W, 2, true> : cook_torrance_blend_backward_kernel<L, W, 2, false>)   \
+                  : (multi ? cook_torrance_blend_backward_kernel<L, W, 1, true> : cook_torrance_blend_backward_kernel<L, W, 1, false>)
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: PBR_BLEND_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC); break;
+        case 1: PBR_BLEND_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR); break;
+        case 2: PBR_BLEND_BWD(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED); break;
+        case 3: PBR_BLEND_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC); break;
+        case 4: PBR_BLEND_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR); break;
+        default: PBR_BLEND_BWD(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED); break;
+    }
+#undef PBR_BLEND_BWD
+    hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(64, 1, 1), 0, st, k, b, g1, g2);
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
 
 int pbr_blend_normal_sign(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, void *stream) {
     using namespace pbr;
@@ -56,15 +116,7 @@ int pbr_cook_torrance_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, 
     fill_args(d, vec, k);
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
     KBlend b;
-    std::memset(&b, 0, sizeof(b));
-    b.albedo = bl->albedo.data; b.normal = bl->normal.data; b.rough = bl->roughness.data;
-    b.metal = bl->metallic.data; b.spec = bl->specular.data;
-    b.a_bs = bl->albedo.batch_stride; b.a_cs = bl->albedo.channel_stride;
-    b.n_bs = bl->normal.batch_stride; b.n_cs = bl->normal.channel_stride;
-    b.r_bs = bl->roughness.batch_stride; b.m_bs = bl->metallic.batch_stride;
-    b.s_bs = bl->specular.batch_stride; b.s_cs = bl->specular.channel_stride;
-    b.mask = static_cast<const float *>(bl->mask.data); b.k_bs = bl->mask.batch_stride;
-    b.normal_signed = static_cast<const int *>(workspace);
+    fill_blend(bl, workspace, b);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE) {
         // pass 1: one flag per material -- does the blended normal map have a negative component?  (base.py:212)

@@ -184,24 +184,27 @@ def cook_torrance_sharded(maps: Dict[str, Optional[torch.Tensor]], params: Optio
         if plan:
             return shard, plan_cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"), **kw)
         return shard, cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"), **kw)
-    # The exchange path launches a plan directly: it is forward-only.  A tensor that requires grad must not come back
-    # without a grad_fn (training would silently see no gradient), so refuse instead of dropping it.
-    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad
-                                       for t in list(maps.values()) + list(blend) + [params.get(k) if params else None for k in ("view_dir", "light", "light_intensity")]):
-        raise NotImplementedError("gradients through a fused blend evaluated over row bands are not implemented: blend the maps "
-                                  "first (pypbr_amd.blending) and shard the blended material, or detach the inputs")
     signed = torch.zeros(B, dtype=torch.int32, device=albedo.device)       # one flag per material of the FULL batch
     rp = None
     if not empty:
-        rp = plan_cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"),
-                                blend_flags=signed[shard.batch_start:shard.batch_stop], **kw)
+        with torch.no_grad():
+            rp = plan_cook_torrance(*[None if t is None else t.detach() for t in (m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"))],
+                                    blend_flags=signed[shard.batch_start:shard.batch_stop],
+                                    **dict(kw, blend=tuple(None if t is None else t.detach() for t in kw["blend"])))
         signed[shard.batch_start:shard.batch_stop] = rp.blend_normal_sign()
     where = _collective_device(albedo.device, group)
     combined = signed.to(where)
     dist.all_reduce(combined, op=dist.ReduceOp.MAX, group=group)
     if empty:
         return shard, None
-    rp.use_blend_flags(combined[shard.batch_start:shard.batch_stop])
+    mine = combined[shard.batch_start:shard.batch_stop].to(albedo.device)
+    wants_grad = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad
+                                                 for t in list(m.values()) + list(kw["blend"]) + [kw["view_dir"], kw["light"], kw["light_intensity"]])
+    if wants_grad and not plan:
+        # with the whole map's flags in hand the band is an ordinary differentiable evaluation: the fused blend's own backward
+        # kernel (functional._FusedBlendFn) gives the gradients of both materials' maps and of the mask for this rank's rows
+        return shard, cook_torrance(m["albedo"], m.get("normal"), m["roughness"], m.get("metallic"), m.get("specular"), blend_flags=mine, **kw)
+    rp.use_blend_flags(mine)
     if plan:
         return shard, rp
     with torch.cuda.device(rp.device):

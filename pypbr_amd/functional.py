@@ -385,6 +385,9 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
     if kwargs.get("blend") is not None and torch.is_grad_enabled() and any(
             isinstance(t, torch.Tensor) and t.requires_grad
             for t in (albedo, normal, roughness, metallic, specular) + tuple(kwargs["blend"]) + tuple(kwargs.get(k) for k in _PARAM_KEYS)):
+        if _fused_blend_backward_can_take(albedo, kwargs):
+            kw = {k: v for k, v in kwargs.items() if k != "blend"}
+            return _FusedBlendFn.apply(kw, albedo, normal, roughness, metallic, specular, *kwargs["blend"])
         return _blend_then_render_with_grad(albedo, normal, roughness, metallic, specular, **kwargs)
     if USE_TORCH_OPS and _torch_op_can_take(albedo, kwargs):
         return _cook_torrance_via_torch_op(albedo, normal, roughness, metallic, specular, **kwargs)
@@ -398,9 +401,79 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
         return plan.launch()
 
 
+def _fused_blend_backward_can_take(albedo, kw) -> bool:
+    """pbr_cook_torrance_blend_backward covers gradients of the maps of both materials and of the mask: fp32, untiled, a fresh
+    result.  Gradients of view / light parameters through a blend take the unfused differentiable pieces."""
+    if kw.get("out") is not None or kw.get("tile", 1) not in (1, (1, 1)) or kw.get("out_dtype") not in (None, torch.float32):
+        return False
+    if any(isinstance(kw.get(k), torch.Tensor) and kw[k].requires_grad for k in _PARAM_KEYS):
+        return False
+    tensors = [albedo] + [t for t in kw["blend"] if t is not None]
+    return all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+
+
+class _FusedBlendFn(torch.autograd.Function):
+    """blend_with_mask -> re-assignment of the blended normal -> CookTorranceBRDF.forward as ONE kernel forward
+    (pbr_cook_torrance_blend) and ONE kernel backward (pbr_cook_torrance_blend_backward): the gradients of both materials' maps
+    and of the mask, what the reference's autograd derives through examples/example_blend.py:14-32 inside a rendering loss."""
+
+    @staticmethod
+    def forward(ctx, kwargs, *tensors):
+        maps, blend = tensors[:5], tensors[5:11]
+        det = lambda t: None if t is None else t.detach()
+        plan = plan_cook_torrance(*[det(t) for t in maps], blend=tuple(det(t) for t in blend), **kwargs)
+        ctx.plan = plan
+        ctx.shapes = [None if t is None else tuple(t.shape) for t in tensors]
+        ctx.save_for_backward(*[t for t in tensors if t is not None])   # for autograd's in-place-modification check
+        with torch.cuda.device(plan.device):
+            result = plan.launch()
+        plan.out = None
+        return result
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.saved_tensors
+        plan = ctx.plan
+        d = plan.desc
+        B, H, W = d.batch, d.height, d.width
+        g = grad_out.reshape(B, 3, H, W).to(torch.float32).contiguous()
+        dev = g.device
+        channels = (3, 3, 1, 1, 3)
+        need = ctx.needs_input_grad[1:]                       # [0] is the kwargs dict
+
+        def bufs(offset):
+            out = []
+            for i in range(5):
+                want = need[offset + i] and ctx.shapes[offset + i] is not None
+                out.append(torch.empty((B, channels[i], H, W), dtype=torch.float32, device=dev) if want else None)
+            return out
+        b1, b2 = bufs(0), bufs(5)
+        gmask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if need[10] else None
+        G1, G2 = N.MapGrads(*[None if b is None else b.data_ptr() for b in b1]), N.MapGrads(*[None if b is None else b.data_ptr() for b in b2])
+        bd = N.BlendDesc.from_buffer_copy(plan._blend)        # the flags the forward launch left in the workspace are the whole map's
+        bd.sign_mode = N.BLEND_SIGN_GIVEN
+        with torch.cuda.device(dev):
+            N.check(N.lib().pbr_cook_torrance_blend_backward(ctypes.byref(d), ctypes.byref(bd), plan._workspace.data_ptr(), g.data_ptr(),
+                                                             ctypes.byref(G1), ctypes.byref(G2), None if gmask is None else gmask.data_ptr(),
+                                                             _stream_ptr(dev)))
+
+        def shaped(buf, shape):
+            if buf is None:
+                return None
+            lead = shape[0] if len(shape) == buf.dim() else 1
+            if B > 1 and lead == 1:                           # shared by the whole batch: owns the sum over the materials
+                folded = torch.empty((1,) + tuple(buf.shape[1:]), dtype=torch.float32, device=dev)
+                with torch.cuda.device(dev):
+                    N.check(N.lib().pbr_fold_gradient(buf.data_ptr(), folded.data_ptr(), B, buf.shape[1], H, W, 1, 1, 1, _stream_ptr(dev)))
+                buf = folded
+            return buf.reshape(shape)
+        grads = [shaped(b, s) for b, s in zip(b1 + b2, ctx.shapes[:10])]
+        return (None, *grads, shaped(gmask, ctx.shapes[10]))
+
+
 def _blend_then_render_with_grad(albedo, normal, roughness, metallic, specular, *, blend, **kwargs):
-    """The fused blend + render kernel is forward-only.  With a gradient attached the same computation runs unfused
-    through the differentiable pieces -- blend_maps (pbr_blend_maps + pbr_blend_maps_backward) for every map, the
+    """Gradients that the fused backward kernel does not cover (view / light parameters through a blend, tiled maps, fp16):
+    the same computation runs unfused through the differentiable pieces -- blend_maps (pbr_blend_maps + pbr_blend_maps_backward) for every map, the
     re-decode of the blended normal (decode_normal and its backward: base.py:191-242 runs again on assignment), then the
     evaluation with its backward kernel -- so a rendering loss on a blended material (example_blend.py:14-32 inside a
     training loop) reaches both materials, the mask and the light / view parameters."""
@@ -408,7 +481,7 @@ def _blend_then_render_with_grad(albedo, normal, roughness, metallic, specular, 
     if kwargs.get("out") is not None or kwargs.get("tile", 1) not in (1, (1, 1)):
         raise NotImplementedError("gradients through the fused blend need out=None and untiled maps")
     kwargs.pop("blend_flags", None)        # whole maps decide "already signed?" from their own values, as the reference does
-    if kwargs.get("height_total") not in (None, albedo.shape[-2]):
+    if kwargs.get("height_total") not in (None, albedo.shape[-2]):   # (the fused backward kernel takes row bands with given flags)
         # a ROW BAND cannot take that decision from its own rows (base.py:212 looks at the whole map), and the unfused
         # re-decode below has no way to be told the whole map's verdict
         raise NotImplementedError("gradients through a fused blend need the whole map, not a row band: blend the maps first "

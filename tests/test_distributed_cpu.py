@@ -125,14 +125,12 @@ def _worker(rank, world, port, batch, tmpdir):
             shape, kw = seen_kw[-1]
             assert kw["blend"][5].shape == (bshard.batch_stop - bshard.batch_start, 1, bshard.row_stop - bshard.row_start, W) == shape[:1] + (1,) + shape[2:]
         if batch < world:
-            # the exchange path of a fused blend over row bands launches a plan directly (forward-only); inputs that
-            # require grad must be refused, not rendered into a result without a grad_fn
+            # a fused blend over row bands with inputs that require grad must not come back without a grad_fn.  Since
+            # round 3 the band goes through the differentiable call (tests/test_gpu_distributed.py checks the gradients); on this
+            # CPU-only box both forms reach the kernel library's device check -- after the flags' exchange was prepared
             leaf = {k: (v.clone().requires_grad_(True) if k == "albedo" else v) for k, v in maps.items()}
-            with pytest.raises(NotImplementedError, match="row bands"):
+            with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
                 cook_torrance_sharded(leaf, params if rank == 0 else None, light_type="point", blend=second)
-            with torch.no_grad():                                  # without grad mode there is nothing to lose: goes on to the kernel
-                with pytest.raises(RuntimeError, match="ROCm device|no CPU"):
-                    cook_torrance_sharded(leaf, params if rank == 0 else None, light_type="point", blend=second)
         torch.save({"shard": tuple(shard), "out": out, "tshard": tuple(tshard)}, os.path.join(tmpdir, f"rank{rank}.pt"))
         dist.barrier()
         if rank == 0:

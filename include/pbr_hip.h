@@ -250,6 +250,10 @@ int pbr_decode_normal_backward(const void *src, const void *grad_out, void *grad
  * dst [fold_batch ? 1 : batch][channels][h][w]. */
 int pbr_fold_gradient(const void *src, void *dst, int32_t batch, int32_t channels, int32_t h, int32_t w, int32_t ny,
                       int32_t nx, int fold_batch, void *stream);
+/* The same for gradients stored as the maps are (pbr_cook_torrance_backward returns fp16 gradients for fp16 maps): `dtype`
+ * PBR_F32 | PBR_F16 for src and dst alike, the sums are formed in fp32 and rounded once. */
+int pbr_fold_gradient_typed(const void *src, void *dst, int32_t batch, int32_t channels, int32_t h, int32_t w, int32_t ny,
+                            int32_t nx, int fold_batch, int dtype, void *stream);
 
 /*
  * MaterialBase._process_normal_map, base.py:191-242.  channels = 2 or 3, planar

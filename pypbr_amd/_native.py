@@ -32,7 +32,7 @@ EXPORTS = (
     "pbr_blend_normal_sign", "pbr_blend_maps_backward", "pbr_param_grad_workspace_bytes", "pbr_cook_torrance_backward_params",
     "pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
     "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
-    "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward",
+    "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward", "pbr_fold_gradient_typed",
 )
 
 
@@ -120,6 +120,8 @@ def lib():
     L.pbr_cook_torrance_backward_params.restype = ctypes.c_int
     L.pbr_fold_gradient.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_int, vp]
     L.pbr_fold_gradient.restype = ctypes.c_int
+    L.pbr_fold_gradient_typed.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp]
+    L.pbr_fold_gradient_typed.restype = ctypes.c_int
     L.pbr_cook_torrance_backward.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp]
     L.pbr_cook_torrance_backward.restype = ctypes.c_int
     L.pbr_srgb_to_linear.argtypes = [vp, vp, sz, ctypes.c_int, vp]

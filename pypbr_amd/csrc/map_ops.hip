@@ -265,9 +265,9 @@ __global__ __launch_bounds__(256) void keep_normal_kernel(const void *src, void 
 // sum of those.  dst[bo][c][y][x] = sum_{b in group} sum_{ty,tx} src[b][c][ty*h + y][tx*w + x], fixed order.
 // Four consecutive columns per lane (w % 4 == 0, 16-byte aligned planes): the terms of a sum are independent 16-byte
 // loads, four of them in flight at a time; added in the same fixed order as the one-column form below.
-__global__ __launch_bounds__(256) void fold_gradient_quad_kernel(const float *__restrict__ src, float *__restrict__ dst,
+template <typename T>
+__global__ __launch_bounds__(256) void fold_gradient_quad_kernel(const void *__restrict__ src, void *__restrict__ dst,
                                                                  int batch, int channels, int h, int w, int ny, int nx, int fold_batch) {
-    typedef float v4 __attribute__((ext_vector_type(4)));
     const int wq = w >> 2;
     const int64_t plane_q = (int64_t)h * wq, total = (int64_t)(fold_batch ? 1 : batch) * channels * plane_q;
     const int64_t W = (int64_t)nx * w, src_plane = (int64_t)ny * h * W;
@@ -277,26 +277,34 @@ __global__ __launch_bounds__(256) void fold_gradient_quad_kernel(const float *__
         const int64_t pq = i % plane_q, t = i / plane_q;
         const int c = (int)(t % channels), bo = (int)(t / channels);
         const int y = (int)(pq / wq), x = (int)(pq - (int64_t)y * wq) * 4;
-        const float *p0 = src + ((int64_t)(fold_batch ? 0 : bo) * channels + c) * src_plane + (int64_t)y * W + x;
-        auto term = [&](int k) {                         // k = (b, ty, tx) in the order of the sum
+        const int64_t p0 = ((int64_t)(fold_batch ? 0 : bo) * channels + c) * src_plane + (int64_t)y * W + x;
+        auto term = [&](int k) {                         // k = (b, ty, tx) in the order of the sum; in units of 4 elements
             const int b = k / reps, r = k - b * reps, ty = r / nx, tx = r - ty * nx;
-            return p0 + (int64_t)b * channels * src_plane + (int64_t)ty * h * W + (int64_t)tx * w;
+            return (size_t)((p0 + (int64_t)b * channels * src_plane + (int64_t)ty * h * W + (int64_t)tx * w) >> 2);
         };
-        v4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         int k = 0;
         for (; k + 4 <= terms; k += 4) {
-            v4 v[4];
+            float v[4][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const v4 *>(term(k + u)));
+            for (int u = 0; u < 4; ++u) Quad<T>::ld(src, term(k + u), v[u]);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc += v[u];
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += v[u][j];
         }
-        for (; k < terms; ++k) acc += __builtin_nontemporal_load(reinterpret_cast<const v4 *>(term(k)));
-        __builtin_nontemporal_store(acc, reinterpret_cast<v4 *>(dst) + i);
+        for (; k < terms; ++k) {
+            float v[4];
+            Quad<T>::ld(src, term(k), v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += v[j];
+        }
+        Quad<T>::st(dst, (size_t)i, acc);
     }
 }
 
-__global__ __launch_bounds__(256) void fold_gradient_kernel(const float *__restrict__ src, float *__restrict__ dst,
+template <typename T>
+__global__ __launch_bounds__(256) void fold_gradient_kernel(const void *__restrict__ src, void *__restrict__ dst,
                                                             int batch, int channels, int h, int w, int ny, int nx, int fold_batch) {
     const int64_t plane = (int64_t)h * w, total = (int64_t)(fold_batch ? 1 : batch) * channels * plane;
     const int64_t W = (int64_t)nx * w, src_plane = (int64_t)ny * h * W;
@@ -308,11 +316,11 @@ __global__ __launch_bounds__(256) void fold_gradient_kernel(const float *__restr
         float acc = 0.0f;
         const int b0 = fold_batch ? 0 : bo, b1 = fold_batch ? batch : bo + 1;
         for (int b = b0; b < b1; ++b) {
-            const float *p = src + ((int64_t)b * channels + c) * src_plane;
+            const int64_t p = ((int64_t)b * channels + c) * src_plane;
             for (int ty = 0; ty < ny; ++ty)
-                for (int tx = 0; tx < nx; ++tx) acc += p[((int64_t)ty * h + y) * W + (int64_t)tx * w + x];
+                for (int tx = 0; tx < nx; ++tx) acc += Elem<T>::ld(src, (size_t)(p + ((int64_t)ty * h + y) * W + (int64_t)tx * w + x));
         }
-        dst[i] = acc;
+        Elem<T>::st(dst, (size_t)i, acc);
     }
 }
 
@@ -514,6 +522,20 @@ static inline int hip_status() {
 
 static inline bool is_aligned(const void *p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0; }
 
+template <typename T>
+static int fold_launch(const void *src, void *dst, int32_t batch, int32_t channels, int32_t h, int32_t w, int32_t ny, int32_t nx,
+                       int fold_batch, void *stream) {
+    const size_t items = (size_t)(fold_batch ? 1 : batch) * channels * h * w, al = 4 * sizeof(T);
+    if (w % 4 == 0 && is_aligned(src, al) && is_aligned(dst, al)) {
+        hipLaunchKernelGGL((fold_gradient_quad_kernel<T>), dim3(stream_grid(items / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           src, dst, (int)batch, (int)channels, (int)h, (int)w, (int)ny, (int)nx, fold_batch);
+        return hip_status();
+    }
+    hipLaunchKernelGGL((fold_gradient_kernel<T>), dim3(stream_grid(items)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       src, dst, (int)batch, (int)channels, (int)h, (int)w, (int)ny, (int)nx, fold_batch);
+    return hip_status();
+}
+
 }  // namespace pbr
 
 extern "C" {
@@ -650,22 +672,18 @@ int pbr_specular_to_metallic_backward(const void *diffuse, const void *specular,
     return hip_status();
 }
 
-int pbr_fold_gradient(const void *src, void *dst, int32_t batch, int32_t channels, int32_t h, int32_t w, int32_t ny,
-                      int32_t nx, int fold_batch, void *stream) {
-    using namespace pbr;
+int pbr_fold_gradient_typed(const void *src, void *dst, int32_t batch, int32_t channels, int32_t h, int32_t w, int32_t ny,
+                            int32_t nx, int fold_batch, int dtype, void *stream) {
     if (!src || !dst) return PBR_ERR_NULL_MAP;
     if (batch < 1 || channels < 1 || h < 1 || w < 1 || ny < 1 || nx < 1) return PBR_ERR_SHAPE;
-    const size_t items = (size_t)(fold_batch ? 1 : batch) * channels * h * w;
-    if (w % 4 == 0 && is_aligned(src, 16) && is_aligned(dst, 16)) {
-        hipLaunchKernelGGL(fold_gradient_quad_kernel, dim3(stream_grid(items / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           static_cast<const float *>(src), static_cast<float *>(dst), (int)batch, (int)channels, (int)h, (int)w,
-                           (int)ny, (int)nx, fold_batch);
-        return hip_status();
-    }
-    hipLaunchKernelGGL(fold_gradient_kernel, dim3(stream_grid(items)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const float *>(src), static_cast<float *>(dst), (int)batch, (int)channels, (int)h, (int)w,
-                       (int)ny, (int)nx, fold_batch);
-    return hip_status();
+    if (dtype == PBR_F32) return pbr::fold_launch<float>(src, dst, batch, channels, h, w, ny, nx, fold_batch, stream);
+    if (dtype == PBR_F16) return pbr::fold_launch<__half>(src, dst, batch, channels, h, w, ny, nx, fold_batch, stream);
+    return PBR_ERR_DTYPE;
+}
+
+int pbr_fold_gradient(const void *src, void *dst, int32_t batch, int32_t channels, int32_t h, int32_t w, int32_t ny,
+                      int32_t nx, int fold_batch, void *stream) {
+    return pbr_fold_gradient_typed(src, dst, batch, channels, h, w, ny, nx, fold_batch, PBR_F32, stream);
 }
 
 int pbr_decode_normal(const void *src, void *dst, int32_t channels, int64_t pixels, int dtype,

@@ -193,16 +193,17 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> cook_torrance_backwar
     return {ga, gn, gr, gm, gs, gp};
 }
 
-// src [B,C,ny*h,nx*w] fp32 -> [fold_batch ? 1 : B, C, h, w]: the sums autograd performs for a repeat() / a broadcast.
+// src [B,C,ny*h,nx*w] fp32 | fp16 -> [fold_batch ? 1 : B, C, h, w] of the same type: the sums autograd performs for a repeat() / a broadcast
+// (formed in fp32, rounded once for fp16 gradients).
 Tensor fold_gradient(const Tensor &src, int64_t h, int64_t w, bool fold_batch) {
-    TORCH_CHECK_VALUE(src.dim() == 4 && src.is_cuda() && src.scalar_type() == at::kFloat, "fold_gradient needs a float32 [B,C,H,W] device tensor");
+    TORCH_CHECK_VALUE(src.dim() == 4 && src.is_cuda(), "fold_gradient needs a [B,C,H,W] device tensor");
     TORCH_CHECK_VALUE(h >= 1 && w >= 1 && src.size(2) % h == 0 && src.size(3) % w == 0, "whole repeats only");
     const Tensor s = src.contiguous();
     const c10::DeviceGuard guard(s.device());
     Tensor dst = at::empty({fold_batch ? 1 : s.size(0), s.size(1), h, w}, s.options());
-    check_status(pbr_fold_gradient(s.data_ptr(), dst.data_ptr(), (int32_t)s.size(0), (int32_t)s.size(1), (int32_t)h, (int32_t)w,
-                                   (int32_t)(s.size(2) / h), (int32_t)(s.size(3) / w), fold_batch ? 1 : 0, current_stream(s)),
-                 "pbr_hip::fold_gradient");
+    check_status(pbr_fold_gradient_typed(s.data_ptr(), dst.data_ptr(), (int32_t)s.size(0), (int32_t)s.size(1), (int32_t)h, (int32_t)w,
+                                         (int32_t)(s.size(2) / h), (int32_t)(s.size(3) / w), fold_batch ? 1 : 0, dtype_code(s, "src"),
+                                         current_stream(s)), "pbr_hip::fold_gradient");
     return dst;
 }
 

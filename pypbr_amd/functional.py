@@ -645,14 +645,11 @@ class _CookTorranceFn(torch.autograd.Function):
                 raise NotImplementedError("gradients of a tiled evaluation need the whole output, not a row band")
             shared = B > 1 and (len(shape) == 3 or shape[0] == 1)
             if tiled or shared:
-                if gdtype != torch.float32:
-                    raise NotImplementedError("gradients of fp16 maps that are tiled or shared by the batch are not implemented "
-                                              "(the fold kernel sums in float32 storage)")
                 h, w = (d.map_height, d.map_width) if tiled else (H, W)
-                folded = torch.empty((1 if shared else B, b.shape[1], h, w), dtype=torch.float32, device=b.device)
-                with torch.cuda.device(b.device):
-                    N.check(N.lib().pbr_fold_gradient(b.data_ptr(), folded.data_ptr(), B, b.shape[1], h, w, H // h, W // w,
-                                                      int(shared), _stream_ptr(b.device)))
+                folded = torch.empty((1 if shared else B, b.shape[1], h, w), dtype=gdtype, device=b.device)
+                with torch.cuda.device(b.device):      # fp16 gradients: summed in fp32, rounded once
+                    N.check(N.lib().pbr_fold_gradient_typed(b.data_ptr(), folded.data_ptr(), B, b.shape[1], h, w, H // h, W // w,
+                                                            int(shared), _DTYPES[gdtype], _stream_ptr(b.device)))
                 b = folded
             grads.append(b.reshape(shape))
         pgrads = [None, None, None]

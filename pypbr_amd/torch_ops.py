@@ -165,10 +165,7 @@ def _register():
                 continue
             shared = B > 1 and t.shape[0] == 1
             if tiled or shared:        # a map repeated by the fused tile(), or shared by the batch, owns the SUM over its uses
-                if g.dtype != torch.float32:
-                    raise NotImplementedError("gradients of fp16 maps that are tiled or shared by the batch are not implemented "
-                                              "(the fold kernel sums in float32 storage)")
-                g = torch.ops.pbr_hip.fold_gradient(g, H, W, shared)
+                g = torch.ops.pbr_hip.fold_gradient(g, H, W, shared)   # (fp16 gradients: summed in fp32, rounded once)
             grads.append(g)
         L = lights.numel() // 3
         pg = [None, None, None]

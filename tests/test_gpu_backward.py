@@ -438,3 +438,52 @@ def test_streamed_backward_is_bit_identical_to_the_one_tile_kernels():
                         assert torch.equal(x, y), (name, run, float((x.float() - y.float()).abs().max()))
     finally:
         lib.pbr_set_tuning(N.TUNE_BWD_RUN, -1)
+
+
+@pytest.mark.parametrize("binding", ["torch_op", "ctypes"])
+def test_gradients_of_fp16_maps_that_are_tiled_or_shared_by_the_batch(binding):
+    """Round 3: a fused tile() repeat, or one map shared by the whole batch, owns the SUM of the per-pixel gradients also when
+    the maps (hence their gradients) are fp16: pbr_fold_gradient_typed adds in fp32 and rounds once.  Ground truth: float64
+    oracle autograd on the exact fp32 up-casts of the fp16 maps (materialised repeat / broadcast)."""
+    import torch_oracle as O
+    from pypbr_amd import functional as F
+    F.USE_TORCH_OPS = binding == "torch_op"
+    try:
+        g = torch.Generator().manual_seed(23)
+        h, w, B = 12, 24, 3
+        mk = lambda c, lo=0.0, sc=1.0: (torch.rand(B, c, h, w, generator=g) * sc + lo).half()
+        a, r, m = mk(3), mk(1, 0.35, 0.6), mk(1)
+        n = torch.cat([torch.rand(B, 2, h, w, generator=g) - 0.5, torch.ones(B, 1, h, w)], 1).half()
+        rshared = r[:1].clone()                                          # ONE roughness map for the whole batch
+        view, light, inten = torch.tensor([0.0, 0.1, 1.0]), torch.tensor([0.2, 0.1, 0.9]), torch.tensor([1.0, 0.9, 0.8])
+        kw = dict(view_dir=view, light=light, light_intensity=inten, light_type="point", light_size=2.0)
+        okw = dict(view=view.double(), light=light.double(), intensity=inten.double(), light_type="point", light_size=2.0)
+        # (1) tiled 2 x 2, batch of 3, roughness shared: both folds at once
+        wt = torch.rand(B, 3, 2 * h, 2 * w, generator=g) - 0.4
+        leaves64 = [t.float().double().requires_grad_(True) for t in (a, n, rshared, m)]
+        ref = torch.stack([O.cook_torrance(leaves64[0][b].repeat(1, 2, 2), leaves64[1][b].repeat(1, 2, 2), leaves64[2][0].repeat(1, 2, 2),
+                                           leaves64[3][b].repeat(1, 2, 2), None, **okw) for b in range(B)])
+        (ref * wt.double()).sum().backward()
+        leaves = [t.clone().cuda().requires_grad_(True) for t in (a, n, rshared, m)]
+        out = F.cook_torrance(*leaves, tile=2, **kw)
+        assert out.shape == (B, 3, 2 * h, 2 * w) and (out.detach().cpu().double() - ref.detach()).abs().max().item() <= 1e-5
+        (out * wt.cuda()).sum().backward()
+        for name, x, y in zip(("albedo", "normal", "roughness (shared, tiled)", "metallic"), leaves, leaves64):
+            assert x.grad.dtype == torch.float16 and x.grad.shape == x.shape
+            err = (x.grad.float().cpu().double() - y.grad).abs()
+            # fp16 storage of each of the up to 12 per-pixel gradients of a sum (2^-11 relative each) and of the sum itself
+            assert bool((err <= 1.5e-3 * y.grad.abs() + 5e-3).all()), (name, float(err.max()), float(y.grad.abs().max()))
+        # (2) the fold itself, exactly: the same evaluation on materialised repeats and an expanded roughness map gives the
+        # per-pixel fp16 gradients; their float64 sum, rounded once to fp16, is what the typed fold kernel must return
+        rep = [t.clone().cuda() for t in (a, n, rshared.expand(B, -1, -1, -1).contiguous(), m)]
+        rep = [t.repeat(1, 1, 2, 2).requires_grad_(True) for t in rep]
+        (F.cook_torrance(*rep, **kw) * wt.cuda()).sum().backward()
+        for i, (name, x) in enumerate(zip(("albedo", "normal", "roughness", "metallic"), leaves)):
+            per_pixel = rep[i].grad.float().cpu().double()                                      # [B, C, 2h, 2w]
+            want = per_pixel.reshape(B, -1, 2, h, 2, w).sum(dim=(2, 4))
+            if i == 2:
+                want = want.sum(dim=0, keepdim=True)
+            diff = (x.grad.float().cpu().double() - want).abs()                  # fp32 accumulation, then ONE rounding to fp16
+            assert bool((diff <= 2.0 ** -11 * want.abs() + 2.0 ** -24).all()), (name, float(diff.max()))
+    finally:
+        F.USE_TORCH_OPS = True

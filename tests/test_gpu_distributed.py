@@ -93,6 +93,28 @@ def _rank(rank, world, port, backend, results):
             want = full[:, :, shard.row_start:shard.row_stop]
             assert torch.equal(out, want), ("blend row bands", flip, rank, float((out - want).abs().max()))
             log.append(("fused blend, row bands, negative row at the bottom: %s" % flip, tuple(shard)))
+            # with inputs that require grad the band keeps its graph -- the fused blend's own backward
+            # kernel, the whole map's flags exchanged -- and its gradients are the rows of the unsharded gradients
+            leaf1 = {k: v.clone().requires_grad_(True) for k, v in m1.items()}
+            leaf2 = tuple(None if t is None else t.clone().requires_grad_(True) for t in second)
+            shard_g, out_g = cook_torrance_sharded(leaf1, params if rank == 0 else None, light_type="point", blend=leaf2)
+            assert out_g.requires_grad and torch.equal(out_g.detach(), want)
+            wt = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(10)).to(dev)
+            (out_g * wt[:, :, shard.row_start:shard.row_stop]).sum().backward()
+            full1 = {k: v.clone().requires_grad_(True) for k, v in m1.items()}
+            full2 = tuple(None if t is None else t.clone().requires_grad_(True) for t in second)
+            full_g = F.cook_torrance(full1["albedo"], full1["normal"], full1["roughness"], full1["metallic"], view_dir=params["view_dir"],
+                                     light=params["light"], light_intensity=params["light_intensity"], light_type="point", light_size=1.0, blend=full2)
+            (full_g * wt).sum().backward()
+            rows = slice(shard.row_start, shard.row_stop)
+            outside = torch.ones(H, dtype=torch.bool); outside[rows] = False
+            for k in leaf1:
+                assert torch.equal(leaf1[k].grad[:, :, rows], full1[k].grad[:, :, rows]), ("sharded blend gradient", k, rank)
+                assert float(leaf1[k].grad[:, :, outside].abs().sum()) == 0.0            # rows this rank does not own: no contribution
+            for a, b in zip(leaf2, full2):
+                if a is not None:
+                    assert torch.equal(a.grad[:, :, rows], b.grad[:, :, rows])
+            log.append(("fused blend, row bands, gradients: %s" % flip, tuple(shard)))
             # and a band WITHOUT the exchanged flags is refused, not silently decoded from its own rows
             with pytest.raises(NotImplementedError):
                 F.cook_torrance(*[t[:, :, :32] for t in (m1["albedo"], m1["normal"], m1["roughness"], m1["metallic"])], view_dir=params["view_dir"],

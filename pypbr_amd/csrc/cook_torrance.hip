@@ -36,6 +36,7 @@ int g_lds_bytes = -1;
 int g_xcd_log2 = -1;
 int g_bwd_vec = 0;
 int g_bwd_run = -1;
+int g_bwd_wide = -1;
 int g_batch_inner = -1;
 int g_interleave = 0;
 int g_scalar_base = 1;
@@ -197,6 +198,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_RESIZE_ROWS: slot = &pbr::g_resize_rows; break;
         case PBR_TUNE_BWD_RUN: slot = &pbr::g_bwd_run; break;
         case PBR_TUNE_RESIZE_XCD: slot = &pbr::g_resize_xcd; break;
+        case PBR_TUNE_BWD_WIDE: slot = &pbr::g_bwd_wide; break;
         default: return -1;
     }
     const int old = *slot;

@@ -33,6 +33,7 @@ extern int g_max_vec;              // A/B and test knob: at most this many pixel
 extern int g_interleave;           // experiment knob: materials of a batch interleaved workgroup by workgroup
 extern int g_bwd_vec;              // pixels per lane of the backward kernels: 0 = rule (ct_backward.hip), 2 | 4 = forced (A/B)
 extern int g_bwd_run;              // tiles per wave of the streamed backward kernel (fp16 maps, one light): -1 = rule, 0 = off, N = forced
+extern int g_bwd_wide;             // streamed backward kernel with 16-byte memory instructions: -1 = rule, 0 = off, 1 = wherever legal
 extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
 constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
 

@@ -132,11 +132,14 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
         if (per_material > tiles) per_material = tiles;
         if (per_material < 1) per_material = 1;
         // 16-byte memory instructions (cook_torrance_backward_stream16_kernel): every plane 16-byte aligned with strides that keep
-        // it so, the FULL case only.  g_bwd_wide: -1 = rule, 0 = the 4-byte form, 1 = forced where legal (A/B)
+        // it so, the FULL case only.  g_bwd_wide: -1 = rule, 0 = the 4-byte form, 1 = forced where legal (A/B).  Measured on a
+        // 4096^2 material (tools/bwd_wide_ab.py, alternating in one process, round 3): 143.5 us against 142.9 us for the 4-byte
+        // form (metallic), 169.4 against 170.0 (specular) -- 4 + 2 vector-memory instructions per tile instead of 14 + 8 change
+        // nothing: the kernel is not limited by how its memory requests are shaped.  The rule is therefore "off".
         auto al16 = [](const pbr_map &m) {
             return !m.data || ((reinterpret_cast<uintptr_t>(m.data) & 15u) == 0 && m.batch_stride % 8 == 0 && m.channel_stride % 8 == 0);
         };
-        bool wide = full && g_bwd_wide != 0 && al16(d->albedo) && al16(d->normal) && al16(d->roughness) && al16(d->metallic) && al16(d->specular) &&
+        bool wide = full && g_bwd_wide > 0 && al16(d->albedo) && al16(d->normal) && al16(d->roughness) && al16(d->metallic) && al16(d->specular) &&
                     (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0 && k.o_cs % 8 == 0;
         for (int i = 0; i < 5 && wide; ++i) wide = (reinterpret_cast<uintptr_t>(gs[i]) & 15u) == 0;
         if (wide)

@@ -201,6 +201,26 @@ int pbr_cook_torrance_backward_params(const pbr_render_desc *desc, const void *g
                                       void *g_normal, void *g_roughness, void *g_metallic, void *g_specular,
                                       void *g_params, void *workspace, void *stream);
 
+/*
+ * The rendering-loss step of docs/source/tutorials/06_advanced.rst:73-107 for the PREDICTED material, as one pass:
+ *     loss = nn.MSELoss()(CookTorranceBRDF(...)(predicted_material, ...), target);  loss.backward()
+ * `desc` describes the predicted material and the evaluation exactly as for pbr_cook_torrance (its `out` is ignored; out_dtype
+ * PBR_F32; fp32 or fp16 maps; any workflow, light type and light count; untiled); `target` is the reference rendering
+ * [B][3][H][W] fp32 contiguous (e.g. pbr_cook_torrance of the ground-truth material, computed once).  Writes *loss (a DEVICE
+ * float) = mean((out - target)^2) over all B*3*H*W values and, into every non-NULL g_*, d loss / d map -- contiguous, shaped
+ * like the map, in the maps' storage type -- with torch's sub-gradient conventions, as pbr_cook_torrance_backward.  The
+ * colour is never written: 32 + 12 bytes read and 32 written per pixel, against 44 + 36 + 76 for evaluate / MSE / backward.
+ * `workspace`: pbr_mse_step_workspace_bytes(desc) bytes of device memory (one partial sum per workgroup, added in fp64 in a
+ * fixed order by a second small kernel on `stream`: deterministic).  An upstream gradient other than 1 (loss * k) is applied
+ * afterwards with pbr_scale_by_device_scalar, which returns at once when the scalar is 1.
+ */
+size_t pbr_mse_step_workspace_bytes(const pbr_render_desc *desc);
+int pbr_cook_torrance_mse_step(const pbr_render_desc *desc, const void *target, void *g_albedo, void *g_normal, void *g_roughness,
+                               void *g_metallic, void *g_specular, void *loss, void *workspace, void *stream);
+/* data[i] *= *scalar for n elements of `dtype`, in place; `scalar` is a DEVICE float (no host synchronisation: the upstream
+ * gradient of a loss lives on the device); a scalar of exactly 1 leaves the data untouched. */
+int pbr_scale_by_device_scalar(void *data, size_t n, int dtype, const void *scalar, void *stream);
+
 /* ---- stand-alone map conversions (same arithmetic as the fused kernel) ------------- */
 
 /* utils.srgb_to_linear, pypbr/utils/functions.py:31-47.  n elements, in-place allowed. */

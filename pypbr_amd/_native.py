@@ -33,6 +33,7 @@ EXPORTS = (
     "pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
     "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
     "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward", "pbr_fold_gradient_typed",
+    "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar",
 )
 
 
@@ -120,6 +121,12 @@ def lib():
     L.pbr_cook_torrance_backward_params.restype = ctypes.c_int
     L.pbr_fold_gradient.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_int, vp]
     L.pbr_fold_gradient.restype = ctypes.c_int
+    L.pbr_mse_step_workspace_bytes.argtypes = [ctypes.POINTER(RenderDesc)]
+    L.pbr_mse_step_workspace_bytes.restype = ctypes.c_size_t
+    L.pbr_cook_torrance_mse_step.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pbr_cook_torrance_mse_step.restype = ctypes.c_int
+    L.pbr_scale_by_device_scalar.argtypes = [vp, sz, ctypes.c_int, vp, vp]
+    L.pbr_scale_by_device_scalar.restype = ctypes.c_int
     L.pbr_fold_gradient_typed.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp]
     L.pbr_fold_gradient_typed.restype = ctypes.c_int
     L.pbr_cook_torrance_backward.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp]

@@ -213,9 +213,20 @@ __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const Li
 // upstream gradient.  s_param / n_param: the PGRAD instantiations' LDS accumulators.
 //   `sink(ga, gn, gr, gm, gs)`: what happens to the lane's gradients w.r.t. the texels the shading read -- by default they are
 //   stored (backward_body below); the fused blend's backward (ct_blend_backward.hpp) carries them on through the blend.
-template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD, class Sink>
+//   `loss`: NoLoss -- the upstream gradient is `go`, as loaded; MseLoss<VEC> -- the fused rendering-loss step (ct_loss.hip): the
+//   upstream gradient of a pixel is formed HERE from the colour the forward re-evaluation just produced, 2 (out - target) * scale,
+//   and the squared differences are summed into loss.sq.
+struct NoLoss { static constexpr bool on = false; };
+template <int VEC> struct MseLoss {
+    static constexpr bool on = true;
+    float tgt[3][VEC];      // the lane's pixels of the target image
+    float scale;            // 2 / N  (d mean((out - target)^2) / d out = scale * (out - target))
+    float sq;               // sum of squared differences over the lane's pixels
+};
+
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD, class Sink, class Loss>
 __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b, const LanePos &p, Texels<VEC> &t, float (&go)[3][VEC],
-                                                 float *s_param, int n_param, Sink &&sink) {
+                                                 float *s_param, int n_param, Sink &&sink, Loss &loss) {
     constexpr bool kPacked = sizeof(TM) == 2 || MULTI;
     using R = typename RealOf<VEC, kPacked>::type;
     constexpr int NG = RealOf<VEC, kPacked>::N;
@@ -264,8 +275,21 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
         pixel_terms(nraw, V, rough, base, f0, kd_scale, pt);
         const R xs = LIGHT == PBR_LIGHT_POINT ? xgrid[g] : splat<R>(0.0f);
         R gout_c[3];
+        if constexpr (!Loss::on) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], g);
+            for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], g);
+        }
+        auto loss_gradient = [&](const R (&lin)[3]) {           // lin: the clamped linear colour of the pixel (:177), as the forward kernel holds it
+            if constexpr (Loss::on) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const R out = a.out_srgb ? linear_to_srgb_unit(lin[c]) : lin[c];               // :179-180
+                    const R d = out - gather<R>(loss.tgt[c], g);
+                    loss.sq += hsum(d * d);
+                    gout_c[c] = d * loss.scale;
+                }
+            }
+        };
 
         // ---- adjoint of the linear colour before per-light clamps
         R g_col[3];
@@ -278,6 +302,10 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
                 eval_light(pt, light_geom<LIGHT, R>(lu, V, xs, ys), lu.inten, e);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) sum[c] = sum[c] + e.uc[c];
+            }
+            if constexpr (Loss::on) {
+                const R lin[3] = {clamp01(sum[0]), clamp01(sum[1]), clamp01(sum[2])};
+                loss_gradient(lin);
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -296,6 +324,7 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
             LightEvalT<R> e;
             eval_light(pt, lg, lu.inten, e);
             if (!MULTI) {
+                if constexpr (Loss::on) loss_gradient(e.uc);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
@@ -368,31 +397,44 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
     sink(ga, gn, gr, gm, gs);
 }
 
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD, class Sink>
+__device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b, const LanePos &p, Texels<VEC> &t, float (&go)[3][VEC],
+                                                 float *s_param, int n_param, Sink &&sink) {
+    NoLoss none;
+    backward_body_to<LIGHT, WF, VEC, MULTI, TM, PGRAD>(a, b, p, t, go, s_param, n_param, sink, none);
+}
+
+// The default sink: the lane's gradients go to the dense gradient planes [B][C][H*W] (the result's channel stride).
+template <int WF, int VEC, typename TM>
+__device__ __forceinline__ void store_gradients(const KArgs &a, const BArgs &b, const LanePos &p, float (&ga)[3][VEC], float (&gn)[3][VEC],
+                                                float (&gr)[VEC], float (&gm)[VEC], float (&gs)[3][VEC]) {
+    auto put = [&](void *plane, int channels, int c, const float *v) {
+        if (p.sb) Ld<TM, VEC>::template store<true>(plane_at<TM>(plane, ((int64_t)p.b0 * channels + c) * a.o_cs, (uint32_t)p.pix), 0, v);
+        else Ld<TM, VEC>::template store<true>(plane, ((int64_t)p.b * channels + c) * a.o_cs + p.pix, v);
+    };
+    if (b.g_albedo) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(b.g_albedo, 3, c, ga[c]);
+    }
+    if (b.g_normal && a.has_normal) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(b.g_normal, 3, c, gn[c]);
+    }
+    if (b.g_rough) put(b.g_rough, 1, 0, gr);
+    if (WF != PBR_WORKFLOW_SPECULAR) {
+        if (b.g_metal) put(b.g_metal, 1, 0, gm);
+    } else if (b.g_spec) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(b.g_spec, 3, c, gs[c]);
+    }
+}
+
 template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD>
 __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, const LanePos &p, Texels<VEC> &t, float (&go)[3][VEC],
                                               float *s_param, int n_param) {
     backward_body_to<LIGHT, WF, VEC, MULTI, TM, PGRAD>(a, b, p, t, go, s_param, n_param,
         [&](float (&ga)[3][VEC], float (&gn)[3][VEC], float (&gr)[VEC], float (&gm)[VEC], float (&gs)[3][VEC]) {
-            // gradient planes are dense: [B][C][H*W] with the result's channel stride
-            auto put = [&](void *plane, int channels, int c, const float *v) {
-                if (p.sb) Ld<TM, VEC>::template store<true>(plane_at<TM>(plane, ((int64_t)p.b0 * channels + c) * a.o_cs, (uint32_t)p.pix), 0, v);
-                else Ld<TM, VEC>::template store<true>(plane, ((int64_t)p.b * channels + c) * a.o_cs + p.pix, v);
-            };
-            if (b.g_albedo) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) put(b.g_albedo, 3, c, ga[c]);
-            }
-            if (b.g_normal && a.has_normal) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) put(b.g_normal, 3, c, gn[c]);
-            }
-            if (b.g_rough) put(b.g_rough, 1, 0, gr);
-            if (WF != PBR_WORKFLOW_SPECULAR) {
-                if (b.g_metal) put(b.g_metal, 1, 0, gm);
-            } else if (b.g_spec) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) put(b.g_spec, 3, c, gs[c]);
-            }
+            store_gradients<WF, VEC, TM>(a, b, p, ga, gn, gr, gm, gs);
         });
 }
 

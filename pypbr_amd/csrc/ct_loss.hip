@@ -1,0 +1,175 @@
+// ct_loss.hip -- the rendering-loss step as ONE kernel (C ABI: pbr_cook_torrance_mse_step).
+//
+// The documented training use of the reference (docs/source/tutorials/06_advanced.rst:73-107) is
+//     loss = nn.MSELoss()(brdf(predicted_material, ...), brdf(ground_truth_material, ...))
+// followed by loss.backward().  The ground-truth rendering is a constant of the step (rendered once, by pbr_cook_torrance);
+// what a step repeats for the PREDICTED material is: evaluate (44 B/pixel), subtract / square / mean and its backward
+// (36 B/pixel of elementwise torch kernels), the backward kernel (76 B/pixel).  Here it is one pass: the predicted maps and the
+// target image are read once (32 + 12 B/pixel), the colour is formed in registers, its difference to the target gives the
+// pixel's share of the loss AND its upstream gradient 2 (out - target) / N, the chain rule runs back through the shading (the
+// very code of cook_torrance_backward_kernel: backward_body_to with the MseLoss policy), and the four map gradients are
+// written (32 B/pixel): 76 B/pixel instead of 156.
+//
+// The loss itself: every workgroup (one wave) leaves its sum of squared differences in a workspace row; a second small kernel
+// adds the rows in fp64 in a fixed order (deterministic) and writes mean = sum / N.
+#include "ct_backward.hpp"
+#include "ct_launch.hpp"
+
+namespace pbr {
+
+// Waves per SIMD the register allocation must leave room for: the four-pixel fp32 body needs 242 VGPRs in the backward kernel
+// and, left alone, 256 + 21 AGPRs here (the target pixels and the squared differences on top) = ONE wave; held to two.  The
+// packed pair for fp16 maps fits 128 VGPRs in the backward kernel, not here (56 bytes of scratch): three waves.
+template <int VEC, bool MULTI, typename TM>
+constexpr int mse_min_waves() { return VEC == 4 ? 2 : (VEC == 2 && !MULTI && sizeof(TM) == 2 ? 3 : 1); }
+
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(mse_min_waves<VEC, MULTI, TM>())))
+void cook_torrance_mse_step_kernel(const KArgs a, const BArgs b, const float *__restrict__ target, float scale, float *__restrict__ partials) {
+    const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
+    const int ty = (int)a.div_tx.div(tile);
+    const LanePos p = lane_pos<VEC, true>(a, (int)tile - ty * a.tiles_x, ty);      // lanes outside the map shade a clamped position: every lane reaches the sum
+    Texels<VEC> t;
+    MseLoss<VEC> loss;
+    loss.scale = scale;
+    loss.sq = 0.0f;
+    float go[3][VEC];                                                              // unused by the MseLoss policy
+    const int64_t opix = p.b * a.o_bs + p.pix;
+    if constexpr (sizeof(TM) == 4) {
+        load_texels<WF, TM, VEC, true>(a, a.has_normal != 0, p, t);
+    } else if (p.sb) {
+        if (a.has_normal) load_texels_fixed<WF, TM, VEC, true, true, true>(a, p, t); else load_texels_fixed<WF, TM, VEC, true, true, false>(a, p, t);
+    } else {
+        if (a.has_normal) load_texels_fixed<WF, TM, VEC, true, false, true>(a, p, t); else load_texels_fixed<WF, TM, VEC, true, false, false>(a, p, t);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Ld<float, VEC>::template load<true>(target, opix + c * a.o_cs, loss.tgt[c]);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) go[c][j] = 0.0f;
+    }
+    backward_body_to<LIGHT, WF, VEC, MULTI, TM, false>(a, b, p, t, go, nullptr, 0,
+        [&](float (&ga)[3][VEC], float (&gn)[3][VEC], float (&gr)[VEC], float (&gm)[VEC], float (&gs)[3][VEC]) {
+            if (p.valid) store_gradients<WF, VEC, TM>(a, b, p, ga, gn, gr, gm, gs);
+        }, loss);
+    const float mine = p.valid ? loss.sq : 0.0f;
+    const float total = wave_sum(mine);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+// partials[n] (fp32, one per workgroup) -> *loss = sum / count, added in fp64 in a fixed order
+__global__ __launch_bounds__(256) void mse_finish_kernel(const float *__restrict__ partials, int n, double inv_count, float *__restrict__ loss) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * inv_count);
+}
+
+// x *= *scalar (device scalar), in place; returns at once when the scalar is exactly 1 (the usual upstream gradient of a loss)
+template <typename T>
+__global__ __launch_bounds__(256) void scale_by_device_scalar_kernel(T *__restrict__ x, size_t n, const float *__restrict__ scalar) {
+    const float k = *scalar;
+    if (k == 1.0f) return;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) x[i] = (T)((float)x[i] * k);
+}
+
+using MseFn = void (*)(const KArgs, const BArgs, const float *, float, float *);
+
+template <int L, int W>
+static MseFn pick_mse(bool half_maps, int vec, bool multi) {
+    if (half_maps) {
+        if (vec == 2) return multi ? cook_torrance_mse_step_kernel<L, W, 2, true, __half> : cook_torrance_mse_step_kernel<L, W, 2, false, __half>;
+        return multi ? cook_torrance_mse_step_kernel<L, W, 1, true, __half> : cook_torrance_mse_step_kernel<L, W, 1, false, __half>;
+    }
+    if (vec == 4) return cook_torrance_mse_step_kernel<L, W, 4, false, float>;
+    if (vec == 2) return multi ? cook_torrance_mse_step_kernel<L, W, 2, true, float> : cook_torrance_mse_step_kernel<L, W, 2, false, float>;
+    return multi ? cook_torrance_mse_step_kernel<L, W, 1, true, float> : cook_torrance_mse_step_kernel<L, W, 1, false, float>;
+}
+
+// Pixels per lane: the loss is a sum over pixels, so no lane may see a pixel twice (the overlapping last lane of a ragged row,
+// lane_pos: dup) -- the widest lane that divides the width.  fp32 maps with one light: 4 (the scalar four-pixel body, as the
+// backward kernel); fp16 maps or several lights: 2 (the packed pair).
+static int mse_vec(const pbr_render_desc *d) {
+    const bool pair_body = d->map_dtype == PBR_F16 || d->n_lights > 1;
+    if (g_max_vec == 1 || (d->width & 1)) return 1;
+    // four pixels per lane: directional lights only -- with a point light the body does not fit two waves' worth of registers
+    // (72-88 bytes of scratch per lane at 256 VGPRs); g_bwd_vec = 4 forces it for A/B runs, 2 forbids it
+    const bool four = d->light_type == PBR_LIGHT_DIRECTIONAL ? g_bwd_vec != 2 : g_bwd_vec == 4;
+    if (!pair_body && d->width % 4 == 0 && g_max_vec >= 4 && four) return 4;
+    return 2;
+}
+
+static int64_t mse_tiles(const pbr_render_desc *d, int vec) {
+    KArgs k;
+    fill_args(d, vec, k, 6);
+    return k.n_tiles;
+}
+
+}  // namespace pbr
+
+extern "C" {
+
+size_t pbr_mse_step_workspace_bytes(const pbr_render_desc *d) {
+    if (pbr::validate(d) != PBR_OK || pbr::is_tiled(d)) return 0;
+    const int64_t tiles = pbr::mse_tiles(d, 1);            // one pixel per lane: the most workgroups any launch of this descriptor has
+    return tiles < 0 ? 0 : (size_t)tiles * sizeof(float);
+}
+
+int pbr_cook_torrance_mse_step(const pbr_render_desc *d, const void *target, void *g_albedo, void *g_normal, void *g_roughness,
+                               void *g_metallic, void *g_specular, void *loss, void *workspace, void *stream) {
+    using namespace pbr;
+    const int rc = validate(d);
+    if (rc != PBR_OK) return rc;
+    if (!target || !loss || !workspace) return PBR_ERR_NULL_MAP;
+    if (d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;        // the target image and the colour it is compared with are fp32
+    if (is_tiled(d) || nan_light_size(d)) return PBR_ERR_UNSUPPORTED;
+    const int vec = mse_vec(d);
+    KArgs k;
+    fill_args(d, vec, k, 6);                                  // one-wave workgroups: one partial sum per workgroup, no LDS reduction
+    if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+    k.o_cs = (int64_t)d->height * d->width; k.o_bs = 3 * k.o_cs;     // target and gradient planes are contiguous
+    const BArgs b = {nullptr, g_albedo, g_normal, g_roughness, g_metallic, g_specular, nullptr};
+    const double count = 3.0 * (double)d->batch * (double)d->height * (double)d->width;
+    const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT, half_maps = d->map_dtype == PBR_F16;
+    MseFn fn = nullptr;
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: fn = pick_mse<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(half_maps, vec, multi); break;
+        case 1: fn = pick_mse<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(half_maps, vec, multi); break;
+        case 2: fn = pick_mse<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(half_maps, vec, multi); break;
+        case 3: fn = pick_mse<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(half_maps, vec, multi); break;
+        case 4: fn = pick_mse<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(half_maps, vec, multi); break;
+        default: fn = pick_mse<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(half_maps, vec, multi); break;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(64, 1, 1), 0, st, k, b, static_cast<const float *>(target),
+                       (float)(2.0 / count), static_cast<float *>(workspace));
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) return 1000 + (int)err;
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const float *>(workspace), (int)k.n_tiles, 1.0 / count,
+                       static_cast<float *>(loss));
+    err = hipGetLastError();
+    return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
+
+int pbr_scale_by_device_scalar(void *data, size_t n, int dtype, const void *scalar, void *stream) {
+    using namespace pbr;
+    if (!data || !scalar) return PBR_ERR_NULL_MAP;
+    if (dtype != PBR_F32 && dtype != PBR_F16) return PBR_ERR_DTYPE;
+    if (n == 0) return PBR_OK;
+    const size_t blocks = (n + 255) / 256;
+    const unsigned grid = (unsigned)(blocks > 2048 ? 2048 : blocks);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == PBR_F32) hipLaunchKernelGGL((scale_by_device_scalar_kernel<float>), dim3(grid), dim3(256), 0, st, static_cast<float *>(data), n, static_cast<const float *>(scalar));
+    else hipLaunchKernelGGL((scale_by_device_scalar_kernel<_Float16>), dim3(grid), dim3(256), 0, st, static_cast<_Float16 *>(data), n, static_cast<const float *>(scalar));
+    const hipError_t err = hipGetLastError();
+    return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
+
+}  // extern "C"

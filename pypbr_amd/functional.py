@@ -662,6 +662,78 @@ class _CookTorranceFn(torch.autograd.Function):
         return (*grads, *pgrads, None)
 
 
+# ------------------------------------------------------------------ the rendering-loss step as one kernel
+class _MseStepFn(torch.autograd.Function):
+    """loss = mean((cook_torrance(maps) - target)^2) with its gradients from ONE kernel (pbr_cook_torrance_mse_step): forward
+    evaluates, compares and differentiates in a single pass over the maps (32 + 12 bytes read, 32 written per pixel) and keeps
+    the four gradients; backward hands them over, scaled by the upstream gradient on the device (no host synchronisation; a
+    scalar of exactly 1 -- `loss.backward()` -- costs one early-out launch per map)."""
+
+    @staticmethod
+    def forward(ctx, albedo, normal, roughness, metallic, specular, target, kwargs):
+        maps = (albedo, normal, roughness, metallic, specular)
+        plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **kwargs)
+        d = plan.desc
+        B, H, W = d.batch, d.height, d.width
+        plan.out = None                                     # the colour is never written
+        tgt = target.detach().to(torch.float32).reshape(B, 3, H, W).contiguous()
+        dev = tgt.device
+        gdtype = torch.float32 if d.map_dtype == N.F32 else torch.float16
+        channels = (3, 3, 1, 1, 3)
+        present = (True, bool(d.normal.data), True, bool(d.metallic.data), bool(d.specular.data))
+        bufs = []
+        for i in range(5):
+            want = ctx.needs_input_grad[i] and present[i] and maps[i] is not None
+            bufs.append(torch.empty((B, channels[i], H, W), dtype=gdtype, device=dev) if want else None)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        lib = N.lib()
+        ws = torch.empty(max(1, lib.pbr_mse_step_workspace_bytes(ctypes.byref(d)) // 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(lib.pbr_cook_torrance_mse_step(ctypes.byref(d), tgt.data_ptr(), *[None if b is None else b.data_ptr() for b in bufs],
+                                                   loss.data_ptr(), ws.data_ptr(), _stream_ptr(dev)))
+        ctx.grads, ctx.shapes = bufs, [None if t is None else tuple(t.shape) for t in maps]
+        ctx.save_for_backward(*[t for t in maps if t is not None])
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        ctx.saved_tensors                                   # in-place edits of the maps since forward are detected, as for any op
+        k = grad_loss.detach().to(torch.float32).reshape(1).contiguous()
+        out = []
+        for b, shape in zip(ctx.grads, ctx.shapes):
+            if b is None:
+                out.append(None)
+                continue
+            with torch.cuda.device(b.device):
+                N.check(N.lib().pbr_scale_by_device_scalar(b.data_ptr(), b.numel(), _DTYPES[b.dtype], k.data_ptr(), _stream_ptr(b.device)))
+            out.append(b.reshape(shape))
+        ctx.grads = None
+        return (*out, None, None)
+
+
+def rendering_loss_mse(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughness: torch.Tensor,
+                       metallic: Optional[torch.Tensor] = None, specular: Optional[torch.Tensor] = None, *,
+                       target: torch.Tensor, **kwargs) -> torch.Tensor:
+    """`torch.nn.MSELoss()(cook_torrance(albedo, normal, roughness, metallic | specular, **kwargs), target)` -- the rendering loss of
+    docs/source/tutorials/06_advanced.rst:73-107 for the predicted material -- as a 0-dim tensor on the maps' device.  When a map
+    requires grad and the evaluation qualifies (whole untiled maps of the batch, fp32 result, light / view parameters without
+    gradients, every map with its own planes) loss and gradients come out of ONE kernel, pbr_cook_torrance_mse_step; otherwise
+    it is the differentiable evaluation followed by torch's MSE (same value to fp32 rounding, same gradients)."""
+    maps = (albedo, normal, roughness, metallic, specular)
+    params = tuple(kwargs.get(k) for k in _PARAM_KEYS)
+    grad_maps = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in maps)
+    grad_other = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in params + (target,))
+    B = albedo.shape[0] if albedo.dim() == 4 else 1
+    shared = any(t is not None and B > 1 and (t.dim() == 3 or t.shape[0] == 1) for t in maps)
+    plain = all(kwargs.get(k) in (None, d) for k, d in (("out", None), ("blend", None), ("out_dtype", torch.float32))) and \
+        kwargs.get("tile", 1) in (1, (1, 1)) and not kwargs.get("autotune")
+    if grad_maps and not grad_other and plain and not shared and albedo.is_cuda:
+        kw = {k: v for k, v in kwargs.items() if k not in ("out", "blend", "out_dtype", "tile", "autotune")}
+        return _MseStepFn.apply(albedo, normal, roughness, metallic, specular, target, kw)
+    out = cook_torrance(albedo, normal, roughness, metallic, specular, **kwargs)
+    return torch.nn.functional.mse_loss(out.float(), target.to(out.device, torch.float32).reshape(out.shape))
+
+
 # ------------------------------------------------------------------ stand-alone conversions
 _PINNED_OUT = []            # weak references to page-locked results still held by callers
 PINNED_RESULT_CAP = int(os.environ.get("PBR_PINNED_RESULT_CAP", str(1 << 30)))

@@ -17,11 +17,10 @@
 
 namespace pbr {
 
-// Waves per SIMD the register allocation must leave room for: the four-pixel fp32 body needs 242 VGPRs in the backward kernel
-// and, left alone, 256 + 21 AGPRs here (the target pixels and the squared differences on top) = ONE wave; held to two.  The
-// packed pair for fp16 maps fits 128 VGPRs in the backward kernel, not here (56 bytes of scratch): three waves.
+// Waves per SIMD the register allocation must leave room for: the packed pair for fp16 maps fits 128 VGPRs (four waves) in the
+// backward kernel, not here -- the target pixels and the squared differences come on top (56 bytes of scratch): three waves.
 template <int VEC, bool MULTI, typename TM>
-constexpr int mse_min_waves() { return VEC == 4 ? 2 : (VEC == 2 && !MULTI && sizeof(TM) == 2 ? 3 : 1); }
+constexpr int mse_min_waves() { return VEC == 2 && !MULTI && sizeof(TM) == 2 ? 3 : 1; }
 
 template <int LIGHT, int WF, int VEC, bool MULTI, typename TM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(mse_min_waves<VEC, MULTI, TM>())))
@@ -57,18 +56,33 @@ void cook_torrance_mse_step_kernel(const KArgs a, const BArgs b, const float *__
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
 }
 
-// partials[n] (fp32, one per workgroup) -> *loss = sum / count, added in fp64 in a fixed order
-__global__ __launch_bounds__(256) void mse_finish_kernel(const float *__restrict__ partials, int n, double inv_count, float *__restrict__ loss) {
-    __shared__ double red[256];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += partials[i];
+// partials[n] (fp32, one per workgroup of the step kernel) -> *loss = sum / count, in two stages, fp64, fixed order:
+// kMseStageGroups workgroups each add a contiguous block of the partials (coalesced: lane t takes elements t, t + 256, ...) into
+// stage[blockIdx]; then one workgroup adds the stage sums.  (One workgroup walking all 131 072 partials of a 4096^2 launch by
+// itself took longer than the step kernel: the same lesson as the light-gradient finish kernel, ct_backward.hpp.)
+constexpr int kMseStageGroups = 256;
+__device__ __forceinline__ double block_sum_256(double s, double *red) {
     red[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *loss = (float)(red[0] * inv_count);
+    return red[0];
+}
+__global__ __launch_bounds__(256) void mse_stage_kernel(const float *__restrict__ partials, int n, double *__restrict__ stage) {
+    __shared__ double red[256];
+    const int per = (n + kMseStageGroups - 1) / kMseStageGroups;
+    const int i0 = blockIdx.x * per, i1 = min(n, i0 + per);
+    double s = 0.0;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) s += partials[i];
+    const double total = block_sum_256(s, red);
+    if (threadIdx.x == 0) stage[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(256) void mse_finish_kernel(const double *__restrict__ stage, double inv_count, float *__restrict__ loss) {
+    __shared__ double red[256];
+    const double total = block_sum_256(threadIdx.x < kMseStageGroups ? stage[threadIdx.x] : 0.0, red);
+    if (threadIdx.x == 0) *loss = (float)(total * inv_count);
 }
 
 // x *= *scalar (device scalar), in place; returns at once when the scalar is exactly 1 (the usual upstream gradient of a loss)
@@ -88,23 +102,19 @@ static MseFn pick_mse(bool half_maps, int vec, bool multi) {
         if (vec == 2) return multi ? cook_torrance_mse_step_kernel<L, W, 2, true, __half> : cook_torrance_mse_step_kernel<L, W, 2, false, __half>;
         return multi ? cook_torrance_mse_step_kernel<L, W, 1, true, __half> : cook_torrance_mse_step_kernel<L, W, 1, false, __half>;
     }
-    if (vec == 4) return cook_torrance_mse_step_kernel<L, W, 4, false, float>;
     if (vec == 2) return multi ? cook_torrance_mse_step_kernel<L, W, 2, true, float> : cook_torrance_mse_step_kernel<L, W, 2, false, float>;
     return multi ? cook_torrance_mse_step_kernel<L, W, 1, true, float> : cook_torrance_mse_step_kernel<L, W, 1, false, float>;
 }
 
 // Pixels per lane: the loss is a sum over pixels, so no lane may see a pixel twice (the overlapping last lane of a ragged row,
-// lane_pos: dup) -- the widest lane that divides the width.  fp32 maps with one light: 4 (the scalar four-pixel body, as the
-// backward kernel); fp16 maps or several lights: 2 (the packed pair).
-static int mse_vec(const pbr_render_desc *d) {
-    const bool pair_body = d->map_dtype == PBR_F16 || d->n_lights > 1;
-    if (g_max_vec == 1 || (d->width & 1)) return 1;
-    // four pixels per lane: directional lights only -- with a point light the body does not fit two waves' worth of registers
-    // (72-88 bytes of scratch per lane at 256 VGPRs); g_bwd_vec = 4 forces it for A/B runs, 2 forbids it
-    const bool four = d->light_type == PBR_LIGHT_DIRECTIONAL ? g_bwd_vec != 2 : g_bwd_vec == 4;
-    if (!pair_body && d->width % 4 == 0 && g_max_vec >= 4 && four) return 4;
-    return 2;
-}
+// lane_pos: dup): two when the width is even, else one.  Two also for fp32 maps with one light, where the backward kernel takes
+// four: with the target pixels on top the four-pixel body needs 256 VGPRs + 21 AGPRs (one wave per SIMD; held to two waves it
+// spills 72-88 bytes), and measured on a 4096^2 material it loses -- point light 295 against 228 us, directional 225 against 219
+// (tools/loss_step_probe.py, round 3).
+static int mse_vec(const pbr_render_desc *d) { return g_max_vec == 1 || (d->width & 1) ? 1 : 2; }
+
+// workspace: the step kernel's partial sums (fp32, one per workgroup), then kMseStageGroups stage sums (fp64, 8-byte aligned)
+static size_t mse_stage_offset(size_t tiles) { return (tiles * sizeof(float) + 7) & ~(size_t)7; }
 
 static int64_t mse_tiles(const pbr_render_desc *d, int vec) {
     KArgs k;
@@ -119,7 +129,7 @@ extern "C" {
 size_t pbr_mse_step_workspace_bytes(const pbr_render_desc *d) {
     if (pbr::validate(d) != PBR_OK || pbr::is_tiled(d)) return 0;
     const int64_t tiles = pbr::mse_tiles(d, 1);            // one pixel per lane: the most workgroups any launch of this descriptor has
-    return tiles < 0 ? 0 : (size_t)tiles * sizeof(float);
+    return tiles < 0 ? 0 : pbr::mse_stage_offset((size_t)tiles) + (size_t)pbr::kMseStageGroups * sizeof(double);
 }
 
 int pbr_cook_torrance_mse_step(const pbr_render_desc *d, const void *target, void *g_albedo, void *g_normal, void *g_roughness,
@@ -152,8 +162,9 @@ int pbr_cook_torrance_mse_step(const pbr_render_desc *d, const void *target, voi
                        (float)(2.0 / count), static_cast<float *>(workspace));
     hipError_t err = hipGetLastError();
     if (err != hipSuccess) return 1000 + (int)err;
-    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, st, static_cast<const float *>(workspace), (int)k.n_tiles, 1.0 / count,
-                       static_cast<float *>(loss));
+    double *stage = reinterpret_cast<double *>(static_cast<char *>(workspace) + mse_stage_offset((size_t)mse_tiles(d, 1)));
+    hipLaunchKernelGGL(mse_stage_kernel, dim3(kMseStageGroups), dim3(256), 0, st, static_cast<const float *>(workspace), (int)k.n_tiles, stage);
+    hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, st, stage, 1.0 / count, static_cast<float *>(loss));
     err = hipGetLastError();
     return err == hipSuccess ? PBR_OK : 1000 + (int)err;
 }

@@ -42,10 +42,7 @@ for light_type, light in (("point", [0.1, 0.1, 1.0]), ("directional", [0.3, -0.2
     px = S * S
     bpp = (16 + 12 + 16) if half else 76
     ts = {}
-    for vec in ((2, 4) if not half else (0,)):
-        lib.pbr_set_tuning(N.TUNE_BWD_VEC, vec)
-        ts[vec] = timed(fused, 100, 300)
-    lib.pbr_set_tuning(N.TUNE_BWD_VEC, 0)
+    ts[0] = timed(fused, 100, 300)
     leaves = [t.clone().requires_grad_(True) for t in maps]
 
     def step(fused_path):

@@ -199,6 +199,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_BWD_RUN: slot = &pbr::g_bwd_run; break;
         case PBR_TUNE_RESIZE_XCD: slot = &pbr::g_resize_xcd; break;
         case PBR_TUNE_BWD_WIDE: slot = &pbr::g_bwd_wide; break;
+        case PBR_TUNE_RESIZE_UP2: slot = &pbr::g_resize_up2; break;
         default: return -1;
     }
     const int old = *slot;

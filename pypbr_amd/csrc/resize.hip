@@ -36,6 +36,7 @@
 namespace pbr {
 
 int g_resize_xcd = 1;              // XCD-contiguous tile order of the strip kernel: 1 = chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many tiles (A/B knob PBR_TUNE_RESIZE_XCD)
+int g_resize_up2 = 1;              // up-scales take the two-tap register kernel (0: the strip kernel, A/B knob PBR_TUNE_RESIZE_UP2)
 int g_resize_rows = 0;             // output rows per tile of the strip form: 0 = rule, else forced (A/B knob PBR_TUNE_RESIZE_ROWS)
 
 struct AxisFilter {
@@ -335,6 +336,83 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
     else width_to_global<16>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid);
 }
 
+
+// ---- up-scaling on both axes: two taps per axis, registers only (round 3) --------------------------------------------------
+// With scale <= 1 on both axes an output pixel has at most two taps per axis (support = 1), so neither the tap tables nor the
+// LDS strip of resize_strip_kernel are needed: a lane owns FOUR consecutive output pixels of a row.  Their taps lie in at most five
+// consecutive input columns; the lane loads six from each of the row's two input rows (one 16-byte and one 8-byte load per row,
+// element-aligned), blends the rows first (the same order as the strip kernel: height, then width), and picks each output's two
+// columns out of the six with selects.  Five vector-memory instructions per four output pixels instead of tables + LDS + barriers;
+// the launch is bound by its writes (2.25 output pixels per input pixel at 1.5x).  One-wave workgroups = 256 output pixels of a
+// row; workgroups are dealt to the XCDs in runs of kUpRun (every XCD keeps whole bands of output rows, so the input rows two
+// output rows share meet in one L2).
+constexpr int kUpRunLog2 = 9;
+typedef float rf4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef float rf2 __attribute__((ext_vector_type(2), aligned(4)));
+
+constexpr int kUpRows = 4;                                  // output rows per lane: the column taps are formed once for all of them
+
+__device__ __forceinline__ void two_taps(const AxisFilter &f, int i, int &first, float &w0, float &w1) {
+    int n; float center;
+    tap_window(f, i, first, n, center);
+    const float a = tap_weight(f, 0, first, center), b = n > 1 ? tap_weight(f, 1, first, center) : 0.0f;
+    const float inv = __builtin_amdgcn_rcpf(a + b);         // a + b > 0: the window always holds the tap nearest the centre (1 ulp; the
+    w0 = a * inv; w1 = b * inv;                             // strip kernel divides -- results agree to ~1e-7, both <= 2e-6 from ATen)
+}
+
+__global__ __launch_bounds__(64) void resize_up2_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_in, int w_in, int h_out,
+                                                        int w_out, int groups_x, int groups_y, uint32_t xcd_groups, AxisFilter fw, AxisFilter fh) {
+    uint32_t wg = blockIdx.x;
+    if (wg < xcd_groups) {                                  // XCD x takes runs of 1 << kUpRunLog2 consecutive workgroups (tile_of_workgroup's map)
+        const uint32_t c = kUpRunLog2, xcd = wg & 7u, slot = wg >> 3;
+        wg = ((slot >> c) << (c + 3)) + (xcd << c) + (slot & ((1u << c) - 1u));
+    }
+    const uint32_t band = wg / (uint32_t)groups_x, gx = wg - band * (uint32_t)groups_x;    // band = plane * groups_y + (y / kUpRows)
+    const int plane = (int)(band / (uint32_t)groups_y), yb = (int)(band - (uint32_t)plane * (uint32_t)groups_y) * kUpRows;
+    const int x0 = ((int)gx * 64 + (int)threadIdx.x) * 4;
+    if (x0 >= w_out) return;
+    int first[4]; float wa[4], wb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) two_taps(fw, min(x0 + k, w_out - 1), first[k], wa[k], wb[k]);
+    const int xb = min(first[0], w_in - 6);                 // six columns from xb on, inside the row
+    int o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = first[k] - xb;       // 0 .. 5 (5 only at the right edge, where the second tap's weight is 0)
+    const float *sp = src + (int64_t)plane * h_in * w_in + xb;
+    float *dp = dst + ((int64_t)plane * h_out) * w_out + x0;
+    const bool whole = x0 + 4 <= w_out;
+#pragma unroll
+    for (int r = 0; r < kUpRows; ++r) {
+        const int y = yb + r;
+        if (y >= h_out) break;
+        int y0; float wy0, wy1;
+        two_taps(fh, y, y0, wy0, wy1);
+        const int y1 = min(y0 + 1, h_in - 1);               // a one-tap window at the last row: weight 0 on a valid row
+        const float *r0 = sp + (int64_t)y0 * w_in, *r1 = sp + (int64_t)y1 * w_in;
+        const rf4 a4 = *reinterpret_cast<const rf4 *>(r0), b4 = *reinterpret_cast<const rf4 *>(r1);
+        const rf2 a2 = *reinterpret_cast<const rf2 *>(r0 + 4), b2 = *reinterpret_cast<const rf2 *>(r1 + 4);
+        float mid[6];                                       // height pass first, as the strip kernel: acc = w0 v0, then fma(w1, v1, acc)
+        mid[0] = fmaf(wy1, b4.x, wy0 * a4.x); mid[1] = fmaf(wy1, b4.y, wy0 * a4.y); mid[2] = fmaf(wy1, b4.z, wy0 * a4.z);
+        mid[3] = fmaf(wy1, b4.w, wy0 * a4.w); mid[4] = fmaf(wy1, b2.x, wy0 * a2.x); mid[5] = fmaf(wy1, b2.y, wy0 * a2.y);
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ok = o[k];
+            const float va = ok == 0 ? mid[0] : (ok == 1 ? mid[1] : (ok == 2 ? mid[2] : (ok == 3 ? mid[3] : (ok == 4 ? mid[4] : mid[5]))));
+            const float vb = ok == 0 ? mid[1] : (ok == 1 ? mid[2] : (ok == 2 ? mid[3] : (ok == 3 ? mid[4] : mid[5])));
+            out[k] = fmaf(wb[k], vb, wa[k] * va);
+        }
+        float *q = dp + (int64_t)y * w_out;
+        if (whole) {
+            typedef float sf4 __attribute__((ext_vector_type(4), aligned(4)));
+            const sf4 v = {out[0], out[1], out[2], out[3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<sf4 *>(q));
+        } else {
+            for (int k = 0; k < w_out - x0; ++k) q[k] = out[k];
+        }
+    }
+}
+
 static AxisFilter make_filter(int n_in, int n_out, bool antialias) {
     AxisFilter f;
     f.scale = (float)n_in / (float)n_out;            // area_pixel_compute_scale<float>, align_corners = False
@@ -366,6 +444,18 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
     hipStream_t s = static_cast<hipStream_t>(stream);
     float *tmp = static_cast<float *>(workspace);
     const AxisFilter fw = make_filter(w_in, w_out, antialias != 0), fh = make_filter(h_in, h_out, antialias != 0);
+    if (g_resize_up2 && fw.scale <= 1.0f && fh.scale <= 1.0f && w_in >= 6) {
+        // up-scaling (or 1:1) on both axes: the two-tap register form.  3 x 4096^2 -> 6144^2 (tools/resize_sweep.py, round 3).
+        const int64_t groups_x = (w_out + 255) / 256, groups_y = (h_out + kUpRows - 1) / kUpRows, n_groups = groups_x * groups_y * planes;
+        if (n_groups <= INT32_MAX) {
+            const uint32_t span = 8u << kUpRunLog2;
+            const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
+            hipLaunchKernelGGL(resize_up2_kernel, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(src), static_cast<float *>(dst),
+                               (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)groups_x, (int)groups_y, xcd_groups, fw, fh);
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+        }
+    }
     {   // strip form: tap tables + the height-reduced strip [toh][pitch] of a toh x 64 output tile in LDS, up to 16 taps per axis
         const int kx = (int)(2.0f * fw.support) + 3, ky = (int)(2.0f * fh.support) + 3;      // taps per output: xsize <= 2 support + 2
         const bool vec_ok = w_in % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;

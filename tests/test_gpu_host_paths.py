@@ -337,3 +337,37 @@ def _remembered_verdicts(normal_of, signed, encoded):
     again = normal_of(signed)
     assert again is not signed and not torch.equal(again, signed)
     assert torch.allclose(again, torch.nn.functional.normalize(signed * 2 - 1, dim=0), atol=2e-6)
+
+
+def test_resize_upscale_two_tap_kernel_equals_the_strip_kernel_and_aten():
+    """Round 3: up-scales on both axes run the register-only two-tap kernel (resize.hip: resize_up2_kernel).  Same tap rule, same
+    order of operations as the strip kernel (its weights normalised with v_rcp instead of a division: <= 2e-7 apart, knob
+    PBR_TUNE_RESIZE_UP2 = 0), and <= 5e-6 from ATen's
+    F.interpolate -- ragged output widths, the 1:1 case, tiny inputs, non-square scales, with and without antialias (no-ops
+    when up-scaling), several planes."""
+    from pypbr_amd import _native as N, functional as F
+    lib = N.lib()
+    g = torch.Generator().manual_seed(61)
+    cases = [((3, 37, 53), (80, 97)), ((3, 37, 53), (37, 53)), ((1, 6, 6), (13, 7)), ((2, 3, 9, 11), (9, 250)), ((3, 64, 64), (96, 96)),
+             ((1, 40, 100), (41, 257)), ((3, 50, 7), (333, 8)), ((1, 128, 256), (192, 1021))]
+    try:
+        for shape, size in cases:
+            x = torch.rand(*shape, generator=g)
+            for aa in (True, False):
+                lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
+                fast = F.resize(x.cuda(), size, antialias=aa)
+                lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 0)
+                strip = F.resize(x.cuda(), size, antialias=aa)
+                assert (fast - strip).abs().max().item() <= 2e-7, (shape, size, aa, float((fast - strip).abs().max()))
+                ref = torch.nn.functional.interpolate(x.reshape(-1, 1, *shape[-2:]), size=size, mode="bilinear", align_corners=False, antialias=aa)
+                # (ATen's non-antialiased kernel forms its two weights from src = scale (i + 0.5) - 0.5 directly: a few ulp of the tap
+                # position away from the antialias rule both kernels here use for every setting)
+                assert (fast.cpu().reshape(ref.shape) - ref).abs().max().item() <= 5e-6, (shape, size, aa)
+        # a down-scale on one axis keeps the strip kernel (more than two taps there): the knob changes nothing
+        x = torch.rand(3, 64, 64, generator=g).cuda()
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
+        a = F.resize(x, (100, 30))
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 0)
+        assert torch.equal(a, F.resize(x, (100, 30)))
+    finally:
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)

@@ -350,7 +350,7 @@ constexpr int kUpRunLog2 = 9;
 typedef float rf4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef float rf2 __attribute__((ext_vector_type(2), aligned(4)));
 
-constexpr int kUpRows = 4;                                  // output rows per lane: the column taps are formed once for all of them
+// kUpRows (template parameter ROWS): output rows per lane -- the column taps are formed once for all of them
 
 __device__ __forceinline__ void two_taps(const AxisFilter &f, int i, int &first, float &w0, float &w1) {
     int n; float center;
@@ -360,6 +360,7 @@ __device__ __forceinline__ void two_taps(const AxisFilter &f, int i, int &first,
     w0 = a * inv; w1 = b * inv;                             // strip kernel divides -- results agree to ~1e-7, both <= 2e-6 from ATen)
 }
 
+template <int kUpRows>
 __global__ __launch_bounds__(64) void resize_up2_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_in, int w_in, int h_out,
                                                         int w_out, int groups_x, int groups_y, uint32_t xcd_groups, AxisFilter fw, AxisFilter fh) {
     uint32_t wg = blockIdx.x;
@@ -446,11 +447,17 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
     const AxisFilter fw = make_filter(w_in, w_out, antialias != 0), fh = make_filter(h_in, h_out, antialias != 0);
     if (g_resize_up2 && fw.scale <= 1.0f && fh.scale <= 1.0f && w_in >= 6) {
         // up-scaling (or 1:1) on both axes: the two-tap register form.  3 x 4096^2 -> 6144^2 (tools/resize_sweep.py, round 3).
-        const int64_t groups_x = (w_out + 255) / 256, groups_y = (h_out + kUpRows - 1) / kUpRows, n_groups = groups_x * groups_y * planes;
+        // Output rows per lane.  Measured (tools/resize_up_ab.py, 3 planes, us, rows 2 / 4 / 8; strip kernel for scale):
+        //   4096^2 -> 6144^2  131.4 / 121.6 / 110.8 (157)    -> 8192^2  215.3 / 195.5 / 184.7 (270)    2048^2 -> 4096^2  59.0 / 53.6 / 53.0 (64)
+        //   4096^2 -> 4608^2   79.1 /  70.0 /  73.1 (101)    -> 4096^2   63.7 /  61.2 /  66.0 (95)
+        // 8 from 1.25x up (the column taps' share shrinks as the rows grow), 4 below.  A/B knob PBR_TUNE_RESIZE_ROWS (2 | 4 | 8).
+        const int rows = g_resize_rows == 2 || g_resize_rows == 4 || g_resize_rows == 8 ? g_resize_rows : (fh.scale <= 0.8f ? 8 : 4);
+        const int64_t groups_x = (w_out + 255) / 256, groups_y = (h_out + rows - 1) / rows, n_groups = groups_x * groups_y * planes;
         if (n_groups <= INT32_MAX) {
             const uint32_t span = 8u << kUpRunLog2;
             const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
-            hipLaunchKernelGGL(resize_up2_kernel, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(src), static_cast<float *>(dst),
+            auto fn = rows == 2 ? resize_up2_kernel<2> : (rows == 8 ? resize_up2_kernel<8> : resize_up2_kernel<4>);
+            hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(src), static_cast<float *>(dst),
                                (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)groups_x, (int)groups_y, xcd_groups, fw, fh);
             const hipError_t e = hipGetLastError();
             return e == hipSuccess ? PBR_OK : 1000 + (int)e;

@@ -16,10 +16,11 @@ for S, ho in ((4096, 6144), (4096, 8192), (4096, 4608), (2048, 4096), (4096, 409
     a = torch.rand(3, S, S, device=dev)
     out = torch.empty(3, ho, ho, device=dev)
     ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, S, ho) // 4), device=dev)
-    res = {0: [], 1: []}
+    res = {0: [], 1: [], 2: [], 8: []}
     for rnd in range(3):
-        for knob in (0, 1):
-            lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, knob)
+        for knob in (0, 1, 2, 8):
+            lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1 if knob else 0)
+            lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, knob if knob > 1 else 0)
             for _ in range(30):
                 lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), 3, S, S, ho, ho, 1, ws.data_ptr(), stream)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,5 +32,6 @@ for S, ho in ((4096, 6144), (4096, 8192), (4096, 4608), (2048, 4096), (4096, 409
             res[knob].append(e0.elapsed_time(e1) / 50 * 1e3)
     mb = 12 * (S * S + ho * ho) / 1e6
     print(f"3 x {S}^2 -> {ho}^2 ({mb:.0f} MB): strip {min(res[0]):7.1f} us = {mb / min(res[0]) * 1e3:5.0f} GB/s   two-tap {min(res[1]):7.1f} us = "
-          f"{mb / min(res[1]) * 1e3:5.0f} GB/s ({mb / min(res[1]) * 1e3 / 8000:.3f} of 8 TB/s)   all: {['%.1f' % t for t in res[0]]} / {['%.1f' % t for t in res[1]]}")
+          f"{mb / min(res[1]) * 1e3:5.0f} GB/s ({mb / min(res[1]) * 1e3 / 8000:.3f} of 8 TB/s)   rows 2: {min(res[2]):.1f}  rows 8: {min(res[8]):.1f}")
 lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
+lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, 0)

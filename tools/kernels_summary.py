@@ -119,4 +119,8 @@ for key in sorted(rec):
     elif match:
         ent["cases"] = [cs["case"] for cs in match]
     out.append(ent)
+# a record whose stated bytes are not what moved is not evidence (round 2: a fraction of 1.24, a traffic ratio of 0.667): say so loudly
+for ent in out:
+    if ent.get("frac_of_8TBps_at_avg", 0) > 1.0 or not 0.9 <= ent.get("traffic_over_algorithmic", 1.0) <= 2.5:
+        print("SUSPECT RECORD: %s frac %s traffic ratio %s" % (ent["kernel"], ent.get("frac_of_8TBps_at_avg"), ent.get("traffic_over_algorithmic")), file=sys.stderr)
 print(json.dumps(out, indent=1))

@@ -143,9 +143,12 @@ if want("map_ops"):
            timed(lambda: lib.pbr_specular_to_metallic(a.data_ptr(), n.data_ptr(), o3.data_ptr(), o3b.data_ptr(), a.numel(), 0, N.F32, stream)))
     report("map_ops decode_normal 3 ch [0,1]-encoded 4096^2, one pass: probe, decode + record any negative (3 planes in, 3 out), fix-up kernel that returns at once", "decode_normal_speculative_kernel", 24 * PX,
            timed(lambda: lib.pbr_decode_normal(n.data_ptr(), o3.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
-    n_signed = n * 2 - 1
-    report("map_ops decode_normal 3 ch already signed 4096^2, one pass: the probe sees a negative value, the decode returns at once, the map is copied as it is (3 planes in, 3 out)", "keep_normal_kernel", 24 * PX,
-           timed(lambda: lib.pbr_decode_normal(n_signed.data_ptr(), o3.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
+    # fp16 here, so that the copy kernel of THIS case has a name of its own: keep_normal_kernel<float> also runs -- and returns at
+    # once -- in the encoded-map case above, and the counter averages are per kernel name (round 2's record mixed the two: 0.667)
+    n_signed = (n * 2 - 1).half()
+    o3h = torch.empty_like(n_signed)
+    report("map_ops decode_normal 3 ch already signed 4096^2 fp16, one pass: the probe sees a negative value, the decode returns at once, the map is copied as it is (3 planes in, 3 out)", "keep_normal_kernel<__half>", 12 * PX,
+           timed(lambda: lib.pbr_decode_normal(n_signed.data_ptr(), o3h.data_ptr(), 3, PX, N.F16, flag.data_ptr(), stream)))
     n_inplace = n.clone()
     n_late = n.clone()
     n_late.view(-1)[-1] = -1.0
@@ -157,15 +160,62 @@ if want("map_ops"):
            timed(lambda: lib.pbr_blend_maps(a.data_ptr(), n.data_ptr(), m.data_ptr(), o3.data_ptr(), 3, PX, 0, stream)))
     report("blend_maps normals 4096^2 (7 planes in, 3 out)", "blend_kernel<true>", 40 * PX,
            timed(lambda: lib.pbr_blend_maps(a.data_ptr(), n.data_ptr(), m.data_ptr(), o3.data_ptr(), 3, PX, 1, stream)))
+    m_other = torch.rand(1, S, S, device=DEV, generator=g)            # two DISTINCT property maps (round 2 passed one buffer twice: 8 B/pixel moved, 12 counted)
     report("sigmoid mask 4096^2 (2 in, 1 out)", "sigmoid_mask_kernel", 12 * PX,
-           timed(lambda: lib.pbr_blend_sigmoid_mask(m.data_ptr(), m.data_ptr(), o1.data_ptr(), PX, 0.0, 0.1, stream)))
-    del a, n, m, o3, o3b, o1
+           timed(lambda: lib.pbr_blend_sigmoid_mask(m.data_ptr(), m_other.data_ptr(), o1.data_ptr(), PX, 0.0, 0.1, stream)))
+    # round 3: gradients of the map ops
+    g3 = torch.rand(3, S, S, device=DEV, generator=g)
+    report("map_ops srgb_to_linear backward 3 x 4096^2 fp32 (map + upstream gradient in, gradient out)", "colour_backward_kernel<float, true>", 36 * PX,
+           timed(lambda: lib.pbr_srgb_to_linear_backward(a.data_ptr(), g3.data_ptr(), o3.data_ptr(), a.numel(), N.F32, stream)))
+    report("map_ops metallic -> diffuse/specular backward 4096^2 (4 map planes + 6 gradient planes in, 4 out)", "metallic_to_specular_backward_kernel<float, true>", 56 * PX,
+           timed(lambda: lib.pbr_metallic_to_specular_backward(a.data_ptr(), m.data_ptr(), g3.data_ptr(), n.data_ptr(), o3.data_ptr(), o1.data_ptr(), 1, PX, 1, N.F32, stream)))
+    report("map_ops diffuse/specular -> basecolor/metallic backward 4096^2 (6 + 6 planes in, 6 out)", "specular_to_metallic_backward_kernel<float>", 72 * PX,
+           timed(lambda: lib.pbr_specular_to_metallic_backward(a.data_ptr(), n.data_ptr(), g3.data_ptr(), g3.data_ptr(), o3.data_ptr(), o3b.data_ptr(), a.numel(), 0, N.F32, stream)))
+    del a, n, m, o3, o3b, o1, g3, m_other
 if want("resize"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)
     for (ho, wo), aa in (((S // 2, S // 2), True), ((S // 4, S // 4), True), ((S * 3 // 2, S * 3 // 2), False)):
         out = torch.empty(3, ho, wo, device=DEV)
         ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, S, wo) // 4), device=DEV)
-        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", "resize_strip_kernel", 12 * (PX + ho * wo),
+        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", "resize_strip_kernel" if ho < S else "resize_up2_kernel<8>", 12 * (PX + ho * wo),
                timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), 3, S, S, ho, wo, int(aa), ws.data_ptr(), stream)))
         del out, ws
+if want("blend_bwd"):
+    m1, m2 = synth_material(S, DEV, 21), synth_material(S, DEV, 22)
+    mask = torch.rand(1, S, S, device=DEV)
+    p = F.plan_cook_torrance(*m1, blend=(m2[0], m2[1], m2[2], m2[3], None, mask), **PT)
+    p.launch(stream)
+    gout = torch.rand(1, 3, S, S, device=DEV)
+    g1, g2, gm = [torch.empty_like(t) for t in m1], [torch.empty_like(t) for t in m2], torch.empty_like(mask)
+    G1 = N.MapGrads(g1[0].data_ptr(), g1[1].data_ptr(), g1[2].data_ptr(), g1[3].data_ptr(), None)
+    G2 = N.MapGrads(g2[0].data_ptr(), g2[1].data_ptr(), g2[2].data_ptr(), g2[3].data_ptr(), None)
+    bd = N.BlendDesc.from_buffer_copy(p._blend)
+    bd.sign_mode = N.BLEND_SIGN_GIVEN
+    report("blend_bwd: backward of the fused blend + render, 4096^2 (17 map planes + 3 gradient planes in, 17 gradient planes out)",
+           "cook_torrance_blend_backward_kernel<1, 0, 2, false>", 148 * PX,
+           timed(lambda: N.check(lib.pbr_cook_torrance_blend_backward(ctypes.byref(p.desc), ctypes.byref(bd), p._workspace.data_ptr(), gout.data_ptr(),
+                                                                      ctypes.byref(G1), ctypes.byref(G2), gm.data_ptr(), stream))))
+    del m1, m2, mask, p, gout, g1, g2, gm
+if want("loss_step"):
+    for dtype, tag, kern, bpp in ((torch.float32, "loss_step_f32", "cook_torrance_mse_step_kernel<1, 0, 2, false, float>", 76),
+                                  (torch.float16, "loss_step_f16", "cook_torrance_mse_step_kernel<1, 0, 2, false, __half>", 44)):
+        maps = synth_material(S, DEV, 3, dtype)
+        target = F.cook_torrance(*synth_material(S, DEV, 4, dtype), **PT).float()
+        plan = F.plan_cook_torrance(*maps, **PT)
+        grads = [torch.empty_like(t) for t in maps]
+        loss = torch.empty((), device=DEV)
+        ws = torch.empty(max(1, lib.pbr_mse_step_workspace_bytes(ctypes.byref(plan.desc)) // 4), device=DEV)
+        report(f"{tag}: rendering-loss step 1 x 4096^2 point metallic ({dtype}): 8 map planes + target image in, 8 gradient planes out (+ two small reduction kernels)",
+               kern, bpp * PX,
+               timed(lambda: N.check(lib.pbr_cook_torrance_mse_step(ctypes.byref(plan.desc), target.data_ptr(), *[t.data_ptr() for t in grads], None,
+                                                                    loss.data_ptr(), ws.data_ptr(), stream))))
+        del maps, target, plan, grads
+if want("resize_bwd"):
+    g = torch.Generator(device=DEV).manual_seed(0)
+    ho = S // 2
+    gout = torch.rand(3, ho, ho, device=DEV, generator=g)
+    gin = torch.empty(3, S, S, device=DEV)
+    ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(3, S, S, ho, ho) // 4), device=DEV)
+    report("resize backward 3 x 2048^2 gradient -> 4096^2 (two gather passes through a workspace)", "resize_backward_cols_kernel", 12 * (PX + ho * ho) + 24 * S * ho,
+           timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, S, S, ho, ho, 1, ws.data_ptr(), stream)))

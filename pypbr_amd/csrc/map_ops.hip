@@ -74,24 +74,27 @@ __global__ __launch_bounds__(256) void colour_kernel(const void *src, void *dst,
 
 // ---- metallic -> diffuse/specular (metallic.py:98-108) ---------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void metallic_to_specular_kernel(const void *albedo, const void *metallic,
-                                                                   void *diffuse, void *specular, int batch,
+__global__ __launch_bounds__(256) void metallic_to_specular_kernel(const void *__restrict__ albedo, const void *__restrict__ metallic,
+                                                                   void *__restrict__ diffuse, void *__restrict__ specular, int batch,
                                                                    int64_t P, int albedo_srgb, int vec_ok) {
     const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec_ok) {                       // P % 4 == 0, 16-byte accesses: 4 pixels of one material per lane
         const size_t P4 = (size_t)P / 4, total4 = (size_t)batch * P4;
         for (size_t q = tid; q < total4; q += stride) {
             const size_t b = q / P4, pq = q - b * P4;
-            float m[4];
+            // all four loads of the lane first (outputs never alias inputs: the results are new maps), then the six stores: with
+            // the loads of a channel behind the previous channel's stores a lane had one load in flight at a time
+            float m[4], a[3][4];
             Quad<T>::ld(metallic, q, m);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Quad<T>::ld(albedo, (b * 3 + c) * P4 + pq, a[c]);
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const size_t o = (b * 3 + c) * P4 + pq;
-                float a[4], d[4], sp[4];
-                Quad<T>::ld(albedo, o, a);
+                float d[4], sp[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float lin = albedo_srgb ? srgb_to_linear(a[j]) : a[j], om = 1.0f - m[j];
+                    const float lin = albedo_srgb ? srgb_to_linear(a[c][j]) : a[c][j], om = 1.0f - m[j];
                     d[j] = lin * om;
                     sp[j] = fmaf(lin, m[j], kDielectricF0 * om);
                 }

@@ -169,9 +169,10 @@ if want("map_ops"):
            timed(lambda: lib.pbr_srgb_to_linear_backward(a.data_ptr(), g3.data_ptr(), o3.data_ptr(), a.numel(), N.F32, stream)))
     report("map_ops metallic -> diffuse/specular backward 4096^2 (4 map planes + 6 gradient planes in, 4 out)", "metallic_to_specular_backward_kernel<float, true>", 56 * PX,
            timed(lambda: lib.pbr_metallic_to_specular_backward(a.data_ptr(), m.data_ptr(), g3.data_ptr(), n.data_ptr(), o3.data_ptr(), o1.data_ptr(), 1, PX, 1, N.F32, stream)))
+    g3b = torch.rand(3, S, S, device=DEV, generator=g)                # two DISTINCT upstream gradients
     report("map_ops diffuse/specular -> basecolor/metallic backward 4096^2 (6 + 6 planes in, 6 out)", "specular_to_metallic_backward_kernel<float>", 72 * PX,
-           timed(lambda: lib.pbr_specular_to_metallic_backward(a.data_ptr(), n.data_ptr(), g3.data_ptr(), g3.data_ptr(), o3.data_ptr(), o3b.data_ptr(), a.numel(), 0, N.F32, stream)))
-    del a, n, m, o3, o3b, o1, g3, m_other
+           timed(lambda: lib.pbr_specular_to_metallic_backward(a.data_ptr(), n.data_ptr(), g3.data_ptr(), g3b.data_ptr(), o3.data_ptr(), o3b.data_ptr(), a.numel(), 0, N.F32, stream)))
+    del a, n, m, o3, o3b, o1, g3, g3b, m_other
 if want("resize"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)
@@ -201,7 +202,7 @@ if want("loss_step"):
     for dtype, tag, kern, bpp in ((torch.float32, "loss_step_f32", "cook_torrance_mse_step_kernel<1, 0, 2, false, float>", 76),
                                   (torch.float16, "loss_step_f16", "cook_torrance_mse_step_kernel<1, 0, 2, false, __half>", 44)):
         maps = synth_material(S, DEV, 3, dtype)
-        target = F.cook_torrance(*synth_material(S, DEV, 4, dtype), **PT).float()
+        target = torch.rand(1, 3, S, S, device=DEV)                   # any image serves the traffic measurement (no extra kernel under the counters)
         plan = F.plan_cook_torrance(*maps, **PT)
         grads = [torch.empty_like(t) for t in maps]
         loss = torch.empty((), device=DEV)
@@ -217,5 +218,8 @@ if want("resize_bwd"):
     gout = torch.rand(3, ho, ho, device=DEV, generator=g)
     gin = torch.empty(3, S, S, device=DEV)
     ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(3, S, S, ho, ho) // 4), device=DEV)
-    report("resize backward 3 x 2048^2 gradient -> 4096^2 (two gather passes through a workspace)", "resize_backward_cols_kernel", 12 * (PX + ho * ho) + 24 * S * ho,
-           timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, S, S, ho, ho, 1, ws.data_ptr(), stream)))
+    us = timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, S, S, ho, ho, 1, ws.data_ptr(), stream))
+    # two kernels: rows pass (gradient [3][2048][2048] in, workspace [3][4096][2048] out), columns pass (workspace in, [3][4096][4096] out);
+    # `us` is the whole call, the per-kernel durations come from the kernel trace
+    report("resize backward 3 x 2048^2 gradient -> 4096^2, rows pass", "resize_backward_rows_kernel", 12 * (ho * ho + S * ho), us, whole_call_us=round(us, 1))
+    report("resize backward 3 x 2048^2 gradient -> 4096^2, columns pass", "resize_backward_cols_kernel", 12 * (S * ho + PX), us, whole_call_us=round(us, 1))

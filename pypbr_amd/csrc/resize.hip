@@ -337,6 +337,90 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
 }
 
 
+// ---- table-driven form of the two passes (round 3, after the counters: the generic kernels above re-derive every candidate's
+// window per element and are VALU-bound -- 132 + 221 us for a 2048^2 -> 4096^2 gradient, VALUs saturated, 0.15 of HBM).
+// A small kernel writes, per INPUT index k of an axis, the first contributing output `lo[k]`, their number `cnt[k]` and the
+// normalised weights w[j][k] (j-major: lanes that walk k read them coalesced); the passes are then pure fma streams.
+// More than kBwdMaxTaps contributors per input (up-scales from ~3x on) keep the generic kernels: the launcher decides from the
+// scale (contributors <= (2 support + 2) / scale + 2).
+constexpr int kBwdMaxTaps = 12;
+__global__ __launch_bounds__(256) void resize_backward_table_kernel(int *__restrict__ lo_out, int *__restrict__ cnt_out, float *__restrict__ w,
+                                                                    int n_out, AxisFilter f) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= f.n_in) return;
+    int lo, hi, first = -1, n = 0;
+    candidates(f, k, n_out, lo, hi);
+    for (int i = lo; i <= hi; ++i) {
+        int xmin, sz; float center;
+        tap_window(f, i, xmin, sz, center);
+        if (k < xmin || k >= xmin + sz) continue;
+        if (first < 0) first = i;
+        const int j = i - first;                            // contributors are contiguous (windows are monotone in i)
+        float wsum = 0.0f;                                  // the output's normalisation, as resize_norm_kernel forms it
+        for (int q = 0; q < sz; ++q) wsum += tap_weight(f, q, xmin, center);
+        if (j < kBwdMaxTaps) w[(size_t)j * f.n_in + k] = tap_weight(f, k - xmin, xmin, center) * (wsum != 0.0f ? 1.0f / wsum : 0.0f);
+        n = j + 1;
+    }
+    n = min(n, kBwdMaxTaps);                                // (the launcher only comes here when the bound on n fits)
+    for (int j = n; j < kBwdMaxTaps; ++j) w[(size_t)j * f.n_in + k] = 0.0f;
+    lo_out[k] = first < 0 ? 0 : first;
+    cnt_out[k] = n;
+}
+
+// rows pass: tmp[plane][k][x] = sum_j wy[j][k] g[plane][lo[k] + j][x].  One input row k per workgroup row: lo / cnt / weights are
+// uniform (scalar loads), a lane owns four consecutive columns (16-byte accesses).
+__global__ __launch_bounds__(256) void resize_backward_rows_table_kernel(const float *__restrict__ gout, float *__restrict__ tmp, const int *__restrict__ lo,
+                                                                         const int *__restrict__ cnt, const float *__restrict__ w, int h_in, int n_out,
+                                                                         int width) {
+    typedef float v4 __attribute__((ext_vector_type(4), aligned(4)));
+    const int chunks = (width + 1023) / 1024;               // 1-D grid (grid.y stops at 65 535): workgroup -> (row, chunk of 1024 columns)
+    const int row = blockIdx.x / chunks, plane = row / h_in, k = row - plane * h_in;
+    const int x = ((blockIdx.x - row * chunks) * 256 + threadIdx.x) * 4;
+    if (x >= width) return;
+    const int first = lo[k], n = cnt[k];
+    const float *g = gout + ((int64_t)plane * n_out + first) * width + x;
+    float *t = tmp + (int64_t)row * width + x;
+    if (x + 4 <= width) {
+        v4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int j = 0; j < n; ++j) acc += w[(size_t)j * h_in + k] * *reinterpret_cast<const v4 *>(g + (int64_t)j * width);
+        *reinterpret_cast<v4 *>(t) = acc;
+    } else {
+        for (int c = 0; c < width - x; ++c) {
+            float acc = 0.0f;
+            for (int j = 0; j < n; ++j) acc = fmaf(w[(size_t)j * h_in + k], g[(int64_t)j * width + c], acc);
+            t[c] = acc;
+        }
+    }
+}
+
+// columns pass: g_in[row][k] = sum_j wx[j][k] tmp[row][lo[k] + j].  A lane owns input column k for kBwdRows consecutive rows: its
+// offsets and weights are read once (coalesced over k) and reused for every row.
+constexpr int kBwdRows = 8;
+__global__ __launch_bounds__(256) void resize_backward_cols_table_kernel(const float *__restrict__ tmp, float *__restrict__ gin, const int *__restrict__ lo,
+                                                                         const int *__restrict__ cnt, const float *__restrict__ w, int64_t rows, int w_in,
+                                                                         int n_out) {
+    const int chunks = (w_in + 255) / 256;                  // 1-D grid: workgroup -> (group of kBwdRows rows, chunk of 256 columns)
+    const int64_t rgroup = blockIdx.x / chunks;
+    const int k = (int)(blockIdx.x - rgroup * chunks) * 256 + threadIdx.x;
+    if (k >= w_in) return;
+    const int first = lo[k], n = cnt[k];
+    float wk[kBwdMaxTaps];
+#pragma unroll
+    for (int j = 0; j < kBwdMaxTaps; ++j) wk[j] = j < n ? w[(size_t)j * w_in + k] : 0.0f;
+    const int64_t r0 = rgroup * kBwdRows;
+#pragma unroll 2
+    for (int r = 0; r < kBwdRows; ++r) {
+        const int64_t row = r0 + r;
+        if (row >= rows) break;
+        const float *t = tmp + row * n_out + first;
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < kBwdMaxTaps; ++j)
+            if (j < n) acc = fmaf(wk[j], t[j], acc);
+        gin[row * w_in + k] = acc;
+    }
+}
+
 // ---- up-scaling on both axes: two taps per axis, registers only (round 3) --------------------------------------------------
 // With scale <= 1 on both axes an output pixel has at most two taps per axis (support = 1), so neither the tap tables nor the
 // LDS strip of resize_strip_kernel are needed: a lane owns FOUR consecutive output pixels of a row.  Their taps lie in at most five
@@ -507,10 +591,13 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
     return e == hipSuccess ? PBR_OK : 1000 + (int)e;
 }
 
+// workspace layout (floats): tmp [planes][h_in][w_out] | inv_y [h_out] | inv_x [w_out] | wy [kBwdMaxTaps][h_in] | wx [kBwdMaxTaps][w_in] |
+// then ints: lo_y, cnt_y [h_in] | lo_x, cnt_x [w_in]
 size_t pbr_resize_backward_workspace_bytes(int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out, int32_t w_out) {
-    (void)w_in;
-    if (planes < 1 || h_in < 1 || h_out < 1 || w_out < 1) return 0;
-    return ((size_t)planes * (size_t)h_in * (size_t)w_out + (size_t)h_out + (size_t)w_out) * sizeof(float);
+    if (planes < 1 || h_in < 1 || w_in < 1 || h_out < 1 || w_out < 1) return 0;
+    const size_t words = (size_t)planes * (size_t)h_in * (size_t)w_out + (size_t)h_out + (size_t)w_out +
+                         (size_t)pbr::kBwdMaxTaps * ((size_t)h_in + (size_t)w_in) + 2 * ((size_t)h_in + (size_t)w_in) + 4;
+    return words * sizeof(float);
 }
 
 int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
@@ -518,16 +605,29 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
     using namespace pbr;
     if (!grad_out || !grad_in || !workspace) return PBR_ERR_NULL_MAP;
     if (planes < 1 || h_in < 1 || w_in < 1 || h_out < 1 || w_out < 1) return PBR_ERR_SHAPE;
+    if (planes * h_in > INT32_MAX) return PBR_ERR_SHAPE;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const AxisFilter fw = make_filter(w_in, w_out, antialias != 0), fh = make_filter(h_in, h_out, antialias != 0);
     float *tmp = static_cast<float *>(workspace);                    // [planes][h_in][w_out]
     float *inv_y = tmp + (size_t)planes * h_in * w_out, *inv_x = inv_y + h_out;
-    hipLaunchKernelGGL(resize_norm_kernel, dim3((h_out + 255) / 256), dim3(256), 0, s, inv_y, (int)h_out, fh);
-    hipLaunchKernelGGL(resize_norm_kernel, dim3((w_out + 255) / 256), dim3(256), 0, s, inv_x, (int)w_out, fw);
-    hipLaunchKernelGGL(resize_backward_rows_kernel, dim3(stream_grid(planes * h_in * w_out)), dim3(256), 0, s,
-                       static_cast<const float *>(grad_out), tmp, inv_y, planes, (int)h_out, (int)w_out, fh);
-    hipLaunchKernelGGL(resize_backward_cols_kernel, dim3(stream_grid(planes * h_in * w_in)), dim3(256), 0, s,
-                       tmp, static_cast<float *>(grad_in), inv_x, planes * h_in, (int)w_out, fw);
+    float *wy = inv_x + w_out, *wx = wy + (size_t)kBwdMaxTaps * h_in;
+    int *lo_y = reinterpret_cast<int *>(wx + (size_t)kBwdMaxTaps * w_in), *cnt_y = lo_y + h_in, *lo_x = cnt_y + h_in, *cnt_x = lo_x + w_in;
+    const auto g = static_cast<const float *>(grad_out);
+    float *gi = static_cast<float *>(grad_in);
+    auto fits = [](const AxisFilter &f) { return (int)((2.0f * f.support + 2.0f) / f.scale) + 2 <= kBwdMaxTaps; };
+    const int64_t grid_rows = (int64_t)((w_out + 1023) / 1024) * planes * h_in;
+    const int64_t grid_cols = (int64_t)((w_in + 255) / 256) * ((planes * h_in + kBwdRows - 1) / kBwdRows);
+    if (fits(fw) && fits(fh) && grid_rows <= INT32_MAX && grid_cols <= INT32_MAX) {          // table-driven passes
+        hipLaunchKernelGGL(resize_backward_table_kernel, dim3((h_in + 255) / 256), dim3(256), 0, s, lo_y, cnt_y, wy, (int)h_out, fh);
+        hipLaunchKernelGGL(resize_backward_table_kernel, dim3((w_in + 255) / 256), dim3(256), 0, s, lo_x, cnt_x, wx, (int)w_out, fw);
+        hipLaunchKernelGGL(resize_backward_rows_table_kernel, dim3((unsigned)grid_rows), dim3(256), 0, s, g, tmp, lo_y, cnt_y, wy, (int)h_in, (int)h_out, (int)w_out);
+        hipLaunchKernelGGL(resize_backward_cols_table_kernel, dim3((unsigned)grid_cols), dim3(256), 0, s, tmp, gi, lo_x, cnt_x, wx, planes * h_in, (int)w_in, (int)w_out);
+    } else {                                                                                  // many contributors per input: the generic passes
+        hipLaunchKernelGGL(resize_norm_kernel, dim3((h_out + 255) / 256), dim3(256), 0, s, inv_y, (int)h_out, fh);
+        hipLaunchKernelGGL(resize_norm_kernel, dim3((w_out + 255) / 256), dim3(256), 0, s, inv_x, (int)w_out, fw);
+        hipLaunchKernelGGL(resize_backward_rows_kernel, dim3(stream_grid(planes * h_in * w_out)), dim3(256), 0, s, g, tmp, inv_y, planes, (int)h_out, (int)w_out, fh);
+        hipLaunchKernelGGL(resize_backward_cols_kernel, dim3(stream_grid(planes * h_in * w_in)), dim3(256), 0, s, tmp, gi, inv_x, planes * h_in, (int)w_out, fw);
+    }
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? PBR_OK : 1000 + (int)e;
 }

@@ -221,5 +221,5 @@ if want("resize_bwd"):
     us = timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, S, S, ho, ho, 1, ws.data_ptr(), stream))
     # two kernels: rows pass (gradient [3][2048][2048] in, workspace [3][4096][2048] out), columns pass (workspace in, [3][4096][4096] out);
     # `us` is the whole call, the per-kernel durations come from the kernel trace
-    report("resize backward 3 x 2048^2 gradient -> 4096^2, rows pass", "resize_backward_rows_kernel", 12 * (ho * ho + S * ho), us, whole_call_us=round(us, 1))
-    report("resize backward 3 x 2048^2 gradient -> 4096^2, columns pass", "resize_backward_cols_kernel", 12 * (S * ho + PX), us, whole_call_us=round(us, 1))
+    report("resize backward 3 x 2048^2 gradient -> 4096^2, rows pass", "resize_backward_rows_table_kernel", 12 * (ho * ho + S * ho), us, whole_call_us=round(us, 1))
+    report("resize backward 3 x 2048^2 gradient -> 4096^2, columns pass", "resize_backward_cols_table_kernel", 12 * (S * ho + PX), us, whole_call_us=round(us, 1))

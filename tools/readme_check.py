@@ -29,3 +29,13 @@ print(a2.grad.abs().sum().item() > 0, light.grad, [t.shape for t in F.pack_maps(
 out = torch.ops.pbr_hip.cook_torrance(a[None], n[None], r[None], m[None], None, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([[0.1, 0.1, 1.0]]),
                                       torch.ones(1, 3), 1.0, 1, True, True, False, True)
 print(out.shape, torch.equal(out[0], color))
+from pypbr_amd.losses import RenderingLoss
+pred = material.clone()
+pred.albedo = pred._maps["albedo"].clone().requires_grad_()
+loss = RenderingLoss(light_type="point")(pred, material_a)
+loss.backward()
+print(type(loss.grad_fn).__name__, loss.item(), pred._maps["albedo"].grad is not None)
+a3 = a.clone().requires_grad_()
+loss = F.rendering_loss_mse(a3, n, r, m, target=color, view_dir=[0, 0, 1], light=[0.2, 0.1, 1.0], light_intensity=[1, 1, 1])
+loss.backward()
+print(loss.item(), a3.grad.abs().sum().item() > 0)

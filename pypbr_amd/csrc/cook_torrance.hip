@@ -39,6 +39,7 @@ int g_bwd_run = -1;
 int g_bwd_wide = -1;
 int g_batch_inner = -1;
 int g_interleave = 0;
+int g_tile_fold = -1;
 int g_scalar_base = 1;
 int g_max_vec = 8;
 
@@ -120,7 +121,7 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     // launch is then VALU-bound and wants every wave it can get (2048^2 tile(2): 81 us vs 122 us with the streaming
     // settings, 120 us for the materialised 4096^2 maps; tools/tile_probe.py).
     const bool tiled = k.tiled != 0;
-    const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0 && !tiled);
+    const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0 && (!tiled || g_nontemporal == 2));
     // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane
     const bool fp32_one_light = d->map_dtype == PBR_F32 && d->n_lights == 1 && k.bt_log2 == 6 && !tiled;
     size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (fp32_one_light ? kLdsFor11WavesPerCu : 0);
@@ -193,6 +194,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_BWD_VEC: slot = &pbr::g_bwd_vec; break;
         case PBR_TUNE_BATCH_INNER: slot = &pbr::g_batch_inner; break;
         case PBR_TUNE_INTERLEAVE: slot = &pbr::g_interleave; break;
+        case PBR_TUNE_TILE_FOLD: slot = &pbr::g_tile_fold; break;
         case PBR_TUNE_SCALAR_BASE: slot = &pbr::g_scalar_base; break;
         case PBR_TUNE_MAX_VEC: slot = &pbr::g_max_vec; break;
         case PBR_TUNE_RESIZE_ROWS: slot = &pbr::g_resize_rows; break;

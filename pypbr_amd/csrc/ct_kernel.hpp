@@ -62,6 +62,8 @@ struct KArgs {
     int32_t xcd_log2;        // workgroup -> tile remap: each XCD takes runs of (1 << xcd_log2) consecutive tiles (0 = identity)
     int32_t xcd_tiles;       // tiles covered by the remap: n_tiles rounded down to a multiple of 8 << xcd_log2
     int32_t ilv_b, ilv_tiles;// experiment (PBR_TUNE_INTERLEAVE): consecutive workgroups walk ilv_b materials round-robin, ilv_tiles tiles each
+    int32_t fold_log2, fold_reps;   // tiled maps: rows visited in bands of (1 << fold_log2) source rows, all fold_reps vertical repeats of a band back to back (0 = off)
+    FastDiv div_reps;        // band visit / fold_reps
     int32_t xpose;           // 8-pixel lanes, fp32 result: exchange the lanes' 16-byte pieces through LDS before storing
     int32_t sbase;           // every tile lies inside one material and every plane is < 4 GiB: scalar plane addresses (plane_at)
     FastDiv div_h;           // row / H
@@ -215,9 +217,21 @@ __device__ __forceinline__ uint32_t tile_of_workgroup(const KArgs &a, uint32_t w
         const uint32_t t = wg / (uint32_t)a.ilv_b, b = wg - t * (uint32_t)a.ilv_b;
         return b * (uint32_t)a.ilv_tiles + t;
     }
-    if (a.xcd_log2 == 0 || wg >= (uint32_t)a.xcd_tiles) return wg;
-    const uint32_t c = (uint32_t)a.xcd_log2, xcd = wg & 7u, slot = wg >> 3;
-    return ((slot >> c) << (c + 3)) + (xcd << c) + (slot & ((1u << c) - 1u));
+    uint32_t s = wg;
+    if (a.xcd_log2 != 0 && wg < (uint32_t)a.xcd_tiles) {
+        const uint32_t c = (uint32_t)a.xcd_log2, xcd = wg & 7u, slot = wg >> 3;
+        s = ((slot >> c) << (c + 3)) + (xcd << c) + (slot & ((1u << c) - 1u));
+    }
+    if (a.fold_log2 > 0) {
+        // tile(n) (MaterialBase.tile, base.py:524-537): output rows y and y + map_h read the same texels.  In row order the
+        // second visit comes map_h rows -- tens of MB of traffic -- later and misses every L2; here the launch walks bands of
+        // 1 << fold_log2 source rows and visits all vertical repeats of a band back to back.  A band is a whole number of
+        // 8-XCD periods of tiles (fill_args), so the XCD that fetched a texel is the one that reads it again.
+        const uint32_t f = (uint32_t)a.fold_log2, row = a.div_tx.div(s), tx = s - row * (uint32_t)a.tiles_x;
+        const uint32_t visit = row >> f, band = a.div_reps.div(visit), rep = visit - band * (uint32_t)a.fold_reps;
+        s = (rep * (uint32_t)a.map_h + (band << f) + (row & ((1u << f) - 1u))) * (uint32_t)a.tiles_x + tx;
+    }
+    return s;
 }
 
 constexpr int kXposeLdsPerWave = 3 * 144 * 16;       // shade_and_store's piece exchange (8-pixel lanes, fp32 result)

@@ -31,6 +31,7 @@ extern int g_resize_rows;          // resize.hip
 extern int g_resize_up2;           // resize.hip: two-tap register kernel for up-scales (1) or the strip kernel (0)
 extern int g_resize_xcd;           // resize.hip: XCD-contiguous tile order (1) or identity (0)
 extern int g_max_vec;              // A/B and test knob: at most this many pixels per lane (1 = the one-pixel kernels everywhere)
+extern int g_tile_fold;            // tiled maps: log2 of the source rows per band of the fold order (-1 = rule, 0 = row order)
 extern int g_interleave;           // experiment knob: materials of a batch interleaved workgroup by workgroup
 extern int g_bwd_vec;              // pixels per lane of the backward kernels: 0 = rule (ct_backward.hip), 2 | 4 = forced (A/B)
 extern int g_bwd_run;              // tiles per wave of the streamed backward kernel (fp16 maps, one light): -1 = rule, 0 = off, N = forced
@@ -167,6 +168,24 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log
     k.map_h = k.tiled ? d->map_height : d->height_total; k.map_w = k.tiled ? d->map_width : d->width;
     k.div_mh.init((uint32_t)k.map_h); k.div_mw.init((uint32_t)k.map_w);
     k.y_offset = d->y_offset; k.H_total = d->height_total;
+    k.div_reps.init(1);
+    // Measured (tools/tile_probe.py, 2048^2 maps, tile(2), MI355X): the fold order brings the read traffic from 2.0 x to 1.0002 x
+    // the source (PMC) -- and costs fp32 maps 8-17 % of time whatever the band (78-82 us in row order, 87-98 us folded, with or
+    // without the streaming hint): in row order the second visit is served by the 256 MB memory-side cache, and the launch is
+    // VALU-bound either way.  fp16 maps run level (65-69 us both).  The rule therefore folds fp16 maps only.
+    const bool fold_wanted = g_tile_fold > 0 || (g_tile_fold < 0 && d->map_dtype == PBR_F16);
+    if (k.tiled && fold_wanted && by == 1 && d->batch == 1 && d->y_offset == 0 && d->height == d->height_total && !k.ilv_b &&
+        d->height_total > d->map_height && k.n_tiles > 0) {
+        // rows per band: the band's texels (all planes) within ~2 MiB -- 1/8 of it per XCD, beside the result streams in a 4 MiB
+        // L2 -- a power of two that divides map_h, the band a whole number of XCD periods (tools/tile_probe.py: "fold").
+        const int64_t esz = d->map_dtype == PBR_F32 ? 4 : 2;
+        const int64_t row_bytes = (int64_t)d->map_width * esz * (3 + (d->normal.data ? 3 : 0) + 1 + (d->workflow == PBR_WORKFLOW_SPECULAR ? 3 : 1));
+        int fl = g_tile_fold > 0 ? g_tile_fold : 0;
+        if (g_tile_fold < 0) while (fl < 12 && (row_bytes << (fl + 1)) <= (2ll << 20)) ++fl;
+        const int64_t period = 8ll << k.xcd_log2;
+        while (fl > 0 && (d->map_height % (1 << fl) || (((int64_t)k.tiles_x << fl) % period))) --fl;
+        if (fl > 0) { k.fold_log2 = fl; k.fold_reps = d->height_total / d->map_height; k.div_reps.init((uint32_t)k.fold_reps); }
+    }
     // `light_size or 1.0` (:130) is Python truthiness: only None / 0 / 0.0 / -0.0 mean "not given"; a NEGATIVE size is truthy
     // and mirrors the grid (linspace from +|s|/2 down to -|s|/2), NaN is truthy too (the launcher fills the result, below).
     const float size = (d->light_size != 0.0f) ? d->light_size : 1.0f;

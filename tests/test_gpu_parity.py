@@ -674,6 +674,39 @@ def test_fused_tile_equals_materialised_repeat(h, w, tile, dtype, lights):
         F.cook_torrance(a, n, r, m, rows=4, **kw)
 
 
+@pytest.mark.parametrize("dtype,h,w,tile", [(torch.float16, 256, 512, (3, 2)), (torch.float32, 64, 256, (2, 2)), (torch.float16, 48, 1024, (4, 1))])
+def test_fused_tile_fold_order_is_bit_identical(dtype, h, w, tile):
+    """The fold order of a tiled launch (ct_kernel.hpp tile_of_workgroup: all vertical repeats of a band of source rows
+    back to back) is a permutation of the tiles: whatever the band and the XCD order under it, the image equals the
+    one evaluated on the materialised repeat (MaterialBase.tile, base.py:524-537), forward and backward."""
+    from pypbr_amd import functional as F, _native as N
+    ny, nx = tile
+    g = torch.Generator().manual_seed(11)
+    a = torch.rand(3, h, w, generator=g).cuda().to(dtype)
+    n = torch.cat([torch.rand(2, h, w, generator=g) - 0.5, torch.ones(1, h, w)], 0).cuda().to(dtype)
+    r = (torch.rand(1, h, w, generator=g) * 0.8 + 0.2).cuda().to(dtype)
+    m = torch.rand(1, h, w, generator=g).cuda().to(dtype)
+    kw = dict(view_dir=[0.1, 0, 1], light=[0.2, -0.1, 0.9], light_intensity=[1, 0.9, 0.8], light_type="point", light_size=2.0)
+    rep = lambda t: t.repeat(1, ny, nx)
+    ref = F.cook_torrance(rep(a), rep(n), rep(r), rep(m), **kw)
+    gout = torch.rand(ref.shape, generator=g).cuda()
+    leaves0 = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
+    try:
+        N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, 0)
+        (F.cook_torrance(*leaves0, tile=tile, **kw) * gout).sum().backward()
+        for fold in (-1, 1, 2, 3, 4, 8):
+            N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, fold)
+            for sched in (N.SCHEDULE_AUTO, N.SCHEDULE_LINEAR, N.schedule_xcd(1), N.schedule_xcd(3)):
+                out = F.cook_torrance(a, n, r, m, tile=tile, schedule=sched, **kw)
+                assert torch.equal(out, ref), (fold, sched)
+            leaves = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
+            (F.cook_torrance(*leaves, tile=tile, schedule=N.SCHEDULE_LINEAR, **kw) * gout).sum().backward()
+            for x, y in zip(leaves, leaves0):
+                assert torch.equal(x.grad, y.grad), fold
+    finally:
+        N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, -1)
+
+
 def test_fused_tile_gradients_and_material_api():
     from pypbr_amd import functional as F
     from pypbr_amd.materials import BasecolorMetallicMaterial

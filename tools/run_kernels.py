@@ -126,6 +126,11 @@ if want("tiled"):
     report("tiled: 2048^2 maps, fused tile(2) -> 4096^2 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out)",
            "cook_torrance_kernel<1, 0, float, float, 4, false, false>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
     del maps, p
+    maps = [t.half() for t in synth_material(2048, DEV, 32)]
+    p = F.plan_cook_torrance(*maps, tile=2, **PT)
+    report("tiled_f16: 2048^2 fp16 maps, fused tile(2) -> 4096^2 fp32 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out)",
+           "cook_torrance_kernel<1, 0, __half, float, 8, false, false>", 16 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
+    del maps, p
 if want("map_ops"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)

@@ -41,3 +41,22 @@ for nt in (1, 0):          # the nt knob only reaches un-tiled launches: tiled o
         te, tl = timed(eager), timed(lazy)
         print(f"{S}^2 tile({n}) nt={nt} lds={lds}: materialised {te:7.1f} us ({44 * px / te / 1e3:6.0f} GB/s alg.)   "
               f"fused {tl:7.1f} us ({px / tl / 1e3:6.1f} Gpix/s, {lazy.bytes_per_pixel} B/px -> {lazy.bytes_per_pixel * px / tl / 1e3:6.0f} GB/s)", flush=True)
+
+# fold order (PBR_TUNE_TILE_FOLD): all vertical repeats of a band of source rows back to back; bit-identical results
+N.lib().pbr_set_tuning(N.TUNE_NONTEMPORAL, 1)
+N.lib().pbr_set_tuning(N.TUNE_LDS_BYTES, -1)
+want = eager.launch().clone()
+for dt in (torch.float32, torch.float16):
+    mm = [t.to(dt) for t in maps]
+    for xcd in (-1, 2):        # 2 here: the streaming hint on tiled launches too (TUNE_NONTEMPORAL = 2), built-in order
+        N.lib().pbr_set_tuning(N.TUNE_NONTEMPORAL, 2 if xcd == 2 else 1)
+        for fold in (0, -1, 5, 6, 7, 8):
+            N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, fold)
+            pl = F.plan_cook_torrance(*mm, tile=n, **kw)
+            N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, 0)
+            ref = F.plan_cook_torrance(*mm, tile=n, **kw).launch().clone()
+            N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, fold)
+            same = torch.equal(pl.launch(), ref)
+            print(f"{S}^2 tile({n}) {str(dt)[6:]} nt={2 if xcd == 2 else 1} fold={fold:2d}: {timed(pl):7.1f} us  bit-identical to row order: {same}", flush=True)
+N.lib().pbr_set_tuning(N.TUNE_NONTEMPORAL, 1)
+N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, -1)

@@ -195,6 +195,8 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_BATCH_INNER: slot = &pbr::g_batch_inner; break;
         case PBR_TUNE_INTERLEAVE: slot = &pbr::g_interleave; break;
         case PBR_TUNE_TILE_FOLD: slot = &pbr::g_tile_fold; break;
+        case PBR_TUNE_RESIZE_BWD_FUSED: slot = &pbr::g_resize_bwd_fused; break;
+        case PBR_TUNE_RESIZE_QUADS: slot = &pbr::g_resize_quads; break;
         case PBR_TUNE_SCALAR_BASE: slot = &pbr::g_scalar_base; break;
         case PBR_TUNE_MAX_VEC: slot = &pbr::g_max_vec; break;
         case PBR_TUNE_RESIZE_ROWS: slot = &pbr::g_resize_rows; break;

@@ -28,6 +28,8 @@ extern int g_lds_bytes;
 extern int g_batch_inner;          // materials per lane of the several-lights kernels: -1 = rule (4 | 2 | off), 0 = off, 2 | 4 = forced
 extern int g_scalar_base;          // scalar plane addresses (KArgs::sbase): 0 never, 1 = rule (single materials), 2 = whenever the launch allows them
 extern int g_resize_rows;          // resize.hip
+extern int g_resize_bwd_fused;     // resize.hip: gradient of resize in one pass (1) or two passes through the workspace (0)
+extern int g_resize_quads;         // resize.hip: 16-byte stores in the strip kernel's width pass
 extern int g_resize_up2;           // resize.hip: two-tap register kernel for up-scales (1) or the strip kernel (0)
 extern int g_resize_xcd;           // resize.hip: XCD-contiguous tile order (1) or identity (0)
 extern int g_max_vec;              // A/B and test knob: at most this many pixels per lane (1 = the one-pixel kernels everywhere)

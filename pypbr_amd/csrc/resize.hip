@@ -36,6 +36,8 @@
 namespace pbr {
 
 int g_resize_xcd = 1;              // XCD-contiguous tile order of the strip kernel: 1 = chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many tiles (A/B knob PBR_TUNE_RESIZE_XCD)
+int g_resize_quads = 1;           // strip kernel's width pass with four columns per lane and 16-byte stores: 1 = rule (gradients at least twice their upstream), 2 = wherever legal, 0 = never (A/B knob PBR_TUNE_RESIZE_QUADS)
+int g_resize_bwd_fused = 1;       // the gradient in one pass (strip kernel, transposed tables); 0: two passes through the workspace (A/B knob PBR_TUNE_RESIZE_BWD_FUSED)
 int g_resize_up2 = 1;              // up-scales take the two-tap register kernel (0: the strip kernel, A/B knob PBR_TUNE_RESIZE_UP2)
 int g_resize_rows = 0;             // output rows per tile of the strip form: 0 = rule, else forced (A/B knob PBR_TUNE_RESIZE_ROWS)
 
@@ -177,7 +179,7 @@ constexpr int kTileW = 64;
 // Only taps inside a window are ever used (0 x inf must not become NaN).  The sums are formed height-first, ATen's
 // width-first: the same products added in another order, a few ulp apart (tests: <= 2e-6 from ATen).
 // LDS: wx[K][64] wy[K][toh] | xo[64] xn[64] yo[toh] yn[toh] | mid[toh][pitch] + 16 floats of slack.
-struct StripGeom { int toh, tiles_x, tiles_y, kx, ky, pitch, vec_ok, xcd_chunk, xcd_tiles; };     // XCD-contiguous order: tiles per chunk (0 = identity), tiles covered by whole blocks of 8 chunks
+struct StripGeom { int toh, tiles_x, tiles_y, kx, ky, pitch, vec_ok, xcd_chunk, xcd_tiles, quads; };     // XCD-contiguous order: tiles per chunk (0 = identity), tiles covered by whole blocks of 8 chunks
 
 template <int K, bool VEC>
 __device__ __forceinline__ void height_from_global(const float *__restrict__ sp, float *mid, const float *wy, const int *yo, const int *yn,
@@ -252,8 +254,44 @@ __device__ __forceinline__ void width_to_global(const float *mid, float *dp, con
     }
 }
 
+// The same pass with FOUR consecutive columns per lane and 16-byte stores (rows of the result 16-byte aligned, whole quads): the
+// launches that write more than they read -- the gradient of a down-scale, 4 output bytes per input byte at 2x -- are bound by
+// their stores, and a wave's 4-byte stores fill a 256-byte piece of a row where its 16-byte stores fill four rows of the tile.
+// Same taps, same order per column: bit-identical to the one-column form.
+template <int K>
+__device__ __forceinline__ void width_to_global_quads(const float *mid, float *dp, const float *wx, const int *xo, const int *xn, int pitch,
+                                                      int oh, int ow, int oy0, int ox0, int w_out, int tid) {
+    constexpr int kLanes = kTileW / 4;                                       // lanes per tile row
+    const int i4 = (tid & (kLanes - 1)) * 4;
+    if (i4 >= ow) return;
+    int off[4], n[4];
+    float w[4][K];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        off[c] = xo[i4 + c]; n[c] = xn[i4 + c];
+#pragma unroll
+        for (int j = 0; j < K; ++j) w[c][j] = j < n[c] ? wx[j * kTileW + i4 + c] : 0.0f;
+    }
+    for (int r = tid / kLanes; r < oh; r += 256 / kLanes) {
+        const float *q = mid + r * pitch;
+        float a[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < K; ++j) a[c] = fmaf(w[c][j], j < n[c] ? q[off[c] + j] : 0.0f, a[c]);
+        *reinterpret_cast<float4 *>(dp + (int64_t)(oy0 + r) * w_out + ox0 + i4) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+
+// TABLES (the gradient, pbr_resize_bilinear_backward): the same two phases with the tap tables TRANSPOSED -- per gradient-input
+// index k the first upstream index that reads it, their number and the normalised weights, as resize_backward_tables_kernel
+// wrote them to global memory -- instead of derived from the filter: "dst" is the gradient of the resize's input, "src" the
+// upstream gradient.  Phase 0 copies the tile's slices of the tables into the same LDS arrays; phases 1 and 2 do not change.
+struct StripTables { const int *lo_x, *cnt_x, *lo_y, *cnt_y; const float *w_x, *w_y; int nx, ny, h_src; };
+
+template <bool TABLES>
 __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_out,
-                                                           int w_out, int w_in, StripGeom tg, AxisFilter fw, AxisFilter fh) {
+                                                           int w_out, int w_in, StripGeom tg, AxisFilter fw, AxisFilter fh, StripTables tb) {
     extern __shared__ float lds[];
     float *wx = lds, *wy = wx + tg.kx * kTileW;
     int *xo = reinterpret_cast<int *>(wy + tg.ky * tg.toh), *xn = xo + kTileW, *yo = xn + kTileW, *yn = yo + tg.toh;
@@ -275,23 +313,44 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
     const int ox0 = tx * kTileW, oy0 = ty * tg.toh;
     const int ow = min(kTileW, w_out - ox0), oh = min(tg.toh, h_out - oy0);
     const int tid = threadIdx.x;
-    int xlo, n0, xl, nl; float c0;                                   // tap windows are monotone in the output index
-    tap_window(fw, ox0, xlo, n0, c0);
-    tap_window(fw, ox0 + ow - 1, xl, nl, c0);
-    const int xbase = tg.vec_ok ? (xlo & ~3) : xlo;
-    const int in_cols = xl + nl - xbase;
+    int xlo = 0, n0, xl = 0, nl = 0; float c0;                       // tap windows are monotone in the output index
+    __shared__ int win[2];
+    if (TABLES) {
+        // the upstream columns the tile reads: first and one-past-last over its columns WITH contributors (without antialiasing a
+        // down-scale leaves columns that no output reads: cnt = 0)
+        if (tid < kTileW) {
+            int lo = INT32_MAX, hi = 0;
+            if (tid < ow) {
+                const int n = tb.cnt_x[ox0 + tid];
+                if (n > 0) { lo = tb.lo_x[ox0 + tid]; hi = lo + n; }
+            }
+            for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+            if (tid == 0) { win[0] = lo == INT32_MAX ? 0 : lo; win[1] = lo == INT32_MAX ? 0 : hi; }
+        }
+    } else {
+        tap_window(fw, ox0, xlo, n0, c0);
+        tap_window(fw, ox0 + ow - 1, xl, nl, c0);
+    }
     // ---- phase 0: tap tables (wave 0: columns; waves 1-3: rows, with their ABSOLUTE first input row) and the largest tap counts
     if (tid < 2) tap_max[tid] = 0;
     __syncthreads();
+    if (TABLES) { xlo = win[0]; xl = win[1]; }
+    const int xbase = tg.vec_ok ? (xlo & ~3) : xlo;
+    const int in_cols = xl + nl - xbase;
     if (tid < kTileW) {
         int xmin = 0, n = 0; float center = 0.0f, wsum = 0.0f;
-        if (tid < ow) {
-            tap_window(fw, ox0 + tid, xmin, n, center);
-            for (int j = 0; j < n; ++j) wsum += tap_weight(fw, j, xmin, center);
+        if (TABLES) {
+            if (tid < ow) { xmin = tb.lo_x[ox0 + tid]; n = min(tb.cnt_x[ox0 + tid], tg.kx); }
+            for (int j = 0; j < tg.kx; ++j) wx[j * kTileW + tid] = j < n ? tb.w_x[(size_t)j * tb.nx + ox0 + tid] : 0.0f;
+        } else {
+            if (tid < ow) {
+                tap_window(fw, ox0 + tid, xmin, n, center);
+                for (int j = 0; j < n; ++j) wsum += tap_weight(fw, j, xmin, center);
+            }
+            const float inv = wsum != 0.0f ? 1.0f / wsum : 0.0f;
+            for (int j = 0; j < tg.kx; ++j) wx[j * kTileW + tid] = j < n ? tap_weight(fw, j, xmin, center) * inv : 0.0f;
         }
-        const float inv = wsum != 0.0f ? 1.0f / wsum : 0.0f;
-        for (int j = 0; j < tg.kx; ++j) wx[j * kTileW + tid] = j < n ? tap_weight(fw, j, xmin, center) * inv : 0.0f;
-        xo[tid] = tid < ow ? xmin - xbase : 0;
+        xo[tid] = tid < ow && n > 0 ? xmin - xbase : 0;
         xn[tid] = n;
         int m = n;
         for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
@@ -300,12 +359,17 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
         int m = 0;
         for (int o = tid - kTileW; o < tg.toh; o += 256 - kTileW) {
             int ymin = 0, n = 0; float center = 0.0f, wsum = 0.0f;
-            if (o < oh) {
-                tap_window(fh, oy0 + o, ymin, n, center);
-                for (int j = 0; j < n; ++j) wsum += tap_weight(fh, j, ymin, center);
+            if (TABLES) {
+                if (o < oh) { ymin = tb.lo_y[oy0 + o]; n = min(tb.cnt_y[oy0 + o], tg.ky); }
+                for (int j = 0; j < tg.ky; ++j) wy[j * tg.toh + o] = j < n ? tb.w_y[(size_t)j * tb.ny + oy0 + o] : 0.0f;
+            } else {
+                if (o < oh) {
+                    tap_window(fh, oy0 + o, ymin, n, center);
+                    for (int j = 0; j < n; ++j) wsum += tap_weight(fh, j, ymin, center);
+                }
+                const float inv = wsum != 0.0f ? 1.0f / wsum : 0.0f;
+                for (int j = 0; j < tg.ky; ++j) wy[j * tg.toh + o] = j < n ? tap_weight(fh, j, ymin, center) * inv : 0.0f;
             }
-            const float inv = wsum != 0.0f ? 1.0f / wsum : 0.0f;
-            for (int j = 0; j < tg.ky; ++j) wy[j * tg.toh + o] = j < n ? tap_weight(fh, j, ymin, center) * inv : 0.0f;
             yo[o] = ymin;
             yn[o] = n;
             m = max(m, n);
@@ -316,7 +380,7 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
     __syncthreads();
     const int kx = tap_max[0], ky = tap_max[1];
     // ---- phase 1: height pass, global -> mid
-    const float *sp = src + (int64_t)plane * fh.n_in * w_in + xbase;
+    const float *sp = src + (int64_t)plane * (TABLES ? tb.h_src : fh.n_in) * w_in + xbase;
     const int cols_left = w_in - xbase;
 #define PBR_HEIGHT(KK) (tg.vec_ok ? height_from_global<KK, true>(sp, mid, wy, yo, yn, tg.toh, oh, in_cols, tg.pitch, w_in, cols_left, tid) \
                                   : height_from_global<KK, false>(sp, mid, wy, yo, yn, tg.toh, oh, in_cols, tg.pitch, w_in, cols_left, tid))
@@ -329,11 +393,15 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
     __syncthreads();
     // ---- phase 2: width pass, mid -> output
     float *dp = dst + (int64_t)plane * h_out * w_out;
-    if (kx <= 4) width_to_global<4>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid);
-    else if (kx <= 6) width_to_global<6>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid);
-    else if (kx <= 8) width_to_global<8>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid);
-    else if (kx <= 12) width_to_global<12>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid);
+    const bool quads = tg.quads && (ow & 3) == 0;
+#define PBR_WIDTH(KK) (quads ? width_to_global_quads<KK>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid) \
+                             : width_to_global<KK>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid))
+    if (kx <= 4) PBR_WIDTH(4);
+    else if (kx <= 6) PBR_WIDTH(6);
+    else if (kx <= 8) PBR_WIDTH(8);
+    else if (kx <= 12) PBR_WIDTH(12);
     else width_to_global<16>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid);
+#undef PBR_WIDTH
 }
 
 
@@ -344,9 +412,8 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
 // More than kBwdMaxTaps contributors per input (up-scales from ~3x on) keep the generic kernels: the launcher decides from the
 // scale (contributors <= (2 support + 2) / scale + 2).
 constexpr int kBwdMaxTaps = 12;
-__global__ __launch_bounds__(256) void resize_backward_table_kernel(int *__restrict__ lo_out, int *__restrict__ cnt_out, float *__restrict__ w,
-                                                                    int n_out, AxisFilter f) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void backward_table_entry(int *__restrict__ lo_out, int *__restrict__ cnt_out, float *__restrict__ w, int n_out,
+                                                     const AxisFilter &f, int k) {
     if (k >= f.n_in) return;
     int lo, hi, first = -1, n = 0;
     candidates(f, k, n_out, lo, hi);
@@ -365,6 +432,14 @@ __global__ __launch_bounds__(256) void resize_backward_table_kernel(int *__restr
     for (int j = n; j < kBwdMaxTaps; ++j) w[(size_t)j * f.n_in + k] = 0.0f;
     lo_out[k] = first < 0 ? 0 : first;
     cnt_out[k] = n;
+}
+
+// both axes in one launch: workgroups [0, groups_y) write the row tables, the others the column tables
+__global__ __launch_bounds__(256) void resize_backward_tables_kernel(int *__restrict__ lo_y, int *__restrict__ cnt_y, float *__restrict__ wy, int h_out,
+                                                                     AxisFilter fh, int *__restrict__ lo_x, int *__restrict__ cnt_x,
+                                                                     float *__restrict__ wx, int w_out, AxisFilter fw, int groups_y) {
+    if ((int)blockIdx.x < groups_y) backward_table_entry(lo_y, cnt_y, wy, h_out, fh, blockIdx.x * 256 + threadIdx.x);
+    else backward_table_entry(lo_x, cnt_x, wx, w_out, fw, (blockIdx.x - groups_y) * 256 + threadIdx.x);
 }
 
 // rows pass: tmp[plane][k][x] = sum_j wy[j][k] g[plane][lo[k] + j][x].  One input row k per workgroup row: lo / cnt / weights are
@@ -574,9 +649,10 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
                 // down-scales but 4 % slower for large up-scales (eight write fronts far apart); 32 ... 1024 tiles are within 2 %.
                 int64_t chunk = g_resize_xcd == 0 ? 0 : (g_resize_xcd >= 8 ? g_resize_xcd : (g_resize_xcd == 2 ? n_tiles / 8 : 64));
                 if (chunk > n_tiles / 8) chunk = n_tiles / 8;
-                const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0)};
-                hipLaunchKernelGGL(resize_strip_kernel, dim3((unsigned)(planes * tx * tyy)), dim3(256), lds, s,
-                                   static_cast<const float *>(src), static_cast<float *>(dst), (int)h_out, (int)w_out, (int)w_in, tg, fw, fh);
+                const int quads = g_resize_quads == 2 && w_out % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;      // forward down-scales: 62.7 against 54.0 us with them (4096^2 -> 2048^2), so only on demand
+                const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0), quads};
+                hipLaunchKernelGGL(resize_strip_kernel<false>, dim3((unsigned)(planes * tx * tyy)), dim3(256), lds, s,
+                                   static_cast<const float *>(src), static_cast<float *>(dst), (int)h_out, (int)w_out, (int)w_in, tg, fw, fh, StripTables{});
                 const hipError_t e = hipGetLastError();
                 return e == hipSuccess ? PBR_OK : 1000 + (int)e;
             }
@@ -617,11 +693,42 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
     auto fits = [](const AxisFilter &f) { return (int)((2.0f * f.support + 2.0f) / f.scale) + 2 <= kBwdMaxTaps; };
     const int64_t grid_rows = (int64_t)((w_out + 1023) / 1024) * planes * h_in;
     const int64_t grid_cols = (int64_t)((w_in + 255) / 256) * ((planes * h_in + kBwdRows - 1) / kBwdRows);
-    if (fits(fw) && fits(fh) && grid_rows <= INT32_MAX && grid_cols <= INT32_MAX) {          // table-driven passes
-        hipLaunchKernelGGL(resize_backward_table_kernel, dim3((h_in + 255) / 256), dim3(256), 0, s, lo_y, cnt_y, wy, (int)h_out, fh);
-        hipLaunchKernelGGL(resize_backward_table_kernel, dim3((w_in + 255) / 256), dim3(256), 0, s, lo_x, cnt_x, wx, (int)w_out, fw);
-        hipLaunchKernelGGL(resize_backward_rows_table_kernel, dim3((unsigned)grid_rows), dim3(256), 0, s, g, tmp, lo_y, cnt_y, wy, (int)h_in, (int)h_out, (int)w_out);
-        hipLaunchKernelGGL(resize_backward_cols_table_kernel, dim3((unsigned)grid_cols), dim3(256), 0, s, tmp, gi, lo_x, cnt_x, wx, planes * h_in, (int)w_in, (int)w_out);
+    if (fits(fw) && fits(fh) && grid_rows <= INT32_MAX && grid_cols <= INT32_MAX) {          // table-driven
+        const int groups_y = (h_in + 255) / 256, groups_x = (w_in + 255) / 256;
+        hipLaunchKernelGGL(resize_backward_tables_kernel, dim3(groups_y + groups_x), dim3(256), 0, s, lo_y, cnt_y, wy, (int)h_out, fh, lo_x, cnt_x, wx,
+                           (int)w_out, fw, groups_y);
+        // One pass: the strip kernel with the transposed tables (resize_strip_kernel<true>): a toh x 64 tile of the gradient, the
+        // rows pass from global memory into the LDS strip, the columns pass out of it.  3 x 2048^2 gradient -> 4096^2: see DESIGN.md 3.8.
+        const int kx = (int)((2.0f * fw.support + 2.0f) / fw.scale) + 2, ky = (int)((2.0f * fh.support + 2.0f) / fh.scale) + 2;     // <= kBwdMaxTaps
+        const bool vec_ok = w_out % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0;
+        const int cols_max = (int)((float)(kTileW - 1 + 2.0f * fw.support) / fw.scale) + 8;     // upstream columns a tile of 64 reads, + alignment
+        const int pitch = ((cols_max + 3) & ~3) + 4;
+        auto lds_for = [&](int rows) {
+            return sizeof(float) * ((size_t)kx * kTileW + (size_t)ky * rows + 2 * (kTileW + rows) + (size_t)rows * pitch + 16);
+        };
+        // Rows per tile: here more rows win up to ~48 KiB of LDS (tools/resize_bwd_probe.py, us at 32 / 64 / 128 rows: 2048^2 -> 4096^2
+        // 123 / 79 / 67, 3000^2 -> 4096^2 138 / 98 / 84, 6144^2 -> 4096^2 184 / 150 / -, 4096^2 -> 2048^2 59 / 60 / 115): the strip's
+        // halo rows are re-read per tile, and a gradient tile reads few bytes for what it writes.
+        int toh = 8;
+        for (int rows : {128, 64, 32, 16})
+            if (lds_for(rows) <= 48 * 1024) { toh = rows; break; }
+        if (g_resize_rows > 0) toh = g_resize_rows;
+        const size_t lds = lds_for(toh);
+        const int64_t tx = (w_in + kTileW - 1) / kTileW, tyy = (h_in + toh - 1) / toh, n_tiles = planes * tx * tyy;
+        if (g_resize_bwd_fused && lds <= 64 * 1024 && n_tiles <= INT32_MAX) {
+            int64_t chunk = g_resize_xcd == 0 ? 0 : (g_resize_xcd >= 8 ? g_resize_xcd : (g_resize_xcd == 2 ? n_tiles / 8 : 64));
+            if (chunk > n_tiles / 8) chunk = n_tiles / 8;
+            // 16-byte stores where the gradient is at least twice its upstream (2048^2 -> 4096^2: 66.7 against 69.3 us; the other way,
+            // 4096^2 -> 2048^2, 70.6 against 59.4: a quarter of the lanes then walk the LDS strip)
+            const int quads = (g_resize_quads == 2 || (g_resize_quads == 1 && (int64_t)h_in * w_in >= 2 * (int64_t)h_out * w_out)) && w_in % 4 == 0 &&
+                              (reinterpret_cast<uintptr_t>(grad_in) & 15u) == 0;
+            const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0), quads};
+            const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out};
+            hipLaunchKernelGGL(resize_strip_kernel<true>, dim3((unsigned)n_tiles), dim3(256), lds, s, g, gi, (int)h_in, (int)w_in, (int)w_out, tg, fw, fh, tb);
+        } else {                                                                              // two passes through the workspace
+            hipLaunchKernelGGL(resize_backward_rows_table_kernel, dim3((unsigned)grid_rows), dim3(256), 0, s, g, tmp, lo_y, cnt_y, wy, (int)h_in, (int)h_out, (int)w_out);
+            hipLaunchKernelGGL(resize_backward_cols_table_kernel, dim3((unsigned)grid_cols), dim3(256), 0, s, tmp, gi, lo_x, cnt_x, wx, planes * h_in, (int)w_in, (int)w_out);
+        }
     } else {                                                                                  // many contributors per input: the generic passes
         hipLaunchKernelGGL(resize_norm_kernel, dim3((h_out + 255) / 256), dim3(256), 0, s, inv_y, (int)h_out, fh);
         hipLaunchKernelGGL(resize_norm_kernel, dim3((w_out + 255) / 256), dim3(256), 0, s, inv_x, (int)w_out, fw);

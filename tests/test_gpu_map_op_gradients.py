@@ -155,6 +155,40 @@ def test_resize_gradient_full_size_adjoint():
         assert bool(torch.isfinite(x.grad).all())
 
 
+@pytest.mark.parametrize("shape,size,antialias", [((37, 53), (20, 31), True), ((64, 256), (32, 128), True), ((200, 260), (67, 90), True),
+                                                  ((40, 64), (100, 160), False), ((130, 131), (129, 64), True), ((256, 512), (128, 256), True)])
+def test_resize_gradient_one_pass_equals_two_passes(shape, size, antialias):
+    """pbr_resize_bilinear_backward in one pass (the strip kernel with the transposed tap tables, 4-byte and 16-byte stores) forms the
+    same sums in the same order as its two passes through the workspace: bit-identical, ragged tiles and unaligned rows included."""
+    from pypbr_amd import _native as N
+    lib = N.lib()
+    g = torch.Generator().manual_seed(14)
+    (h, w), (ho, wo) = shape, size
+    gout = (torch.rand(3, ho, wo, generator=g) - 0.5).cuda()
+    ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(3, h, w, ho, wo) // 4), device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    got = {}
+    try:
+        for fused, quads, rows in ((0, 1, 0), (1, 0, 0), (1, 2, 0), (1, 2, 16), (1, 1, 32)):
+            lib.pbr_set_tuning(N.TUNE_RESIZE_BWD_FUSED, fused)
+            lib.pbr_set_tuning(N.TUNE_RESIZE_QUADS, quads)
+            lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, rows)
+            gin = torch.full((3, h, w), float("nan"), device="cuda")
+            N.check(lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, h, w, ho, wo, int(antialias), ws.data_ptr(), stream))
+            got[(fused, quads, rows)] = gin
+    finally:
+        lib.pbr_set_tuning(N.TUNE_RESIZE_BWD_FUSED, 1)
+        lib.pbr_set_tuning(N.TUNE_RESIZE_QUADS, 1)
+        lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, 0)
+    ref = got[(0, 1, 0)]
+    assert bool(torch.isfinite(ref).all())
+    for key, val in got.items():
+        assert torch.equal(val, ref), key
+    x = torch.zeros(1, 3, h, w, dtype=torch.float64, requires_grad=True)
+    (TF.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False, antialias=antialias)[0] * gout.cpu().double()).sum().backward()
+    assert (ref.cpu().double() - x.grad[0]).abs().max().item() <= 2e-5
+
+
 def test_sigmoid_mask_gradient_and_height_blend_through_the_mask():
     from pypbr_amd import blending as B
     g = torch.Generator().manual_seed(6)

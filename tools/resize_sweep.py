@@ -17,6 +17,8 @@ cases = [(2048, True), (1024, True), (3000, True), (1365, True), (6144, False), 
 rows = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,4,8,16,32,64").split(",")]
 if len(sys.argv) > 2:                     # second argument: tile order, 1 = XCD-contiguous (default), 0 = identity
     lib.pbr_set_tuning(N.TUNE_RESIZE_XCD, int(sys.argv[2]))
+if len(sys.argv) > 3:                     # third: width pass with 16-byte stores (1, default) or one column per lane (0)
+    lib.pbr_set_tuning(N.TUNE_RESIZE_QUADS, int(sys.argv[3]))
 for ho, aa in cases:
     out = torch.empty(3, ho, ho, device=dev)
     ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, S, ho) // 4), device=dev)

@@ -13,6 +13,7 @@
 
 #include "../../include/pbr_hip.h"
 #include "brdf_math.hpp"
+#include "stream_shape.hpp"
 
 namespace pbr {
 
@@ -214,9 +215,9 @@ int pbr_blend_maps(const void *map1, const void *map2, const void *mask, void *o
     auto a = static_cast<const float *>(map1), b = static_cast<const float *>(map2), m = static_cast<const float *>(mask);
     const int vec_ok = pixels % 4 == 0 && ((reinterpret_cast<uintptr_t>(map1) | reinterpret_cast<uintptr_t>(map2) | reinterpret_cast<uintptr_t>(mask) |
                                             reinterpret_cast<uintptr_t>(out)) & 15u) == 0;
-    const dim3 grid(blend_grid(vec_ok ? pixels / 4 : pixels));
-    if (is_normal) hipLaunchKernelGGL(blend_kernel<true>, grid, dim3(256), 0, s, a, b, m, static_cast<float *>(out), 3, pixels, vec_ok);
-    else hipLaunchKernelGGL(blend_kernel<false>, grid, dim3(256), 0, s, a, b, m, static_cast<float *>(out), (int)channels, pixels, vec_ok);
+    const StreamShape sh = stream_shape((size_t)(vec_ok ? pixels / 4 : pixels), is_normal ? kShapeBlendNormal : kShapeBlend);
+    if (is_normal) hipLaunchKernelGGL(blend_kernel<true>, dim3(sh.grid), dim3(sh.block), sh.lds, s, a, b, m, static_cast<float *>(out), 3, pixels, vec_ok);
+    else hipLaunchKernelGGL(blend_kernel<false>, dim3(sh.grid), dim3(sh.block), sh.lds, s, a, b, m, static_cast<float *>(out), (int)channels, pixels, vec_ok);
     return blend_status();
 }
 
@@ -225,7 +226,8 @@ int pbr_blend_sigmoid_mask(const void *prop1, const void *prop2, void *mask, int
     using namespace pbr;
     if (!prop1 || !prop2 || !mask) return PBR_ERR_NULL_MAP;
     if (n < 1) return PBR_ERR_SHAPE;
-    hipLaunchKernelGGL(sigmoid_mask_kernel, dim3(blend_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream),
+    const StreamShape sh = stream_shape((size_t)n, kShapeMask);
+    hipLaunchKernelGGL(sigmoid_mask_kernel, dim3(sh.grid), dim3(sh.block), sh.lds, static_cast<hipStream_t>(stream),
                        static_cast<const float *>(prop1), static_cast<const float *>(prop2), static_cast<float *>(mask), n,
                        shift, 1.0f / (blend_width + 1e-6f));
     return blend_status();
@@ -268,10 +270,9 @@ int pbr_blend_maps_backward(const void *map1, const void *map2, const void *mask
     for (const void *p : {map1, map2, mask, grad_out, (const void *)g_map1, (const void *)g_map2, (const void *)g_mask})
         if (p && (reinterpret_cast<uintptr_t>(p) & 15u)) vec = false;
     if (vec) {
-        const int64_t vblocks = (pixels / 4 + 255) / 256;
-        const dim3 vgrid((unsigned)(vblocks > 256 * 8 ? 256 * 8 : vblocks));
-        if (is_normal) hipLaunchKernelGGL((blend_backward_kernel<true, 4>), vgrid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
-        else hipLaunchKernelGGL((blend_backward_kernel<false, 4>), vgrid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
+        const StreamShape sh = stream_shape((size_t)(pixels / 4), kShapeBlendBwd);
+        if (is_normal) hipLaunchKernelGGL((blend_backward_kernel<true, 4>), dim3(sh.grid), dim3(sh.block), sh.lds, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
+        else hipLaunchKernelGGL((blend_backward_kernel<false, 4>), dim3(sh.grid), dim3(sh.block), sh.lds, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
     } else if (is_normal) {
         hipLaunchKernelGGL((blend_backward_kernel<true, 1>), grid, dim3(256), 0, s, a, b, k, g, ga, gb, gk, (int)channels, pixels, accumulate_mask);
     } else {

@@ -11,6 +11,7 @@
 
 #include "../../include/pbr_hip.h"
 #include "ct_kernel.hpp"
+#include "stream_shape.hpp"
 
 namespace pbr {
 

@@ -15,6 +15,7 @@
 
 #include "../../include/pbr_hip.h"
 #include "brdf_math.hpp"
+#include "stream_shape.hpp"
 
 namespace pbr {
 
@@ -512,6 +513,8 @@ __global__ __launch_bounds__(256) void specular_to_metallic_backward_kernel(cons
     }
 }
 
+int g_stream_shape = -1, g_stream_lds = -1;      // launch shape of the streaming kernels: ct_launch.hpp
+
 static inline unsigned stream_grid(size_t work_items) {
     const size_t blocks = (work_items + 255) / 256;
     const size_t cap = 256 * 8;                                     // 256 CUs x 8 blocks, grid-stride beyond
@@ -550,14 +553,14 @@ static int colour_launch(const void *src, void *dst, size_t n, int dtype, void *
     if (n == 0) return PBR_OK;
     const size_t al = dtype == PBR_F32 ? 16 : 8;
     const int vec_ok = is_aligned(src, al) && is_aligned(dst, al);
-    const unsigned grid = stream_grid(vec_ok ? (n + 3) / 4 : n);
+    const StreamShape sh = stream_shape(vec_ok ? (n + 3) / 4 : n, kShapeColour);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == PBR_F32) {
-        if (to_linear) hipLaunchKernelGGL((colour_kernel<float, true>), dim3(grid), dim3(256), 0, s, src, dst, n, vec_ok);
-        else hipLaunchKernelGGL((colour_kernel<float, false>), dim3(grid), dim3(256), 0, s, src, dst, n, vec_ok);
+        if (to_linear) hipLaunchKernelGGL((colour_kernel<float, true>), dim3(sh.grid), dim3(sh.block), sh.lds, s, src, dst, n, vec_ok);
+        else hipLaunchKernelGGL((colour_kernel<float, false>), dim3(sh.grid), dim3(sh.block), sh.lds, s, src, dst, n, vec_ok);
     } else {
-        if (to_linear) hipLaunchKernelGGL((colour_kernel<__half, true>), dim3(grid), dim3(256), 0, s, src, dst, n, vec_ok);
-        else hipLaunchKernelGGL((colour_kernel<__half, false>), dim3(grid), dim3(256), 0, s, src, dst, n, vec_ok);
+        if (to_linear) hipLaunchKernelGGL((colour_kernel<__half, true>), dim3(sh.grid), dim3(sh.block), sh.lds, s, src, dst, n, vec_ok);
+        else hipLaunchKernelGGL((colour_kernel<__half, false>), dim3(sh.grid), dim3(sh.block), sh.lds, s, src, dst, n, vec_ok);
     }
     return hip_status();
 }
@@ -579,12 +582,12 @@ int pbr_metallic_to_specular(const void *albedo, const void *metallic, void *dif
     const size_t al = dtype == PBR_F32 ? 16 : 8;
     const int vec_ok = pixels % 4 == 0 && is_aligned(albedo, al) && is_aligned(metallic, al) && is_aligned(diffuse, al) && is_aligned(specular, al);
     const size_t items = (size_t)batch * (size_t)pixels;
-    const unsigned grid = stream_grid(vec_ok ? items / 4 : items);
+    const StreamShape sh = stream_shape(vec_ok ? items / 4 : items, kShapeM2S);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == PBR_F32)
-        hipLaunchKernelGGL((metallic_to_specular_kernel<float>), dim3(grid), dim3(256), 0, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb, vec_ok);
+        hipLaunchKernelGGL((metallic_to_specular_kernel<float>), dim3(sh.grid), dim3(sh.block), sh.lds, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb, vec_ok);
     else
-        hipLaunchKernelGGL((metallic_to_specular_kernel<__half>), dim3(grid), dim3(256), 0, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb, vec_ok);
+        hipLaunchKernelGGL((metallic_to_specular_kernel<__half>), dim3(sh.grid), dim3(sh.block), sh.lds, s, albedo, metallic, diffuse, specular, (int)batch, pixels, albedo_is_srgb, vec_ok);
     return hip_status();
 }
 
@@ -596,12 +599,12 @@ int pbr_specular_to_metallic(const void *diffuse, const void *specular, void *ba
     if (n == 0) return PBR_OK;
     const size_t al = dtype == PBR_F32 ? 16 : 8;
     const int vec_ok = is_aligned(diffuse, al) && is_aligned(specular, al) && is_aligned(basecolor, al) && is_aligned(metallic, al);
-    const unsigned grid = stream_grid(vec_ok ? (n + 3) / 4 : n);
+    const StreamShape sh = stream_shape(vec_ok ? (n + 3) / 4 : n, kShapeS2M);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == PBR_F32)
-        hipLaunchKernelGGL((specular_to_metallic_kernel<float>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb, vec_ok);
+        hipLaunchKernelGGL((specular_to_metallic_kernel<float>), dim3(sh.grid), dim3(sh.block), sh.lds, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb, vec_ok);
     else
-        hipLaunchKernelGGL((specular_to_metallic_kernel<__half>), dim3(grid), dim3(256), 0, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb, vec_ok);
+        hipLaunchKernelGGL((specular_to_metallic_kernel<__half>), dim3(sh.grid), dim3(sh.block), sh.lds, s, diffuse, specular, basecolor, metallic, n, albedo_is_srgb, vec_ok);
     return hip_status();
 }
 
@@ -613,14 +616,14 @@ static int colour_backward_launch(const void *src, const void *gout, void *gin, 
     if (n == 0) return PBR_OK;
     const size_t al = dtype == PBR_F32 ? 16 : 8;
     const int vec_ok = is_aligned(src, al) && is_aligned(gout, al) && is_aligned(gin, al);
-    const unsigned grid = stream_grid(vec_ok ? (n + 3) / 4 : n);
+    const StreamShape sh = stream_shape(vec_ok ? (n + 3) / 4 : n, kShapeColourBwd);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == PBR_F32) {
-        if (to_linear) hipLaunchKernelGGL((colour_backward_kernel<float, true>), dim3(grid), dim3(256), 0, s, src, gout, gin, n, vec_ok);
-        else hipLaunchKernelGGL((colour_backward_kernel<float, false>), dim3(grid), dim3(256), 0, s, src, gout, gin, n, vec_ok);
+        if (to_linear) hipLaunchKernelGGL((colour_backward_kernel<float, true>), dim3(sh.grid), dim3(sh.block), sh.lds, s, src, gout, gin, n, vec_ok);
+        else hipLaunchKernelGGL((colour_backward_kernel<float, false>), dim3(sh.grid), dim3(sh.block), sh.lds, s, src, gout, gin, n, vec_ok);
     } else {
-        if (to_linear) hipLaunchKernelGGL((colour_backward_kernel<__half, true>), dim3(grid), dim3(256), 0, s, src, gout, gin, n, vec_ok);
-        else hipLaunchKernelGGL((colour_backward_kernel<__half, false>), dim3(grid), dim3(256), 0, s, src, gout, gin, n, vec_ok);
+        if (to_linear) hipLaunchKernelGGL((colour_backward_kernel<__half, true>), dim3(sh.grid), dim3(sh.block), sh.lds, s, src, gout, gin, n, vec_ok);
+        else hipLaunchKernelGGL((colour_backward_kernel<__half, false>), dim3(sh.grid), dim3(sh.block), sh.lds, s, src, gout, gin, n, vec_ok);
     }
     return hip_status();
 }
@@ -645,9 +648,9 @@ int pbr_metallic_to_specular_backward(const void *albedo, const void *metallic, 
     auto ok = [&](const void *p) { return !p || is_aligned(p, al); };
     const bool vec = pixels % 4 == 0 && ok(albedo) && ok(metallic) && ok(g_diffuse) && ok(g_specular) && ok(g_albedo) && ok(g_metallic);
     const size_t items = (size_t)batch * (size_t)pixels;
-    const unsigned grid = stream_grid(vec ? items / 4 : items);
+    const StreamShape sh = stream_shape(vec ? items / 4 : items, kShapeM2SBwd);
     hipStream_t s = static_cast<hipStream_t>(stream);
-#define PBR_M2S_BWD(T, V) hipLaunchKernelGGL((metallic_to_specular_backward_kernel<T, V>), dim3(grid), dim3(256), 0, s, albedo, metallic, \
+#define PBR_M2S_BWD(T, V) hipLaunchKernelGGL((metallic_to_specular_backward_kernel<T, V>), dim3(sh.grid), dim3(sh.block), sh.lds, s, albedo, metallic, \
                                              g_diffuse, g_specular, g_albedo, g_metallic, (int)batch, pixels, albedo_is_srgb)
     if (dtype == PBR_F32) { if (vec) PBR_M2S_BWD(float, true); else PBR_M2S_BWD(float, false); }
     else { if (vec) PBR_M2S_BWD(__half, true); else PBR_M2S_BWD(__half, false); }
@@ -664,13 +667,13 @@ int pbr_specular_to_metallic_backward(const void *diffuse, const void *specular,
     const size_t al = dtype == PBR_F32 ? 16 : 8;
     auto ok = [&](const void *p) { return !p || is_aligned(p, al); };
     const int vec_ok = ok(diffuse) && ok(specular) && ok(g_basecolor) && ok(g_metallic) && ok(g_diffuse) && ok(g_specular);
-    const unsigned grid = stream_grid(vec_ok ? (n + 3) / 4 : n);
+    const StreamShape sh = stream_shape(vec_ok ? (n + 3) / 4 : n, kShapeS2MBwd);
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (dtype == PBR_F32)
-        hipLaunchKernelGGL((specular_to_metallic_backward_kernel<float>), dim3(grid), dim3(256), 0, s, diffuse, specular, g_basecolor, g_metallic,
+        hipLaunchKernelGGL((specular_to_metallic_backward_kernel<float>), dim3(sh.grid), dim3(sh.block), sh.lds, s, diffuse, specular, g_basecolor, g_metallic,
                            g_diffuse, g_specular, n, albedo_is_srgb, vec_ok);
     else
-        hipLaunchKernelGGL((specular_to_metallic_backward_kernel<__half>), dim3(grid), dim3(256), 0, s, diffuse, specular, g_basecolor, g_metallic,
+        hipLaunchKernelGGL((specular_to_metallic_backward_kernel<__half>), dim3(sh.grid), dim3(sh.block), sh.lds, s, diffuse, specular, g_basecolor, g_metallic,
                            g_diffuse, g_specular, n, albedo_is_srgb, vec_ok);
     return hip_status();
 }

@@ -184,7 +184,7 @@ if want("resize"):
     for (ho, wo), aa in (((S // 2, S // 2), True), ((S // 4, S // 4), True), ((S * 3 // 2, S * 3 // 2), False)):
         out = torch.empty(3, ho, wo, device=DEV)
         ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, S, wo) // 4), device=DEV)
-        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", "resize_strip_kernel<false>" if ho < S else "resize_up2_kernel<8>", 12 * (PX + ho * wo),
+        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", "resize_strip_kernel<false, false>" if ho < S else "resize_up2_kernel<8>", 12 * (PX + ho * wo),
                timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), 3, S, S, ho, wo, int(aa), ws.data_ptr(), stream)))
         del out, ws
 if want("blend_bwd"):
@@ -225,5 +225,5 @@ if want("resize_bwd"):
     ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(3, S, S, ho, ho) // 4), device=DEV)
     us = timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, S, S, ho, ho, 1, ws.data_ptr(), stream))
     # one pass: the strip kernel with the transposed tap tables (plus the small kernel that writes the tables); `us` is the whole call
-    report("resize backward 3 x 2048^2 gradient -> 4096^2 (3 planes of 2048^2 in, 3 of 4096^2 out)", "resize_strip_kernel<true>", 12 * (ho * ho + PX), us,
+    report("resize backward 3 x 2048^2 gradient -> 4096^2 (3 planes of 2048^2 in, 3 of 4096^2 out)", "resize_strip_kernel<true, true>", 12 * (ho * ho + PX), us,
            whole_call_us=round(us, 1))

@@ -265,6 +265,8 @@ class RenderPlan:
 
     def launch(self, stream: Optional[int] = None) -> torch.Tensor:
         """Enqueue on `stream` (raw hipStream_t) or torch's current stream of the maps' device."""
+        if self.out.numel() == 0 and (self._keep[3] is not None or self._keep[4] is not None):
+            return self.result         # zero-sized maps: the reference's whole-map ops return an empty (3, H, W) image; nothing to enqueue
         st = _stream_ptr(self.device) if stream is None else stream
         if getattr(self, "_blend", None) is not None:
             rc = N.lib().pbr_cook_torrance_blend(self._ref, self._blend_ref, self._workspace.data_ptr(), st)
@@ -519,7 +521,7 @@ USE_TORCH_OPS = True       # tests flip this to compare the two bindings of the 
 def _torch_op_can_take(albedo, kw) -> bool:
     """`torch.ops.pbr_hip.cook_torrance` (pypbr_amd/torch_ops.py) covers the plain evaluation; explicit output buffers,
     schedules, autotuning and the fused blend stay on the ctypes plan."""
-    if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda:
+    if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda or albedo.numel() == 0:      # zero-sized maps: RenderPlan.launch returns the empty image
         return False
     if kw.get("out") is not None or kw.get("blend") is not None or kw.get("autotune") or kw.get("schedule", N.SCHEDULE_AUTO) != N.SCHEDULE_AUTO:
         return False

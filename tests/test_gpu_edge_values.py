@@ -56,3 +56,24 @@ def test_degenerate_values_stay_finite_and_match_the_oracle(light_type, view, li
     F.cook_torrance(*leaves, **kw).sum().backward()
     for name, t in zip(("albedo", "normal", "roughness", "metallic"), leaves):
         assert bool(torch.isfinite(t.grad).all()), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(0, 5), (4, 0), (0, 0)])
+def test_zero_sized_maps_give_an_empty_image_like_the_reference(shape):
+    """The reference's forward is whole-map torch ops (cooktorrance.py:92-182): on maps with no pixels it returns an empty
+    (3, H, W) image for both light types (checked against the ATen restatement); so does the build, without a launch."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import torch_oracle as O
+    from pypbr_amd import functional as F
+    h, w = shape
+    a, r, m = torch.rand(3, h, w), torch.rand(1, h, w), torch.rand(1, h, w)
+    for lt in ("point", "directional"):
+        want = O.cook_torrance(a, None, r, m, None, view=torch.tensor([0.0, 0, 1]), light=torch.tensor([0.1, 0.1, 1.0]),
+                               intensity=torch.tensor([1.0, 1, 1]), light_type=lt)
+        got = F.cook_torrance(a.cuda(), None, r.cuda(), m.cuda(), view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1],
+                              light_type=lt)
+        assert tuple(got.shape) == tuple(want.shape) == (3, h, w) and got.is_cuda
+    with pytest.raises(ValueError):           # the workflow check still applies (cooktorrance.py:113-114)
+        F.cook_torrance(a.cuda(), None, r.cuda(), None, None, view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1])

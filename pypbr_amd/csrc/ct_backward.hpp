@@ -224,10 +224,13 @@ template <int VEC> struct MseLoss {
     float sq;               // sum of squared differences over the lane's pixels
 };
 
+#ifndef PBR_MSE_PACKED
+#define PBR_MSE_PACKED 1      // the loss step with fp32 maps in packed pairs too (A/B: build with -DPBR_MSE_PACKED=0)
+#endif
 template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD, class Sink, class Loss>
 __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b, const LanePos &p, Texels<VEC> &t, float (&go)[3][VEC],
                                                  float *s_param, int n_param, Sink &&sink, Loss &loss) {
-    constexpr bool kPacked = sizeof(TM) == 2 || MULTI;
+    constexpr bool kPacked = sizeof(TM) == 2 || MULTI || (Loss::on && PBR_MSE_PACKED);
     using R = typename RealOf<VEC, kPacked>::type;
     constexpr int NG = RealOf<VEC, kPacked>::N;
     float accV[3] = {0.0f, 0.0f, 0.0f}, accL[3] = {0.0f, 0.0f, 0.0f}, accI[3] = {0.0f, 0.0f, 0.0f};   // one-light PGRAD

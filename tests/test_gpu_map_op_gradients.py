@@ -257,3 +257,14 @@ def test_to_basecolor_metallic_and_to_srgb_keep_the_graph():
     back.to_srgb()
     (back._maps["albedo"].sum() + back._maps["metallic"].sum()).backward()
     assert d.grad is not None and s.grad is not None and bool(torch.isfinite(d.grad).all()) and float(s.grad.abs().sum()) > 0
+
+
+def test_resize_and_its_gradient_on_random_shapes():
+    """tools/resize_fuzz.py: 150 random shapes (extents 1 ... 513, 1-4 planes, views off a 16-byte boundary, with and without
+    antialiasing) through every resize path and its gradient, against ATen."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("resize_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "resize_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(150, 11, verbose=False)

@@ -935,3 +935,15 @@ def test_resize_tile_orders_are_bit_identical():
             assert (outs[0].cpu() - ref).abs().max().item() <= 3e-5, (shape, size)
     finally:
         lib.pbr_set_tuning(N.TUNE_RESIZE_XCD, 1)
+
+
+def test_random_shapes_workflows_flags_and_lights_against_the_oracle():
+    """tools/render_fuzz.py: 80 random cases (1-3 materials, extents 1 ... 260, all three workflows, both light types, 1-3 lights, fp32 /
+    fp16 maps, optional normal map, every flag, three light sizes; gradients on 40 % of the fp32 cases) against the ATen restatement of
+    the reference: every value within 1e-5 (roughness >= 0.2: criterion (i)), every gradient within 5e-5 (1 + |g64|)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("render_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "render_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(80, 5, verbose=False)

@@ -154,3 +154,16 @@ def test_rendering_loss_module_follows_the_tutorial():
                                          metallic=leaves["metallic"].detach().cpu())
     cpu_pred._maps["normal"] = pred._maps["normal"].cpu()
     assert abs(RenderingLoss()(cpu_pred, gt).item() - loss.item()) <= 2e-6 * (1 + loss.item())
+
+
+@pytest.mark.gpu
+def test_fused_blend_and_loss_step_on_random_shapes():
+    """tools/fused_fuzz.py: 40 random cases (1-2 materials, extents 1 ... 257, all workflows / light types / flags, shared and per-material
+    masks, fp16 maps for the loss step, an upstream scale): blend + render forward and one-pass backward, and the one-kernel loss step,
+    against the unfused differentiable pieces."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fused_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fused_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(40, 9, verbose=False)

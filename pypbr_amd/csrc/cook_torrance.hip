@@ -197,6 +197,7 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_TILE_FOLD: slot = &pbr::g_tile_fold; break;
         case PBR_TUNE_RESIZE_BWD_FUSED: slot = &pbr::g_resize_bwd_fused; break;
         case PBR_TUNE_RESIZE_QUADS: slot = &pbr::g_resize_quads; break;
+        case PBR_TUNE_MSE_STREAM: slot = &pbr::g_mse_stream; break;
         case PBR_TUNE_STREAM_SHAPE: slot = &pbr::g_stream_shape; break;
         case PBR_TUNE_STREAM_LDS: slot = &pbr::g_stream_lds; break;
         case PBR_TUNE_SCALAR_BASE: slot = &pbr::g_scalar_base; break;

@@ -63,7 +63,7 @@ static BwdStream16Fn pick_bwd_stream16(const pbr_render_desc *d) {
 // Rounds of the streamed backward kernel (ct_backward.hpp: its grid is rounds x the waves the chip holds at once), or 0 when
 // the launch does not qualify: fp16 maps, one light, untiled, rows a whole number of 128-pixel tiles, 4-byte aligned planes
 // with even strides (its loads and stores move two fp16 values per lane).  g_bwd_run: -1 = rule, 0 = never, N = N rounds (A/B).
-static int stream_run(const pbr_render_desc *d, const void *grad_out, void *const g[5]) {
+int stream_run(const pbr_render_desc *d, const void *grad_out, void *const g[5]) {
     if (g_bwd_run == 0 || d->map_dtype != PBR_F16 || d->n_lights != 1 || is_tiled(d) || d->width % 128) return 0;
     if ((int64_t)d->height * d->width >= (1ll << 30) || d->batch > 65535) return 0;
     auto ok = [](const pbr_map &m) {

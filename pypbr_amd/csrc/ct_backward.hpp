@@ -541,10 +541,10 @@ __device__ __forceinline__ void dma_dword(const void *plane, int64_t uniform_ele
     __builtin_amdgcn_global_load_lds(g, (lds_ptr)buf, 4, OFF, 2);
 }
 
-template <int LIGHT, int WF, bool FULL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PBR_BWD_STREAM_WAVES)))
-void cook_torrance_backward_stream_kernel(const KArgs a, const BArgs b, const int tiles_per_material, const int n_stores) {
-    __shared__ uint32_t buf[kStreamLdsWords];
+// The body, shared with the streamed rendering-loss step (ct_loss.hip): with a Loss policy `b.gout` is the TARGET image -- same three fp32
+// planes, same DMA slots -- and the upstream gradient is formed from it inside backward_body_to.
+template <int LIGHT, int WF, bool FULL, class Loss>
+__device__ __forceinline__ void backward_stream_body(const KArgs &a, const BArgs &b, const int tiles_per_material, const int n_stores, uint32_t *buf, Loss &loss) {
     const int lane = threadIdx.x, mat = blockIdx.y;
     const int t0 = blockIdx.x, t1 = tiles_per_material, step = gridDim.x;      // tiles t0, t0 + step, ... of material `mat`
     if (FULL) {      // the usual rendering-loss launch: sRGB in and out, a normal map, every gradient wanted -- no flag branches
@@ -638,8 +638,25 @@ void cook_torrance_backward_stream_kernel(const KArgs a, const BArgs b, const in
         p.b = p.b0 = mat; p.y = ty; p.x = (t - ty * a.tiles_x) * 128 + 2 * lane;
         p.pix = p.src = (int64_t)t * 128 + 2 * lane;
         p.valid = true; p.sb = true; p.dup = 0;
-        backward_body<LIGHT, WF, 2, false, __half, false>(a, b, p, tx, go, nullptr, 0);
+        if constexpr (Loss::on) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { loss.tgt[c][0] = go[c][0]; loss.tgt[c][1] = go[c][1]; }
+            backward_body_to<LIGHT, WF, 2, false, __half, false>(a, b, p, tx, go, nullptr, 0,
+                [&](float (&ga)[3][2], float (&gn)[3][2], float (&gr)[2], float (&gm)[2], float (&gs)[3][2]) {
+                    store_gradients<WF, 2, __half>(a, b, p, ga, gn, gr, gm, gs);
+                }, loss);
+        } else {
+            backward_body<LIGHT, WF, 2, false, __half, false>(a, b, p, tx, go, nullptr, 0);
+        }
     }
+}
+
+template <int LIGHT, int WF, bool FULL>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PBR_BWD_STREAM_WAVES)))
+void cook_torrance_backward_stream_kernel(const KArgs a, const BArgs b, const int tiles_per_material, const int n_stores) {
+    __shared__ uint32_t buf[kStreamLdsWords];
+    NoLoss none;
+    backward_stream_body<LIGHT, WF, FULL>(a, b, tiles_per_material, n_stores, buf, none);
 }
 
 // ------------------------------------------------------------------ streamed form with 16-byte memory instructions (round 3)

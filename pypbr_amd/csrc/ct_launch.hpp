@@ -31,6 +31,7 @@ extern int g_scalar_base;          // scalar plane addresses (KArgs::sbase): 0 n
 extern int g_resize_rows;          // resize.hip
 extern int g_resize_bwd_fused;     // resize.hip: gradient of resize in one pass (1) or two passes through the workspace (0)
 extern int g_resize_quads;         // resize.hip: 16-byte stores in the strip kernel's width pass
+extern int g_mse_stream;           // ct_loss.hip: streamed loss step for fp16 maps (1) or the one-tile kernels (0)
 extern int g_resize_up2;           // resize.hip: two-tap register kernel for up-scales (1) or the strip kernel (0)
 extern int g_resize_xcd;           // resize.hip: XCD-contiguous tile order (1) or identity (0)
 extern int g_max_vec;              // A/B and test knob: at most this many pixels per lane (1 = the one-pixel kernels everywhere)

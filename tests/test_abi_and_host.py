@@ -503,12 +503,13 @@ def test_isa_assumptions_of_the_hand_scheduled_kernels_hold_and_the_checker_can_
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import check_isa as C
-    for name in ("ct_backward", "cook_torrance"):
+    for name in ("ct_backward", "ct_loss", "cook_torrance"):
         if not os.path.exists(os.path.join(C.CSRC, name + ".o")):
             subprocess.check_call(["make", "-s", "-j4", "-C", C.CSRC])
             break
     report = C.check()
-    assert len(report) == 30 and sum("backward_stream<" in r for r in report) == 12 and sum("backward_stream16<" in r for r in report) == 6
+    assert len(report) == 42 and sum("backward_stream<" in r for r in report) == 12 and sum("backward_stream16<" in r for r in report) == 6 and \
+        sum("mse_stream<" in r for r in report) == 12
 
     import tempfile
     tmp = tempfile.mkdtemp()

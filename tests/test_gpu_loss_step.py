@@ -167,3 +167,27 @@ def test_fused_blend_and_loss_step_on_random_shapes():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.run(40, 9, verbose=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size,dtype", [(64, torch.float32), (128, torch.float16)])
+def test_whole_training_step_is_capturable_into_a_hip_graph(size, dtype):
+    """tools/graph_step_probe.py: rendering loss through autograd (the one-kernel step; fp16 maps of 128-pixel rows: its streamed form) + an SGD
+    update of the maps, captured with torch.cuda.graph and replayed -- every library call only enqueues.  Five replays leave the maps exactly where
+    five eager steps leave them (the kernels are deterministic)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("graph_step_probe", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "graph_step_probe.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    leaves_a, target = mod.make(size, dtype)
+    leaves_b = [t.detach().clone().requires_grad_(True) for t in leaves_a]
+    graph, loss = mod.capture(leaves_a, target)              # three warm-up steps + the captured one (capturing does not run it)
+    for _ in range(5):
+        graph.replay()
+    for _ in range(3 + 5):
+        eager_loss = mod.train_step(leaves_b, target)
+    torch.cuda.synchronize()
+    for x, y in zip(leaves_a, leaves_b):
+        assert torch.equal(x.detach(), y.detach())
+    assert float(loss.detach()) == float(eager_loss.detach())

@@ -76,7 +76,7 @@ def _metadata(code_object):
     return out
 
 
-def _stores_follow_loads(insts, is_load, is_store):
+def _stores_follow_loads(insts, is_load, is_store, tail_stores=0):
     """The stores of a tile must issue AFTER the next tile's DMA loads (the hand-counted vmcnt relies on it).  Block layout in
     the object file is the compiler's business, so this looks at straight-line segments (split at every branch): every store
     lies in ONE segment, and inside it no DMA load follows the first store.  Returns a description of the violation or None."""
@@ -89,6 +89,11 @@ def _stores_follow_loads(insts, is_load, is_store):
     if cur:
         segments.append(cur)
     with_stores = [seg for seg in segments if any(is_store(mn) for mn, _ in seg)]
+    if tail_stores:      # the loss step's kernels: after the loop one more store (the wave's partial sum), in the segment that ends the program
+        last = with_stores[-1] if with_stores else []
+        if sum(1 for mn, _ in last if is_store(mn)) != tail_stores or not last or last[-1][0] != "s_endpgm":
+            return "expected %d store(s) in the segment that ends the program" % tail_stores
+        with_stores = with_stores[:-1]
     if len(with_stores) != 1:
         return "stores spread over %d straight-line segments" % len(with_stores)
     seen_store = False
@@ -102,9 +107,11 @@ def _stores_follow_loads(insts, is_load, is_store):
 def check_stream_kernel(sym, insts, meta):
     m = re.search(r"stream_kernelILi(\d)ELi(\d)ELb(\d)E", sym)
     light, wf, full = int(m.group(1)), int(m.group(2)), m.group(3) == "1"
-    what = "backward_stream<%s,%s,%s>" % ("point" if light else "directional", WF_NAMES[wf], "FULL" if full else "flags")
+    mse = "mse_stream_kernel" in sym                    # the loss step: the same schedule + ONE store of the wave's partial sum after the loop
+    tail = 1 if mse else 0
+    what = "%s_stream<%s,%s,%s>" % ("mse" if mse else "backward", "point" if light else "directional", WF_NAMES[wf], "FULL" if full else "flags")
     n_maps = 10 if wf == 1 else 8                       # albedo 3 + normal 3 + roughness + (metallic | specular 3)
-    n_dma, n_stores = n_maps + 6, n_maps                # + the upstream gradient: 3 planes x 2 loads; one gradient plane per map plane
+    n_dma, n_stores = n_maps + 6, n_maps                # + the upstream gradient | target: 3 planes x 2 loads; one gradient plane per map plane
     ops = [mn for mn, _ in insts]
     fail = []
     if meta.get("private_segment_fixed_size", -1) != 0:
@@ -123,7 +130,8 @@ def check_stream_kernel(sym, insts, meta):
     stores = sum(1 for o in ops if o.startswith("global_store"))
     reads32 = [t for mn, t in insts if mn == "ds_read_b32"]
     reads64 = [t for mn, t in insts if mn == "ds_read_b64"]
-    other_ds = sorted({o for o in ops if o.startswith("ds_") and o not in ("ds_read_b32", "ds_read_b64")})
+    allowed_ds = ("ds_read_b32", "ds_read_b64") + (("ds_bpermute_b32",) if mse else ())       # the wave reduction of the partial sum (no LDS memory access)
+    other_ds = sorted({o for o in ops if o.startswith("ds_") and o not in allowed_ds})
     if other_ds:
         fail.append("unexpected LDS instructions %s" % other_ds)
     waits = []
@@ -142,13 +150,13 @@ def check_stream_kernel(sym, insts, meta):
         want = sorted([256 * q for q in range(n_maps if wf == 1 else 8)] + [2560 + 256 * k for k in range(6)])
         if offsets(dma) != sorted(want + want):
             fail.append("DMA offsets %s, expected twice %s" % (offsets(dma), want))
-        if stores != n_stores:
-            fail.append("%d global stores per tile, the hand-counted wait assumes %d" % (stores, n_stores))
+        if stores != n_stores + tail:
+            fail.append("%d global stores, the hand-counted wait assumes %d per tile%s" % (stores, n_stores, " + the partial sum" if tail else ""))
         if sorted(waits) != [0, n_stores]:
             fail.append("s_waitcnt vmcnt(...) values %s, expected exactly [0, %d] (a compiler-inserted wait?)" % (sorted(waits), n_stores))
         if offsets(reads32) != [256 * q for q in range(n_maps)] or offsets(reads64) != [0, 512, 1024]:
             fail.append("LDS reads b32 %s / b64 %s: not exactly the hand-written ones" % (offsets(reads32), offsets(reads64)))
-        order = _stores_follow_loads(insts, lambda mn: mn == "global_load_lds_dword", lambda mn: mn.startswith("global_store"))
+        order = _stores_follow_loads(insts, lambda mn: mn == "global_load_lds_dword", lambda mn: mn.startswith("global_store"), tail)
         if order:
             fail.append(order)
         # the hand-written reads come right after the hand-counted wait, before anything else touches vector memory
@@ -240,7 +248,7 @@ def check_xpose_kernel(sym, insts, meta):
 
 def check(verbose=False):
     """Raises IsaError listing every violated assumption; returns the report lines."""
-    objs = {name: os.path.join(CSRC, name + ".o") for name in ("ct_backward", "cook_torrance")}
+    objs = {name: os.path.join(CSRC, name + ".o") for name in ("ct_backward", "ct_loss", "cook_torrance")}
     for path in objs.values():
         if not os.path.exists(path):
             raise IsaError("%s is missing: run `make -C pypbr_amd/csrc` first" % path)
@@ -260,6 +268,15 @@ def check(verbose=False):
         if len(stream) != 12:
             failures.append("expected 12 instantiations of cook_torrance_backward_stream_kernel, found %d" % len(stream))
         for s in stream:
+            line, bad = check_stream_kernel(s, fns[s], meta.get(s, {}))
+            report.append(line)
+            failures += bad
+        co = _code_object(objs["ct_loss"], tmp)
+        fns, meta = _functions(co), _metadata(co)
+        mse = sorted(s for s in fns if "cook_torrance_mse_stream_kernel" in s)
+        if len(mse) != 12:
+            failures.append("expected 12 instantiations of cook_torrance_mse_stream_kernel, found %d" % len(mse))
+        for s in mse:
             line, bad = check_stream_kernel(s, fns[s], meta.get(s, {}))
             report.append(line)
             failures += bad

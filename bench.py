@@ -166,6 +166,11 @@ def cpu_baseline(cfg, budget_s=40.0):
         per_pixel = None
         for size, passes in legs:
             left = budget_s - (time.perf_counter() - t_start)
+            if threads > 16 and per_pixel is None and left < 20.0:
+                # the all-cores leg cannot be predicted from a smaller one, and where the process's CPU share is a fraction of
+                # os.cpu_count() its first pass alone takes ~16 s: only started with that much budget left
+                skipped.append(f"all sizes x {threads} threads (an oversubscribed first pass can take ~20 s; {left:.0f} s of the budget left)")
+                break
             if left <= 0 or (per_pixel is not None and per_pixel * size * size * passes > left):
                 skipped.append(f"{size}^2 x {threads} threads")
                 continue

@@ -205,7 +205,7 @@ if want("blend_bwd"):
     del m1, m2, mask, p, gout, g1, g2, gm
 if want("loss_step"):
     for dtype, tag, kern, bpp in ((torch.float32, "loss_step_f32", "cook_torrance_mse_step_kernel<1, 0, 2, false, float>", 76),
-                                  (torch.float16, "loss_step_f16", "cook_torrance_mse_step_kernel<1, 0, 2, false, __half>", 44)):
+                                  (torch.float16, "loss_step_f16", "cook_torrance_mse_stream_kernel<1, 0, true>", 44)):
         maps = synth_material(S, DEV, 3, dtype)
         target = torch.rand(1, 3, S, S, device=DEV)                   # any image serves the traffic measurement (no extra kernel under the counters)
         plan = F.plan_cook_torrance(*maps, **PT)

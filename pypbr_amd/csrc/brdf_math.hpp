@@ -84,7 +84,24 @@ __device__ __forceinline__ f32x2 fma_sat(f32x2 a, f32x2 b, f32x2 c) {
     asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// gfx940+ "trans forwarding" hazard: a non-transcendental VALU instruction that reads a VGPR written by the transcendental instruction
+// IMMEDIATELY before it needs one wait state.  The compiler inserts it for its own instructions, NOT in front of inline assembly -- the
+// packed v_pk_fma_f32 right behind a v_exp_f32 then reads the OLD register in lanes 0-3 of every 8 (found in round 3: a loss kernel whose
+// schedule put them back to back; tools/check_isa.py now scans every kernel of the build for the pattern).  Where an operand IS the direct result
+// of v_exp / v_log / v_rcp / v_rsq, use these forms: the wait state travels inside the assembly.
+__device__ __forceinline__ f32x2 mul_sat_after_trans(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 fma_sat_after_trans(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("s_nop 0\n\tv_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ float mul_sat(float a, float b) { return clamp01(a * b); }          // v_mul_f32 ... clamp
+__device__ __forceinline__ float mul_sat_after_trans(float a, float b) { return clamp01(a * b); }
+__device__ __forceinline__ float fma_sat_after_trans(float a, float b, float c) { return clamp01(fmaf(a, b, c)); }
 __device__ __forceinline__ float fma_sat(float a, float b, float c) { return clamp01(fmaf(a, b, c)); }
 __device__ __forceinline__ f32x2 fma_(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 max_(f32x2 a, f32x2 b) { return f32x2{fmaxf(a.x, b.x), fmaxf(a.y, b.y)}; }
@@ -111,7 +128,7 @@ template <class R> __device__ __forceinline__ R srgb_to_linear(R x) {
 // utils/functions.py:50-66; `c` must already be in [0,1] (callers clamp).
 template <class R> __device__ __forceinline__ R linear_to_srgb_unit(R c) {
     const R lo = c * 12.92f;
-    const R hi = fma_sat(splat<R>(1.055f), exp2_hw(log2_hw(c) * (1.0f / 2.4f)), splat<R>(-0.055f));   // clamp = output modifier
+    const R hi = fma_sat_after_trans(splat<R>(1.055f), exp2_hw(log2_hw(c) * (1.0f / 2.4f)), splat<R>(-0.055f));   // clamp = output modifier
     return select_(le_(c, splat<R>(0.0031308f)), lo, hi);                            // lo <= 0.0405 needs none
 }
 template <class R> __device__ __forceinline__ R linear_to_srgb(R x) { return linear_to_srgb_unit(clamp01(x)); }
@@ -165,7 +182,7 @@ __device__ __forceinline__ LightGeomT<R> point_light_geom(const Vec3 &V, const V
     g.h = {fma_(d.x, rinv, splat<R>(V.x)), fma_(d.y, rinv, splat<R>(V.y)), fma_(d.z, rinv, splat<R>(V.z))};   // :155
     const R rh = rsq(dot_plus(g.h, g.h, 1e-24f));
     g.rhh = rh * rh;
-    g.p5 = pow5(splat<R>(1.0f) - mul_sat(dotu(g.h, V), rh));         // :156-158, :196
+    g.p5 = pow5(splat<R>(1.0f) - mul_sat_after_trans(dotu(g.h, V), rh));         // :156-158, :196  (rh: the v_rsq's own result)
     g.om5 = splat<R>(1.0f) - g.p5;
     return g;
 }

@@ -215,6 +215,7 @@ int pbr_cook_torrance_mse_step(const pbr_render_desc *d, const void *target, voi
         const bool spec = d->workflow == PBR_WORKFLOW_SPECULAR;
         const int n_stores = (g_albedo ? 3 : 0) + (g_normal && d->normal.data ? 3 : 0) + (g_roughness ? 1 : 0) +
                              (spec ? (g_specular ? 3 : 0) : (g_metallic ? 1 : 0));
+        // every run-time flag on and every gradient wanted: the instantiation without flag branches (as in ct_backward.hip)
         const bool full = d->albedo_is_srgb && d->return_srgb && d->normal.data && g_albedo && g_normal && g_roughness &&
                           (spec ? (g_specular && d->specular_is_srgb) : (g_metallic && (d->workflow == PBR_WORKFLOW_METALLIC || d->specular_is_srgb)));
         int dev = 0, cus = 256;

@@ -508,7 +508,7 @@ def test_isa_assumptions_of_the_hand_scheduled_kernels_hold_and_the_checker_can_
             subprocess.check_call(["make", "-s", "-j4", "-C", C.CSRC])
             break
     report = C.check()
-    assert len(report) == 42 and sum("backward_stream<" in r for r in report) == 12 and sum("backward_stream16<" in r for r in report) == 6 and \
+    assert len(report) == 43 and sum("backward_stream<" in r for r in report) == 12 and sum("backward_stream16<" in r for r in report) == 6 and \
         sum("mse_stream<" in r for r in report) == 12
 
     import tempfile
@@ -551,3 +551,11 @@ def test_isa_assumptions_of_the_hand_scheduled_kernels_hold_and_the_checker_can_
     swapped = list(good)
     swapped[w[-1]], swapped[r[0]] = swapped[r[0]], swapped[w[-1]]
     assert C.check_xpose_kernel(sym, swapped, meta[sym])[1]
+    # the trans-forwarding hazard scan (every kernel of the build is clean, see `report`): the sequences it must flag and must not
+    hazard = {"k": [("v_exp_f32_e32", "v91, v91"), ("v_pk_fma_f32", "v[140:141], v[6:7], v[90:91], v[8:9] clamp")]}     # the round-3 bug, verbatim
+    assert C.trans_forwarding_violations(hazard)
+    assert C.trans_forwarding_violations({"k": [("v_rsq_f32_e32", "v5, v4"), ("v_mul_f32_e32", "v6, v5, v7")]})
+    assert not C.trans_forwarding_violations({"k": [("v_exp_f32_e32", "v91, v91"), ("s_nop", "0"), ("v_pk_fma_f32", "v[140:141], v[6:7], v[90:91], v[8:9] clamp")]})
+    assert not C.trans_forwarding_violations({"k": [("v_exp_f32_e32", "v91, v91"), ("v_exp_f32_e32", "v92, v91")]})            # trans -> trans: no hazard
+    assert not C.trans_forwarding_violations({"k": [("v_exp_f32_e32", "v91, v91"), ("v_mul_f32_e32", "v91, v6, v7")]})         # written, not read
+    assert any("trans-forwarding hazard" in r for r in report)

@@ -209,3 +209,45 @@ def test_streamed_backward_full_shape_2x4096_fp16():
         g64 = leaf.grad
         err = (x[b, :, y0:].float().cpu().double() - g64).abs()
         assert bool((err <= 1e-3 * (1e-3 + g64.abs()) + 2e-5 * (1 + g64.abs())).all()), (name, float(err.max()))      # fp16 gradient storage
+
+
+@pytest.mark.parametrize("B,dtype", [(1, torch.float32), (2, torch.float16)])
+def test_loss_step_full_shape_4096(B, dtype):
+    """The one-kernel rendering-loss step at full size: fp32 maps (131 072 one-wave workgroups, the two-stage reduction of their partial
+    sums) and 2 x 4096^2 fp16 maps (the streamed form: a few thousand persistent waves, one partial each).  The loss against
+    evaluate + torch's MSE; the gradients against the backward kernel fed with that loss's upstream gradient -- the same chain rule on the
+    same pixels -- over whole planes; and the streamed form against the one-tile kernels bit for bit."""
+    from pypbr_amd import _native as N, functional as F
+    lib = N.lib()
+    H = W = 4096
+    maps = _maps(B, H, W, 41, dtype)
+    kw = dict(view_dir=[0.0, 0.1, 1.0], light=[0.1, 0.1, 1.0], light_intensity=[1.0, 0.9, 0.8], light_type="point", light_size=1.0)
+    target = torch.rand(B, 3, H, W, device="cuda", generator=torch.Generator(device="cuda").manual_seed(42))
+
+    def fused(stream_knob):
+        lib.pbr_set_tuning(N.TUNE_MSE_STREAM, stream_knob)
+        leaves = [t.clone().requires_grad_() for t in maps]
+        loss = F.rendering_loss_mse(*leaves, target=target, **kw)
+        assert type(loss.grad_fn).__name__ == "_MseStepFnBackward"
+        loss.backward()
+        return loss.detach(), [t.grad for t in leaves]
+    try:
+        loss1, g1 = fused(1)
+        loss0, g0 = fused(0)
+    finally:
+        lib.pbr_set_tuning(N.TUNE_MSE_STREAM, 1)
+    assert abs(float(loss1) - float(loss0)) <= 2e-6 * float(loss0)                  # another summation order of the partial sums
+    for x, y in zip(g1, g0):
+        assert torch.equal(x, y)                                                     # (fp32 maps: the same kernel twice -- deterministic)
+    leaves = [t.clone().requires_grad_() for t in maps]
+    out = F.cook_torrance(*leaves, **kw)
+    ref_loss = torch.nn.functional.mse_loss(out.float(), target)
+    ref_loss.backward()
+    assert abs(float(loss1) - float(ref_loss)) <= 2e-6 * float(ref_loss)
+    for name, x, leaf in zip(("albedo", "normal", "roughness", "metallic"), g1, leaves):
+        scale = float(leaf.grad.float().abs().max())
+        err = float((x.float() - leaf.grad.float()).abs().max())
+        # fp32: the two paths form 2 (out - target) / N with different roundings (a few ulp); fp16: gradients of a mean over 10^8 values sit in
+        # fp16's subnormal range, where one rounding is 6e-8 absolute
+        assert err <= (2e-5 * scale if dtype == torch.float32 else 2e-3 * scale + 1.3e-7), (name, err, scale)
+        assert bool(torch.isfinite(x).all())

@@ -191,3 +191,43 @@ def test_whole_training_step_is_capturable_into_a_hip_graph(size, dtype):
     for x, y in zip(leaves_a, leaves_b):
         assert torch.equal(x.detach(), y.detach())
     assert float(loss.detach()) == float(eager_loss.detach())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workflow", ["metallic", "specular", "converted"])
+@pytest.mark.parametrize("light_type", ["point", "directional"])
+@pytest.mark.parametrize("flags", [dict(), dict(return_srgb=False), dict(albedo_is_srgb=False)])
+def test_streamed_loss_step_equals_the_one_tile_kernels(workflow, light_type, flags):
+    """fp16 maps with rows of whole 128-pixel tiles take cook_torrance_mse_stream_kernel; PBR_TUNE_MSE_STREAM = 0 takes the one-tile kernels.
+    Same chain rule on the same pixels: gradients bit for bit, the loss to fp32 rounding (another summation order) -- for every flag
+    combination, several materials, one and several tiles per wave.  (The flag-free instantiation failed exactly this: ct_loss.hip.)"""
+    from pypbr_amd import _native as N, functional as F
+    lib = N.lib()
+    g = torch.Generator(device="cuda").manual_seed(77)
+    for B, H, W in ((1, 2, 256), (2, 3, 128), (2, 160, 384)):
+        rnd = lambda *s: torch.rand(*s, device="cuda", generator=g)
+        a = rnd(B, 3, H, W).half()
+        n = torch.nn.functional.normalize(torch.cat([rnd(B, 2, H, W) - 0.5, torch.ones(B, 1, H, W, device="cuda")], 1), dim=1).half()
+        r = (rnd(B, 1, H, W) * 0.6 + 0.3).half()
+        m = rnd(B, 1, H, W).half() if workflow != "specular" else None
+        s = rnd(B, 3, H, W).half() if workflow == "specular" else None
+        kw = dict(view_dir=[0.0, 0.1, 1.0], light=[0.1, 0.1, 1.0] if light_type == "point" else [0.3, 0.2, 1.0], light_intensity=[1.0, 0.9, 0.8],
+                  light_type=light_type, light_size=1.5 if light_type == "point" else None, **flags)
+        if workflow == "converted":
+            kw.update(convert_to_diffuse_specular=True)
+        target = rnd(B, 3, H, W)
+        got = {}
+        try:
+            for knob in (1, 0):
+                lib.pbr_set_tuning(N.TUNE_MSE_STREAM, knob)
+                leaves = [None if t is None else t.clone().requires_grad_() for t in (a, n, r, m, s)]
+                loss = F.rendering_loss_mse(*leaves, target=target, **kw) * 64.0            # keep the fp16 gradients out of the subnormal range
+                loss.backward()
+                got[knob] = (float(loss.detach()), [None if t is None else t.grad for t in leaves])
+        finally:
+            lib.pbr_set_tuning(N.TUNE_MSE_STREAM, 1)
+        assert abs(got[1][0] - got[0][0]) <= 2e-6 * abs(got[0][0]), (B, H, W, got[1][0], got[0][0])
+        for x, y in zip(got[1][1], got[0][1]):
+            assert (x is None and y is None) or torch.equal(x, y), (B, H, W)
+        ref = torch.nn.functional.mse_loss(F.cook_torrance(a, n, r, m, s, **kw).float(), target) * 64.0
+        assert abs(got[1][0] - float(ref)) <= 2e-6 * float(ref)

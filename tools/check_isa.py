@@ -246,6 +246,38 @@ def check_xpose_kernel(sym, insts, meta):
            ["%s: %s" % (short, f) for f in fail]
 
 
+TRANS_OPS = ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "v_sin_f32", "v_cos_f32", "v_rcp_iflag_f32",
+             "v_exp_f16", "v_log_f16", "v_rcp_f16", "v_rsq_f16", "v_sqrt_f16", "v_sin_f16", "v_cos_f16", "v_exp_legacy_f32", "v_log_legacy_f32")
+
+
+def _vgprs(text):
+    out = set()
+    for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def trans_forwarding_violations(fns):
+    """gfx940+ hazard: a non-transcendental VALU instruction that reads a VGPR written by the transcendental instruction IMMEDIATELY before
+    it needs one wait state (any instruction, or s_nop, in between).  The compiler inserts it for its own instructions but not in front of
+    inline assembly (brdf_math.hpp: the packed clamp forms) -- back to back, the consumer reads the old register in some lanes.  Found in round 3
+    by a full-size parity test; this scan makes it a build failure.  Returns [(symbol, producer, consumer)]."""
+    bad = []
+    for sym, insts in fns.items():
+        prev = None
+        for mn, ops in insts:
+            base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", mn)
+            if prev is not None and mn.startswith("v_") and base not in TRANS_OPS:
+                parts = ops.split(",")
+                if _vgprs(prev[1].split(",")[0]) & _vgprs(",".join(parts[1:])):
+                    bad.append((sym, "%s %s" % prev, "%s %s" % (mn, ops)))
+            prev = (mn, ops) if base in TRANS_OPS else None
+    return bad
+
+
 def check(verbose=False):
     """Raises IsaError listing every violated assumption; returns the report lines."""
     objs = {name: os.path.join(CSRC, name + ".o") for name in ("ct_backward", "ct_loss", "cook_torrance")}
@@ -292,6 +324,15 @@ def check(verbose=False):
             line, bad = check_xpose_kernel(s, fns[s], meta.get(s, {}))
             report.append(line)
             failures += bad
+        # every kernel of every object: the trans-forwarding hazard (inline-assembly consumers are not covered by the compiler)
+        n_kernels = 0
+        for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".o")):
+            sub = tempfile.mkdtemp(prefix="pbr_isa_", dir=tmp)
+            fns = _functions(_code_object(path, sub))
+            n_kernels += len(fns)
+            for sym, producer, consumer in trans_forwarding_violations(fns):
+                failures.append("%s: %s directly followed by %s (needs a wait state: use the *_after_trans forms of brdf_math.hpp)" % (sym[:80], producer, consumer))
+        report.append("trans-forwarding hazard: %d kernels scanned" % n_kernels)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     if verbose:

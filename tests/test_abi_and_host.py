@@ -559,3 +559,6 @@ def test_isa_assumptions_of_the_hand_scheduled_kernels_hold_and_the_checker_can_
     assert not C.trans_forwarding_violations({"k": [("v_exp_f32_e32", "v91, v91"), ("v_exp_f32_e32", "v92, v91")]})            # trans -> trans: no hazard
     assert not C.trans_forwarding_violations({"k": [("v_exp_f32_e32", "v91, v91"), ("v_mul_f32_e32", "v91, v6, v7")]})         # written, not read
     assert any("trans-forwarding hazard" in r for r in report)
+    assert C.store_data_violations({"k": [("global_store_dwordx4", "v[26:27], v[18:21], off nt"), ("v_mov_b32_e32", "v19, 0")]})
+    assert not C.store_data_violations({"k": [("global_store_dwordx4", "v[26:27], v[18:21], off nt"), ("s_nop", "0"), ("v_mov_b32_e32", "v19, 0")]})
+    assert not C.store_data_violations({"k": [("global_store_dwordx2", "v[26:27], v[18:19], off"), ("v_mov_b32_e32", "v19, 0")]})

@@ -278,6 +278,23 @@ def trans_forwarding_violations(fns):
     return bad
 
 
+def store_data_violations(fns):
+    """The other hazard an inline-assembly instruction can sit in front of unseen: a vector-memory store of more than 64 bits whose data
+    registers are overwritten by the VALU instruction right behind it (one wait state needed).  The 16-byte form of the streamed backward
+    kernel stores through inline assembly.  Returns [(symbol, store, writer)]."""
+    bad = []
+    for sym, insts in fns.items():
+        prev = None
+        for mn, ops in insts:
+            if prev is not None and mn.startswith("v_"):
+                parts = prev[1].split(",")
+                data = _vgprs(parts[1]) if len(parts) > 1 else set()          # global_store_dwordxN vaddr, vdata, saddr
+                if data & _vgprs(ops.split(",")[0]):
+                    bad.append((sym, "%s %s" % prev, "%s %s" % (mn, ops)))
+            prev = (mn, ops) if re.match(r"(global|flat|buffer)_store_dwordx[34]", mn) else None
+    return bad
+
+
 def check(verbose=False):
     """Raises IsaError listing every violated assumption; returns the report lines."""
     objs = {name: os.path.join(CSRC, name + ".o") for name in ("ct_backward", "ct_loss", "cook_torrance")}
@@ -332,7 +349,9 @@ def check(verbose=False):
             n_kernels += len(fns)
             for sym, producer, consumer in trans_forwarding_violations(fns):
                 failures.append("%s: %s directly followed by %s (needs a wait state: use the *_after_trans forms of brdf_math.hpp)" % (sym[:80], producer, consumer))
-        report.append("trans-forwarding hazard: %d kernels scanned" % n_kernels)
+            for sym, store, writer in store_data_violations(fns):
+                failures.append("%s: %s directly followed by %s, which overwrites its data (needs a wait state)" % (sym[:80], store, writer))
+        report.append("trans-forwarding hazard, store-data hazard: %d kernels scanned" % n_kernels)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     if verbose:

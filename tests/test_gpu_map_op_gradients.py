@@ -268,3 +268,15 @@ def test_resize_and_its_gradient_on_random_shapes():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.run(150, 11, verbose=False)
+
+
+def test_map_operations_on_random_shapes_dtypes_and_alignments():
+    """tools/map_ops_fuzz.py: 60 random cases (extents 1 ... 300, unbatched and batched, fp32 / fp16, views that start 1-3 elements off an
+    allocation's start) through the colour transfers, both workflow conversions, the normal decode, blends and masks, with gradients,
+    against the ATen restatements of the reference."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("map_ops_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "map_ops_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(60, 13, verbose=False)

@@ -947,3 +947,14 @@ def test_random_shapes_workflows_flags_and_lights_against_the_oracle():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     mod.run(80, 5, verbose=False)
+
+
+def test_fused_tile_on_random_shapes_bands_fold_bands_and_orders():
+    """tools/tile_fuzz.py: 60 random cases (maps 1 ... 128 rows x 4 ... 1536 columns, repeats 1-4 x 1-3, fp32 / fp16, 1-2 lights, 1-2 materials,
+    every fold band and workgroup order, a random row band each): bit-identical to the evaluation of the materialised repeat."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("tile_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "tile_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.run(60, 17, verbose=False)

@@ -63,6 +63,12 @@ def run(cases=150, seed=0, verbose=True):
         if want_grad:
             dev = [None if t is None else t.requires_grad_(True) for t in dev]
         fkw = dict(view_dir=view, light=lights if L > 1 else lights[0], light_intensity=inten if L > 1 else inten[0], light_type=lt, light_size=size, **flags)
+        want_params = want_grad and wf != "converted" and rng.random() < 0.5        # gradients of view / light / intensity too (the light-gradient kernels)
+        if want_params:
+            pv = torch.tensor(view, requires_grad=True)
+            pl = torch.tensor(lights if L > 1 else lights[0], requires_grad=True)
+            pi = torch.tensor(inten if L > 1 else inten[0], requires_grad=True)
+            fkw.update(view_dir=pv, light=pl, light_intensity=pi)
         if wf == "converted":
             fkw.update(convert_to_diffuse_specular=True, specular_is_srgb=quirk)
         out = F.cook_torrance(*dev, **fkw)
@@ -77,7 +83,23 @@ def run(cases=150, seed=0, verbose=True):
             wt = torch.rand(out.shape, generator=g) - 0.5
             (out * wt.cuda()).sum().backward()
             leaves = [None if t is None else t.double().requires_grad_(True) for t in maps_cpu]
-            (oracle(leaves, torch.float64) * wt.double()).sum().backward()
+            if want_params:
+                qv = torch.tensor(view, dtype=torch.float64, requires_grad=True)
+                ql = torch.tensor(lights, dtype=torch.float64, requires_grad=True)
+                qi = torch.tensor(inten, dtype=torch.float64, requires_grad=True)
+                kw64 = {k: v for k, v in okw.items() if k != "view"}
+                if L > 1:
+                    ref64 = O.cook_torrance_batched(*leaves, lights=ql, intensities=qi, view=qv, **kw64)
+                else:
+                    ref64 = O.cook_torrance_batched(*leaves, light=ql[0], intensity=qi[0], view=qv, **kw64)
+                (ref64 * wt.double()).sum().backward()
+                for name, got, want in (("view", pv.grad, qv.grad), ("light", pl.grad, ql.grad if L > 1 else ql.grad[0]), ("intensity", pi.grad, qi.grad if L > 1 else qi.grad[0])):
+                    e = float((got.double().cpu() - want).abs().max() / (1 + want.abs().max()))
+                    eg = max(eg, e)
+                    if not e <= 5e-5:
+                        raise AssertionError(f"render fuzz {desc}: gradient of {name} off by {e:.2e}")
+            else:
+                (oracle(leaves, torch.float64) * wt.double()).sum().backward()
             for name, x, y in zip(("albedo", "normal", "roughness", "metallic", "specular"), dev, leaves):
                 if x is None:
                     continue

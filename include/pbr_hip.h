@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PBR_HIP_ABI_VERSION 4      /* 4: light_size follows Python truthiness (negative / NaN are not "absent"); gradients of the map ops */
+#define PBR_HIP_ABI_VERSION 5      /* 5: pbr_render_desc.device_params (view / light / intensity read from device memory); 4: light_size follows Python truthiness, gradients of the map ops */
 #define PBR_MAX_LIGHTS 16
 
 /* ---- status codes (negative = caller error, positive = HIP runtime error code + 1000) */
@@ -114,6 +114,11 @@ typedef struct pbr_render_desc {
     int64_t out_channel_stride;   /* elements between the result's channel planes; 0 = height * width (contiguous).
                                      Rows are always contiguous.  Lets the result of material b sit right behind its
                                      maps ("material-major" batches) */
+    const void *device_params;    /* NULL: view_dir / lights / intensities above are used.  Else a block of pbr_device_params_bytes() bytes
+                                     written by pbr_prepare_device_params (earlier on the same stream): the kernels read view, light and
+                                     intensity from it -- parameters that live in device memory (a light being fitted: cooktorrance.py:95-96,
+                                     :126-140 are torch ops on device tensors upstream) never travel through the host, so a step neither
+                                     synchronises nor bakes their values into a captured graph.  n_lights still counts the rows */
 } pbr_render_desc;
 
 #define PBR_SCHEDULE_AUTO 0
@@ -219,6 +224,16 @@ int pbr_cook_torrance_mse_step(const pbr_render_desc *desc, const void *target, 
                                void *g_metallic, void *g_specular, void *loss, void *workspace, void *stream);
 /* data[i] *= *scalar for n elements of `dtype`, in place; `scalar` is a DEVICE float (no host synchronisation: the upstream
  * gradient of a loss lives on the device); a scalar of exactly 1 leaves the data untouched. */
+/* ABI 5: view / light / intensity from DEVICE memory.  `view_dir` [3], `lights` [n_lights][3], `intensities` [intensity_rows][3] with
+ * intensity_rows = 1 (one intensity for every light) or n_lights: fp32 device pointers; a NULL pointer takes that parameter from the descriptor
+ * (d->view_dir / d->lights / d->intensities: host values), so only what lives on the device needs to be there.  Writes `block` (pbr_device_params_bytes() bytes,
+ * 16-byte aligned): the normalised view vector and per light what pbr_cook_torrance otherwise folds on the host (cooktorrance.py:95-96,
+ * :126-127, :155-158).  Reads d->light_type, d->n_lights and the host parameters of the descriptor.  Put the block's address into pbr_render_desc.device_params of the
+ * launches that follow on the stream (forward, backward, backward_params, blend, mse_step). */
+size_t pbr_device_params_bytes(void);
+int pbr_prepare_device_params(const pbr_render_desc *d, const void *view_dir, const void *lights, const void *intensities,
+                              int32_t intensity_rows, void *block, void *stream);
+
 int pbr_scale_by_device_scalar(void *data, size_t n, int dtype, const void *scalar, void *stream);
 /* The same for up to five buffers of one dtype in ONE launch (the gradients a step leaves): data[j] has n[j] elements, count <= 5. */
 int pbr_scale_list_by_device_scalar(void *const *data, const size_t *n, int count, int dtype, const void *scalar, void *stream);

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBR_HIP_LIB") or os.path.join(_HERE, "libpbr_hip.so")   # env override: A/B of two builds
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_LIGHTS = 16
 
 F32, F16 = 0, 1
@@ -33,7 +33,7 @@ EXPORTS = (
     "pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
     "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
     "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward", "pbr_fold_gradient_typed",
-    "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar", "pbr_scale_list_by_device_scalar",
+    "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar", "pbr_scale_list_by_device_scalar", "pbr_device_params_bytes", "pbr_prepare_device_params",
 )
 
 
@@ -55,6 +55,7 @@ class RenderDesc(ctypes.Structure):
         ("schedule", ctypes.c_int32), ("map_height", ctypes.c_int32), ("map_width", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
         ("out_batch_stride", ctypes.c_int64), ("out_channel_stride", ctypes.c_int64),
+        ("device_params", ctypes.c_void_p),
     ]
 
 
@@ -129,6 +130,10 @@ def lib():
     L.pbr_scale_by_device_scalar.restype = ctypes.c_int
     L.pbr_scale_list_by_device_scalar.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.c_int, ctypes.c_int, vp, vp]
     L.pbr_scale_list_by_device_scalar.restype = ctypes.c_int
+    L.pbr_device_params_bytes.argtypes = []
+    L.pbr_device_params_bytes.restype = ctypes.c_size_t
+    L.pbr_prepare_device_params.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, i32, vp, vp]
+    L.pbr_prepare_device_params.restype = ctypes.c_int
     L.pbr_fold_gradient_typed.argtypes = [vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_int, ctypes.c_int, vp]
     L.pbr_fold_gradient_typed.restype = ctypes.c_int
     L.pbr_cook_torrance_backward.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp]

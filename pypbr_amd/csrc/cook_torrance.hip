@@ -98,6 +98,37 @@ static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
 
 }  // namespace pbr
 
+namespace pbr {
+// pbr_prepare_device_params: one wave; lane i folds light i (fold_light: the host's own code), lane 0 the view vector and the grey flag.
+// A parameter given as a NULL device pointer comes from the descriptor (host values, carried in the kernel arguments).
+struct HostParams { float view[3]; float lights[PBR_MAX_LIGHTS][3]; float inten[PBR_MAX_LIGHTS][3]; };
+__global__ __launch_bounds__(64) void prepare_device_params_kernel(const float *__restrict__ view, const float *__restrict__ lights,
+                                                                   const float *__restrict__ inten, int intensity_rows, int n_lights, int light_type,
+                                                                   const HostParams hp, DevParams *__restrict__ out) {
+    const int i = threadIdx.x;
+    float raw[3];
+    for (int c = 0; c < 3; ++c) raw[c] = view ? view[c] : hp.view[c];
+    float V[3];
+    normalize_host(raw, V);
+    auto intensity = [&](int l, int c) { return inten ? inten[3 * (intensity_rows == 1 ? 0 : l) + c] : hp.inten[l][c]; };
+    if (i == 0) {
+        int grey = 1;
+        for (int l = 0; l < n_lights; ++l)
+            if (intensity(l, 0) != intensity(l, 1) || intensity(l, 0) != intensity(l, 2)) grey = 0;
+        for (int c = 0; c < 3; ++c) { out->V[c] = V[c]; out->raw_view[c] = raw[c]; }
+        out->grey = grey;
+    }
+    if (i < n_lights) {
+        float L[3], I[3];
+        for (int c = 0; c < 3; ++c) { L[c] = lights ? lights[3 * i + c] : hp.lights[i][c]; I[c] = intensity(i, c); }
+        LightU u;
+        fold_light(light_type, V, L, I, u);
+        out->lights[i] = u;
+        for (int c = 0; c < 3; ++c) out->raw_lights[i][c] = L[c];
+    }
+}
+}  // namespace pbr
+
 extern "C" {
 
 int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
@@ -212,6 +243,26 @@ int pbr_set_tuning(int knob, int value) {
     const int old = *slot;
     *slot = value;
     return old;
+}
+
+size_t pbr_device_params_bytes(void) { return sizeof(pbr::DevParams); }
+
+int pbr_prepare_device_params(const pbr_render_desc *d, const void *view_dir, const void *lights, const void *intensities,
+                              int32_t intensity_rows, void *block, void *stream) {
+    using namespace pbr;
+    if (!d || !block) return PBR_ERR_NULL_MAP;
+    if (d->abi_version != PBR_HIP_ABI_VERSION || d->n_lights < 1 || d->n_lights > PBR_MAX_LIGHTS) return PBR_ERR_SHAPE;
+    if (d->light_type != PBR_LIGHT_POINT && d->light_type != PBR_LIGHT_DIRECTIONAL) return PBR_ERR_LIGHT_TYPE;
+    if (intensities && intensity_rows != 1 && intensity_rows != d->n_lights) return PBR_ERR_SHAPE;
+    HostParams hp;
+    for (int c = 0; c < 3; ++c) hp.view[c] = d->view_dir[c];
+    for (int i = 0; i < PBR_MAX_LIGHTS; ++i)
+        for (int c = 0; c < 3; ++c) { hp.lights[i][c] = d->lights[i][c]; hp.inten[i][c] = d->intensities[i][c]; }
+    hipLaunchKernelGGL(prepare_device_params_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), static_cast<const float *>(view_dir),
+                       static_cast<const float *>(lights), static_cast<const float *>(intensities), (int)intensity_rows, (int)d->n_lights,
+                       (int)d->light_type, hp, static_cast<DevParams *>(block));
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PBR_OK : 1000 + (int)e;
 }
 
 }  // extern "C"

@@ -172,6 +172,7 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
                            (int)k.n_tiles, n_param);
         f.stage = stage; f.out = static_cast<float *>(g_params);
         f.n_rows = kParamStageRows; f.n_lights = d->n_lights; f.light_type = d->light_type;
+        f.dev = k.dev;
         for (int c = 0; c < 3; ++c) f.view[c] = d->view_dir[c];
         for (int i = 0; i < d->n_lights; ++i)
             for (int c = 0; c < 3; ++c) f.lights[i][c] = d->lights[i][c];

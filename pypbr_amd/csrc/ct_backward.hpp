@@ -238,7 +238,7 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { t.nm[0][j] = 0.0f; t.nm[1][j] = 0.0f; t.nm[2][j] = 1.0f; }
     }
-    const Vec3 V = {a.V[0], a.V[1], a.V[2]};
+    const Vec3 V = view_of(a);
     float ys = 0.0f;
     if (LIGHT == PBR_LIGHT_POINT) ys = linspace_at(a.y0, a.y1, a.ystep, a.H_total, p.y + a.y_offset);
 
@@ -300,7 +300,7 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
         if (MULTI) {                                 // pass 1: the summed colour decides the outer clamp / encode slope
             R sum[3] = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
             for (int l = 0; l < nl; ++l) {
-                const LightU &lu = a.lights[l];
+                const LightU lu = light_of(a, l);
                 LightEvalT<R> e;
                 eval_light(pt, light_geom<LIGHT, R>(lu, V, xs, ys), lu.inten, e);
 #pragma unroll
@@ -322,7 +322,7 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
         adj.g_a2 = adj.g_k = adj.g_ndv = splat<R>(0.0f);
         adj.g_n = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
         for (int l = 0; l < nl; ++l) {
-            const LightU &lu = a.lights[l];
+            const LightU lu = light_of(a, l);
             const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs, ys);
             LightEvalT<R> e;
             eval_light(pt, lg, lu.inten, e);
@@ -857,6 +857,7 @@ __global__ __launch_bounds__(256) void param_grad_stage_kernel(const float *__re
 struct ParamFinishArgs {
     const double *stage; float *out; int32_t n_rows, n_lights, light_type;      // n_rows = kParamStageRows rows of stage sums
     float view[3]; float lights[PBR_MAX_LIGHTS][3];
+    uint64_t dev;                     // parameters in device memory (address of the DevParams block): the raw vectors come from it
 };
 __global__ __launch_bounds__(256) void param_grad_finish_kernel(const ParamFinishArgs a) {
     const int vec = blockIdx.x, n_param = 3 + 6 * a.n_lights;
@@ -880,7 +881,13 @@ __global__ __launch_bounds__(256) void param_grad_finish_kernel(const ParamFinis
     double g[3] = {red[0][0], red[1][0], red[2][0]};
     const bool normalised = vec == 0 || (vec <= a.n_lights && a.light_type == PBR_LIGHT_DIRECTIONAL);
     if (normalised) {
-        const float *x = vec == 0 ? a.view : a.lights[vec - 1];
+        float x[3];
+        if (a.dev) {
+            const DevParams *d = reinterpret_cast<const DevParams *>(a.dev);
+            for (int j = 0; j < 3; ++j) x[j] = vec == 0 ? d->raw_view[j] : d->raw_lights[vec - 1][j];
+        } else {
+            for (int j = 0; j < 3; ++j) x[j] = vec == 0 ? a.view[j] : a.lights[vec - 1][j];
+        }
         const double nrm = sqrt((double)x[0] * x[0] + (double)x[1] * x[1] + (double)x[2] * x[2]);
         if (nrm > 1e-12) {
             const double u[3] = {x[0] / nrm, x[1] / nrm, x[2] / nrm};

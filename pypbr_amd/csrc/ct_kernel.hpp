@@ -31,6 +31,16 @@ struct LightU {
     float inten[3];   // :96
 };
 
+// pbr_render_desc.device_params: the same wave-uniform values, prepared on the device (cook_torrance.hip: prepare_device_params_kernel)
+// from parameter tensors that live there.  `raw_*`: the un-normalised inputs, for the chain rule through F.normalize (param_grad_finish_kernel).
+struct DevParams {
+    float V[3];
+    int32_t grey;                      // every light's three intensities are equal
+    LightU lights[PBR_MAX_LIGHTS];
+    float raw_view[3];
+    float raw_lights[PBR_MAX_LIGHTS][3];
+};
+
 // Multiply-shift division of n < 2^31 by a fixed d (Granlund-Montgomery round-up form).
 struct FastDiv {
     uint32_t mul; int32_t sh1, sh2;
@@ -79,7 +89,36 @@ struct KArgs {
     int32_t albedo_srgb, spec_srgb, out_srgb, has_normal;
     int32_t grey_lights;     // every light's three intensities are equal: radiance * intensity once per light, not per channel
     LightU lights[PBR_MAX_LIGHTS];
+    uint64_t dev;            // pbr_render_desc.device_params (address of a DevParams block, 0 = none): when set, V and the light blocks are read from it (view_of / light_of)
 };
+
+// View vector and light block of a launch: kernel arguments, or the device block when the parameters live in device memory.
+// Wave-uniform either way (scalar loads); by value, so that neither the kernel-argument struct nor the block has its address taken.
+// The block is read through the CONSTANT address space: written by an earlier kernel of the stream, never by this one, so its loads are scalar
+// (s_load) like the kernel arguments' -- through a plain pointer the compiler issues per-lane vector loads (the ISA assertions of the streamed
+// kernels caught exactly that).
+typedef const __attribute__((address_space(4))) DevParams *DevParamsPtr;
+__device__ __forceinline__ DevParamsPtr dev_params(uint64_t address) { return (DevParamsPtr)address; }
+__device__ __forceinline__ Vec3 view_of(const KArgs &a) {
+#ifndef PBR_NO_DEV_PARAMS           // build-time A/B switch: the kernels as they were before ABI 5
+    if (a.dev) { const DevParamsPtr d = dev_params(a.dev); return Vec3{d->V[0], d->V[1], d->V[2]}; }
+#endif
+    return Vec3{a.V[0], a.V[1], a.V[2]};
+}
+__device__ __forceinline__ LightU light_of(const KArgs &a, int l) {
+#ifndef PBR_NO_DEV_PARAMS
+    if (a.dev) {
+        const DevParamsPtr d = dev_params(a.dev);
+        LightU u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { u.l[c] = d->lights[l].l[c]; u.h[c] = d->lights[l].h[c]; u.inten[c] = d->lights[l].inten[c]; }
+        u.rhh = d->lights[l].rhh; u.p5 = d->lights[l].p5;
+        return u;
+    }
+#endif
+    return a.lights[l];
+}
+__device__ __forceinline__ bool grey_lights_of(const KArgs &a) { return a.dev ? dev_params(a.dev)->grey != 0 : a.grey_lights != 0; }
 
 // ------------------------------------------------------------------ typed vector I/O
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -499,14 +538,14 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
     constexpr int NG = RealOf<VEC, PACKED>::N;                             // pixel groups per lane
     decode_texels<WF, VEC, PACKED>(a, t);
 
-    const Vec3 V = {a.V[0], a.V[1], a.V[2]};
+    const Vec3 V = view_of(a);
     float ys = 0.0f;
     if (LIGHT == PBR_LIGHT_POINT) ys = linspace_at(a.y0, a.y1, a.ystep, a.H_total, p.y + a.y_offset);
 
     R res[3][NG];
     if constexpr (!MULTI) {
         // ---- one light: group by group, terms and shading back to back (shortest live ranges)
-        const LightU &lu = a.lights[0];
+        const LightU lu = light_of(a, 0);
         R xs[NG];
         if (LIGHT == PBR_LIGHT_POINT) x_grid<R, NG, VEC>(a, p.x, xs);
 #pragma unroll
@@ -538,7 +577,7 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
 #pragma unroll
             for (int g = 0; g < NG; ++g) res[c][g] = splat<R>(0.0f);
         for (int l = 0; l < a.n_lights; ++l) {
-            const LightU &lu = a.lights[l];
+            const LightU lu = light_of(a, l);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[g], ys);
@@ -672,7 +711,7 @@ void cook_torrance_batch_kernel(const KArgs a) {
     } else {
         if (a.has_normal) load_all(std::false_type{}, std::true_type{}); else load_all(std::false_type{}, std::false_type{});
     }
-    const Vec3 V = {a.V[0], a.V[1], a.V[2]};
+    const Vec3 V = view_of(a);
     PixelTermsT<R> pt[NB][NG];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -698,7 +737,7 @@ void cook_torrance_batch_kernel(const KArgs a) {
             for (int g = 0; g < NG; ++g) res[j][c][g] = splat<R>(0.0f);
     auto light_loop = [&](auto grey) {
         for (int l = 0; l < a.n_lights; ++l) {
-            const LightU &lu = a.lights[l];
+            const LightU lu = light_of(a, l);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[g], ys);
@@ -712,7 +751,7 @@ void cook_torrance_batch_kernel(const KArgs a) {
             }
         }
     };
-    if (a.grey_lights) light_loop(std::true_type{}); else light_loop(std::false_type{});
+    if (grey_lights_of(a)) light_loop(std::true_type{}); else light_loop(std::false_type{});
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
 #pragma unroll

@@ -43,10 +43,47 @@ extern int g_bwd_wide;             // streamed backward kernel with 16-byte memo
 extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
 constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
 
-inline void normalize_host(const float v[3], float o[3]) {   // F.normalize(v, dim=0), fp32
-    const float nrm = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+// The folding of view / light parameters into wave-uniform values runs on the host (parameters in pbr_render_desc) or, for parameters that
+// live in device memory, in prepare_device_params_kernel: ONE definition, fp contraction off, IEEE sqrt and division on both sides, so the two
+// produce the same bits.
+#if defined(__HIP_DEVICE_COMPILE__)         // single IEEE operations: the device build runs with -ffp-contract=fast, and HIP's __fmul_rn is a plain
+__device__ __forceinline__ float pbr_unfused(float x) { asm volatile("" : "+v"(x)); return x; }   // `*` that the compiler fuses all the same -- the
+#define PBR_SQRT_RN(x) __fsqrt_rn(x)                                                              // product passes through an opaque statement instead
+#define PBR_DIV_RN(a, b) __fdiv_rn(a, b)
+#define PBR_MUL_RN(a, b) pbr_unfused((a) * (b))
+#define PBR_ADD_RN(a, b) ((a) + (b))
+#else
+#define PBR_SQRT_RN(x) sqrtf(x)
+#define PBR_DIV_RN(a, b) ((a) / (b))
+#define PBR_MUL_RN(a, b) ((a) * (b))
+#define PBR_ADD_RN(a, b) ((a) + (b))
+#endif
+__host__ __device__ inline float dot3_rn(const float a[3], const float b[3]) {           // ((a0 b0 + a1 b1) + a2 b2), every operation rounded
+    return PBR_ADD_RN(PBR_ADD_RN(PBR_MUL_RN(a[0], b[0]), PBR_MUL_RN(a[1], b[1])), PBR_MUL_RN(a[2], b[2]));
+}
+__host__ __device__ inline void normalize_host(const float v[3], float o[3]) {   // F.normalize(v, dim=0), fp32
+    const float nrm = PBR_SQRT_RN(dot3_rn(v, v));
     const float d = nrm > 1e-12f ? nrm : 1e-12f;
-    o[0] = v[0] / d; o[1] = v[1] / d; o[2] = v[2] / d;
+    o[0] = PBR_DIV_RN(v[0], d); o[1] = PBR_DIV_RN(v[1], d); o[2] = PBR_DIV_RN(v[2], d);
+}
+__host__ __device__ inline void fold_light(int light_type, const float V[3], const float raw[3], const float inten[3], LightU &u) {
+    for (int c = 0; c < 3; ++c) u.inten[c] = inten[c];
+    u.rhh = 0.0f; u.p5 = 0.0f;
+    for (int c = 0; c < 3; ++c) u.h[c] = 0.0f;
+    if (light_type == PBR_LIGHT_DIRECTIONAL) {
+        normalize_host(raw, u.l);                                            // :126
+        float hn[3];
+        for (int c = 0; c < 3; ++c) u.h[c] = PBR_ADD_RN(V[c], u.l[c]);       // :155
+        const float hh = dot3_rn(u.h, u.h);
+        u.rhh = PBR_DIV_RN(1.0f, (hh > 1e-24f ? hh : 1e-24f));
+        normalize_host(u.h, hn);
+        float ct = dot3_rn(hn, V);                                           // :156-158
+        ct = ct < 0.0f ? 0.0f : (ct > 1.0f ? 1.0f : ct);
+        const float om = PBR_ADD_RN(1.0f, -ct);
+        u.p5 = PBR_MUL_RN(PBR_MUL_RN(PBR_MUL_RN(om, om), PBR_MUL_RN(om, om)), om);       // :196
+    } else {
+        for (int c = 0; c < 3; ++c) u.l[c] = raw[c];
+    }
 }
 
 inline int validate(const pbr_render_desc *d) {
@@ -205,24 +242,9 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log
     k.grey_lights = 1;
     for (int i = 0; i < d->n_lights; ++i)
         if (d->intensities[i][0] != d->intensities[i][1] || d->intensities[i][0] != d->intensities[i][2]) k.grey_lights = 0;
-    for (int i = 0; i < d->n_lights; ++i) {
-        LightU &u = k.lights[i];
-        for (int c = 0; c < 3; ++c) u.inten[c] = d->intensities[i][c];
-        if (d->light_type == PBR_LIGHT_DIRECTIONAL) {
-            normalize_host(d->lights[i], u.l);                                   // :126
-            float hn[3];
-            for (int c = 0; c < 3; ++c) u.h[c] = k.V[c] + u.l[c];                // :155
-            const float hh = u.h[0] * u.h[0] + u.h[1] * u.h[1] + u.h[2] * u.h[2];
-            u.rhh = 1.0f / (hh > 1e-24f ? hh : 1e-24f);
-            normalize_host(u.h, hn);
-            float ct = hn[0] * k.V[0] + hn[1] * k.V[1] + hn[2] * k.V[2];          // :156-158
-            ct = ct < 0.0f ? 0.0f : (ct > 1.0f ? 1.0f : ct);
-            const float om = 1.0f - ct;
-            u.p5 = (om * om) * (om * om) * om;                                   // :196
-        } else {
-            for (int c = 0; c < 3; ++c) u.l[c] = d->lights[i][c];
-        }
-    }
+    for (int i = 0; i < d->n_lights; ++i) fold_light(d->light_type, k.V, d->lights[i], d->intensities[i], k.lights[i]);
+    k.dev = reinterpret_cast<uint64_t>(d->device_params);
+    if (k.dev) k.grey_lights = 0;            // the intensities are not known here: the kernels ask the block's own flag
 }
 
 // A NaN light_size is truthy (`nan or 1.0` is nan): the reference's point-light grid, hence every value of its result, is NaN

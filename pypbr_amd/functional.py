@@ -74,8 +74,9 @@ _HOST_COPIES_MAX = 64
 
 
 def _host_vec3(v: TensorLike, rows: Optional[int] = None):
-    """Light/view parameters travel in the kernel-argument segment, so they are host values.  A device tensor costs one
-    small blocking D2H copy per call, as the reference's `.to(device)` / scalar reads do.  With
+    """Host values of a light / view parameter for the kernel-argument segment.  Tensors that live on a ROCm device do NOT come here any more
+    (DEVICE_PARAMETERS: the kernels read them from device memory, _device_parameter_tensors); with that switched off a device tensor costs one
+    small blocking D2H copy per call, as the reference's `.to(device)` / scalar reads do, and with
     `set_caching(parameters=True)` the host values are remembered per tensor object and version counter, so a caller
     that keeps its light / view tensors on the GPU and passes the same unchanged tensors call after call (the
     reference's override_device usage) synchronises on the first call only.  Tensors that require grad are read
@@ -103,6 +104,24 @@ def _host_vec3(v: TensorLike, rows: Optional[int] = None):
         return [float(x) for x in t.reshape(3).tolist()]
     t = t.reshape(-1, 3)
     return [[float(x) for x in r] for r in t.tolist()]
+
+
+DEVICE_PARAMETERS = True     # view / light / intensity tensors that live on the device are read there (pbr_render_desc.device_params), not copied to the host
+
+
+def _device_parameter_tensors(view_dir, light, light_intensity, device):
+    """When one of view_dir / light / light_intensity is a tensor on a ROCm device: (view [3] | None, lights [L,3] | None, intensities [1|L,3] | None)
+    -- the device-resident ones as contiguous float32 tensors on `device`, None for those the caller holds on the host (they travel in the
+    descriptor as always).  The kernels then read the device ones from device memory: no blocking read-back, no copy in either direction, and a
+    captured graph sees the tensors' CURRENT values at every replay (a light being fitted by an optimiser).  Else None."""
+    if not DEVICE_PARAMETERS or not any(isinstance(t, torch.Tensor) and t.is_cuda for t in (view_dir, light, light_intensity)):
+        return None
+    on_device = lambda t: isinstance(t, torch.Tensor) and t.is_cuda
+    conv = lambda t, rows: t.detach().to(device, torch.float32).reshape(rows).contiguous() if on_device(t) else None
+    v, lt, it = conv(view_dir, (-1,)), conv(light, (-1, 3)), conv(light_intensity, (-1, 3))
+    if v is not None and v.numel() != 3:
+        raise ValueError("expected a vector of 3 components, got shape %s" % (tuple(v.shape),))
+    return v, lt, it
 
 
 def _as_batched(t: Optional[torch.Tensor], channels: Tuple[int, ...], name: str):
@@ -161,8 +180,13 @@ def build_descriptor(albedo, normal, roughness, metallic, specular, out, *, view
     if albedo.dtype not in _DTYPES or out.dtype not in _DTYPES:
         raise TypeError("maps must be float32 or float16, got %s" % albedo.dtype)
 
-    lights = _host_vec3(light, rows=-1)
-    intens = _host_vec3(light_intensity, rows=-1)
+    dev_params = _device_parameter_tensors(view_dir, light, light_intensity, albedo.device)
+    # parameters that live on the device stay there (pbr_prepare_device_params, plan_cook_torrance); the others travel in the descriptor
+    dv, dl, di = dev_params if dev_params is not None else (None, None, None)
+    lights = [[0.0, 0.0, 0.0]] * dl.shape[0] if dl is not None else _host_vec3(light, rows=-1)
+    intens = [[0.0, 0.0, 0.0]] * di.shape[0] if di is not None else _host_vec3(light_intensity, rows=-1)
+    if dv is not None:
+        view_dir = [0.0, 0.0, 1.0]
     if len(intens) == 1 and len(lights) > 1:
         intens = intens * len(lights)
     if len(lights) != len(intens):
@@ -204,6 +228,7 @@ def build_descriptor(albedo, normal, roughness, metallic, specular, out, *, view
         for c in range(3):
             d.lights[i][c] = l[c]
             d.intensities[i][c] = it[c]
+    d._device_parameters = dev_params          # (view [3], lights [L,3], intensities [1|L,3]) on the maps' device, or None
     return d
 
 
@@ -240,6 +265,25 @@ class RenderPlan:
                                                        ctypes.byref(best)))
         self.desc.schedule = best.value
         return best.value
+
+    def prepare_device_parameters(self, tensors=None, stream: Optional[int] = None):
+        """pbr_prepare_device_params: folds view / light / intensity tensors that live on the device into the block the kernels read
+        (enqueued on the stream; no host access to their values).  Called by plan_cook_torrance; call it again -- or capture it in a graph
+        in front of `launch()` -- after the tensors changed (`tensors` = (view [3] | None, lights [L,3] | None, intensities [1|L,3] | None) to switch to others; None = the
+        descriptor's host values)."""
+        if tensors is not None:
+            self._param_tensors = tuple(tensors)
+        v, lt, it = self._param_tensors
+        lib = N.lib()
+        if getattr(self, "_param_block", None) is None:
+            self._param_block = torch.empty((lib.pbr_device_params_bytes() + 3) // 4, dtype=torch.float32, device=self.device)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        if (lt is not None and lt.shape[0] != self.desc.n_lights) or (it is not None and it.shape[0] not in (1, self.desc.n_lights)):
+            raise ValueError("light / light_intensity rows disagree with the descriptor's %d lights" % self.desc.n_lights)
+        with torch.cuda.device(self.device):
+            N.check(lib.pbr_prepare_device_params(self._ref, ptr(v), ptr(lt), ptr(it), 1 if it is None else it.shape[0], self._param_block.data_ptr(),
+                                                  _stream_ptr(self.device) if stream is None else stream))
+        self.desc.device_params = self._param_block.data_ptr()
 
     def attach_blend(self, blend_desc, workspace, keep_alive):
         """Turns the plan into blend + evaluate (pbr_cook_torrance_blend): material 2 and the mask."""
@@ -330,6 +374,8 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                             convert_to_diffuse_specular=convert_to_diffuse_specular, y_offset=y_offset,
                             height_total=height_total, schedule=schedule, tile=(ny, nx))
     plan = RenderPlan(desc, out, (a, n, r, m, s), squeeze and out.dim() == 4)
+    if desc._device_parameters is not None:
+        plan.prepare_device_parameters(desc._device_parameters)
     if blend is not None:
         if len(blend) != 6:
             raise ValueError("blend = (albedo2, normal2, roughness2, metallic2, specular2, mask)")
@@ -523,6 +569,8 @@ def _torch_op_can_take(albedo, kw) -> bool:
     schedules, autotuning and the fused blend stay on the ctypes plan."""
     if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda or albedo.numel() == 0:      # zero-sized maps: RenderPlan.launch returns the empty image
         return False
+    if DEVICE_PARAMETERS and any(isinstance(kw.get(k), torch.Tensor) and kw[k].is_cuda for k in _PARAM_KEYS):
+        return False                 # parameters on the device: the ctypes plan reads them there (the operator would copy them to the host)
     if kw.get("out") is not None or kw.get("blend") is not None or kw.get("autotune") or kw.get("schedule", N.SCHEDULE_AUTO) != N.SCHEDULE_AUTO:
         return False
     if kw.get("out_dtype") not in (None, torch.float32, torch.float16):

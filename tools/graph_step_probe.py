@@ -48,7 +48,56 @@ def capture(leaves, target):
     return graph, loss
 
 
+def fit_light_step(maps, target, light, lr=0.5):
+    """Fit a point light's position to a target image: evaluation, MSE, backward to the light (light-gradient kernels), SGD update."""
+    light.grad = None
+    loss = torch.nn.functional.mse_loss(F.cook_torrance(*maps, view_dir=[0, 0, 1], light=light, light_intensity=[1, 1, 1], light_type="point", light_size=1.0), target)
+    loss.backward()
+    with torch.no_grad():
+        light.add_(light.grad, alpha=-lr)
+    return loss
+
+
+def light_fitting(S):
+    maps = synth_material(S, dev, 3)
+    target = F.cook_torrance(*maps, view_dir=[0, 0, 1], light=[0.25, -0.15, 0.9], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
+    out = {}
+    for where in ("cpu", "cuda"):
+        light = torch.tensor([-0.2, 0.2, 1.2], device=where, requires_grad=True)
+        for _ in range(10):
+            fit_light_step(maps, target, light)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(100):
+            fit_light_step(maps, target, light)
+        torch.cuda.synchronize()
+        out[where] = (time.perf_counter() - t0) / 100 * 1e6
+    light = torch.tensor([-0.2, 0.2, 1.2], device="cuda", requires_grad=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fit_light_step(maps, target, light)
+    torch.cuda.current_stream().wait_stream(side)
+    light.grad = None
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        fit_light_step(maps, target, light)
+    for _ in range(10):
+        graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        graph.replay()
+    torch.cuda.synchronize()
+    out["graph"] = (time.perf_counter() - t0) / 100 * 1e6
+    print(f"{S}^2 light-fitting step (evaluate, MSE, backward to the light, SGD): light on the host {out['cpu']:7.1f} us (one blocking read-back per step), "
+          f"light on the device {out['cuda']:7.1f} us, captured {out['graph']:7.1f} us", flush=True)
+
+
 if __name__ == "__main__":
+    for S in (256, 1024, 2048):
+        light_fitting(S)
     for S in (256, 512, 1024, 2048):
         leaves, target = make(S)
         for _ in range(20):

@@ -71,7 +71,21 @@ struct Prepared {
     Tensor albedo, roughness;
     OptTensor normal, metallic, specular;
     int64_t B, H, W;           // extent of the OUTPUT band
+    // parameters that live on the device (ABI 5): read there, never copied to the host
+    OptTensor dev_view, dev_lights, dev_intensities;
+    Tensor param_block;
 };
+
+// view / light / intensity tensors on the maps' device stay there: pbr_prepare_device_params folds them into a block the kernels read
+void use_device_parameters(Prepared &p, void *stream) {
+    if (!p.dev_view.has_value() && !p.dev_lights.has_value() && !p.dev_intensities.has_value()) return;
+    p.param_block = at::empty({(int64_t)((pbr_device_params_bytes() + 3) / 4)}, p.albedo.options().dtype(at::kFloat));
+    auto ptr = [](const OptTensor &t) -> const void * { return t.has_value() ? t->data_ptr() : nullptr; };
+    const int32_t rows = p.dev_intensities.has_value() ? (int32_t)(p.dev_intensities->numel() / 3) : 1;
+    check_status(pbr_prepare_device_params(&p.d, ptr(p.dev_view), ptr(p.dev_lights), ptr(p.dev_intensities), rows, p.param_block.data_ptr(), stream),
+                 "pbr_hip::prepare_device_params");
+    p.d.device_params = p.param_block.data_ptr();
+}
 
 // Shared by forward and backward: validates the maps and fills everything of the descriptor except `out`.
 Prepared prepare(const Tensor &albedo, const OptTensor &normal, const Tensor &roughness, const OptTensor &metallic,
@@ -121,9 +135,19 @@ Prepared prepare(const Tensor &albedo, const OptTensor &normal, const Tensor &ro
     d.albedo = map_of(p.albedo); d.normal = map_of(p.normal); d.roughness = map_of(p.roughness);
     d.metallic = map_of(p.metallic);
     d.specular = d.workflow == PBR_WORKFLOW_SPECULAR ? map_of(p.specular) : pbr_map{nullptr, 0, 0};
-    const std::vector<float> v = host_floats(view_dir, 3, "view_dir"), l = host_floats(lights, 3, "lights");
-    std::vector<float> it = host_floats(intensities, 3, "intensities");
-    TORCH_CHECK_VALUE(v.size() == 3, "view_dir must have 3 components");
+    auto on_device = [&](const Tensor &t, int64_t cols, const char *name) {
+        if (!t.is_cuda()) return false;
+        TORCH_CHECK_VALUE(t.numel() % cols == 0 && t.numel() > 0, name, " must hold a multiple of ", cols, " values, got ", t.sizes());
+        TORCH_CHECK_VALUE(t.device() == p.albedo.device(), name, " lives on ", t.device(), ", the maps on ", p.albedo.device());
+        return true;
+    };
+    std::vector<float> v(3, 0.0f), l, it;
+    if (on_device(view_dir, 3, "view_dir")) p.dev_view = view_dir.detach().to(at::kFloat).contiguous(); else v = host_floats(view_dir, 3, "view_dir");
+    TORCH_CHECK_VALUE(view_dir.numel() == 3, "view_dir must have 3 components");
+    if (on_device(lights, 3, "lights")) { p.dev_lights = lights.detach().to(at::kFloat).contiguous(); l.assign((size_t)lights.numel(), 0.0f); }
+    else l = host_floats(lights, 3, "lights");
+    if (on_device(intensities, 3, "intensities")) { p.dev_intensities = intensities.detach().to(at::kFloat).contiguous(); it.assign((size_t)intensities.numel(), 0.0f); }
+    else it = host_floats(intensities, 3, "intensities");
     const size_t L = l.size() / 3;
     TORCH_CHECK_VALUE(L >= 1 && L <= PBR_MAX_LIGHTS, "between 1 and ", PBR_MAX_LIGHTS, " lights are supported, got ", L);
     if (it.size() == 3 && L > 1) { it.resize(3 * L); for (size_t i = 1; i < L; ++i) for (int c = 0; c < 3; ++c) it[3 * i + c] = it[c]; }
@@ -152,6 +176,7 @@ Tensor cook_torrance(const Tensor &albedo, const OptTensor &normal, const Tensor
     Tensor out = at::empty({p.B, 3, p.H, p.W}, p.albedo.options().dtype(half_result ? at::kHalf : at::kFloat));
     p.d.out = out.data_ptr();
     p.d.out_dtype = half_result ? PBR_F16 : PBR_F32;
+    use_device_parameters(p, current_stream(out));
     check_status(pbr_cook_torrance(&p.d, current_stream(out)), "pbr_hip::cook_torrance");
     return out;
 }
@@ -181,6 +206,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> cook_torrance_backwar
     auto ptr = [](const Tensor &t) -> void * { return t.numel() ? t.data_ptr() : nullptr; };
     Tensor gp = at::empty({0}, opts.dtype(at::kFloat));
     void *stream = current_stream(g);
+    use_device_parameters(p, stream);
     if (want_params) {
         gp = at::empty({3 + 6 * (int64_t)p.d.n_lights}, opts.dtype(at::kFloat));
         Tensor ws = at::empty({(int64_t)(pbr_param_grad_workspace_bytes(&p.d) / 4 + 1)}, opts.dtype(at::kFloat));

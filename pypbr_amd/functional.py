@@ -569,8 +569,6 @@ def _torch_op_can_take(albedo, kw) -> bool:
     schedules, autotuning and the fused blend stay on the ctypes plan."""
     if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda or albedo.numel() == 0:      # zero-sized maps: RenderPlan.launch returns the empty image
         return False
-    if DEVICE_PARAMETERS and any(isinstance(kw.get(k), torch.Tensor) and kw[k].is_cuda for k in _PARAM_KEYS):
-        return False                 # parameters on the device: the ctypes plan reads them there (the operator would copy them to the host)
     if kw.get("out") is not None or kw.get("blend") is not None or kw.get("autotune") or kw.get("schedule", N.SCHEDULE_AUTO) != N.SCHEDULE_AUTO:
         return False
     if kw.get("out_dtype") not in (None, torch.float32, torch.float16):
@@ -583,8 +581,8 @@ def _param_tensor(v, rows):
     """view / light / intensity for the operator: a tensor that requires grad goes in as it is (the operator's autograd
     formula returns its gradient); anything else as a small CPU tensor, device tensors through the cached host copy."""
     if isinstance(v, torch.Tensor):
-        if (v.requires_grad and torch.is_grad_enabled()) or not v.is_cuda:
-            return v
+        if (v.requires_grad and torch.is_grad_enabled()) or not v.is_cuda or DEVICE_PARAMETERS:
+            return v                                         # device tensors: the operator reads them on the device (ABI 5)
         return torch.tensor(_host_vec3(v, rows=rows), dtype=torch.float32)
     t = torch.tensor(v, dtype=torch.float32)                 # Python numbers: no round trip (traceable by torch.compile)
     return t.reshape(3) if rows is None else t.reshape(-1, 3)

@@ -9,6 +9,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["operator", "ctypes"], autouse=True)
+def binding(request):
+    """Both bindings of the C ABI: torch.ops.pbr_hip.* (csrc/torch_ops.cpp) and the ctypes plan."""
+    from pypbr_amd import functional as F
+    saved = F.USE_TORCH_OPS
+    F.USE_TORCH_OPS = request.param == "operator"
+    yield request.param
+    F.USE_TORCH_OPS = saved
+
+
 def _maps(B, H, W, seed, dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     a = torch.rand(B, 3, H, W, generator=g)

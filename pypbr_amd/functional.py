@@ -641,7 +641,7 @@ class _CookTorranceFn(torch.autograd.Function):
         if kwargs.get("out") is not None:
             raise NotImplementedError("gradients need out=None (the result must be a fresh tensor)")
         if kwargs.get("blend") is not None:
-            raise NotImplementedError("the fused blend is forward-only; blend with pypbr_amd.blending first to differentiate")
+            raise NotImplementedError("this autograd bridge takes no blend (functional.cook_torrance routes a blend under a gradient to _FusedBlendFn)")
         maps = (albedo, normal, roughness, metallic, specular)
         plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], view_dir=view_dir, light=light,
                                   light_intensity=light_intensity, **kwargs)

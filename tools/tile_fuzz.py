@@ -41,6 +41,19 @@ def run(cases=60, seed=0, verbose=True):
             out = F.cook_torrance(a, n, r, m, tile=(ny, nx), schedule=sched, **kw)
             if not torch.equal(out, ref):
                 raise AssertionError(desc + f": differs from the materialised repeat by {float((out.float() - ref.float()).abs().max()):.2e}")
+            if rng.random() < 0.35 and lights == 1:
+                # gradients: a map repeated by the fused tile owns the SUM of the per-output-pixel gradients (pbr_fold_gradient[_typed]) -- what
+                # autograd gives through the materialised repeat
+                wt = (torch.rand(ref.shape, generator=g) - 0.5).cuda()
+                la = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
+                lb = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
+                (F.cook_torrance(*la, tile=(ny, nx), schedule=sched, **kw).float() * wt).sum().backward()
+                (F.cook_torrance(*[rep(t) for t in lb], **kw).float() * wt).sum().backward()
+                for name, x, y in zip(("albedo", "normal", "roughness", "metallic"), la, lb):
+                    gx, gy = x.grad.float(), y.grad.float()
+                    tol = (2e-3 if half else 2e-6) * float(gy.abs().max()) + (1e-3 if half else 0.0) * gy.abs()      # fp16: one rounding per repeat against one of the sum
+                    if not bool(((gx - gy).abs() <= tol + 1e-12).all()):
+                        raise AssertionError(desc + f": gradient of {name} differs from the materialised repeat's by {float((gx - gy).abs().max()):.2e} (max {float(gy.abs().max()):.2e})")
             if (ny, nx) == (1, 1):
                 continue
             H = ny * h

@@ -358,7 +358,29 @@ const char *pbr_kernel_name(const pbr_render_desc *desc);
 /* Algorithmic HBM bytes per pixel of that dispatch: reads + writes. */
 int pbr_bytes_per_pixel(const pbr_render_desc *desc);
 /* Tuning knobs for A/B runs inside one process; returns the previous value. */
-enum { PBR_TUNE_NONTEMPORAL = 0, PBR_TUNE_BLOCK_LOG2 = 1, PBR_TUNE_F16_VEC = 2, PBR_TUNE_LDS_BYTES = 3, PBR_TUNE_XCD_LOG2 = 4, PBR_TUNE_BWD_VEC = 5, PBR_TUNE_BATCH_INNER = 6, PBR_TUNE_INTERLEAVE = 7, PBR_TUNE_SCALAR_BASE = 8, PBR_TUNE_MAX_VEC = 9, PBR_TUNE_RESIZE_ROWS = 10, PBR_TUNE_BWD_RUN = 11, PBR_TUNE_RESIZE_XCD = 12, PBR_TUNE_BWD_WIDE = 13, PBR_TUNE_RESIZE_UP2 = 14, PBR_TUNE_TILE_FOLD = 15, PBR_TUNE_RESIZE_BWD_FUSED = 16, PBR_TUNE_RESIZE_QUADS = 17, PBR_TUNE_STREAM_SHAPE = 18, PBR_TUNE_STREAM_LDS = 19, PBR_TUNE_MSE_STREAM = 20 };   /* nt hint on/off; workgroup = 1 << value lanes (6..8); fp16 pixels per lane (4|8); unused dynamic LDS per workgroup as an occupancy governor (-1 = built-in rule); consecutive tiles per XCD = 1 << value; ...; 8: scalar plane addresses: 0 never, 1 rule (single materials), 2 whenever the launch allows them; 9: at most this many pixels per lane (8 default; 1 = the one-pixel kernels everywhere); 10: output rows per workgroup of the resize kernel (0 = rule); 11: tiles per wave of the streamed backward kernel for fp16 maps with one light (-1 = rule, 0 = the one-tile kernels); 12: tile order of the resize kernel (1 = XCD-contiguous chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many tiles); 13: the streamed backward kernel with 16-byte memory instructions (-1 = rule, 0 = the 4-byte form, 1 = wherever legal); 14: up-scales on both axes take the two-tap register kernel (1, default) or the strip kernel (0); 15: tiled maps (map_height < height_total): log2 of the source rows per band of the fold order, in which all vertical repeats of a band are visited back to back (-1 = rule, 0 = row order); 16: the gradient of resize in one pass (1, default) or two passes through the workspace (0); 17: the resize strip kernel's width pass with four columns per lane and 16-byte stores: 1 = rule (gradients at least twice the size of their upstream), 2 = wherever legal, 0 = never; 18: launch shape of the streaming map kernels (0 = 2048 workgroups of 256 lanes walking the data, 1 = one item per lane in 256-lane workgroups, 2 = in one-wave workgroups); 19: unused dynamic LDS bytes per workgroup of those kernels (an occupancy cap); 20: the rendering-loss step for fp16 maps with one light as the streamed kernel (1, default) or the one-tile kernels (0) */
+enum {                                  /* A/B knobs of pbr_set_tuning (profiling and tests; -1 / the default = the built-in rule) */
+    PBR_TUNE_NONTEMPORAL = 0,           /* streaming hint on loads and stores: 1 on (default), 0 off, 2 also on tiled launches */
+    PBR_TUNE_BLOCK_LOG2 = 1,            /* workgroup = 1 << value lanes (6..8) */
+    PBR_TUNE_F16_VEC = 2,               /* pixels per lane for fp16 maps (4 | 8) */
+    PBR_TUNE_LDS_BYTES = 3,             /* unused dynamic LDS per workgroup of the render kernel: an occupancy governor (-1 = rule) */
+    PBR_TUNE_XCD_LOG2 = 4,              /* consecutive tiles per XCD = 1 << value (the workgroup -> tile order) */
+    PBR_TUNE_BWD_VEC = 5,               /* pixels per lane of the backward kernels (2 | 4 force) */
+    PBR_TUNE_BATCH_INNER = 6,           /* several lights: materials per lane of the batch-inner kernel (0 = one-material kernel) */
+    PBR_TUNE_INTERLEAVE = 7,            /* experiment: materials of a batch interleaved workgroup by workgroup */
+    PBR_TUNE_SCALAR_BASE = 8,           /* scalar plane addresses: 0 never, 1 rule (single materials), 2 whenever the launch allows them */
+    PBR_TUNE_MAX_VEC = 9,               /* at most this many pixels per lane (8 default; 1 = the one-pixel kernels everywhere) */
+    PBR_TUNE_RESIZE_ROWS = 10,          /* output rows per workgroup of the resize kernels (0 = rule) */
+    PBR_TUNE_BWD_RUN = 11,              /* rounds of the streamed backward kernel for fp16 maps with one light (-1 = rule, 0 = the one-tile kernels) */
+    PBR_TUNE_RESIZE_XCD = 12,           /* tile order of the resize kernel: 1 = XCD-contiguous chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many */
+    PBR_TUNE_BWD_WIDE = 13,             /* streamed backward with 16-byte memory instructions: -1 = rule (off), 0 = the 4-byte form, 1 = wherever legal */
+    PBR_TUNE_RESIZE_UP2 = 14,           /* up-scales on both axes: the two-tap register kernel (1, default) or the strip kernel (0) */
+    PBR_TUNE_TILE_FOLD = 15,            /* tiled maps: log2 of the source rows per band of the fold order (all vertical repeats of a band back to back); -1 = rule, 0 = row order */
+    PBR_TUNE_RESIZE_BWD_FUSED = 16,     /* gradient of resize in one pass (1, default) or two passes through the workspace (0) */
+    PBR_TUNE_RESIZE_QUADS = 17,         /* strip kernel's width pass with four columns per lane and 16-byte stores: 1 = rule, 2 = wherever legal, 0 = never */
+    PBR_TUNE_STREAM_SHAPE = 18,         /* launch shape of the streaming map kernels: 0 = 2048 walking workgroups of 256 lanes, 1 = one item per lane (256-lane groups), 2 = one-wave groups */
+    PBR_TUNE_STREAM_LDS = 19,           /* unused dynamic LDS bytes per workgroup of those kernels (an occupancy cap) */
+    PBR_TUNE_MSE_STREAM = 20            /* rendering-loss step for fp16 maps with one light: the streamed kernel (1, default) or the one-tile kernels (0) */
+};
 int pbr_set_tuning(int knob, int value);
 
 #ifdef __cplusplus

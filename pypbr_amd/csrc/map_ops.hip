@@ -533,7 +533,8 @@ static int fold_launch(const void *src, void *dst, int32_t batch, int32_t channe
                        int fold_batch, void *stream) {
     const size_t items = (size_t)(fold_batch ? 1 : batch) * channels * h * w, al = 4 * sizeof(T);
     if (w % 4 == 0 && is_aligned(src, al) && is_aligned(dst, al)) {
-        hipLaunchKernelGGL((fold_gradient_quad_kernel<T>), dim3(stream_grid(items / 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+        const StreamShape sh = stream_shape(items / 4, kShapeFold);
+        hipLaunchKernelGGL((fold_gradient_quad_kernel<T>), dim3(sh.grid), dim3(sh.block), sh.lds, static_cast<hipStream_t>(stream),
                            src, dst, (int)batch, (int)channels, (int)h, (int)w, (int)ny, (int)nx, fold_batch);
         return hip_status();
     }

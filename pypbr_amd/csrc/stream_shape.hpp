@@ -27,6 +27,6 @@ inline StreamShape stream_shape(size_t work_items, StreamRule rule) {
 //   colour backward 100.3 -> 91.2     metallic_to_specular backward 157.7 -> 152.3     specular_to_metallic backward 66.2 -> 63.1
 //   blend 3 channels 110.7 -> 104.2     blend normals 109.6 -> 98.8     blend backward 190.5 -> 182.0
 constexpr StreamRule kShapeM2S = {2, 20480}, kShapeS2M = {1, 0}, kShapeColour = {2, 0}, kShapeColourBwd = {2, 0}, kShapeM2SBwd = {1, 0},
-                     kShapeS2MBwd = {1, 0}, kShapeBlend = {1, 0}, kShapeBlendNormal = {2, 20480}, kShapeBlendBwd = {1, 0}, kShapeMask = {0, 0};
+                     kShapeS2MBwd = {1, 0}, kShapeBlend = {1, 0}, kShapeBlendNormal = {2, 20480}, kShapeBlendBwd = {1, 0}, kShapeMask = {0, 0}, kShapeFold = {1, 0};      // fold: tile(2) of 3 x 2048^2 44.0 -> 40.8 us, a map shared by 8 materials 81.3 -> 77.9, nine repeats level (tools/fold_probe.py)
 
 }  // namespace pbr

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""pbr_fold_gradient timing: the sums autograd would perform for a tiled (repeat) or batch-shared map.
-python tools/fold_probe.py"""
+"""pbr_fold_gradient (the sum over tile repeats / over a batch that shares a map) by launch shape.  python tools/fold_probe.py"""
 import os
 import sys
 
@@ -12,25 +11,33 @@ from pypbr_amd import _native as N  # noqa: E402
 lib = N.lib()
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream(dev).cuda_stream
-for (B, C, h, w, ny, nx, fold_b) in [(1, 3, 2048, 2048, 2, 2, 0), (1, 1, 2048, 2048, 2, 2, 0), (8, 3, 2048, 2048, 1, 1, 1), (4, 3, 1024, 1024, 4, 4, 0), (2, 3, 1000, 1001, 2, 2, 0)]:
-    src = torch.rand(B, C, ny * h, nx * w, device=dev)
-    dst = torch.empty(1 if fold_b else B, C, h, w, device=dev)
-    ref = src.view(B, C, ny, h, nx, w).sum(dim=(2, 4))
-    if fold_b:
-        ref = ref.sum(dim=0, keepdim=True)
 
-    def run():
-        N.check(lib.pbr_fold_gradient(src.data_ptr(), dst.data_ptr(), B, C, h, w, ny, nx, fold_b, stream))
-    run()
-    err = (dst - ref).abs().max().item()
-    for _ in range(10):
-        run()
+
+def timed(fn, iters=60):
+    for _ in range(30):
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(50):
-        run()
+    for _ in range(iters):
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 50 * 1e3
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+for name, (B, C, h, w, ny, nx, fb) in (("tile(2) of 3 x 2048^2 (4 repeats)", (1, 3, 2048, 2048, 2, 2, 0)), ("a map shared by 8 materials, 3 x 2048^2", (8, 3, 2048, 2048, 1, 1, 1)),
+                                        ("tile(3) of 3 x 1024^2 (9 repeats)", (1, 3, 1024, 1024, 3, 3, 0))):
+    src = torch.rand(B, C, ny * h, nx * w, device=dev)
+    dst = torch.empty(1 if fb else B, C, h, w, device=dev)
     nbytes = 4 * (src.numel() + dst.numel())
-    print(f"B={B} C={C} {h}x{w} tiles {ny}x{nx} fold_batch={fold_b}: {us:7.1f} us  {nbytes / us / 1e3:7.1f} GB/s  max err vs torch sum {err:.1e}")
+    call = lambda: N.check(lib.pbr_fold_gradient(src.data_ptr(), dst.data_ptr(), B, C, h, w, ny, nx, fb, stream))
+    for shape in (0, 1, 2):
+        for lds in (0, 20480):
+            if shape != 2 and lds:
+                continue
+            lib.pbr_set_tuning(N.TUNE_STREAM_SHAPE, shape)
+            lib.pbr_set_tuning(N.TUNE_STREAM_LDS, lds)
+            us = timed(call)
+            print(f"{name} shape={shape} lds={lds}: {us:7.1f} us  {nbytes / us / 1e3:6.0f} GB/s ({nbytes / us / 1e3 / 8000:.3f})", flush=True)
+lib.pbr_set_tuning(N.TUNE_STREAM_SHAPE, -1)
+lib.pbr_set_tuning(N.TUNE_STREAM_LDS, -1)

@@ -379,6 +379,8 @@ enum {                                  /* A/B knobs of pbr_set_tuning (profilin
     PBR_TUNE_RESIZE_QUADS = 17,         /* strip kernel's width pass with four columns per lane and 16-byte stores: 1 = rule, 2 = wherever legal, 0 = never */
     PBR_TUNE_STREAM_SHAPE = 18,         /* launch shape of the streaming map kernels: 0 = 2048 walking workgroups of 256 lanes, 1 = one item per lane (256-lane groups), 2 = one-wave groups */
     PBR_TUNE_STREAM_LDS = 19,           /* unused dynamic LDS bytes per workgroup of those kernels (an occupancy cap) */
+    PBR_TUNE_PACK_SINGLE = 21,          /* one light over fp32 maps: packed (two pixels per instruction) arithmetic: -1 = rule (launches over tiled maps, which are VALU-bound), 0 = never, 1 = always */
+    PBR_TUNE_TILE_REPEAT = 22,          /* tiled maps, whole output, one light: every texel loaded and decoded once and evaluated at all its repeats (-1 = rule: on, 0 = wrap-around addressing) */
     PBR_TUNE_MSE_STREAM = 20            /* rendering-loss step for fp16 maps with one light: the streamed kernel (1, default) or the one-tile kernels (0) */
 };
 int pbr_set_tuning(int knob, int value);

@@ -15,7 +15,7 @@ MAX_LIGHTS = 16
 F32, F16 = 0, 1
 LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 WORKFLOW_METALLIC, WORKFLOW_SPECULAR, WORKFLOW_CONVERTED = 0, 1, 2
-TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, TUNE_XCD_LOG2, TUNE_BWD_VEC, TUNE_BATCH_INNER, TUNE_INTERLEAVE, TUNE_SCALAR_BASE, TUNE_MAX_VEC, TUNE_RESIZE_ROWS, TUNE_BWD_RUN, TUNE_RESIZE_XCD, TUNE_BWD_WIDE, TUNE_RESIZE_UP2, TUNE_TILE_FOLD, TUNE_RESIZE_BWD_FUSED, TUNE_RESIZE_QUADS, TUNE_STREAM_SHAPE, TUNE_STREAM_LDS, TUNE_MSE_STREAM = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20
+TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, TUNE_XCD_LOG2, TUNE_BWD_VEC, TUNE_BATCH_INNER, TUNE_INTERLEAVE, TUNE_SCALAR_BASE, TUNE_MAX_VEC, TUNE_RESIZE_ROWS, TUNE_BWD_RUN, TUNE_RESIZE_XCD, TUNE_BWD_WIDE, TUNE_RESIZE_UP2, TUNE_TILE_FOLD, TUNE_RESIZE_BWD_FUSED, TUNE_RESIZE_QUADS, TUNE_STREAM_SHAPE, TUNE_STREAM_LDS, TUNE_MSE_STREAM, TUNE_PACK_SINGLE, TUNE_TILE_REPEAT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22
 
 OK = 0
 ERR_NULL_MAP, ERR_WORKFLOW, ERR_LIGHT_TYPE, ERR_SHAPE, ERR_DTYPE, ERR_CHANNELS, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
@@ -185,7 +185,7 @@ def lib():
     if L.pbr_abi_version() != ABI_VERSION:
         raise NativeLibraryError("libpbr_hip.so ABI %d, binding expects %d" % (L.pbr_abi_version(), ABI_VERSION))
     for env, knob in (("PBR_TUNE_LDS_BYTES", TUNE_LDS_BYTES), ("PBR_TUNE_NONTEMPORAL", TUNE_NONTEMPORAL),
-                      ("PBR_TUNE_BLOCK_LOG2", TUNE_BLOCK_LOG2), ("PBR_TUNE_XCD_LOG2", TUNE_XCD_LOG2), ("PBR_TUNE_BWD_VEC", TUNE_BWD_VEC), ("PBR_TUNE_BATCH_INNER", TUNE_BATCH_INNER), ("PBR_TUNE_SCALAR_BASE", TUNE_SCALAR_BASE), ("PBR_TUNE_MAX_VEC", TUNE_MAX_VEC), ("PBR_TUNE_RESIZE_ROWS", TUNE_RESIZE_ROWS), ("PBR_TUNE_BWD_RUN", TUNE_BWD_RUN), ("PBR_TUNE_RESIZE_XCD", TUNE_RESIZE_XCD), ("PBR_TUNE_BWD_WIDE", TUNE_BWD_WIDE), ("PBR_TUNE_RESIZE_UP2", TUNE_RESIZE_UP2), ("PBR_TUNE_TILE_FOLD", TUNE_TILE_FOLD), ("PBR_TUNE_RESIZE_BWD_FUSED", TUNE_RESIZE_BWD_FUSED), ("PBR_TUNE_RESIZE_QUADS", TUNE_RESIZE_QUADS), ("PBR_TUNE_STREAM_SHAPE", TUNE_STREAM_SHAPE), ("PBR_TUNE_STREAM_LDS", TUNE_STREAM_LDS), ("PBR_TUNE_MSE_STREAM", TUNE_MSE_STREAM)):      # profiling runs: knobs from the environment
+                      ("PBR_TUNE_BLOCK_LOG2", TUNE_BLOCK_LOG2), ("PBR_TUNE_XCD_LOG2", TUNE_XCD_LOG2), ("PBR_TUNE_BWD_VEC", TUNE_BWD_VEC), ("PBR_TUNE_BATCH_INNER", TUNE_BATCH_INNER), ("PBR_TUNE_SCALAR_BASE", TUNE_SCALAR_BASE), ("PBR_TUNE_MAX_VEC", TUNE_MAX_VEC), ("PBR_TUNE_RESIZE_ROWS", TUNE_RESIZE_ROWS), ("PBR_TUNE_BWD_RUN", TUNE_BWD_RUN), ("PBR_TUNE_RESIZE_XCD", TUNE_RESIZE_XCD), ("PBR_TUNE_BWD_WIDE", TUNE_BWD_WIDE), ("PBR_TUNE_RESIZE_UP2", TUNE_RESIZE_UP2), ("PBR_TUNE_TILE_FOLD", TUNE_TILE_FOLD), ("PBR_TUNE_RESIZE_BWD_FUSED", TUNE_RESIZE_BWD_FUSED), ("PBR_TUNE_RESIZE_QUADS", TUNE_RESIZE_QUADS), ("PBR_TUNE_STREAM_SHAPE", TUNE_STREAM_SHAPE), ("PBR_TUNE_STREAM_LDS", TUNE_STREAM_LDS), ("PBR_TUNE_MSE_STREAM", TUNE_MSE_STREAM), ("PBR_TUNE_PACK_SINGLE", TUNE_PACK_SINGLE), ("PBR_TUNE_TILE_REPEAT", TUNE_TILE_REPEAT)):      # profiling runs: knobs from the environment
         if os.environ.get(env, "") != "":
             L.pbr_set_tuning(knob, int(os.environ[env]))
     _lib = L

@@ -42,12 +42,20 @@ int g_interleave = 0;
 int g_tile_fold = -1;
 int g_scalar_base = 1;
 int g_max_vec = 8;
+int g_pack_single = -1;
+int g_tile_repeat = -1;
 
 struct KernelEntry { KernelFn fn; const char *name; };
 
 // Storage-type pairs built: (f32 -> f32), (f32 -> f16), (f16 -> f32), (f16 -> f16).
 template <int LIGHT, int WF, typename TI, typename TO>
-static KernelFn pick_variant(int vec, bool multi, bool nt) {
+static KernelFn pick_variant(int vec, bool multi, bool nt, bool pack1) {
+    if constexpr (sizeof(TI) == 4) {
+        // fp32 maps, one light, packed body (PACK1): tiled launches (VALU-bound; their loads never carry the streaming hint
+        // unless PBR_TUNE_NONTEMPORAL = 2 asks for it)
+        if (pack1 && vec == 4 && !multi) return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 4, false, true, true>
+                                                   : cook_torrance_kernel<LIGHT, WF, TI, TO, 4, false, false, true>;
+    }
     if constexpr (sizeof(TI) == 2) {
         if (vec == 8 && !multi) {        // pick_vec hands out 8-pixel lanes for ONE light only (several lights are VALU-bound: 4-pixel lanes);
                                          // the 8-pixel multi-light body would not fit 128 VGPRs (it spilled 220-304 bytes when it was instantiated)
@@ -64,11 +72,11 @@ static KernelFn pick_variant(int vec, bool multi, bool nt) {
 }
 
 template <int LIGHT, int WF>
-static KernelFn pick_types(int in_dt, int out_dt, int vec, bool multi, bool nt) {
-    if (in_dt == PBR_F32) return out_dt == PBR_F32 ? pick_variant<LIGHT, WF, float, float>(vec, multi, nt)
-                                                   : pick_variant<LIGHT, WF, float, __half>(vec, multi, nt);
-    if (out_dt == PBR_F32) return pick_variant<LIGHT, WF, __half, float>(vec, multi, nt);
-    return pick_variant<LIGHT, WF, __half, __half>(vec, multi, nt);
+static KernelFn pick_types(int in_dt, int out_dt, int vec, bool multi, bool nt, bool pack1) {
+    if (in_dt == PBR_F32) return out_dt == PBR_F32 ? pick_variant<LIGHT, WF, float, float>(vec, multi, nt, pack1)
+                                                   : pick_variant<LIGHT, WF, float, __half>(vec, multi, nt, pack1);
+    if (out_dt == PBR_F32) return pick_variant<LIGHT, WF, __half, float>(vec, multi, nt, pack1);
+    return pick_variant<LIGHT, WF, __half, __half>(vec, multi, nt, pack1);
 }
 
 static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
@@ -77,21 +85,28 @@ static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
     const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
     const int idt = d->map_dtype, odt = d->out_dtype;
     const int nb = batch_group(d, vec);
+    if (repeat_inner(d)) {
+        std::snprintf(name, sizeof(name), "ctr_%s_%s_%s_%s_v4", point ? "point" : "directional", wf_names[d->workflow],
+                      idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16");
+        return KernelEntry{pick_repeat_kernel(d, nt), name};
+    }
+    // packed arithmetic for ONE light over fp32 maps: the rule is tiled launches only (ct_kernel.hpp: PACK1)
+    const bool pack1 = idt == PBR_F32 && !multi && vec == 4 && (g_pack_single == 1 || (g_pack_single < 0 && is_tiled(d)));
     if (nb) {
         std::snprintf(name, sizeof(name), "ctb_%s_%s_%s_%s_v2_b%d", point ? "point" : "directional", wf_names[d->workflow],
                       idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", nb);
         return KernelEntry{pick_batch_kernel(d, nb, nt), name};
     }
     std::snprintf(name, sizeof(name), "ct_%s_%s_%s_%s_v%d%s", point ? "point" : "directional", wf_names[d->workflow],
-                  idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", vec, multi ? "_multi" : "");
+                  idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", vec, multi ? "_multi" : (pack1 ? "_pk" : ""));
     KernelFn fn = nullptr;
     switch ((point ? 3 : 0) + d->workflow) {
-        case 0: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi, nt); break;
-        case 1: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi, nt); break;
-        case 2: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi, nt); break;
-        case 3: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi, nt); break;
-        case 4: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi, nt); break;
-        default: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi, nt); break;
+        case 0: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi, nt, pack1); break;
+        case 1: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi, nt, pack1); break;
+        case 2: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi, nt, pack1); break;
+        case 3: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi, nt, pack1); break;
+        case 4: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi, nt, pack1); break;
+        default: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi, nt, pack1); break;
     }
     return KernelEntry{fn, name};
 }
@@ -138,6 +153,15 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     if (nan_light_size(d)) return fill_result_nan(d, static_cast<hipStream_t>(stream));
     const int vec = pick_vec(d);
     KArgs k;
+    if (repeat_inner(d)) {           // tile(n), whole output: texels loaded and decoded once, evaluated at every repeat (ct_tiled.hip)
+        fill_repeat_args(d, k);
+        if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+        const KernelEntry e = pick_kernel(d, 4, g_nontemporal != 0);
+        hipLaunchKernelGGL(e.fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), g_lds_bytes >= 0 ? (size_t)g_lds_bytes : 0,
+                           static_cast<hipStream_t>(stream), k);
+        const hipError_t err = hipGetLastError();
+        return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+    }
     const int nb = batch_group(d, vec);
     if (nb) {                        // lane_pos' material index is the group of nb consecutive materials; 2 pixels per lane
         pbr_render_desc g = *d;
@@ -238,6 +262,8 @@ int pbr_set_tuning(int knob, int value) {
         case PBR_TUNE_RESIZE_XCD: slot = &pbr::g_resize_xcd; break;
         case PBR_TUNE_BWD_WIDE: slot = &pbr::g_bwd_wide; break;
         case PBR_TUNE_RESIZE_UP2: slot = &pbr::g_resize_up2; break;
+        case PBR_TUNE_PACK_SINGLE: slot = &pbr::g_pack_single; break;
+        case PBR_TUNE_TILE_REPEAT: slot = &pbr::g_tile_repeat; break;
         default: return -1;
     }
     const int old = *slot;

@@ -89,6 +89,8 @@ struct KArgs {
     int32_t albedo_srgb, spec_srgb, out_srgb, has_normal;
     int32_t grey_lights;     // every light's three intensities are equal: radiance * intensity once per light, not per channel
     LightU lights[PBR_MAX_LIGHTS];
+    int32_t rep_y, rep_x;    // cook_torrance_repeat_kernel: the grid walks the SOURCE maps (H x W texels), every lane evaluates its texels at all rep_y * rep_x positions of the output
+    int32_t out_W, out_Ht;   // ... whose rows are out_W pixels wide and whose point-light grid spans out_Ht x out_W
     uint64_t dev;            // pbr_render_desc.device_params (address of a DevParams block, 0 = none): when set, V and the light blocks are read from it (view_of / light_of)
 };
 
@@ -460,23 +462,34 @@ template <class R> __device__ __forceinline__ R lane_offsets(int g);           /
 template <> __device__ __forceinline__ float lane_offsets<float>(int g) { return (float)g; }
 template <> __device__ __forceinline__ f32x2 lane_offsets<f32x2>(int g) { return f32x2{(float)(2 * g), (float)(2 * g + 1)}; }
 
+template <class R> __device__ __forceinline__ R xs_slow_w(const KArgs &a, int W, int x0, int g);
+template <> __device__ __forceinline__ float xs_slow_w<float>(const KArgs &a, int W, int x0, int g) {
+    return linspace_at(a.x0, a.x1, a.xstep, W, x0 + g);
+}
+template <> __device__ __forceinline__ f32x2 xs_slow_w<f32x2>(const KArgs &a, int W, int x0, int g) {
+    return f32x2{linspace_at(a.x0, a.x1, a.xstep, W, x0 + 2 * g), linspace_at(a.x0, a.x1, a.xstep, W, x0 + 2 * g + 1)};
+}
+
+// `W`: the width the grid spans (a.W, or the output's width when the lanes walk source texels: cook_torrance_repeat_kernel)
 template <class R, int NG, int VEC>
-__device__ __forceinline__ void x_grid(const KArgs &a, int x0, R xs[NG]) {
-    const int half = a.W >> 1;
+__device__ __forceinline__ void x_grid_w(const KArgs &a, int W, int x0, R xs[NG]) {
+    const int half = W >> 1;
     const bool lo = x0 < half;
     const bool one_side = lo == (x0 + VEC - 1 < half);
     if (__all(one_side)) {
         const float sgn = lo ? 1.0f : -1.0f;
-        const float f0 = (float)(lo ? x0 : a.W - 1 - x0);
+        const float f0 = (float)(lo ? x0 : W - 1 - x0);
         const float st = lo ? a.xstep : -a.xstep, base = lo ? a.x0 : a.x1;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
             xs[g] = fma_(splat<R>(st), fma_(splat<R>(sgn), lane_offsets<R>(g), splat<R>(f0)), splat<R>(base));
     } else {
 #pragma unroll
-        for (int g = 0; g < NG; ++g) xs[g] = xs_slow<R>(a, x0, g);
+        for (int g = 0; g < NG; ++g) xs[g] = xs_slow_w<R>(a, W, x0, g);
     }
 }
+template <class R, int NG, int VEC>
+__device__ __forceinline__ void x_grid(const KArgs &a, int x0, R xs[NG]) { x_grid_w<R, NG, VEC>(a, a.W, x0, xs); }
 
 template <int LIGHT, class R>
 __device__ __forceinline__ LightGeomT<R> light_geom(const LightU &lu, const Vec3 &V, R xs, float ys) {
@@ -654,8 +667,12 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
 //   VEC: pixels per lane (4 = 16-byte fp32 accesses, 8 = 16-byte fp16 accesses, 1 = ragged widths /
 //        unaligned views)
 //   MULTI: more than one light (uniform loop) -- the single-light body is straight-line
+//   PACK1: the one-light fp32 body with packed arithmetic too.  Streaming launches lose with it (see RealOf above), but a
+//        launch over TILED maps (MaterialBase.tile fused as wrap-around addressing) re-reads its texels from L2 / the
+//        memory-side cache and is VALU-bound on the scalar body (valu_busy 0.885, profiles/r03_kernels.json): there the
+//        packed body is the faster one (cook_torrance.hip: pick_kernel, PBR_TUNE_PACK_SINGLE).
 // 1-D grid, one tile per workgroup, tiles ordered x fastest.
-template <int LIGHT, int WF, typename TI, typename TO, int VEC, bool MULTI, bool NT>
+template <int LIGHT, int WF, typename TI, typename TO, int VEC, bool MULTI, bool NT, bool PACK1 = false>
 // Occupancy: the one-light kernels are HBM-bound and want exactly 3 waves per SIMD (12 per CU): fewer cannot
 // cover the latency, more only add concurrent plane streams that fight for DRAM pages (measured, DESIGN.md 3.2:
 // 2 -> 126 us, 3 -> 114 us, 4 -> 123 us, uncapped (7) -> 129 us on a 4096^2 map).  amdgpu_waves_per_eu(3,3)
@@ -664,7 +681,7 @@ template <int LIGHT, int WF, typename TI, typename TO, int VEC, bool MULTI, bool
 #define PBR_WAVES_PER_EU 3
 #endif
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(MULTI ? 4 : PBR_WAVES_PER_EU, MULTI ? 8 : PBR_WAVES_PER_EU)))
+__attribute__((amdgpu_waves_per_eu((MULTI || PACK1) ? 4 : PBR_WAVES_PER_EU, (MULTI || PACK1) ? 8 : PBR_WAVES_PER_EU)))
 void cook_torrance_kernel(const KArgs a) {
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
     const int ty = (int)a.div_tx.div(tile);
@@ -675,7 +692,7 @@ void cook_torrance_kernel(const KArgs a) {
 #ifdef PBR_PACK_SINGLE   // build-time experiment switch: packed math for the one-light fp32 kernels too
     shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, true>(a, p, t);
 #else
-    shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, (MULTI || sizeof(TI) == 2)>(a, p, t);
+    shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, (MULTI || sizeof(TI) == 2 || PACK1)>(a, p, t);
 #endif
 }
 
@@ -765,6 +782,77 @@ void cook_torrance_batch_kernel(const KArgs a) {
             }
             if (p.sb) Ld<TO, VEC>::template store<NT>(plane_at<TO>(a.out, (p.b0 * NB + j) * a.o_bs + c * a.o_cs, (uint32_t)p.pix), 0, o);
             else Ld<TO, VEC>::template store<NT>(a.out, pj[j].b * a.o_bs + c * a.o_cs + p.pix, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ repeat-inner kernel (MaterialBase.tile fused, whole output)
+// material.tile(n) (base.py:524-537) repeats every map n x n times; the evaluation of the repeated maps differs between the
+// repeats only in the point light's geometry.  cook_torrance_kernel handles it as wrap-around addressing: every texel is
+// loaded, decoded (the sRGB transfer: 6 transcendentals) and turned into its light-independent terms once per REPEAT, and
+// whether the second read comes from a cache is left to the memory system (measured: 1.40 x the maps from HBM in row order).
+// Here the grid walks the SOURCE maps instead: a lane loads its texels once (streaming loads: nothing is read twice any
+// more), decodes them once, forms PixelTerms once, and then evaluates light geometry + shading + encode at each of the
+// rep_y x rep_x output positions and stores there.  HBM reads are 1.0 x the maps by construction; the decode and the pixel
+// terms cost 1 / (rep_y rep_x) per output pixel; a directional light (position-independent) is evaluated ONCE and stored
+// rep_y x rep_x times.  Same functions in the same order per pixel as cook_torrance_kernel: bit-identical to evaluating the
+// materialised repeat.  One light, 4 texels per lane (fp16 maps: 8-byte loads -- loads are the minor stream here), packed
+// arithmetic; launches that are row bands of the tiled output, have several lights or ragged map widths keep the wrap-around form.
+template <int LIGHT, int WF, typename TI, typename TO, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void cook_torrance_repeat_kernel(const KArgs a) {
+    constexpr int VEC = 4, NG = 2;
+    using R = f32x2;
+    const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
+    const int ty = (int)a.div_tx.div(tile);
+    const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);      // over the SOURCE maps: a.H x a.W texels per material
+    if (!p.valid) return;
+    Texels<VEC> t;
+    load_texels<WF, TI, VEC, NT>(a, a.has_normal != 0, p, t);
+    decode_texels<WF, VEC, true>(a, t);
+    const Vec3 V = view_of(a);
+    const LightU lu = light_of(a, 0);
+    PixelTermsT<R> pt[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) material_terms<WF, VEC, R>(t, g, V, pt[g]);
+
+    const uint32_t lane_out = (uint32_t)(p.y * a.out_W + p.x);              // inside the first repeat; < 2^30 when p.sb (fill_args)
+    auto store_at = [&](int ry, int rx, const R (&res)[3][NG]) {
+        const int64_t rep = (int64_t)ry * a.H * a.out_W + (int64_t)rx * a.W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float o[VEC];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) scatter(o, g, res[c][g]);
+            if (p.sb) Ld<TO, VEC>::template store<NT>(plane_at<TO>(a.out, p.b0 * a.o_bs + c * a.o_cs + rep, lane_out), 0, o);
+            else Ld<TO, VEC>::template store<NT>(a.out, p.b * a.o_bs + c * a.o_cs + rep + (int64_t)p.y * a.out_W + p.x, o);
+        }
+    };
+    auto shade = [&](const R (&xs)[NG], float ys, R (&res)[3][NG]) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[g], ys);
+            R col[3];
+            shade_light(pt[g], lg, lu.inten, col);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) res[c][g] = a.out_srgb ? linear_to_srgb_unit(col[c]) : col[c];      // :179-180
+        }
+    };
+    if (LIGHT == PBR_LIGHT_DIRECTIONAL) {                                   // the light does not know where the pixel is (:125-127)
+        R res[3][NG];
+        const R xs[NG] = {splat<R>(0.0f), splat<R>(0.0f)};
+        shade(xs, 0.0f, res);
+        for (int ry = 0; ry < a.rep_y; ++ry)
+            for (int rx = 0; rx < a.rep_x; ++rx) store_at(ry, rx, res);
+        return;
+    }
+    for (int ry = 0; ry < a.rep_y; ++ry) {
+        const float ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, p.y + ry * a.H);
+        for (int rx = 0; rx < a.rep_x; ++rx) {
+            R xs[NG], res[3][NG];
+            x_grid_w<R, NG, VEC>(a, a.out_W, p.x + rx * a.W, xs);
+            shade(xs, ys, res);
+            store_at(ry, rx, res);
         }
     }
 }

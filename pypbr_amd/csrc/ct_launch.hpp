@@ -35,6 +35,8 @@ extern int g_mse_stream;           // ct_loss.hip: streamed loss step for fp16 m
 extern int g_resize_up2;           // resize.hip: two-tap register kernel for up-scales (1) or the strip kernel (0)
 extern int g_resize_xcd;           // resize.hip: XCD-contiguous tile order (1) or identity (0)
 extern int g_max_vec;              // A/B and test knob: at most this many pixels per lane (1 = the one-pixel kernels everywhere)
+extern int g_pack_single;          // packed arithmetic in the one-light fp32 kernels: -1 = rule (tiled launches), 0 = never, 1 = always
+extern int g_tile_repeat;          // tiled maps, whole output, one light: the repeat-inner kernel (-1 = rule: on, 0 = the wrap-around form, 1 = on)
 extern int g_tile_fold;            // tiled maps: log2 of the source rows per band of the fold order (-1 = rule, 0 = row order)
 extern int g_interleave;           // experiment knob: materials of a batch interleaved workgroup by workgroup
 extern int g_bwd_vec;              // pixels per lane of the backward kernels: 0 = rule (ct_backward.hip), 2 | 4 = forced (A/B)
@@ -266,6 +268,15 @@ inline int fill_result_nan(const pbr_render_desc *d, hipStream_t st) {
 
 using KernelFn = void (*)(const KArgs);
 KernelFn pick_batch_kernel(const pbr_render_desc *d, int nb, bool nt);      // ct_batch.hip
+KernelFn pick_repeat_kernel(const pbr_render_desc *d, bool nt);             // ct_tiled.hip
+void fill_repeat_args(const pbr_render_desc *d, KArgs &k);
+
+// Tiled maps evaluated by the repeat-inner kernel (ct_kernel.hpp: cook_torrance_repeat_kernel): the WHOLE tiled output of one light,
+// map rows a whole number of 4-texel lanes.  Row bands of a tiled output, several lights and ragged map widths take the wrap-around form.
+inline bool repeat_inner(const pbr_render_desc *d) {
+    return g_tile_repeat != 0 && is_tiled(d) && d->n_lights == 1 && d->y_offset == 0 && d->height == d->height_total &&
+           d->map_width % 4 == 0 && g_max_vec >= 4 && !g_interleave;
+}
 
 // Materials per lane for this launch, or 0 for the one-material kernels.  Several lights make the launch VALU-bound, and
 // the light geometry is shared by every material at a pixel position: groups of 4 (or 2) consecutive materials per lane.

@@ -6,9 +6,9 @@ NAME=$1; shift
 R=$(cd "$(dirname "$0")/.." && pwd)
 D=$R/tools/bin/$NAME
 mkdir -p "$D"
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=fast -fno-slp-vectorize -fno-gpu-rdc -Wno-unused-function $*"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -fno-slp-vectorize -fno-gpu-rdc -Wno-unused-function $*"
 pids=()
-for f in cook_torrance ct_batch ct_backward ct_blend ct_loss map_ops resize blend; do
+for f in cook_torrance ct_batch ct_tiled ct_backward ct_blend ct_loss map_ops resize blend; do
     /opt/rocm/bin/hipcc $FLAGS -c "$R/pypbr_amd/csrc/$f.hip" -o "$D/$f.o" &
     pids+=($!)
 done

@@ -7,7 +7,7 @@ import sys
 
 src = sys.argv[1]
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=fast", "-fno-slp-vectorize", "-fno-gpu-rdc", "-S",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "-fno-slp-vectorize", "-fno-gpu-rdc", "-S",
        "--cuda-device-only", "-o", "/dev/null", src, "-Rpass-analysis=kernel-resource-usage"] + sys.argv[3:]
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 name, rows = None, {}

@@ -39,6 +39,9 @@ Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
   cpu_baseline -- the ATen-level restatement of the reference's CPU path (oracle/torch_oracle.py, kind "port": bit-equal to the
                   reference in the dev container) timed on this host's cores, rank 0, N=1 only: 1 thread and all host
                   cores at 256^2 / 1024^2 / 2048^2, CPU model stated.
+
+`python bench.py --example brdf|blend|both [--size 512]`: the reference's example scripts statement by statement on CPU-resident
+materials (tools/example_bench.py): time per statement, transfers, the CPU oracle's time for the same statements.
 """
 import argparse
 import json
@@ -78,11 +81,27 @@ CONFIGS = {
             name="Batch={B} {S}x{S} materials, 16 point lights accumulated in-kernel, fp16 maps, fp32 accumulate and result "
                  "(BASELINE.json configs[4])"),
 }
-# config 5 is VALU-bound.  Vector instructions per (pixel, light) of the batch-inner kernel, counted by rocprofv3
-# (SQ_INSTS_VALU x 64 / (pixels x lights), profiles/r02_kernels.json) -- the algorithmic figure its VALU roofline uses; the
-# chip issues at most one vector instruction per SIMD per 4 cycles for a wave of 64 (16 lanes per clock):
-VALU_INSTR_PER_PIXEL_LIGHT = 29.3
+# config 5 is VALU-bound.  Vector instructions per (pixel, light) of the batch-inner kernel are COUNTED, not assumed: rocprofv3
+# SQ_INSTS_VALU x 64 / (pixels x lights) of the newest committed per-kernel evidence set (recorded_valu below) -- the algorithmic
+# figure its VALU roofline uses; the chip issues at most one vector instruction per SIMD per 4 cycles for a wave of 64:
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4 * 64          # lane-instructions per ns: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles x 64 lanes
+
+
+def recorded_valu():
+    """(vector instructions per (pixel, light) of the 16-light batch-inner kernel, the committed file they come from): the newest
+    profiles/rNN_kernels.json that holds the `fwd_16_lights` case (4 x 4096^2 fp16 maps, 16 point lights) with its SQ pass."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernels.json")), reverse=True):
+        try:
+            with open(path) as f:
+                recs = json.load(f)
+        except (OSError, ValueError):
+            continue
+        for r in recs if isinstance(recs, list) else []:
+            n = (r.get("sq") or {}).get("valu_wave_instructions")
+            if n and str(r.get("case", "")).startswith("fwd_16_lights") and "batch_kernel" in r.get("kernel", ""):
+                return n * 64 / (4 * 4096 * 4096 * 16), "profiles/" + os.path.basename(path)
+    return None, None
 
 
 def synth_material(size, device, seed, dtype=torch.float32, rows=None):
@@ -147,62 +166,64 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(cfg, budget_s=40.0):
+def usable_cores():
+    """The cores this process may actually run on: its affinity mask, capped by the cgroup's CPU quota (a GPU box grants a share of
+    the host; os.cpu_count() reports the whole machine)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(cfg, budget_s=15.0):
     """SURVEY.md 8d / BASELINE.md 4: the ATen restatement of the reference's CPU path with torch.set_num_threads(n) for
-    n = 1, n = 16 (a GPU box's CPU share per GPU) and n = all host cores, at 256^2 (the size BASELINE configs[0] names),
-    1024^2 and 2048^2 (several lights: 256^2, 512^2, 1024^2), this configuration's light and flags, CPU model stated.
+    n = 1 and n = the cores this process can really use (affinity mask and cgroup quota: `usable_cores`; `host_cores` =
+    os.cpu_count() is reported beside it, and no leg runs more threads than are usable), at 256^2 (the size BASELINE configs[0]
+    names), 1024^2 and 2048^2 (several lights: 256^2, 512^2, 1024^2), this configuration's light and flags, CPU model stated.
     Bounded: a leg that the previous (smaller) leg of its thread count predicts to overrun what is left of `budget_s`
     is skipped, and the line says so.  `value` / `cores`: the fastest thread count at the largest size measured."""
     _oracle_path()
-    host = os.cpu_count() or 1
+    host, usable = os.cpu_count() or 1, usable_cores()
     saved = torch.get_num_threads()
     t_start = time.perf_counter()
     table, skipped = [], []
     legs = ((256, 5), (1024, 2), (2048, 1)) if len(cfg["light"]) == 1 else ((256, 2), (512, 1), (1024, 1))
     _oracle_eval(cfg, synth_material(128, "cpu", 98))               # cold first call of the process (~1 s), untimed
-    single = {}                                                     # size -> seconds per pass at 1 thread
-    for threads in sorted({1, min(16, host), host}):
+    for threads in sorted({1, usable}):
         torch.set_num_threads(threads)
         per_pixel = None
         for size, passes in legs:
             left = budget_s - (time.perf_counter() - t_start)
-            if threads > 16 and per_pixel is None and left < 20.0:
-                # the all-cores leg cannot be predicted from a smaller one, and where the process's CPU share is a fraction of
-                # os.cpu_count() its first pass alone takes ~16 s: only started with that much budget left
-                skipped.append(f"all sizes x {threads} threads (an oversubscribed first pass can take ~20 s; {left:.0f} s of the budget left)")
-                break
             if left <= 0 or (per_pixel is not None and per_pixel * size * size * passes > left):
                 skipped.append(f"{size}^2 x {threads} threads")
                 continue
             maps = synth_material(size, "cpu", 99)
             t0 = time.perf_counter()
-            _oracle_eval(cfg, maps)
-            first = time.perf_counter() - t0
-            # a thread count far beyond the process's CPU share (a GPU box grants ~16 cores per GPU, os.cpu_count() says 256)
-            # makes every one of the ~130 ATen ops of a pass wait for its pool: one pass is the data point, the rest is skipped
-            thrash = threads > 1 and size in single and first > 8 * single[size]
-            n = 1
-            if not thrash:
-                for _ in range(passes - 1):
-                    _oracle_eval(cfg, maps)
-                n = passes
-            dt = (time.perf_counter() - t0) / n
-            if threads == 1:
-                single[size] = dt
+            for _ in range(passes):
+                _oracle_eval(cfg, maps)
+            dt = (time.perf_counter() - t0) / passes
             per_pixel = dt / (size * size)
             table.append({"size": size, "threads": threads, "ms": round(dt * 1e3, 1), "Mpixels_per_s": round(size * size / dt / 1e6, 3)})
-            if thrash:
-                skipped.append(f"larger sizes x {threads} threads (oversubscribed: {first / single[size]:.0f}x slower than 1 thread at {size}^2)")
-                break
     torch.set_num_threads(saved)
+    rec = {"value": None, "unit": "Mpixels/s", "cores": None, "usable_cores": usable, "host_cores": host, "kind": "port", "cpu_model": cpu_model(),
+           "table": table}
+    legs_txt = " / ".join(f"{sz}^2 ({p} passes)" for sz, p in legs)
+    if not table:                                                   # e.g. --cpu-budget 0: a skipped baseline, not a lost bench line
+        rec["sample"] = f"nothing measured within the {budget_s:.0f} s budget; skipped: {skipped}"
+        return rec
     biggest = max(e["size"] for e in table)
     best = max((e for e in table if e["size"] == biggest), key=lambda e: e["Mpixels_per_s"])
-    return {"value": best["Mpixels_per_s"], "unit": "Mpixels/s", "cores": best["threads"], "host_cores": host, "kind": "port",
-            "cpu_model": cpu_model(), "table": table,
-            "sample": f"oracle/torch_oracle.py (the reference's ATen ops, bit-equal to it in the dev container), this configuration's "
-                      f"light and flags, one material of " + " / ".join(f"{sz}^2 ({p} passes)" for sz, p in legs) +
-                      f" at 1, 16 and all {host} host threads, {time.perf_counter() - t_start:.1f} s in all; value = the fastest thread "
-                      f"count at {biggest}^2" + (f"; skipped for time: {skipped}" if skipped else "")}
+    rec.update(value=best["Mpixels_per_s"], cores=best["threads"])
+    rec["sample"] = (f"oracle/torch_oracle.py (the reference's ATen ops, bit-equal to it in the dev container), this configuration's light and flags, "
+                     f"one material of {legs_txt} at 1 and {usable} threads (the cores this process may use; the host has {host}), "
+                     f"{time.perf_counter() - t_start:.1f} s in all; value = the fastest thread count at {biggest}^2" +
+                     (f"; skipped for time: {skipped}" if skipped else ""))
+    return rec
 
 
 def parity_of_timed_output(cfg, out, maps, shard, band_rows):
@@ -313,9 +334,17 @@ def main():
     ap.add_argument("--layout", choices=("separate", "arena"), default="arena",
                     help="config 2.  arena (default): the material's maps and result in one allocation, as Material.to(device) lays "
                          "them out (F.pack_maps); separate: five tensors as torch's allocator places them")
-    ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds the cpu_baseline leg may take (legs predicted to overrun are skipped and named)")
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds the cpu_baseline leg may take (legs predicted to overrun are skipped and named)")
     ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1")
+    ap.add_argument("--no-rccl", action="store_true", help="--gpus 1 started plainly: do not form the one-rank RCCL group (no collectives at all)")
+    ap.add_argument("--example", choices=("brdf", "blend", "both"), default=None,
+                    help="instead of the kernel benchmark: examples/example_brdf.py / example_blend.py statement by statement (tools/example_bench.py)")
     args = ap.parse_args()
+    if args.example:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import example_bench
+        return example_bench.main(["--example", args.example] + (["--size", str(args.size)] if args.size else []) +
+                                  (["--no-cpu"] if args.no_cpu_baseline else []))
 
     if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
         launch_ranks(args.gpus)                    # does not return
@@ -346,6 +375,7 @@ def main():
     device = torch.device("cuda", local_rank % torch.cuda.device_count() if SHARE_GPU else local_rank)
     torch.cuda.set_device(device)
     coll = device                                  # where the small collectives' buffers live
+    backend = None
     if distributed:
         import torch.distributed as dist
         if SHARE_GPU:                              # RCCL refuses two ranks on one device
@@ -353,6 +383,23 @@ def main():
             coll = torch.device("cpu")
         else:
             dist.init_process_group("nccl", device_id=device)
+        backend = dist.get_backend()
+    elif world == 1 and not args.no_rccl:
+        # a single rank started plainly (`python bench.py`): an RCCL group of ONE in this process, so that every bench line has been
+        # through init_process_group("nccl"), the light-block broadcast, the barriers and the all-reduce / all-gather of the N > 1 path
+        #  and says so (`per_rank.backend`, `ranks_seen`).  Never fatal: without RCCL the line is measured as before.
+        import datetime
+        import torch.distributed as dist
+        try:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device,
+                                    timeout=datetime.timedelta(seconds=60))
+            distributed, backend = True, dist.get_backend()
+        except Exception as e:                     # noqa: BLE001 -- whatever RCCL or the rendezvous raises
+            backend = "none (init_process_group('nccl') failed: %s)" % str(e).splitlines()[0][:120]
+    ranks_seen = dist.get_world_size() if distributed else 1
 
     def barrier():
         if distributed:
@@ -492,7 +539,7 @@ def main():
                          "kernel_us": round(kernel_all_ms * 1e3, 2), "kernel_us_steady": round(per_rank_us[slow], 2),
                          "pixels_per_launch": per_rank_px[slow], "rank": slow},
             "per_rank": {"kernel_us": [round(u, 2) for u in per_rank_us], "pixels_per_launch": per_rank_px,
-                         "shard_batch_rows": shards,
+                         "shard_batch_rows": shards, "backend": backend, "ranks_seen": ranks_seen,
                          "light_block_broadcast_us": None if bcast_us is None else round(bcast_us, 1)},
         }
         if args.config == 2:
@@ -502,13 +549,16 @@ def main():
             line["roofline"]["kernel_us_cold"] = round(cold_kernel_ms * 1e3, 2)
         if len(cfg["light"]) > 1:
             L = len(cfg["light"])
-            ginstr = VALU_INSTR_PER_PIXEL_LIGHT * per_rank_px[slow] * L / (kernel_all_ms * 1e-3) / 1e9
-            line["roofline_valu"] = {"bound": "valu", "achieved": round(ginstr, 1), "peak": round(VALU_PEAK_GINSTR, 1), "unit": "G lane-instr/s",
-                                     "frac": round(ginstr / VALU_PEAK_GINSTR, 4),
-                                     "light_evals_per_s_G": round(per_rank_px[slow] * L / (kernel_all_ms * 1e-3) / 1e9, 1),
-                                     "basis": f"{VALU_INSTR_PER_PIXEL_LIGHT} vector instructions per (pixel, light) (rocprofv3 SQ_INSTS_VALU, "
-                                              "profiles/r02_kernels.json) against 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz; the "
-                                              "launch is VALU-bound, its HBM fraction is not the measure (SURVEY.md 8d)"}
+            per_pl, valu_src = recorded_valu()
+            evals = per_rank_px[slow] * L / (kernel_all_ms * 1e-3) / 1e9
+            ginstr = None if per_pl is None else per_pl * evals
+            line["roofline_valu"] = {"bound": "valu", "achieved": None if ginstr is None else round(ginstr, 1), "peak": round(VALU_PEAK_GINSTR, 1),
+                                     "unit": "G lane-instr/s", "frac": None if ginstr is None else round(ginstr / VALU_PEAK_GINSTR, 4),
+                                     "light_evals_per_s_G": round(evals, 1),
+                                     "basis": (f"{per_pl:.2f} vector instructions per (pixel, light) (rocprofv3 SQ_INSTS_VALU x 64 / (pixels x lights), {valu_src}) "
+                                               if per_pl is not None else "no committed SQ pass for the 16-light kernel found under profiles/: ") +
+                                              "against 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz; the launch is VALU-bound, its HBM "
+                                              "fraction is not the measure (SURVEY.md 8d)"}
         line.update(extras)
         if not args.no_cpu_baseline:
             line["parity"] = parity_of_timed_output(cfg, plans[0].out, map_sets[0], shard, 8 if S >= 2048 and len(cfg["light"]) == 1 else 4)

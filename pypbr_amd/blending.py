@@ -11,7 +11,7 @@ import torch
 
 from . import _native
 from . import functional as F_
-from .materials import MaterialBase, _through_device
+from .materials import MaterialBase, _compute_device
 
 
 # ---------------------------------------------------------------- device ops (fp32 planar maps)
@@ -154,8 +154,8 @@ def _blend_dicts(maps1: dict, maps2: dict, mask: torch.Tensor) -> dict:
         if m1 is None or m2 is None:
             out[name] = m2 if m1 is None else m1
         else:
-            normal = name == "normal"
-            out[name] = _through_device(m1, lambda a: blend_maps(a, m2.to(a.device), mask.to(a.device), is_normal=normal))
+            a = m1 if m1.is_cuda else m1.to(_compute_device(m1.device))
+            out[name] = blend_maps(a, m2.to(a.device), mask.to(a.device), is_normal=(name == "normal"))
     return out
 
 
@@ -184,13 +184,22 @@ def blend_with_mask(material1: MaterialBase, material2: MaterialBase, mask: torc
     material1.materialize_tile(); material2.materialize_tile()      # blending reads the maps themselves
     blended = material1.__class__()
     blended.device = material1.device
-    maps1, maps2 = material1._maps, material2._maps
-    if (lazy or _LAZY) and _fusable(maps1, maps2, mask):
-        blended.__dict__["_store"] = dict(maps1)
-        blended.__dict__["_lazy_blend"] = (dict(maps2), mask)
-    else:
+    recorded = False
+    if lazy or _LAZY:                    # only RECORDS the blend: the maps stay where they are, no device is needed yet
+        for m in (material1, material2):
+            m.materialize_blend()
+            if m.__dict__.get("_raw_normal"):
+                m._resident(keep=True)   # the fused kernel reads decoded normals
+        if _fusable(material1._raw, material2._raw, mask):
+            blended.__dict__["_store"] = dict(material1._raw)
+            blended.__dict__["_lazy_blend"] = (dict(material2._raw), mask)
+            recorded = True
+    if not recorded:
+        # both materials on the compute device (each in ONE upload when it still sits on the host); the blended maps stay there until
+        # somebody looks at them (materials.py, module docstring)
+        maps1, maps2 = material1._resident(keep=True), material2._resident(keep=True)
         for name, result in _blend_dicts(maps1, maps2, mask).items():
-            setattr(blended, name, result)          # normals pass through _process_normal_map again, as upstream
+            blended._raw[name] = blended._settle(name, result)          # normals pass through _process_normal_map again, as upstream
     blended.albedo_is_srgb = material1.albedo_is_srgb
     return blended, mask
 
@@ -198,30 +207,38 @@ def blend_with_mask(material1: MaterialBase, material2: MaterialBase, mask: torc
 def _resized_like(prop2: torch.Tensor, prop1: torch.Tensor) -> torch.Tensor:
     if prop1.shape == prop2.shape:
         return prop2
-    return _through_device(prop2, lambda t: F_.resize(t, tuple(prop1.shape[1:]), antialias=True))
+    return F_.resize(prop2, tuple(prop1.shape[1:]), antialias=True)
+
+
+def _handed_out(mask: torch.Tensor, material: MaterialBase) -> torch.Tensor:
+    """The mask a blend returns lives where the material's maps are handed out (upstream: the materials' own device)."""
+    home = torch.device(material.device)
+    if mask.device == home:
+        return mask
+    return F_.to_host(mask, home) if home.type == "cpu" else mask.to(home)
 
 
 def blend_on_height(material1: MaterialBase, material2: MaterialBase, blend_width: float = 0.1, shift: float = 0.0):
     """functional.py:148-196."""
     material1.materialize_tile(); material2.materialize_tile()
-    h1, h2 = material1._maps.get("height"), material2._maps.get("height")
-    if h1 is None or h2 is None:
+    if material1._raw.get("height") is None or material2._raw.get("height") is None:
         raise ValueError("Both materials must have height maps for height-based blending.")
-    h2 = _resized_like(h2, h1)
-    mask = _through_device(h1, lambda a: sigmoid_mask(a, h2.to(a.device), blend_width, shift))
-    return blend_with_mask(material1, material2, mask)
+    h1, h2 = material1._resident(keep=True)["height"], material2._resident(keep=True)["height"]
+    mask = sigmoid_mask(h1, _resized_like(h2.to(h1.device), h1), blend_width, shift)
+    blended, _ = blend_with_mask(material1, material2, mask)
+    return blended, _handed_out(mask, material1)
 
 
 def blend_on_properties(material1: MaterialBase, material2: MaterialBase, property_name: str = "metallic",
                         blend_width: float = 0.1):
     """functional.py:199-239."""
     material1.materialize_tile(); material2.materialize_tile()
-    p1, p2 = material1._maps.get(property_name), material2._maps.get(property_name)
-    if p1 is None or p2 is None:
+    if material1._raw.get(property_name) is None or material2._raw.get(property_name) is None:
         raise ValueError(f"Both materials must have '{property_name}' maps for property-based blending.")
-    p2 = _resized_like(p2, p1)
-    mask = _through_device(p1, lambda a: sigmoid_mask(a, p2.to(a.device), blend_width, 0.0))
-    return blend_with_mask(material1, material2, mask)
+    p1, p2 = material1._resident(keep=True)[property_name], material2._resident(keep=True)[property_name]
+    mask = sigmoid_mask(p1, _resized_like(p2.to(p1.device), p1), blend_width, 0.0)
+    blended, _ = blend_with_mask(material1, material2, mask)
+    return blended, _handed_out(mask, material1)
 
 
 def blend_with_gradient(material1: MaterialBase, material2: MaterialBase, direction: str = "horizontal"):
@@ -231,13 +248,9 @@ def blend_with_gradient(material1: MaterialBase, material2: MaterialBase, direct
         raise ValueError("Materials must have at least one map to determine size.")
     if direction not in ("horizontal", "vertical"):
         raise ValueError("Direction must be 'horizontal' or 'vertical'.")
-    dev = torch.device(material1.device)
-    if dev.type == "cuda":
-        mask = gradient_mask(size[0], size[1], direction, dev)
-    else:
-        _native.require_device()
-        mask = gradient_mask(size[0], size[1], direction, torch.device("cuda", torch.cuda.current_device())).to(dev)
-    return blend_with_mask(material1, material2, mask)
+    mask = gradient_mask(size[0], size[1], direction, _compute_device(material1.device))
+    blended, _ = blend_with_mask(material1, material2, mask)
+    return blended, _handed_out(mask, material1)
 
 
 def blend_materials(material1: MaterialBase, material2: MaterialBase, method: str = "mask", **kwargs):

@@ -88,7 +88,7 @@ static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
     if (repeat_inner(d)) {
         std::snprintf(name, sizeof(name), "ctr_%s_%s_%s_%s_v4", point ? "point" : "directional", wf_names[d->workflow],
                       idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16");
-        return KernelEntry{pick_repeat_kernel(d, nt), name};
+        return KernelEntry{pick_repeat_kernel(d, g_nontemporal), name};
     }
     // packed arithmetic for ONE light over fp32 maps: the rule is tiled launches only (ct_kernel.hpp: PACK1)
     const bool pack1 = idt == PBR_F32 && !multi && vec == 4 && (g_pack_single == 1 || (g_pack_single < 0 && is_tiled(d)));

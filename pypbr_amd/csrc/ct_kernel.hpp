@@ -798,7 +798,8 @@ void cook_torrance_batch_kernel(const KArgs a) {
 // rep_y x rep_x times.  Same functions in the same order per pixel as cook_torrance_kernel: bit-identical to evaluating the
 // materialised repeat.  One light, 4 texels per lane (fp16 maps: 8-byte loads -- loads are the minor stream here), packed
 // arithmetic; launches that are row bands of the tiled output, have several lights or ragged map widths keep the wrap-around form.
-template <int LIGHT, int WF, typename TI, typename TO, bool NT>
+// NTL / NTS: the streaming hint on the loads / on the stores.
+template <int LIGHT, int WF, typename TI, typename TO, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void cook_torrance_repeat_kernel(const KArgs a) {
     constexpr int VEC = 4, NG = 2;
@@ -808,7 +809,7 @@ void cook_torrance_repeat_kernel(const KArgs a) {
     const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);      // over the SOURCE maps: a.H x a.W texels per material
     if (!p.valid) return;
     Texels<VEC> t;
-    load_texels<WF, TI, VEC, NT>(a, a.has_normal != 0, p, t);
+    load_texels<WF, TI, VEC, NTL>(a, a.has_normal != 0, p, t);
     decode_texels<WF, VEC, true>(a, t);
     const Vec3 V = view_of(a);
     const LightU lu = light_of(a, 0);
@@ -824,8 +825,8 @@ void cook_torrance_repeat_kernel(const KArgs a) {
             float o[VEC];
 #pragma unroll
             for (int g = 0; g < NG; ++g) scatter(o, g, res[c][g]);
-            if (p.sb) Ld<TO, VEC>::template store<NT>(plane_at<TO>(a.out, p.b0 * a.o_bs + c * a.o_cs + rep, lane_out), 0, o);
-            else Ld<TO, VEC>::template store<NT>(a.out, p.b * a.o_bs + c * a.o_cs + rep + (int64_t)p.y * a.out_W + p.x, o);
+            if (p.sb) Ld<TO, VEC>::template store<NTS>(plane_at<TO>(a.out, p.b0 * a.o_bs + c * a.o_cs + rep, lane_out), 0, o);
+            else Ld<TO, VEC>::template store<NTS>(a.out, p.b * a.o_bs + c * a.o_cs + rep + (int64_t)p.y * a.out_W + p.x, o);
         }
     };
     auto shade = [&](const R (&xs)[NG], float ys, R (&res)[3][NG]) {

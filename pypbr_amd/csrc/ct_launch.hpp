@@ -268,7 +268,7 @@ inline int fill_result_nan(const pbr_render_desc *d, hipStream_t st) {
 
 using KernelFn = void (*)(const KArgs);
 KernelFn pick_batch_kernel(const pbr_render_desc *d, int nb, bool nt);      // ct_batch.hip
-KernelFn pick_repeat_kernel(const pbr_render_desc *d, bool nt);             // ct_tiled.hip
+KernelFn pick_repeat_kernel(const pbr_render_desc *d, int nt_knob);            // ct_tiled.hip
 void fill_repeat_args(const pbr_render_desc *d, KArgs &k);
 
 // Tiled maps evaluated by the repeat-inner kernel (ct_kernel.hpp: cook_torrance_repeat_kernel): the WHOLE tiled output of one light,

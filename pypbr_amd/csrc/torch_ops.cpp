@@ -138,15 +138,17 @@ Prepared prepare(const Tensor &albedo, const OptTensor &normal, const Tensor &ro
     auto on_device = [&](const Tensor &t, int64_t cols, const char *name) {
         if (!t.is_cuda()) return false;
         TORCH_CHECK_VALUE(t.numel() % cols == 0 && t.numel() > 0, name, " must hold a multiple of ", cols, " values, got ", t.sizes());
-        TORCH_CHECK_VALUE(t.device() == p.albedo.device(), name, " lives on ", t.device(), ", the maps on ", p.albedo.device());
         return true;
     };
+    // a parameter on ANOTHER GPU than the maps is brought over, as the reference's `.to(device)` does (cooktorrance.py:95-96) and as the
+    // ctypes plan path does (functional._device_parameter_tensors): the same call must not depend on which binding serves it
+    auto here = [&](const Tensor &t) { return t.detach().to(p.albedo.device(), at::kFloat).contiguous(); };
     std::vector<float> v(3, 0.0f), l, it;
-    if (on_device(view_dir, 3, "view_dir")) p.dev_view = view_dir.detach().to(at::kFloat).contiguous(); else v = host_floats(view_dir, 3, "view_dir");
+    if (on_device(view_dir, 3, "view_dir")) p.dev_view = here(view_dir); else v = host_floats(view_dir, 3, "view_dir");
     TORCH_CHECK_VALUE(view_dir.numel() == 3, "view_dir must have 3 components");
-    if (on_device(lights, 3, "lights")) { p.dev_lights = lights.detach().to(at::kFloat).contiguous(); l.assign((size_t)lights.numel(), 0.0f); }
+    if (on_device(lights, 3, "lights")) { p.dev_lights = here(lights); l.assign((size_t)lights.numel(), 0.0f); }
     else l = host_floats(lights, 3, "lights");
-    if (on_device(intensities, 3, "intensities")) { p.dev_intensities = intensities.detach().to(at::kFloat).contiguous(); it.assign((size_t)intensities.numel(), 0.0f); }
+    if (on_device(intensities, 3, "intensities")) { p.dev_intensities = here(intensities); it.assign((size_t)intensities.numel(), 0.0f); }
     else it = host_floats(intensities, 3, "intensities");
     const size_t L = l.size() / 3;
     TORCH_CHECK_VALUE(L >= 1 && L <= PBR_MAX_LIGHTS, "between 1 and ", PBR_MAX_LIGHTS, " lights are supported, got ", L);

@@ -109,6 +109,20 @@ def _host_vec3(v: TensorLike, rows: Optional[int] = None):
 DEVICE_PARAMETERS = True     # view / light / intensity tensors that live on the device are read there (pbr_render_desc.device_params), not copied to the host
 
 
+_WARNED_PARAMETER_COPY = []
+
+
+def _warn_parameter_copy(t, device):
+    """A device-resident parameter that is not float32 / contiguous / on the maps' device is read through a COPY made now: later
+    edits of the tensor (an optimiser step, a graph replay) are not seen by a plan built from it.  Said once."""
+    if not _WARNED_PARAMETER_COPY:
+        _WARNED_PARAMETER_COPY.append(True)
+        import warnings
+        warnings.warn("pypbr_amd: a view / light / intensity tensor (%s, %s on %s) is not a contiguous float32 tensor on the maps' device (%s); "
+                      "the kernels read a copy made at planning time, so a RenderPlan or captured graph will not see later updates of it"
+                      % (tuple(t.shape), t.dtype, t.device, device), stacklevel=3)
+
+
 def _device_parameter_tensors(view_dir, light, light_intensity, device):
     """When one of view_dir / light / light_intensity is a tensor on a ROCm device: (view [3] | None, lights [L,3] | None, intensities [1|L,3] | None)
     -- the device-resident ones as contiguous float32 tensors on `device`, None for those the caller holds on the host (they travel in the
@@ -117,7 +131,14 @@ def _device_parameter_tensors(view_dir, light, light_intensity, device):
     if not DEVICE_PARAMETERS or not any(isinstance(t, torch.Tensor) and t.is_cuda for t in (view_dir, light, light_intensity)):
         return None
     on_device = lambda t: isinstance(t, torch.Tensor) and t.is_cuda
-    conv = lambda t, rows: t.detach().to(device, torch.float32).reshape(rows).contiguous() if on_device(t) else None
+
+    def conv(t, rows):
+        if not on_device(t):
+            return None
+        c = t.detach().to(device, torch.float32).reshape(rows).contiguous()
+        if c.data_ptr() != t.data_ptr():
+            _warn_parameter_copy(t, device)
+        return c
     v, lt, it = conv(view_dir, (-1,)), conv(light, (-1, 3)), conv(light_intensity, (-1, 3))
     if v is not None and v.numel() != 3:
         raise ValueError("expected a vector of 3 components, got shape %s" % (tuple(v.shape),))
@@ -243,6 +264,8 @@ class RenderPlan:
         self.device = out.device
         self._fn = N.lib().pbr_cook_torrance
         self._ref = ctypes.byref(desc)
+        self._param_tensors = (None, None, None)            # device-resident view / lights / intensities (prepare_device_parameters)
+        self._param_block, self._param_stream = None, None
 
     @property
     def result(self) -> torch.Tensor:
@@ -275,15 +298,16 @@ class RenderPlan:
             self._param_tensors = tuple(tensors)
         v, lt, it = self._param_tensors
         lib = N.lib()
-        if getattr(self, "_param_block", None) is None:
+        if self._param_block is None:
             self._param_block = torch.empty((lib.pbr_device_params_bytes() + 3) // 4, dtype=torch.float32, device=self.device)
         ptr = lambda t: None if t is None else t.data_ptr()
         if (lt is not None and lt.shape[0] != self.desc.n_lights) or (it is not None and it.shape[0] not in (1, self.desc.n_lights)):
             raise ValueError("light / light_intensity rows disagree with the descriptor's %d lights" % self.desc.n_lights)
+        st = _stream_ptr(self.device) if stream is None else stream
         with torch.cuda.device(self.device):
-            N.check(lib.pbr_prepare_device_params(self._ref, ptr(v), ptr(lt), ptr(it), 1 if it is None else it.shape[0], self._param_block.data_ptr(),
-                                                  _stream_ptr(self.device) if stream is None else stream))
+            N.check(lib.pbr_prepare_device_params(self._ref, ptr(v), ptr(lt), ptr(it), 1 if it is None else it.shape[0], self._param_block.data_ptr(), st))
         self.desc.device_params = self._param_block.data_ptr()
+        self._param_stream = st                             # launches on another stream fold the parameters again there (launch)
 
     def attach_blend(self, blend_desc, workspace, keep_alive):
         """Turns the plan into blend + evaluate (pbr_cook_torrance_blend): material 2 and the mask."""
@@ -312,6 +336,10 @@ class RenderPlan:
         if self.out.numel() == 0 and (self._keep[3] is not None or self._keep[4] is not None):
             return self.result         # zero-sized maps: the reference's whole-map ops return an empty (3, H, W) image; nothing to enqueue
         st = _stream_ptr(self.device) if stream is None else stream
+        if self._param_stream is not None and st != self._param_stream:
+            # the parameter block was written by a kernel on ANOTHER stream: nothing orders this launch behind it.  Folding the
+            # parameters again on the launch stream (one wave) does, and picks up the tensors' current values.
+            self.prepare_device_parameters(stream=st)
         if getattr(self, "_blend", None) is not None:
             rc = N.lib().pbr_cook_torrance_blend(self._ref, self._blend_ref, self._workspace.data_ptr(), st)
         else:
@@ -718,46 +746,57 @@ class _MseStepFn(torch.autograd.Function):
     scalar of exactly 1 -- `loss.backward()` -- costs one early-out launch per map)."""
 
     @staticmethod
-    def forward(ctx, albedo, normal, roughness, metallic, specular, target, kwargs):
-        maps = (albedo, normal, roughness, metallic, specular)
-        plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **kwargs)
+    def _launch(plan, target, maps, wanted):
+        """One pbr_cook_torrance_mse_step: -> (loss, gradient buffers in the maps' own shapes | None)."""
         d = plan.desc
         B, H, W = d.batch, d.height, d.width
-        plan.out = None                                     # the colour is never written
-        tgt = target.detach().to(torch.float32).reshape(B, 3, H, W).contiguous()
-        dev = tgt.device
+        dev = plan.device                                   # the maps' device: a target handed over on the CPU, or on another GPU, is brought here
+        tgt = target.detach().to(dev, torch.float32).reshape(B, 3, H, W).contiguous()
         gdtype = torch.float32 if d.map_dtype == N.F32 else torch.float16
-        channels = (3, 3, 1, 1, 3)
-        present = (True, bool(d.normal.data), True, bool(d.metallic.data), bool(d.specular.data))
-        bufs = []
-        for i in range(5):
-            want = ctx.needs_input_grad[i] and present[i] and maps[i] is not None
-            # in the map's OWN shape ([C,H,W] or [B,C,H,W]: the same memory layout), so that backward returns the buffer itself, not a view of
-            # it -- autograd takes ownership of such a gradient instead of cloning it (a 4096^2 fp16 albedo: 73 us per step)
-            bufs.append(torch.empty(tuple(maps[i].shape), dtype=gdtype, device=dev) if want else None)
+        # in the map's OWN shape ([C,H,W] or [B,C,H,W]: the same memory layout), so that backward returns the buffer itself, not a view of
+        # it -- autograd takes ownership of such a gradient instead of cloning it (a 4096^2 fp16 albedo: 73 us per step)
+        bufs = [torch.empty(tuple(maps[i].shape), dtype=gdtype, device=dev) if wanted[i] else None for i in range(5)]
         loss = torch.empty((), dtype=torch.float32, device=dev)
         lib = N.lib()
         ws = torch.empty(max(1, lib.pbr_mse_step_workspace_bytes(ctypes.byref(d)) // 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             N.check(lib.pbr_cook_torrance_mse_step(ctypes.byref(d), tgt.data_ptr(), *[None if b is None else b.data_ptr() for b in bufs],
                                                    loss.data_ptr(), ws.data_ptr(), _stream_ptr(dev)))
-        ctx.grads, ctx.shapes = bufs, [None if t is None else tuple(t.shape) for t in maps]
-        ctx.save_for_backward(*[t for t in maps if t is not None])
+        return loss, bufs
+
+    @staticmethod
+    def forward(ctx, albedo, normal, roughness, metallic, specular, target, kwargs):
+        maps = (albedo, normal, roughness, metallic, specular)
+        plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **kwargs)
+        d = plan.desc
+        plan.out = None                                     # the colour is never written
+        present = (True, bool(d.normal.data), True, bool(d.metallic.data), bool(d.specular.data))
+        wanted = [bool(ctx.needs_input_grad[i] and present[i] and maps[i] is not None) for i in range(5)]
+        loss, bufs = _MseStepFn._launch(plan, target, maps, wanted)
+        ctx.plan, ctx.wanted, ctx.grads = plan, wanted, bufs
+        ctx.present = [t is not None for t in maps]
+        ctx.save_for_backward(*[t for t in maps if t is not None], target)
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
-        ctx.saved_tensors                                   # in-place edits of the maps since forward are detected, as for any op
-        k = grad_loss.detach().to(torch.float32).reshape(1).contiguous()
-        live = [b for b in ctx.grads if b is not None]
-        if live:                                            # all gradients in ONE launch (they share a dtype and a device)
+        saved = ctx.saved_tensors                           # in-place edits of the maps since forward are detected, as for any op
+        grads = ctx.grads
+        ctx.grads = None                                    # handed over below: autograd may keep the very buffers (e.g. as .grad)
+        if grads is None:
+            # differentiated again (retain_graph=True on the earlier backward): the first call gave its buffers away, so the step is
+            # evaluated once more for fresh ones -- the common single backward never pays for a copy
+            it = iter(saved[:-1])
+            maps = [next(it) if p else None for p in ctx.present]
+            _, grads = _MseStepFn._launch(ctx.plan, saved[-1], maps, ctx.wanted)
+        live = [b for b in grads if b is not None]
+        if live:                                            # all gradients scaled in ONE launch (they share a dtype and a device)
+            k = grad_loss.detach().to(live[0].device, torch.float32).reshape(1).contiguous()
             ptrs = (ctypes.c_void_p * len(live))(*[b.data_ptr() for b in live])
             counts = (ctypes.c_size_t * len(live))(*[b.numel() for b in live])
             with torch.cuda.device(live[0].device):
                 N.check(N.lib().pbr_scale_list_by_device_scalar(ptrs, counts, len(live), _DTYPES[live[0].dtype], k.data_ptr(), _stream_ptr(live[0].device)))
-        out = list(ctx.grads)
-        ctx.grads = None
-        return (*out, None, None)
+        return (*grads, None, None)
 
 
 def rendering_loss_mse(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughness: torch.Tensor,
@@ -1035,6 +1074,52 @@ def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool =
     return tuple(views)
 
 
+def upload_packed(tensors: Sequence[torch.Tensor], device, tail_planes: int = 0):
+    """CPU tensors -> tensors on `device` with ONE host-to-device copy: the maps are laid out in a page-locked host arena exactly as
+    they will sit in the device allocation, which then arrives as a single DMA transfer (five separate `t.to(device)` of pageable
+    tensors are five transfers, each bounced through the runtime's own staging buffers).  Maps that share dtype and (H, W) -- a
+    material's maps as a rule -- are packed as DENSE planes in the order given, so that the whole material is one [P,H,W] block:
+    whole-material operations (MaterialBase.resize) then take one launch over all planes; `tail_planes` more planes of that shape are
+    left free behind them (the decoded normal map lands there).  Otherwise every map starts 256-byte aligned.  Returns
+    (views in the order given, the [P + tail_planes, H, W] block or None).  Pure data movement, no arithmetic."""
+    dev = torch.device(device)
+    ts = [t.detach() for t in tensors]
+    if not ts:
+        return [], None
+    same = all(t.dtype == ts[0].dtype and t.dim() == 3 and t.shape[-2:] == ts[0].shape[-2:] for t in ts)
+    esz = ts[0].element_size()
+    if same:
+        plane = ts[0].shape[-2] * ts[0].shape[-1] * esz
+        offs, off = [], 0
+        for t in ts:
+            offs.append(off)
+            off += t.shape[0] * plane
+        total, extra = off, tail_planes * plane
+    else:
+        offs, off = [], 0
+        for t in ts:
+            offs.append(off)
+            off += -(-t.numel() * t.element_size() // 256) * 256
+        total, extra = off, 0
+    try:
+        host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+    except RuntimeError:                   # page-locking refused: a pageable arena is still one transfer
+        host = torch.empty(total, dtype=torch.uint8)
+    for t, o in zip(ts, offs):
+        n = t.numel() * t.element_size()
+        host[o:o + n].view(t.dtype).view(t.shape).copy_(t)
+    arena = _aligned_arena(total + extra, dev)
+    arena[:total].copy_(host, non_blocking=True)
+    views = []
+    for t, o in zip(ts, offs):
+        n = t.numel() * t.element_size()
+        views.append(arena[o:o + n].view(t.dtype).view(t.shape))
+    block = None
+    if same:
+        block = arena.view(ts[0].dtype).view(-1, ts[0].shape[-2], ts[0].shape[-1])
+    return views, block
+
+
 # 0 = dense planes (the default).  Measured with 4352 (17 x 256 B, tools/skew_ab.sh): batches of 2048^2 maps +1 %
 # (16 maps: 467.6 -> 462.5 us), 64 x 2048^2 +0.6 %, 4 x 4096^2 level, the bench workload (one 4096^2 material) 1.5 % SLOWER
 # (114.0 -> 116.1 us) -- so it stays an experiment knob.
@@ -1141,9 +1226,10 @@ def resize(texture: torch.Tensor, size, antialias: bool = True) -> torch.Tensor:
     return _resize_raw(texture.contiguous(), ho, wo, antialias)
 
 
-def _decode_normal_raw(t: torch.Tensor):
+def _decode_normal_raw(t: torch.Tensor, out: Optional[torch.Tensor] = None):
     C, H, W = t.shape
-    out = torch.empty((3, H, W), dtype=t.dtype, device=t.device)
+    if out is None:
+        out = torch.empty((3, H, W), dtype=t.dtype, device=t.device)
     flag = torch.empty(1, dtype=torch.int32, device=t.device)
     with torch.cuda.device(t.device):
         N.check(N.lib().pbr_decode_normal(t.data_ptr(), out.data_ptr(), C, H * W, _DTYPES[t.dtype],

@@ -7,8 +7,11 @@ Upstream the class lives in the tutorial, not in the package:
     loss = nn.MSELoss()(rendered_pred, rendered_gt)
 
 Same constructor, same forward arguments, same value and gradients here.  The ground-truth rendering is one launch of the fused
-evaluation (no gradient flows into it); the predicted material's evaluation, the MSE and their backward are ONE kernel
-(functional.rendering_loss_mse -> pbr_cook_torrance_mse_step) whenever the predicted maps are plain tensors on a ROCm device.
+evaluation; it runs without a graph when nothing it depends on requires grad (the usual case: the predicted material's evaluation,
+the MSE and their backward are then ONE kernel, functional.rendering_loss_mse -> pbr_cook_torrance_mse_step, whenever the predicted
+maps are plain tensors on a ROCm device).  When `view_dir` / `light_dir` / `light_intensity` -- shared by both renderings upstream --
+or a ground-truth map require grad, the ground truth is rendered differentiably, as upstream renders it: a light being fitted receives
+the gradient of BOTH branches.
 """
 import torch
 import torch.nn as nn
@@ -37,7 +40,15 @@ class RenderingLoss(nn.Module):
         if isinstance(ground_truth_material, torch.Tensor):
             rendered_gt = ground_truth_material
         else:
-            with torch.no_grad():
+            # 06_advanced.rst:101-102 renders both materials under autograd.  Without a graph only when nothing could receive a gradient
+            # through this branch: no ground-truth map and none of the shared light / view tensors requires grad.
+            gt_maps = list(ground_truth_material.__dict__.get("_store", {}).values())
+            pending = ground_truth_material.__dict__.get("_lazy_blend")
+            if pending is not None:
+                gt_maps += list(pending[0].values()) + [pending[1]]
+            differentiable = torch.is_grad_enabled() and any(
+                isinstance(t, torch.Tensor) and t.requires_grad for t in gt_maps + [self.view_dir, self.light_dir, self.light_intensity])
+            with torch.enable_grad() if differentiable else torch.no_grad():
                 rendered_gt = self.brdf(ground_truth_material, self.view_dir, self.light_dir, self.light_intensity, self.light_size)
         a, n, r, m, s = self._maps(predicted_material)
         fusable = (predicted_material.__dict__.get("_lazy_blend") is None and predicted_material.lazy_tile == (1, 1)

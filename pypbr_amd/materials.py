@@ -7,9 +7,19 @@ Mirrors the part of pypbr.materials the hot path touches (SURVEY.md 8a rows H13-
 Reference: /root/reference/pypbr/materials/{base,metallic,diffuse}.py.
 
 Every computation (normal decode, colour transfer, workflow conversion) runs in
-libpbr_hip.so on a ROCm device.  Maps that live on the CPU are staged through the
-device and brought back; with no device present those calls raise -- there is no
+libpbr_hip.so on a ROCm device; with no device present those calls raise -- there is no
 ATen/CPU arithmetic in this package.
+
+Where the maps live.  A material's `device` is where its maps are HANDED OUT (the reference's
+default: the CPU, e.g. examples/example_brdf.py).  Internally a map stays where it was last
+produced: a CPU material's first whole-material operation (`resize`, `to_linear`, a workflow
+conversion, a blend) uploads all its maps in ONE host-to-device copy (functional.upload_packed),
+runs on the device and leaves the results THERE; later operations and `CookTorranceBRDF` read them
+in place.  Only a caller that looks at a map (`material.albedo`, `_maps`, `as_dict()`, `clone()`,
+`linear_albedo` ...) brings it home, once.  Round 3 staged every map through the device and back
+per operation: load -> resize -> tile -> render was 5 x (H2D + launch + D2H) for the resize, the
+same again for the normal decode, and one more upload of everything for the render
+("What's missing" #3); now it is one upload and the download of the image.
 
 Differences from the reference, all supersets:
   * maps may be any floating torch.Tensor on any device (the reference only files
@@ -83,6 +93,23 @@ def _through_device(t: torch.Tensor, fn):
     return F_.to_host(res, t.device)
 
 
+def _normalised(device) -> torch.device:
+    """torch.device("cuda") names the current device: spelled out, so that it compares equal to the tensors that live there."""
+    device = device if isinstance(device, torch.device) else torch.device(device)
+    if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def _compute_device(home) -> torch.device:
+    """Where a material handed out on `home` is computed: `home` itself when it is a ROCm device, else the current one."""
+    home = torch.device(home)
+    if home.type == "cuda":
+        return home
+    _native.require_device()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
 # "Already signed?" (base.py:212: `normal_map.min() < 0`) is a property of the tensor's VALUES, and for a signed map the
 # reference returns the very tensor it was given.  The rendering-loss loop wraps the same decoded normal map in a new
 # material every step; with functional.set_caching(decode_verdicts=True) the first decode of a tensor leaves its verdict
@@ -120,7 +147,7 @@ class MaterialBase:
     def __init__(self, albedo=None, albedo_is_srgb: bool = True, normal=None, roughness=None,
                  normal_convention: NormalConvention = NormalConvention.OPENGL,
                  device: torch.device = torch.device("cpu"), **kwargs):
-        self.device = device if isinstance(device, torch.device) else torch.device(device)
+        self.device = _normalised(device)
         self.normal_convention = normal_convention
         self._maps = {}
         self.albedo_is_srgb = albedo_is_srgb
@@ -135,7 +162,8 @@ class MaterialBase:
         if name in ("albedo_is_srgb", "_maps", "device", "normal_convention", "specular_is_srgb"):
             object.__setattr__(self, name, value)
         elif _is_map_value(value):
-            self._maps[name] = self._ingest(name, value)
+            self.materialize_blend()                       # an assignment to a lazily blended material lands on blended maps
+            self._raw[name] = self._ingest(name, value)
         else:
             object.__setattr__(self, name, value)
 
@@ -143,24 +171,80 @@ class MaterialBase:
         d = self.__dict__
         pending = d.get("_lazy_blend")
         if name in d.get("_store", {}) or (pending is not None and name in pending[0]):   # a map only material 2 has
-            if d.get("_lazy_tile", (1, 1)) != (1, 1):
-                self.materialize_tile()   # anything but the BRDF sees the repeated maps (CookTorranceBRDF reads _store itself)
-            return self._maps[name]
+            return self._maps[name]       # anything but the BRDF sees blended, repeated maps at home (CookTorranceBRDF reads _store itself)
         raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
 
-    # `_maps` is the reference's name -> tensor dict.  It lives in `_store`; reading it first resolves a pending
-    # lazy blend (blending.blend_with_mask(..., lazy=True)), so whoever looks at the maps sees blended maps --
-    # only CookTorranceBRDF reads `_store` / `_lazy_blend` directly and hands both materials to the fused kernel.
+    # `_maps` is the reference's name -> tensor dict: the PUBLIC view.  Reading it first resolves a pending lazy blend
+    # (blending.blend_with_mask(..., lazy=True)) and a pending tile(n, lazy=True), decodes a normal map whose decode was
+    # deferred, and brings every map that still sits on the compute device home to `self.device` -- whoever looks at the maps
+    # sees what the reference's dict would hold.  The package's own code goes through `_raw` (the same dict, as it stands) and `_resident()`.
     @property
     def _maps(self):
         d = self.__dict__
         if d.get("_lazy_blend") is not None:
             self.materialize_blend()
+        if d.get("_lazy_tile", (1, 1)) != (1, 1):
+            self.materialize_tile()
+        self._bring_home()
         return d.setdefault("_store", {})
 
     @_maps.setter
     def _maps(self, value):
         self.__dict__["_store"] = value
+
+    @property
+    def _raw(self) -> dict:
+        """The name -> tensor dict as it stands: maps wherever they were last produced, a deferred normal still encoded."""
+        return self.__dict__.setdefault("_store", {})
+
+    def _is_away(self) -> bool:
+        """A map of this material sits on another device than the one it is handed out on."""
+        return any(t is not None and t.device != self.device for t in self._raw.values())
+
+    def _bring_home(self):
+        store, home = self._raw, self.device
+        if self.__dict__.get("_raw_normal"):
+            self.__dict__["_raw_normal"] = False
+            store["normal"] = self._process_normal_map(store["normal"])
+        for name, t in store.items():
+            if t is not None and t.device != home:
+                store[name] = F_.to_host(t, home) if home.type == "cpu" else t.to(home)
+
+    def _resident(self, keep: bool = True) -> dict:
+        """name -> tensor on the compute device for every map that is present.  Maps that are still on the host travel in ONE
+        copy (functional.upload_packed; a deferred normal map first, its decoded form written behind the others so that the
+        material is one dense block of planes).  `keep=True`: the device tensors become the material's maps (the operation that
+        asked is about to replace them anyway); `keep=False` (CookTorranceBRDF): host maps stay the material's maps -- the
+        reference re-reads them every call -- except a deferred normal, whose decoded form is the map from now on."""
+        self.materialize_blend()
+        d, store = self.__dict__, self._raw
+        compute = _compute_device(self.device)
+        names = [k for k, t in store.items() if t is not None]
+        away = [k for k in names if store[k].device != compute]
+        out = {k: store[k] for k in names}
+        pending = bool(d.get("_raw_normal"))
+        if away:
+            grads = [k for k in away if store[k].requires_grad]
+            for k in grads:
+                out[k] = store[k].to(compute)                    # differentiable copy, on its own
+            plain = [k for k in away if k not in grads]
+            if pending and "normal" in plain:                    # raw normal first: everything behind it is one dense block
+                plain = ["normal"] + [k for k in plain if k != "normal"]
+            if plain:
+                views, block = F_.upload_packed([store[k] for k in plain], compute, tail_planes=3 if pending and "normal" in plain else 0)
+                out.update(zip(plain, views))
+                if pending and "normal" in plain and block is not None:
+                    out["normal"] = F_._decode_normal_raw(out["normal"], out=block[-3:])[0]
+                    pending = False
+        if pending:
+            out["normal"] = F_.decode_normal(out["normal"])
+        if d.get("_raw_normal"):
+            d["_raw_normal"] = False
+            store["normal"] = out["normal"]
+        if keep:
+            for k in away:
+                store[k] = out[k]
+        return out
 
     def materialize_blend(self):
         """Carries out a pending lazy blend: the maps become real blended tensors (blend.hip kernels)."""
@@ -171,12 +255,22 @@ class MaterialBase:
             other, mask = pending
             store = self.__dict__["_store"]
             for name, result in _blend_dicts(dict(store), other, mask).items():
-                store[name] = self._ingest(name, result)      # normals pass through _process_normal_map, as upstream
+                store[name] = self._settle(name, result)      # normals pass through _process_normal_map, as upstream
         return self
+
+    def _settle(self, name, t):
+        """A map PRODUCED by this package (a blend, a conversion) becomes the material's: it stays on the device it was computed on,
+        a normal map passes through _process_normal_map as on any assignment upstream."""
+        if t is None:
+            return None
+        if name == "normal":
+            return self._process_normal_map(t)
+        return t
 
     def _ingest(self, name, value):
         if value is None:
             return None
+        fresh = False                                # nobody else holds the tensor: its decode may wait for the first device operation
         if isinstance(value, torch.Tensor):
             if value.is_cuda and self.device.type == "cpu":
                 self.device = value.device           # a device tensor pulls the material onto its device (module docstring)
@@ -185,10 +279,20 @@ class MaterialBase:
             t = torch.from_numpy(value).float().to(self.device)
         elif _is_image(value):
             t = _image_to_tensor(value).to(self.device)
+            fresh = True
         else:  # pragma: no cover  (guarded by _is_map_value)
             raise TypeError(f"Unsupported image type: {type(value)}. Supported types are PIL.Image.Image, "
                             "np.ndarray, and torch.FloatTensor.")
         if name == "normal":
+            self.__dict__["_raw_normal"] = False
+            if fresh and t.device.type == "cpu" and t.dim() == 3 and torch.cuda.is_available():
+                # base.py:191-242 decodes at assignment.  A map freshly decoded from an image file lives on the host and nobody
+                # can look at it but through this material: it is stored as loaded, and decoded on the device together with the
+                # first operation that uploads the material (or when somebody reads it) -- one transfer less in each direction.
+                if t.shape[0] not in (2, 3):
+                    raise ValueError("Normal map must have 2 or 3 channels.")
+                self.__dict__["_raw_normal"] = True
+                return t
             return self._process_normal_map(t)
         return t
 
@@ -209,20 +313,20 @@ class MaterialBase:
 
     # -- device management (base.py:245-259)
     def to(self, device):
-        """base.py:245-259.  Moving to a ROCm device packs the maps into ONE allocation (functional.pack_maps):
-        a launch streams every plane of the material at once, and planes that share an allocation stay close together
-        in the address space (1-6 % faster and steadier than maps scattered over the heap)."""
-        self.device = torch.device(device) if not isinstance(device, torch.device) else device
-        maps = self._maps
-        names = [k for k, t in maps.items() if t is not None]
-        if (self.device.type == "cuda" and names and any(maps[k].device != self.device for k in names)
-                and not any(maps[k].requires_grad for k in names)):
-            for k, v in zip(names, F_.pack_maps(*[maps[k] for k in names], device=self.device)):
-                maps[k] = v
+        """base.py:245-259.  Moving to a ROCm device takes ONE host-to-device copy of all maps into one allocation
+        (functional.upload_packed): a launch streams every plane of the material at once, and planes that share an allocation stay
+        close together in the address space (1-6 % faster and steadier than maps scattered over the heap)."""
+        self.device = _normalised(device)
+        self.materialize_blend()
+        if self.device.type == "cuda":
+            self._resident(keep=True)
         else:
-            for k in names:
-                maps[k] = maps[k].to(self.device)
+            self._bring_home()
         return self
+
+    def _bring_home_normal(self):
+        self.__dict__["_raw_normal"] = False
+        self._raw["normal"] = self._process_normal_map(self._raw["normal"])
 
     # -- properties
     @property
@@ -262,46 +366,74 @@ class MaterialBase:
         self.__dict__.pop("_device_cache", None)
         return self
 
+    def _convert_in_place(self, name, flag, fn):
+        """One map through a colour transfer, on the device, the result left there (module docstring)."""
+        if self._raw.get(name) is not None:
+            self._raw[name] = fn(self._resident(keep=True)[name])
+
     # -- colour space, in place, returning self (base.py:754-778)
     def to_linear(self):
-        albedo = self._maps.get("albedo")
-        if albedo is not None and self.albedo_is_srgb:
-            self._maps["albedo"] = _through_device(albedo, F_.srgb_to_linear)
+        self.materialize_blend()
+        if self._raw.get("albedo") is not None and self.albedo_is_srgb:
+            self._convert_in_place("albedo", "albedo_is_srgb", F_.srgb_to_linear)
             self.albedo_is_srgb = False
         return self
 
     def to_srgb(self):
-        albedo = self._maps.get("albedo")
-        if albedo is not None and not self.albedo_is_srgb:
-            self._maps["albedo"] = _through_device(albedo, F_.linear_to_srgb)
+        self.materialize_blend()
+        if self._raw.get("albedo") is not None and not self.albedo_is_srgb:
+            self._convert_in_place("albedo", "albedo_is_srgb", F_.linear_to_srgb)
             self.albedo_is_srgb = True
         return self
 
     # -- the two calls around the BRDF in examples/example_brdf.py:11 (SURVEY.md 8f, N1)
     def resize(self, size, antialias: bool = True):
-        """Resize every map (base.py:490-504): bilinear, antialiased by default; in place, returns self."""
+        """Resize every map (base.py:490-504): bilinear, antialiased by default; in place, returns self.  All float32 (C,H,W) maps
+        of one size -- a material's maps as a rule -- go through ONE pbr_resize_bilinear launch over all their planes; the results
+        stay on the device (module docstring)."""
         self.materialize_tile()
-        for name, t in self._maps.items():
-            if t is not None:
-                self._maps[name] = _through_device(t, lambda x: F_.resize(x, size, antialias=antialias))
+        maps = self._resident(keep=True)
+        store = self._raw
+        groups = {}
+        for name, t in maps.items():
+            if t.dim() == 3 and t.dtype == torch.float32 and not (t.requires_grad and torch.is_grad_enabled()):
+                groups.setdefault(tuple(t.shape[-2:]), []).append(name)
+            else:
+                store[name] = F_.resize(t, size, antialias=antialias)
+        for names in groups.values():
+            names.sort(key=lambda k: maps[k].data_ptr())
+            ts = [maps[k] for k in names]
+            out = F_.resize(_as_block(ts), size, antialias=antialias)
+            p = 0
+            for k, t in zip(names, ts):
+                store[k] = out[p:p + t.shape[0]]
+                p += t.shape[0]
         return self
 
     # -- pure indexing (base.py:524-537); no arithmetic involved
     def tile(self, num_tiles: int, lazy: bool = False):
         """Repeat every map num_tiles x num_tiles (base.py:524-537).  `lazy=True` (build extension) only records
-        the repeat: the maps stay as they are, `CookTorranceBRDF` hands the count to the kernel, which wraps its
-        texel addresses -- each texel then leaves HBM once instead of num_tiles^2 times and no copy is made."""
-        if num_tiles < 1:
-            raise ValueError("num_tiles must be >= 1")
-        if lazy:
+        the repeat: the maps stay as they are, `CookTorranceBRDF` hands the count to the kernel, which evaluates every texel at
+        all its repeats -- each texel then leaves HBM once instead of num_tiles^2 times and no copy is made; whoever else looks at
+        the maps sees the repeated ones.  A material whose maps are waiting on the compute device (module docstring) records the
+        repeat likewise."""
+        if num_tiles <= 0:                 # upstream: map.repeat(1, 0, 0) -> empty maps; a negative count is torch's RuntimeError
+            self.materialize_tile()
+            store = self._raw
+            for name, t in store.items():
+                if t is not None:
+                    store[name] = t.repeat(*((1,) * (t.dim() - 2) + (num_tiles, num_tiles)))
+            return self
+        if lazy or self._is_away():
             ny, nx = self.lazy_tile
             object.__setattr__(self, "_lazy_tile", (ny * num_tiles, nx * num_tiles))
             return self
         self.materialize_tile()
-        for name, t in self._maps.items():
+        store = self._maps
+        for name, t in store.items():
             if t is not None:
                 reps = (1,) * (t.dim() - 2) + (num_tiles, num_tiles)
-                self._maps[name] = t.repeat(*reps)
+                store[name] = t.repeat(*reps)
         return self
 
     @property
@@ -310,27 +442,55 @@ class MaterialBase:
         return self.__dict__.get("_lazy_tile", (1, 1))
 
     def materialize_tile(self):
-        """Turns a pending lazy repeat into real maps (anything but the BRDF needs them)."""
+        """Turns a pending lazy repeat into real maps (anything but the BRDF needs them), where the maps are."""
         ny, nx = self.lazy_tile
         if (ny, nx) != (1, 1):
             object.__setattr__(self, "_lazy_tile", (1, 1))
-            for name, t in self._maps.items():
+            self.materialize_blend()
+            if self.__dict__.get("_raw_normal"):
+                self._bring_home_normal()
+            store = self._raw
+            for name, t in store.items():
                 if t is not None:
-                    self._maps[name] = t.repeat(*((1,) * (t.dim() - 2) + (ny, nx)))
+                    store[name] = t.repeat(*((1,) * (t.dim() - 2) + (ny, nx)))
         return self
 
     def clone(self):
         """Deep copy: tensors cloned, flags copied (base.py:880-912)."""
         self.materialize_blend()          # a pending lazy blend is carried out first: the copy must not blend again
+        if self.__dict__.get("_raw_normal"):
+            self._bring_home_normal()
         new = copy.copy(self)
         new.__dict__.pop("_device_cache", None)
         new.__dict__["_lazy_blend"] = None
-        object.__setattr__(new, "_maps", {k: (None if v is None else v.clone()) for k, v in self._maps.items()})
+        object.__setattr__(new, "_maps", {k: (None if v is None else v.clone()) for k, v in self._raw.items()})
+        return new
+
+    @classmethod
+    def _assemble(cls, device, maps: dict, **flags):
+        """A material of this class around maps this package produced (a conversion): they stay where they were computed."""
+        new = cls(device=device, **flags)
+        for name, t in maps.items():
+            if t is not None:
+                new._raw[name] = new._settle(name, t)
         return new
 
     def __repr__(self):
-        body = ", ".join(f"{k}={None if v is None else tuple(v.shape)}" for k, v in self._maps.items())
+        body = ", ".join(f"{k}={None if v is None else tuple(v.shape)}" for k, v in self._raw.items())
         return f"{type(self).__name__}({body})"
+
+
+def _as_block(ts):
+    """[P,H,W] over the planes of (C_i,H,W) tensors: a view when they sit back to back in one allocation (functional.upload_packed,
+    a previous resize), else a copy."""
+    first = ts[0]
+    plane = first.shape[-2] * first.shape[-1]
+    adjacent = all(t.is_contiguous() for t in ts) and all(
+        a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.data_ptr() + a.numel() * a.element_size() == b.data_ptr()
+        for a, b in zip(ts, ts[1:]))
+    if adjacent:
+        return first.as_strided((sum(t.shape[0] for t in ts), first.shape[-2], first.shape[-1]), (plane, first.shape[-1], 1))
+    return torch.cat(ts, dim=0)
 
 
 class BasecolorMetallicMaterial(MaterialBase):
@@ -355,18 +515,17 @@ class BasecolorMetallicMaterial(MaterialBase):
         diffuse and specular maps and -- as upstream -- is flagged specular_is_srgb=True
         unless told otherwise."""
         self.materialize_tile()
-        albedo, metallic = self._maps.get("albedo"), self._maps.get("metallic")
-        if albedo is None or metallic is None:
+        self.materialize_blend()
+        if self._raw.get("albedo") is None or self._raw.get("metallic") is None:
             raise ValueError("Both albedo and metallic maps are required for conversion.")
+        maps = self._resident(keep=True)
+        albedo, metallic = maps["albedo"], maps["metallic"]
         if metallic.shape[-2:] != albedo.shape[-2:]:       # metallic.py:93-96: TF.resize(metallic, albedo.shape[1:], antialias=True)
-            size = tuple(albedo.shape[-2:])
-            metallic = _through_device(metallic, lambda t: F_.resize(t, size, antialias=True))
-        srgb = self.albedo_is_srgb
-        diffuse, specular = _through_device(
-            albedo, lambda a: F_.metallic_to_diffuse_specular(a, metallic.to(a.device), albedo_is_srgb=srgb))
-        return DiffuseSpecularMaterial(albedo=diffuse, specular=specular, normal=self._maps.get("normal"),
-                                       roughness=self._maps.get("roughness"), albedo_is_srgb=albedo_is_srgb,
-                                       specular_is_srgb=specular_is_srgb, device=self.device)
+            metallic = F_.resize(metallic, tuple(albedo.shape[-2:]), antialias=True)
+        diffuse, specular = F_.metallic_to_diffuse_specular(albedo, metallic, albedo_is_srgb=self.albedo_is_srgb)
+        return DiffuseSpecularMaterial._assemble(
+            self.device, dict(albedo=diffuse, normal=maps.get("normal"), roughness=maps.get("roughness"), specular=specular),
+            albedo_is_srgb=albedo_is_srgb, specular_is_srgb=specular_is_srgb)
 
 
 class DiffuseSpecularMaterial(MaterialBase):
@@ -398,33 +557,30 @@ class DiffuseSpecularMaterial(MaterialBase):
     def to_basecolor_metallic_material(self, albedo_is_srgb: bool = False):
         """diffuse.py:93-158: RAW specular (not linear_specular), 3-channel metallic."""
         self.materialize_tile()
-        albedo, specular = self._maps.get("albedo"), self._maps.get("specular")
-        if albedo is None or specular is None:
+        self.materialize_blend()
+        if self._raw.get("albedo") is None or self._raw.get("specular") is None:
             raise ValueError("Both albedo (diffuse) and specular maps are required for conversion.")
+        maps = self._resident(keep=True)
+        albedo, specular = maps["albedo"], maps["specular"]
         if specular.shape[-2:] != albedo.shape[-2:]:       # diffuse.py:117-118: TF.resize(self.specular, diffuse.shape[1:], antialias=True)
-            size = tuple(albedo.shape[-2:])
-            specular = _through_device(specular, lambda t: F_.resize(t, size, antialias=True))
-        srgb = self.albedo_is_srgb
-        base, metallic = _through_device(
-            albedo, lambda d: F_.diffuse_specular_to_basecolor_metallic(d, specular.to(d.device), albedo_is_srgb=srgb))
-        return BasecolorMetallicMaterial(albedo=base, metallic=metallic, normal=self._maps.get("normal"),
-                                         roughness=self._maps.get("roughness"), albedo_is_srgb=albedo_is_srgb,
-                                         device=self.device)
+            specular = F_.resize(specular, tuple(albedo.shape[-2:]), antialias=True)
+        base, metallic = F_.diffuse_specular_to_basecolor_metallic(albedo, specular, albedo_is_srgb=self.albedo_is_srgb)
+        return BasecolorMetallicMaterial._assemble(
+            self.device, dict(albedo=base, normal=maps.get("normal"), roughness=maps.get("roughness"), metallic=metallic),
+            albedo_is_srgb=albedo_is_srgb)
 
     def to_linear(self):
         """diffuse.py:160-175."""
         super().to_linear()
-        specular = self._maps.get("specular")
-        if specular is not None and self.specular_is_srgb:
-            self._maps["specular"] = _through_device(specular, F_.srgb_to_linear)
+        if self._raw.get("specular") is not None and self.specular_is_srgb:
+            self._convert_in_place("specular", "specular_is_srgb", F_.srgb_to_linear)
             self.specular_is_srgb = False
         return self
 
     def to_srgb(self):
         """diffuse.py:177-190."""
         super().to_srgb()
-        specular = self._maps.get("specular")
-        if specular is not None and not self.specular_is_srgb:
-            self._maps["specular"] = _through_device(specular, F_.linear_to_srgb)
+        if self._raw.get("specular") is not None and not self.specular_is_srgb:
+            self._convert_in_place("specular", "specular_is_srgb", F_.linear_to_srgb)
             self.specular_is_srgb = True
         return self

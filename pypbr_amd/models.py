@@ -17,7 +17,7 @@ from torch import Tensor
 
 from . import _native
 from . import functional as F_
-from .materials import MaterialBase
+from .materials import MaterialBase, _normalised
 
 
 # Device copies kept by `material.cache_on_device()` (see CookTorranceBRDF._staged): id(material) -> (weakref, bytes), least
@@ -45,6 +45,18 @@ def _register_device_cache(material, nbytes):
         total -= n
 
 
+def _upload_together(tensors, compute):
+    """Device copies of the tensors that are not on `compute` yet: the host-resident ones in ONE transfer (functional.upload_packed),
+    tensors of another device one by one; `None` and tensors already there pass through."""
+    host = [i for i, t in enumerate(tensors) if t is not None and t.device.type == "cpu"]
+    moved = [None if t is None else (t if t.device == compute or t.device.type == "cpu" else t.to(compute)) for t in tensors]
+    if host:
+        views, _ = F_.upload_packed([tensors[i] for i in host], compute)
+        for i, v in zip(host, views):
+            moved[i] = v
+    return tuple(moved)
+
+
 class BRDFModel(nn.Module, ABC):
     """Abstract base class for BRDF models (cooktorrance.py:27-30)."""
 
@@ -69,7 +81,7 @@ class CookTorranceBRDF(BRDFModel):
     @staticmethod
     def _staged(material, maps, blend, compute):
         """Device copies of maps that live elsewhere (CPU-resident materials: the reference's default, e.g.
-        examples/example_brdf.py), in ONE allocation (functional.pack_maps).  By default the maps are uploaded on every
+        examples/example_brdf.py), in ONE allocation and ONE transfer (functional.upload_packed).  By default the maps are uploaded on every
         call -- the reference re-reads its maps every call too.  Opt-in (`material.cache_on_device()`, or
         functional.set_caching(device_maps=True) for every material): the copy is kept on the material, so a loop that
         evaluates an unchanged material again and again uploads it once (a 4096^2 material: 9.6 ms of PCIe per call
@@ -91,7 +103,7 @@ class CookTorranceBRDF(BRDFModel):
             moved = hit[3]
             _touch_device_cache(material)
         else:
-            moved = F_.pack_maps(*tensors, device=compute)
+            moved = _upload_together(tensors, compute)
             if cacheable:
                 refs = tuple(None if t is None else weakref.ref(t) for t in tensors)
                 material.__dict__["_device_cache"] = (compute, versions, refs, moved)
@@ -108,7 +120,7 @@ class CookTorranceBRDF(BRDFModel):
         on the device and the result is returned on the CPU; nothing is computed on the
         CPU.  `light_dir_or_position` / `light_intensity` may be (L,3) for L lights.
         """
-        out_device = torch.device(self.override_device or material.device)
+        out_device = _normalised(self.override_device or material.device)
 
         pending = material.__dict__.get("_lazy_blend")
         blend = None
@@ -129,6 +141,10 @@ class CookTorranceBRDF(BRDFModel):
             # package is read through its raw store: attribute access would materialise a pending tile(n, lazy=True),
             # which this call hands to the kernel as wrap-around addressing instead.
             store = material.__dict__.get("_store") if isinstance(material, MaterialBase) else None
+            if store is not None and material.__dict__.get("_raw_normal"):
+                # a normal map whose decode was deferred (materials.py, _ingest): the whole material goes up in one transfer and the
+                # normal is decoded on arrival; its decoded form stays the material's map, the others are re-read next call as ever
+                store = {**store, **material._resident(keep=False)}
 
             def probe(name):
                 if store is None:

@@ -367,7 +367,7 @@ def test_lazy_blend_and_lazy_tile_protocol_on_the_host():
     assert not B._fusable(m1._maps, m2._maps, mk.double())
     # lazy tile: only the reported size changes
     t = mat().tile(3, lazy=True)
-    assert t.lazy_tile == (3, 3) and t.size == (3 * H, 3 * W) and t._maps["albedo"].shape == (3, H, W)
+    assert t.lazy_tile == (3, 3) and t.size == (3 * H, 3 * W) and t._raw["albedo"].shape == (3, H, W)
     assert t.tile(2, lazy=True).lazy_tile == (6, 6)
     assert t.materialize_tile().albedo.shape == (3, 6 * H, 6 * W) and t.lazy_tile == (1, 1)     # torch.repeat: indexing only
 
@@ -562,3 +562,19 @@ def test_isa_assumptions_of_the_hand_scheduled_kernels_hold_and_the_checker_can_
     assert C.store_data_violations({"k": [("global_store_dwordx4", "v[26:27], v[18:21], off nt"), ("v_mov_b32_e32", "v19, 0")]})
     assert not C.store_data_violations({"k": [("global_store_dwordx4", "v[26:27], v[18:21], off nt"), ("s_nop", "0"), ("v_mov_b32_e32", "v19, 0")]})
     assert not C.store_data_violations({"k": [("global_store_dwordx2", "v[26:27], v[18:19], off"), ("v_mov_b32_e32", "v19, 0")]})
+
+
+def test_upload_packed_layout_on_the_host():
+    """functional.upload_packed is data movement only: its layout runs against a CPU 'device' too.  Maps of one dtype and (H, W) become
+    ONE dense block of planes in the order given (+ free tail planes for the decoded normal map); anything else starts 256-byte aligned."""
+    g = torch.Generator().manual_seed(3)
+    n_raw, a, r = torch.rand(2, 6, 10, generator=g), torch.rand(3, 6, 10, generator=g), torch.rand(1, 6, 10, generator=g)
+    views, block = F.upload_packed([n_raw, a, r], "cpu", tail_planes=3)
+    assert [tuple(v.shape) for v in views] == [(2, 6, 10), (3, 6, 10), (1, 6, 10)] and all(torch.equal(v, t) for v, t in zip(views, (n_raw, a, r)))
+    assert block.shape == (9, 6, 10) and torch.equal(block[:2], n_raw) and torch.equal(block[2:5], a) and torch.equal(block[5:6], r)
+    assert views[1].data_ptr() == views[0].data_ptr() + n_raw.numel() * 4 and views[2].data_ptr() == views[1].data_ptr() + a.numel() * 4
+    block[-3:].fill_(7.0)                                       # the tail is the block's own memory, behind the maps
+    assert torch.equal(views[2], r)
+    mixed, none = F.upload_packed([a, torch.rand(1, 3, 5, generator=g).half()], "cpu")
+    assert none is None and mixed[1].dtype == torch.float16 and mixed[1].data_ptr() % 256 == 0 and torch.equal(mixed[0], a)
+    assert F.upload_packed([], "cpu") == ([], None)

@@ -72,12 +72,12 @@ def test_cpu_material_keeps_its_device_copy_between_calls():
     assert "_device_cache" not in plain.__dict__                      # default: nothing kept
     mat = _material(seed=5).cache_on_device()
     calls = []
-    real = F.pack_maps
+    real = F.upload_packed                                            # the one transfer a staging of host maps takes
 
     def counting(*a, **k):
         calls.append(1)
         return real(*a, **k)
-    F.pack_maps = counting
+    F.upload_packed = counting
     try:
         o1 = brdf(mat, *ARGS)
         o2 = brdf(mat, *ARGS)
@@ -94,7 +94,7 @@ def test_cpu_material_keeps_its_device_copy_between_calls():
         brdf(mat, *ARGS)
         assert len(calls) == 4
     finally:
-        F.pack_maps = real
+        F.upload_packed = real
     dev = _material(seed=5, device="cuda")
     dev._maps["roughness"].mul_(0.5); dev.albedo = mat.albedo.cuda()
     assert torch.equal(brdf(dev, *ARGS).cpu(), brdf(mat, *ARGS))

@@ -35,7 +35,7 @@ for dt in (torch.float32, torch.float16):
         eager = F.plan_cook_torrance(*[t.repeat(1, n, n) for t in maps], **kw)
         want = eager.launch().clone()
         #            repeat pack fold nt
-        variants = [(1, 0, 0, 1), (1, 0, 0, 0), (0, 0, 0, 1), (0, 1, 0, 1), (0, 1, 5, 1), (0, -1, -1, 1)]
+        variants = [(1, 0, 0, 1), (1, 0, 0, 0), (1, 0, 0, 2), (1, 0, 0, 3), (1, 0, 0, 4), (0, 0, 0, 1), (0, 1, 0, 1), (0, 1, 5, 1), (0, -1, -1, 1)]
         plans, same, times = {}, {}, {v: [] for v in variants + ["materialised"]}
         for v in variants:
             setk(v)

@@ -12,9 +12,14 @@
  * segment, i.e. in SGPRs: the wave-uniform broadcast is free).
  *
  * Threading: every call only enqueues work on `stream` (a hipStream_t passed as
- * void*, NULL = the null stream); no call synchronises with the host, allocates
- * device memory, or keeps state between calls (same contract as the reference:
- * synchronous-looking, stateless, re-entrant).  Inputs are never written.
+ * void*, NULL = the null stream); no call synchronises with the host or allocates
+ * device memory, and a call's behaviour is a function of its arguments (same
+ * contract as the reference: synchronous-looking, stateless, re-entrant) -- with ONE
+ * documented exception: pbr_set_tuning below is a process-global test / bench /
+ * profiling hook (atomic words) that changes which schedule later calls of the whole
+ * process pick.  Results never depend on it, only speed; product code leaves it alone
+ * and passes per-call settings through pbr_render_desc.tuning instead.  Inputs are
+ * never written.
  *
  * Map layout (pypbr/materials/base.py: maps are (C,H,W) float32, channel-first):
  * planar [B][C][H][W], rows contiguous (row stride == width).  `batch_stride`
@@ -31,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBR_HIP_ABI_VERSION 5      /* 5: pbr_render_desc.device_params (view / light / intensity read from device memory); 4: light_size follows Python truthiness, gradients of the map ops */
+#define PBR_HIP_ABI_VERSION 6      /* 6: pbr_render_desc.tuning (per-call schedule knobs; pbr_set_tuning demoted to a process-global test hook); 5: pbr_render_desc.device_params (view / light / intensity read from device memory); 4: light_size follows Python truthiness, gradients of the map ops */
 #define PBR_MAX_LIGHTS 16
 
 /* ---- status codes (negative = caller error, positive = HIP runtime error code + 1000) */
@@ -62,6 +67,44 @@ typedef struct pbr_map {
     int64_t batch_stride;         /* elements between materials */
     int64_t channel_stride;       /* elements between channel planes */
 } pbr_map;
+
+/* ---- schedule knobs ------------------------------------------------------------------
+ * HOW a launch is scheduled (never WHAT it computes: every setting gives bit-identical results).  Each knob has a built-in rule
+ * (measured on MI355X); a caller that knows better passes a pbr_tuning with the descriptor -- per call, caller-owned,
+ * nothing outlives the call.  Entries left at PBR_TUNE_UNSET follow the rule (or the process-wide test hook pbr_set_tuning). */
+enum {
+    PBR_TUNE_NONTEMPORAL = 0,           /* streaming hint on loads and stores: 1 = rule, 0 off, 2 also on launches over tiled maps (repeat-inner kernel: 2 loads + stores, 3 stores only, 4 loads only) */
+    PBR_TUNE_BLOCK_LOG2 = 1,            /* workgroup = 1 << value lanes (6..8); 0 = rule */
+    PBR_TUNE_F16_VEC = 2,               /* pixels per lane for fp16 maps (4 | 8) */
+    PBR_TUNE_LDS_BYTES = 3,             /* unused dynamic LDS per workgroup of the render kernel: an occupancy governor (-1 = rule) */
+    PBR_TUNE_XCD_LOG2 = 4,              /* consecutive tiles per XCD = 1 << value (the workgroup -> tile order); -1 = the descriptor's schedule */
+    PBR_TUNE_BWD_VEC = 5,               /* pixels per lane of the backward kernels (2 | 4 force; 0 = rule) */
+    PBR_TUNE_BATCH_INNER = 6,           /* several lights: materials per lane of the batch-inner kernel (-1 = rule, 0 = one-material kernel) */
+    PBR_TUNE_INTERLEAVE = 7,            /* experiment: materials of a batch interleaved workgroup by workgroup */
+    PBR_TUNE_SCALAR_BASE = 8,           /* scalar plane addresses: 0 never, 1 rule (single materials), 2 whenever the launch allows them */
+    PBR_TUNE_MAX_VEC = 9,               /* at most this many pixels per lane (8 default; 1 = the one-pixel kernels everywhere) */
+    PBR_TUNE_RESIZE_ROWS = 10,          /* output rows per workgroup of the resize kernels (0 = rule) */
+    PBR_TUNE_BWD_RUN = 11,              /* rounds of the streamed backward kernel for fp16 maps with one light (-1 = rule, 0 = the one-tile kernels) */
+    PBR_TUNE_RESIZE_XCD = 12,           /* tile order of the resize kernel: 1 = XCD-contiguous chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many */
+    PBR_TUNE_BWD_WIDE = 13,             /* streamed backward with 16-byte memory instructions: -1 = rule (off), 0 = the 4-byte form, 1 = wherever legal */
+    PBR_TUNE_RESIZE_UP2 = 14,           /* up-scales on both axes: the two-tap register kernel (1, default) or the strip kernel (0) */
+    PBR_TUNE_TILE_FOLD = 15,            /* tiled maps, wrap-around form: log2 of the source rows per band of the fold order (all vertical repeats of a band back to back); -1 = rule, 0 = row order */
+    PBR_TUNE_RESIZE_BWD_FUSED = 16,     /* gradient of resize in one pass (1, default) or two passes through the workspace (0) */
+    PBR_TUNE_RESIZE_QUADS = 17,         /* strip kernel's width pass with four columns per lane and 16-byte stores: 1 = rule, 2 = wherever legal, 0 = never */
+    PBR_TUNE_STREAM_SHAPE = 18,         /* launch shape of the streaming map kernels: -1 = each kernel's rule, 0 = 2048 walking workgroups of 256 lanes, 1 = one item per lane (256-lane groups), 2 = one-wave groups */
+    PBR_TUNE_STREAM_LDS = 19,           /* unused dynamic LDS bytes per workgroup of those kernels (an occupancy cap); -1 = rule */
+    PBR_TUNE_MSE_STREAM = 20,           /* rendering-loss step for fp16 maps with one light: the streamed kernel (1, default) or the one-tile kernels (0) */
+    PBR_TUNE_PACK_SINGLE = 21,          /* one light over fp32 maps: packed (two pixels per instruction) arithmetic: -1 = rule (wrap-around launches over tiled maps, which are VALU-bound), 0 = never, 1 = always */
+    PBR_TUNE_TILE_REPEAT = 22,          /* tiled maps, whole output, one light: every texel loaded and decoded once and evaluated at all its repeats (-1 = rule: on, 0 = wrap-around addressing) */
+    PBR_TUNE_COUNT = 23
+};
+#define PBR_TUNE_UNSET INT32_MIN
+#define PBR_TUNE_SLOTS 32               /* room for knobs of later versions: a pbr_tuning never changes size */
+typedef struct pbr_tuning {
+    int32_t knob[PBR_TUNE_SLOTS];       /* indexed by PBR_TUNE_*; PBR_TUNE_UNSET = no opinion.  Initialise with pbr_tuning_init */
+} pbr_tuning;
+/* Sets every entry to PBR_TUNE_UNSET. */
+void pbr_tuning_init(pbr_tuning *t);
 
 /*
  * One evaluation = CookTorranceBRDF.forward for `batch` materials and `n_lights`
@@ -119,6 +162,7 @@ typedef struct pbr_render_desc {
                                      intensity from it -- parameters that live in device memory (a light being fitted: cooktorrance.py:95-96,
                                      :126-140 are torch ops on device tensors upstream) never travel through the host, so a step neither
                                      synchronises nor bakes their values into a captured graph.  n_lights still counts the rows */
+    const pbr_tuning *tuning;     /* NULL: the built-in rules.  Else per-call schedule knobs (above), read during the call only */
 } pbr_render_desc;
 
 #define PBR_SCHEDULE_AUTO 0
@@ -222,8 +266,6 @@ int pbr_cook_torrance_backward_params(const pbr_render_desc *desc, const void *g
 size_t pbr_mse_step_workspace_bytes(const pbr_render_desc *desc);
 int pbr_cook_torrance_mse_step(const pbr_render_desc *desc, const void *target, void *g_albedo, void *g_normal, void *g_roughness,
                                void *g_metallic, void *g_specular, void *loss, void *workspace, void *stream);
-/* data[i] *= *scalar for n elements of `dtype`, in place; `scalar` is a DEVICE float (no host synchronisation: the upstream
- * gradient of a loss lives on the device); a scalar of exactly 1 leaves the data untouched. */
 /* ABI 5: view / light / intensity from DEVICE memory.  `view_dir` [3], `lights` [n_lights][3], `intensities` [intensity_rows][3] with
  * intensity_rows = 1 (one intensity for every light) or n_lights: fp32 device pointers; a NULL pointer takes that parameter from the descriptor
  * (d->view_dir / d->lights / d->intensities: host values), so only what lives on the device needs to be there.  Writes `block` (pbr_device_params_bytes() bytes,
@@ -234,6 +276,8 @@ size_t pbr_device_params_bytes(void);
 int pbr_prepare_device_params(const pbr_render_desc *d, const void *view_dir, const void *lights, const void *intensities,
                               int32_t intensity_rows, void *block, void *stream);
 
+/* data[i] *= *scalar for n elements of `dtype`, in place; `scalar` is a DEVICE float (no host synchronisation: the upstream
+ * gradient of a loss lives on the device); a scalar of exactly 1 leaves the data untouched. */
 int pbr_scale_by_device_scalar(void *data, size_t n, int dtype, const void *scalar, void *stream);
 /* The same for up to five buffers of one dtype in ONE launch (the gradients a step leaves): data[j] has n[j] elements, count <= 5. */
 int pbr_scale_list_by_device_scalar(void *const *data, const size_t *n, int count, int dtype, const void *scalar, void *stream);
@@ -348,7 +392,7 @@ int pbr_blend_sigmoid_mask_backward(const void *mask, const void *grad_out, void
                                     void *stream);
 int pbr_blend_gradient_mask(void *mask, int32_t height, int32_t width, int vertical, void *stream);
 
-/* ---- introspection / tuning (bench and tests only) --------------------------------- */
+/* ---- introspection; the process-global tuning hook (tests, benches, profiling) ------ */
 int pbr_abi_version(void);
 /* sizeof(pbr_render_desc) as compiled: bindings check their struct layout against it. */
 size_t pbr_render_desc_size(void);
@@ -357,32 +401,11 @@ const char *pbr_error_string(int code);
 const char *pbr_kernel_name(const pbr_render_desc *desc);
 /* Algorithmic HBM bytes per pixel of that dispatch: reads + writes. */
 int pbr_bytes_per_pixel(const pbr_render_desc *desc);
-/* Tuning knobs for A/B runs inside one process; returns the previous value. */
-enum {                                  /* A/B knobs of pbr_set_tuning (profiling and tests; -1 / the default = the built-in rule) */
-    PBR_TUNE_NONTEMPORAL = 0,           /* streaming hint on loads and stores: 1 on (default), 0 off, 2 also on tiled launches */
-    PBR_TUNE_BLOCK_LOG2 = 1,            /* workgroup = 1 << value lanes (6..8) */
-    PBR_TUNE_F16_VEC = 2,               /* pixels per lane for fp16 maps (4 | 8) */
-    PBR_TUNE_LDS_BYTES = 3,             /* unused dynamic LDS per workgroup of the render kernel: an occupancy governor (-1 = rule) */
-    PBR_TUNE_XCD_LOG2 = 4,              /* consecutive tiles per XCD = 1 << value (the workgroup -> tile order) */
-    PBR_TUNE_BWD_VEC = 5,               /* pixels per lane of the backward kernels (2 | 4 force) */
-    PBR_TUNE_BATCH_INNER = 6,           /* several lights: materials per lane of the batch-inner kernel (0 = one-material kernel) */
-    PBR_TUNE_INTERLEAVE = 7,            /* experiment: materials of a batch interleaved workgroup by workgroup */
-    PBR_TUNE_SCALAR_BASE = 8,           /* scalar plane addresses: 0 never, 1 rule (single materials), 2 whenever the launch allows them */
-    PBR_TUNE_MAX_VEC = 9,               /* at most this many pixels per lane (8 default; 1 = the one-pixel kernels everywhere) */
-    PBR_TUNE_RESIZE_ROWS = 10,          /* output rows per workgroup of the resize kernels (0 = rule) */
-    PBR_TUNE_BWD_RUN = 11,              /* rounds of the streamed backward kernel for fp16 maps with one light (-1 = rule, 0 = the one-tile kernels) */
-    PBR_TUNE_RESIZE_XCD = 12,           /* tile order of the resize kernel: 1 = XCD-contiguous chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many */
-    PBR_TUNE_BWD_WIDE = 13,             /* streamed backward with 16-byte memory instructions: -1 = rule (off), 0 = the 4-byte form, 1 = wherever legal */
-    PBR_TUNE_RESIZE_UP2 = 14,           /* up-scales on both axes: the two-tap register kernel (1, default) or the strip kernel (0) */
-    PBR_TUNE_TILE_FOLD = 15,            /* tiled maps: log2 of the source rows per band of the fold order (all vertical repeats of a band back to back); -1 = rule, 0 = row order */
-    PBR_TUNE_RESIZE_BWD_FUSED = 16,     /* gradient of resize in one pass (1, default) or two passes through the workspace (0) */
-    PBR_TUNE_RESIZE_QUADS = 17,         /* strip kernel's width pass with four columns per lane and 16-byte stores: 1 = rule, 2 = wherever legal, 0 = never */
-    PBR_TUNE_STREAM_SHAPE = 18,         /* launch shape of the streaming map kernels: 0 = 2048 walking workgroups of 256 lanes, 1 = one item per lane (256-lane groups), 2 = one-wave groups */
-    PBR_TUNE_STREAM_LDS = 19,           /* unused dynamic LDS bytes per workgroup of those kernels (an occupancy cap) */
-    PBR_TUNE_PACK_SINGLE = 21,          /* one light over fp32 maps: packed (two pixels per instruction) arithmetic: -1 = rule (launches over tiled maps, which are VALU-bound), 0 = never, 1 = always */
-    PBR_TUNE_TILE_REPEAT = 22,          /* tiled maps, whole output, one light: every texel loaded and decoded once and evaluated at all its repeats (-1 = rule: on, 0 = wrap-around addressing) */
-    PBR_TUNE_MSE_STREAM = 20            /* rendering-loss step for fp16 maps with one light: the streamed kernel (1, default) or the one-tile kernels (0) */
-};
+/* The process-global hook behind the knobs above (pbr_tuning): sets the value every later call of the PROCESS uses for `knob`
+ * unless its descriptor overrides it; returns the previous value, -1 for an unknown knob.  For tests, benches and profiling runs
+ * (the Python binding feeds PBR_TUNE_* environment variables through it at load).  Atomic, so it may be called while other threads
+ * launch; it is still shared state -- a knob left set changes which kernel a later, unrelated caller gets (never its results) --
+ * which is why product code uses pbr_render_desc.tuning.  pbr_set_tuning(knob, PBR_TUNE_UNSET) restores the rule. */
 int pbr_set_tuning(int knob, int value);
 
 #ifdef __cplusplus

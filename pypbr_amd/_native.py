@@ -9,13 +9,20 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBR_HIP_LIB") or os.path.join(_HERE, "libpbr_hip.so")   # env override: A/B of two builds
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_LIGHTS = 16
 
 F32, F16 = 0, 1
 LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 WORKFLOW_METALLIC, WORKFLOW_SPECULAR, WORKFLOW_CONVERTED = 0, 1, 2
 TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, TUNE_XCD_LOG2, TUNE_BWD_VEC, TUNE_BATCH_INNER, TUNE_INTERLEAVE, TUNE_SCALAR_BASE, TUNE_MAX_VEC, TUNE_RESIZE_ROWS, TUNE_BWD_RUN, TUNE_RESIZE_XCD, TUNE_BWD_WIDE, TUNE_RESIZE_UP2, TUNE_TILE_FOLD, TUNE_RESIZE_BWD_FUSED, TUNE_RESIZE_QUADS, TUNE_STREAM_SHAPE, TUNE_STREAM_LDS, TUNE_MSE_STREAM, TUNE_PACK_SINGLE, TUNE_TILE_REPEAT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22
+
+TUNE_COUNT, TUNE_SLOTS, TUNE_UNSET = 23, 32, -2 ** 31
+TUNE_NAMES = {"nontemporal": TUNE_NONTEMPORAL, "block_log2": TUNE_BLOCK_LOG2, "f16_vec": TUNE_F16_VEC, "lds_bytes": TUNE_LDS_BYTES, "xcd_log2": TUNE_XCD_LOG2,
+              "bwd_vec": TUNE_BWD_VEC, "batch_inner": TUNE_BATCH_INNER, "interleave": TUNE_INTERLEAVE, "scalar_base": TUNE_SCALAR_BASE, "max_vec": TUNE_MAX_VEC,
+              "resize_rows": TUNE_RESIZE_ROWS, "bwd_run": TUNE_BWD_RUN, "resize_xcd": TUNE_RESIZE_XCD, "bwd_wide": TUNE_BWD_WIDE, "resize_up2": TUNE_RESIZE_UP2,
+              "tile_fold": TUNE_TILE_FOLD, "resize_bwd_fused": TUNE_RESIZE_BWD_FUSED, "resize_quads": TUNE_RESIZE_QUADS, "stream_shape": TUNE_STREAM_SHAPE,
+              "stream_lds": TUNE_STREAM_LDS, "mse_stream": TUNE_MSE_STREAM, "pack_single": TUNE_PACK_SINGLE, "tile_repeat": TUNE_TILE_REPEAT}
 
 OK = 0
 ERR_NULL_MAP, ERR_WORKFLOW, ERR_LIGHT_TYPE, ERR_SHAPE, ERR_DTYPE, ERR_CHANNELS, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
@@ -33,12 +40,26 @@ EXPORTS = (
     "pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
     "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
     "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward", "pbr_fold_gradient_typed",
-    "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar", "pbr_scale_list_by_device_scalar", "pbr_device_params_bytes", "pbr_prepare_device_params",
+    "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar", "pbr_scale_list_by_device_scalar", "pbr_device_params_bytes", "pbr_prepare_device_params", "pbr_tuning_init",
 )
 
 
 class PbrMap(ctypes.Structure):
     _fields_ = [("data", ctypes.c_void_p), ("batch_stride", ctypes.c_int64), ("channel_stride", ctypes.c_int64)]
+
+
+class Tuning(ctypes.Structure):
+    """pbr_tuning: per-call schedule knobs (PBR_TUNE_* index; TUNE_UNSET = the rule).  `Tuning.of(nontemporal=0, ...)` builds one."""
+    _fields_ = [("knob", ctypes.c_int32 * TUNE_SLOTS)]
+
+    @classmethod
+    def of(cls, **knobs):
+        t = cls()
+        for i in range(TUNE_SLOTS):
+            t.knob[i] = TUNE_UNSET
+        for name, value in knobs.items():
+            t.knob[TUNE_NAMES[name]] = int(value)
+        return t
 
 
 class RenderDesc(ctypes.Structure):
@@ -56,6 +77,7 @@ class RenderDesc(ctypes.Structure):
         ("reserved", ctypes.c_int32),
         ("out_batch_stride", ctypes.c_int64), ("out_channel_stride", ctypes.c_int64),
         ("device_params", ctypes.c_void_p),
+        ("tuning", ctypes.POINTER(Tuning)),
     ]
 
 
@@ -179,6 +201,8 @@ def lib():
     for name in ("pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask"):
         getattr(L, name).restype = ctypes.c_int
     L.pbr_render_desc_size.restype = ctypes.c_size_t
+    L.pbr_tuning_init.argtypes = [ctypes.POINTER(Tuning)]
+    L.pbr_tuning_init.restype = None
     if L.pbr_render_desc_size() != ctypes.sizeof(RenderDesc):
         raise NativeLibraryError("pbr_render_desc layout mismatch: library %d bytes, binding %d"
                                  % (L.pbr_render_desc_size(), ctypes.sizeof(RenderDesc)))

@@ -28,22 +28,17 @@
 
 namespace pbr {
 
-// tuning knobs (declared in ct_launch.hpp, set through pbr_set_tuning)
-int g_nontemporal = 1;
-int g_block_log2 = 0;
-int g_f16_vec = 8;
-int g_lds_bytes = -1;
-int g_xcd_log2 = -1;
-int g_bwd_vec = 0;
-int g_bwd_run = -1;
-int g_bwd_wide = -1;
-int g_batch_inner = -1;
-int g_interleave = 0;
-int g_tile_fold = -1;
-int g_scalar_base = 1;
-int g_max_vec = 8;
-int g_pack_single = -1;
-int g_tile_repeat = -1;
+// The process-wide values of the schedule knobs (tuning.hpp), initialised to the rules.  Indexed by PBR_TUNE_*.
+static constexpr int kKnobRules[PBR_TUNE_COUNT] = {
+    /* NONTEMPORAL */ 1, /* BLOCK_LOG2 */ 0, /* F16_VEC */ 8, /* LDS_BYTES */ -1, /* XCD_LOG2 */ -1, /* BWD_VEC */ 0, /* BATCH_INNER */ -1,
+    /* INTERLEAVE */ 0, /* SCALAR_BASE */ 1, /* MAX_VEC */ 8, /* RESIZE_ROWS */ 0, /* BWD_RUN */ -1, /* RESIZE_XCD */ 1, /* BWD_WIDE */ -1,
+    /* RESIZE_UP2 */ 1, /* TILE_FOLD */ -1, /* RESIZE_BWD_FUSED */ 1, /* RESIZE_QUADS */ 1, /* STREAM_SHAPE */ -1, /* STREAM_LDS */ -1,
+    /* MSE_STREAM */ 1, /* PACK_SINGLE */ -1, /* TILE_REPEAT */ -1};
+std::atomic<int> g_knobs[PBR_TUNE_COUNT] = {
+    {kKnobRules[0]}, {kKnobRules[1]}, {kKnobRules[2]}, {kKnobRules[3]}, {kKnobRules[4]}, {kKnobRules[5]}, {kKnobRules[6]}, {kKnobRules[7]},
+    {kKnobRules[8]}, {kKnobRules[9]}, {kKnobRules[10]}, {kKnobRules[11]}, {kKnobRules[12]}, {kKnobRules[13]}, {kKnobRules[14]}, {kKnobRules[15]},
+    {kKnobRules[16]}, {kKnobRules[17]}, {kKnobRules[18]}, {kKnobRules[19]}, {kKnobRules[20]}, {kKnobRules[21]}, {kKnobRules[22]}};
+thread_local const pbr_tuning *t_tuning = nullptr;
 
 struct KernelEntry { KernelFn fn; const char *name; };
 
@@ -148,6 +143,7 @@ extern "C" {
 
 int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     using namespace pbr;
+    const TuningScope tuning(d);
     const int rc = validate(d);
     if (rc != PBR_OK) return rc;
     if (nan_light_size(d)) return fill_result_nan(d, static_cast<hipStream_t>(stream));
@@ -221,6 +217,7 @@ int pbr_cook_torrance_autotune(const pbr_render_desc *d, void *stream, int32_t *
 }
 
 const char *pbr_kernel_name(const pbr_render_desc *d) {
+    const pbr::TuningScope tuning(d);
     if (pbr::validate(d) != PBR_OK) return nullptr;
     return pbr::pick_kernel(d, pbr::pick_vec(d), true).name;
 }
@@ -239,36 +236,13 @@ int pbr_bytes_per_pixel(const pbr_render_desc *d) {
 }
 
 int pbr_set_tuning(int knob, int value) {
-    int *slot = nullptr;
-    switch (knob) {
-        case PBR_TUNE_NONTEMPORAL: slot = &pbr::g_nontemporal; break;
-        case PBR_TUNE_BLOCK_LOG2: slot = &pbr::g_block_log2; break;
-        case PBR_TUNE_F16_VEC: slot = &pbr::g_f16_vec; break;
-        case PBR_TUNE_LDS_BYTES: slot = &pbr::g_lds_bytes; break;
-        case PBR_TUNE_XCD_LOG2: slot = &pbr::g_xcd_log2; break;
-        case PBR_TUNE_BWD_VEC: slot = &pbr::g_bwd_vec; break;
-        case PBR_TUNE_BATCH_INNER: slot = &pbr::g_batch_inner; break;
-        case PBR_TUNE_INTERLEAVE: slot = &pbr::g_interleave; break;
-        case PBR_TUNE_TILE_FOLD: slot = &pbr::g_tile_fold; break;
-        case PBR_TUNE_RESIZE_BWD_FUSED: slot = &pbr::g_resize_bwd_fused; break;
-        case PBR_TUNE_RESIZE_QUADS: slot = &pbr::g_resize_quads; break;
-        case PBR_TUNE_MSE_STREAM: slot = &pbr::g_mse_stream; break;
-        case PBR_TUNE_STREAM_SHAPE: slot = &pbr::g_stream_shape; break;
-        case PBR_TUNE_STREAM_LDS: slot = &pbr::g_stream_lds; break;
-        case PBR_TUNE_SCALAR_BASE: slot = &pbr::g_scalar_base; break;
-        case PBR_TUNE_MAX_VEC: slot = &pbr::g_max_vec; break;
-        case PBR_TUNE_RESIZE_ROWS: slot = &pbr::g_resize_rows; break;
-        case PBR_TUNE_BWD_RUN: slot = &pbr::g_bwd_run; break;
-        case PBR_TUNE_RESIZE_XCD: slot = &pbr::g_resize_xcd; break;
-        case PBR_TUNE_BWD_WIDE: slot = &pbr::g_bwd_wide; break;
-        case PBR_TUNE_RESIZE_UP2: slot = &pbr::g_resize_up2; break;
-        case PBR_TUNE_PACK_SINGLE: slot = &pbr::g_pack_single; break;
-        case PBR_TUNE_TILE_REPEAT: slot = &pbr::g_tile_repeat; break;
-        default: return -1;
-    }
-    const int old = *slot;
-    *slot = value;
-    return old;
+    if (knob < 0 || knob >= PBR_TUNE_COUNT) return -1;
+    return pbr::g_knobs[knob].exchange(value == PBR_TUNE_UNSET ? pbr::kKnobRules[knob] : value, std::memory_order_relaxed);
+}
+
+void pbr_tuning_init(pbr_tuning *t) {
+    if (!t) return;
+    for (int i = 0; i < PBR_TUNE_SLOTS; ++i) t->knob[i] = PBR_TUNE_UNSET;
 }
 
 size_t pbr_device_params_bytes(void) { return sizeof(pbr::DevParams); }

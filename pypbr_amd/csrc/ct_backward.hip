@@ -188,10 +188,12 @@ extern "C" {
 
 int pbr_cook_torrance_backward(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal,
                                void *g_roughness, void *g_metallic, void *g_specular, void *stream) {
+    const pbr::TuningScope tuning(d);
     return pbr::launch_backward(d, grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, nullptr, nullptr, stream);
 }
 
 size_t pbr_param_grad_workspace_bytes(const pbr_render_desc *d) {
+    const pbr::TuningScope tuning(d);
     if (pbr::validate(d) != PBR_OK) return 0;
     const int64_t tiles = pbr::max_tiles(d);
     return tiles < 0 ? 0 : pbr::stage_offset_bytes(d) + (size_t)pbr::kParamStageRows * (size_t)(3 + 6 * d->n_lights) * sizeof(double);
@@ -200,6 +202,7 @@ size_t pbr_param_grad_workspace_bytes(const pbr_render_desc *d) {
 int pbr_cook_torrance_backward_params(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal,
                                       void *g_roughness, void *g_metallic, void *g_specular, void *g_params,
                                       void *workspace, void *stream) {
+    const pbr::TuningScope tuning(d);
     if (!g_params) return PBR_ERR_NULL_MAP;
     return pbr::launch_backward(d, grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, g_params, workspace, stream);
 }

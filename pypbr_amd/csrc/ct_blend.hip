@@ -50,6 +50,7 @@ extern "C" {
 
 int pbr_cook_torrance_blend_backward(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, const void *grad_out,
                                      const pbr_map_grads *g_material1, const pbr_map_grads *g_material2, void *g_mask, void *stream) {
+    const pbr::TuningScope tuning(d);
     using namespace pbr;
     const int rc = check_blend(d, bl, workspace);
     if (rc != PBR_OK) return rc;
@@ -96,6 +97,7 @@ int pbr_cook_torrance_blend_backward(const pbr_render_desc *d, const pbr_blend_d
 }
 
 int pbr_blend_normal_sign(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, void *stream) {
+    const pbr::TuningScope tuning(d);
     using namespace pbr;
     const int rc = check_blend(d, bl, workspace);
     if (rc != PBR_OK) return rc;
@@ -103,6 +105,7 @@ int pbr_blend_normal_sign(const pbr_render_desc *d, const pbr_blend_desc *bl, vo
 }
 
 int pbr_cook_torrance_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, void *stream) {
+    const pbr::TuningScope tuning(d);
     using namespace pbr;
     const int rc = check_blend(d, bl, workspace);
     if (rc != PBR_OK) return rc;

@@ -12,37 +12,19 @@
 #include "../../include/pbr_hip.h"
 #include "ct_kernel.hpp"
 #include "stream_shape.hpp"
+#include "tuning.hpp"
 
 namespace pbr {
 
-// Measured A/B on MI355X, 4096x4096 point/metallic (tools/tune.py, DESIGN.md "Schedule experiments"):
-// nt hint on: -5 % time; one-wave workgroups: -2 % vs 256 lanes (no LDS/barrier, so nothing is lost).
-extern int g_nontemporal;
-extern int g_block_log2;           // workgroup size: 64 (6), 128 (7) or 256 (8) lanes; 0 = rule (64; 256 for the one-pixel kernels)
-extern int g_f16_vec;              // pixels per lane for fp16 maps with one light: 8 (16-byte loads) or 4
-// Dynamic LDS per one-wave workgroup, unused by the kernel: an occupancy governor finer than whole waves per
-// SIMD (160 KiB / value = waves per CU).  amdgpu_waves_per_eu(3,3) on the kernel allows 12 waves per CU; the
-// fp32 one-light kernels stream fastest with 11 in flight (in-process A/B, DESIGN.md 3.2: 115.3 vs 118.5 us on
-// 4096^2, 33.3 vs 34.0 us on 2048^2, 249.8 vs 254.1 us on 8 x 2048^2 directional), the fp16 and multi-light
-// kernels with no cap.  -1 = that rule; >= 0 = this many bytes for every launch (A/B runs).
-extern int g_lds_bytes;
-extern int g_batch_inner;          // materials per lane of the several-lights kernels: -1 = rule (4 | 2 | off), 0 = off, 2 | 4 = forced
-extern int g_scalar_base;          // scalar plane addresses (KArgs::sbase): 0 never, 1 = rule (single materials), 2 = whenever the launch allows them
-extern int g_resize_rows;          // resize.hip
-extern int g_resize_bwd_fused;     // resize.hip: gradient of resize in one pass (1) or two passes through the workspace (0)
-extern int g_resize_quads;         // resize.hip: 16-byte stores in the strip kernel's width pass
-extern int g_mse_stream;           // ct_loss.hip: streamed loss step for fp16 maps (1) or the one-tile kernels (0)
-extern int g_resize_up2;           // resize.hip: two-tap register kernel for up-scales (1) or the strip kernel (0)
-extern int g_resize_xcd;           // resize.hip: XCD-contiguous tile order (1) or identity (0)
-extern int g_max_vec;              // A/B and test knob: at most this many pixels per lane (1 = the one-pixel kernels everywhere)
-extern int g_pack_single;          // packed arithmetic in the one-light fp32 kernels: -1 = rule (tiled launches), 0 = never, 1 = always
-extern int g_tile_repeat;          // tiled maps, whole output, one light: the repeat-inner kernel (-1 = rule: on, 0 = the wrap-around form, 1 = on)
-extern int g_tile_fold;            // tiled maps: log2 of the source rows per band of the fold order (-1 = rule, 0 = row order)
-extern int g_interleave;           // experiment knob: materials of a batch interleaved workgroup by workgroup
-extern int g_bwd_vec;              // pixels per lane of the backward kernels: 0 = rule (ct_backward.hip), 2 | 4 = forced (A/B)
-extern int g_bwd_run;              // tiles per wave of the streamed backward kernel (fp16 maps, one light): -1 = rule, 0 = off, N = forced
-extern int g_bwd_wide;             // streamed backward kernel with 16-byte memory instructions: -1 = rule, 0 = off, 1 = wherever legal
-extern int g_xcd_log2;             // >= 0 overrides the descriptor's schedule (A/B runs): tiles per XCD run = 1 << value
+// The schedule knobs (g_nontemporal, g_block_log2, ...) are read through tuning.hpp: per call (pbr_render_desc.tuning), else the
+// process-wide test hook (pbr_set_tuning), else the rule.  What the rules are and why:
+//   * nt hint on: -5 % time; one-wave workgroups: -2 % vs 256 lanes (no LDS / barrier, so nothing is lost) -- 4096x4096 point /
+//     metallic, tools/tune.py, DESIGN.md "Schedule experiments";
+//   * g_lds_bytes: dynamic LDS per one-wave workgroup, unused by the kernel: an occupancy governor finer than whole waves per SIMD
+//     (160 KiB / value = waves per CU).  amdgpu_waves_per_eu(3,3) on the kernel allows 12 waves per CU; the fp32 one-light kernels
+//     stream fastest with 11 in flight (in-process A/B, DESIGN.md 3.2: 115.3 vs 118.5 us on 4096^2, 33.3 vs 34.0 us on 2048^2,
+//     249.8 vs 254.1 us on 8 x 2048^2 directional), the fp16 and multi-light kernels with no cap.  -1 = that rule; >= 0 = this
+//     many bytes for every launch.
 constexpr int kLdsFor11WavesPerCu = 14848;   // floor(163840 / 14848) = 11
 
 // The folding of view / light parameters into wave-uniform values runs on the host (parameters in pbr_render_desc) or, for parameters that

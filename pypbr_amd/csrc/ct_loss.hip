@@ -17,7 +17,6 @@
 
 namespace pbr {
 
-int g_mse_stream = 1;          // fp16 maps, one light: the streamed form of the loss step (A/B knob PBR_TUNE_MSE_STREAM)
 
 // Waves per SIMD the register allocation must leave room for: the packed pair for fp16 maps fits 128 VGPRs (four waves) in the
 // backward kernel, not here -- the target pixels and the squared differences come on top (56 bytes of scratch): three waves.
@@ -189,6 +188,7 @@ static int64_t mse_tiles(const pbr_render_desc *d, int vec) {
 extern "C" {
 
 size_t pbr_mse_step_workspace_bytes(const pbr_render_desc *d) {
+    const pbr::TuningScope tuning(d);
     if (pbr::validate(d) != PBR_OK || pbr::is_tiled(d)) return 0;
     const int64_t tiles = pbr::mse_tiles(d, 1);            // one pixel per lane: the most workgroups any launch of this descriptor has
     return tiles < 0 ? 0 : pbr::mse_stage_offset((size_t)tiles) + (size_t)pbr::kMseStageGroups * sizeof(double);
@@ -196,6 +196,7 @@ size_t pbr_mse_step_workspace_bytes(const pbr_render_desc *d) {
 
 int pbr_cook_torrance_mse_step(const pbr_render_desc *d, const void *target, void *g_albedo, void *g_normal, void *g_roughness,
                                void *g_metallic, void *g_specular, void *loss, void *workspace, void *stream) {
+    const pbr::TuningScope tuning(d);
     using namespace pbr;
     const int rc = validate(d);
     if (rc != PBR_OK) return rc;

@@ -513,7 +513,6 @@ __global__ __launch_bounds__(256) void specular_to_metallic_backward_kernel(cons
     }
 }
 
-int g_stream_shape = -1, g_stream_lds = -1;      // launch shape of the streaming kernels: ct_launch.hpp
 
 static inline unsigned stream_grid(size_t work_items) {
     const size_t blocks = (work_items + 255) / 256;

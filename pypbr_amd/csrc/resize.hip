@@ -32,14 +32,10 @@
 #include <cstdint>
 
 #include "../../include/pbr_hip.h"
+#include "tuning.hpp"
 
 namespace pbr {
 
-int g_resize_xcd = 1;              // XCD-contiguous tile order of the strip kernel: 1 = chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many tiles (A/B knob PBR_TUNE_RESIZE_XCD)
-int g_resize_quads = 1;           // strip kernel's width pass with four columns per lane and 16-byte stores: 1 = rule (gradients at least twice their upstream), 2 = wherever legal, 0 = never (A/B knob PBR_TUNE_RESIZE_QUADS)
-int g_resize_bwd_fused = 1;       // the gradient in one pass (strip kernel, transposed tables); 0: two passes through the workspace (A/B knob PBR_TUNE_RESIZE_BWD_FUSED)
-int g_resize_up2 = 1;              // up-scales take the two-tap register kernel (0: the strip kernel, A/B knob PBR_TUNE_RESIZE_UP2)
-int g_resize_rows = 0;             // output rows per tile of the strip form: 0 = rule, else forced (A/B knob PBR_TUNE_RESIZE_ROWS)
 
 struct AxisFilter {
     float scale, support, invscale;

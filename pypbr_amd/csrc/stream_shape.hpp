@@ -2,6 +2,8 @@
 #pragma once
 #include <cstddef>
 
+#include "tuning.hpp"
+
 namespace pbr {
 
 // Launch shape of the streaming map kernels (map_ops.hip, blend.hip): all of them are grid-stride loops over blockDim-agnostic
@@ -9,7 +11,6 @@ namespace pbr {
 // 256-lane workgroups, 2 = one item per lane in one-wave workgroups; lds = unused dynamic LDS per workgroup, which caps the resident
 // waves the way the render kernel's occupancy governor does.  Each launcher names its rule; PBR_TUNE_STREAM_SHAPE / _LDS override
 // it (-1 = rule) for A/B runs (tools/stream_shape_probe.py).
-extern int g_stream_shape, g_stream_lds;
 struct StreamRule { int shape, lds; };
 struct StreamShape { unsigned grid, block; size_t lds; };
 inline StreamShape stream_shape(size_t work_items, StreamRule rule) {

@@ -279,6 +279,17 @@ class RenderPlan:
     def bytes_per_pixel(self) -> int:
         return N.lib().pbr_bytes_per_pixel(self._ref)
 
+    def set_tuning(self, **knobs):
+        """Per-call schedule knobs of THIS plan (pbr_render_desc.tuning; names of _native.TUNE_NAMES, e.g. nontemporal=0, xcd_log2=6):
+        they travel with the descriptor, touch no process-wide state and change speed only, never results.  No arguments: back to the rules."""
+        if knobs:
+            self._tuning = N.Tuning.of(**knobs)
+            self.desc.tuning = ctypes.pointer(self._tuning)
+        else:
+            self._tuning = None
+            self.desc.tuning = None
+        return self
+
     def autotune(self, stream: Optional[int] = None) -> int:
         """pbr_cook_torrance_autotune on this plan's buffers: blocks, rewrites `out`, stores and returns the
         fastest schedule.  Not inside a stream capture."""
@@ -359,7 +370,7 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                        out: Optional[torch.Tensor] = None, schedule: int = N.SCHEDULE_AUTO,
                        autotune: bool = False, tile=1, rows: Optional[int] = None,
                        blend: Optional[Sequence[Optional[torch.Tensor]]] = None,
-                       blend_flags: Optional[torch.Tensor] = None) -> RenderPlan:
+                       blend_flags: Optional[torch.Tensor] = None, tuning: Optional[dict] = None) -> RenderPlan:
     """Validates the maps, allocates the output and fills the C-ABI descriptor; see `cook_torrance`.
     `schedule`: workgroup order (N.SCHEDULE_AUTO | N.SCHEDULE_LINEAR | N.schedule_xcd(c)), results do not depend
     on it; `autotune=True` measures the candidates on these very buffers once (blocking, a few launches) and
@@ -373,7 +384,8 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
     fp32 maps, both materials complete; `mask` [1,H,W] or [B,1,H,W].  Whether a blended normal map counts as already
     signed is decided over the WHOLE map (base.py:212); the launch works that out itself unless the maps are a row band
     of a taller untiled map -- then pass `blend_flags` (int32 [B] on the device: `RenderPlan.blend_normal_sign()` of
-    every band, combined with max; distributed.cook_torrance_sharded does this)."""
+    every band, combined with max; distributed.cook_torrance_sharded does this).
+    `tuning={"nontemporal": 0, ...}`: per-call schedule knobs of this plan (RenderPlan.set_tuning); speed only, never results."""
     if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda:
         raise RuntimeError("pypbr_amd.functional.cook_torrance needs maps on a ROCm device "
                            "(use material.to('cuda')); there is no CPU path")
@@ -402,6 +414,8 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
                             convert_to_diffuse_specular=convert_to_diffuse_specular, y_offset=y_offset,
                             height_total=height_total, schedule=schedule, tile=(ny, nx))
     plan = RenderPlan(desc, out, (a, n, r, m, s), squeeze and out.dim() == 4)
+    if tuning:
+        plan.set_tuning(**tuning)
     if desc._device_parameters is not None:
         plan.prepare_device_parameters(desc._device_parameters)
     if blend is not None:
@@ -594,10 +608,10 @@ USE_TORCH_OPS = True       # tests flip this to compare the two bindings of the 
 
 def _torch_op_can_take(albedo, kw) -> bool:
     """`torch.ops.pbr_hip.cook_torrance` (pypbr_amd/torch_ops.py) covers the plain evaluation; explicit output buffers,
-    schedules, autotuning and the fused blend stay on the ctypes plan."""
+    schedules, per-call tuning, autotuning and the fused blend stay on the ctypes plan."""
     if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda or albedo.numel() == 0:      # zero-sized maps: RenderPlan.launch returns the empty image
         return False
-    if kw.get("out") is not None or kw.get("blend") is not None or kw.get("autotune") or kw.get("schedule", N.SCHEDULE_AUTO) != N.SCHEDULE_AUTO:
+    if kw.get("out") is not None or kw.get("blend") is not None or kw.get("autotune") or kw.get("tuning") or kw.get("schedule", N.SCHEDULE_AUTO) != N.SCHEDULE_AUTO:
         return False
     if kw.get("out_dtype") not in (None, torch.float32, torch.float16):
         return False
@@ -619,7 +633,7 @@ def _param_tensor(v, rows):
 def _cook_torrance_via_torch_op(albedo, normal, roughness, metallic=None, specular=None, *, view_dir, light, light_intensity,
                                 light_type="point", light_size=None, albedo_is_srgb=True, specular_is_srgb=True, return_srgb=True,
                                 convert_to_diffuse_specular=False, y_offset=0, height_total=None, out_dtype=None, tile=1, rows=None,
-                                out=None, schedule=N.SCHEDULE_AUTO, autotune=False, blend=None, blend_flags=None):
+                                out=None, schedule=N.SCHEDULE_AUTO, autotune=False, blend=None, blend_flags=None, tuning=None):
     # (out / schedule / autotune / blend are at their defaults here -- _torch_op_can_take -- and named so that an unknown
     # keyword raises TypeError exactly as on the plan path; blend_flags without a blend means nothing on either path)
     lt = str(light_type).lower()

@@ -98,6 +98,8 @@ def recorded_valu():
         except (OSError, ValueError):
             continue
         for r in recs if isinstance(recs, list) else []:
+            if "kernel" not in r:                   # the collection's stamp (tools/stamp_profiles.py)
+                continue
             n = (r.get("sq") or {}).get("valu_wave_instructions")
             if n and str(r.get("case", "")).startswith("fwd_16_lights") and "batch_kernel" in r.get("kernel", ""):
                 return n * 64 / (4 * 4096 * 4096 * 16), "profiles/" + os.path.basename(path)
@@ -560,6 +562,8 @@ def main():
                                               "against 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz; the launch is VALU-bound, its HBM "
                                               "fraction is not the measure (SURVEY.md 8d)"}
         line.update(extras)
+        from pypbr_amd import _native
+        line["build"] = _native.build_stamp()          # the commit, the library's sha256, the sources it was built from (stale = not these)
         if not args.no_cpu_baseline:
             line["parity"] = parity_of_timed_output(cfg, plans[0].out, map_sets[0], shard, 8 if S >= 2048 and len(cfg["light"]) == 1 else 4)
             if world == 1:

@@ -394,6 +394,9 @@ int pbr_blend_gradient_mask(void *mask, int32_t height, int32_t width, int verti
 
 /* ---- introspection; the process-global tuning hook (tests, benches, profiling) ------ */
 int pbr_abi_version(void);
+/* First 16 hex digits of the SHA-256 over the sources this library was built from (every .hip and .hpp file of csrc, this header, the Makefile,
+ * in sorted order): evidence files carry it, and collectors refuse a library that is not the one the sources next to it would build. */
+const char *pbr_build_id(void);
 /* sizeof(pbr_render_desc) as compiled: bindings check their struct layout against it. */
 size_t pbr_render_desc_size(void);
 const char *pbr_error_string(int code);

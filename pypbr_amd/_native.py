@@ -40,7 +40,7 @@ EXPORTS = (
     "pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
     "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
     "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward", "pbr_fold_gradient_typed",
-    "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar", "pbr_scale_list_by_device_scalar", "pbr_device_params_bytes", "pbr_prepare_device_params", "pbr_tuning_init",
+    "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar", "pbr_scale_list_by_device_scalar", "pbr_device_params_bytes", "pbr_prepare_device_params", "pbr_tuning_init", "pbr_build_id",
 )
 
 
@@ -201,6 +201,8 @@ def lib():
     for name in ("pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask"):
         getattr(L, name).restype = ctypes.c_int
     L.pbr_render_desc_size.restype = ctypes.c_size_t
+    L.pbr_build_id.argtypes = []
+    L.pbr_build_id.restype = ctypes.c_char_p
     L.pbr_tuning_init.argtypes = [ctypes.POINTER(Tuning)]
     L.pbr_tuning_init.restype = None
     if L.pbr_render_desc_size() != ctypes.sizeof(RenderDesc):
@@ -214,6 +216,45 @@ def lib():
             L.pbr_set_tuning(knob, int(os.environ[env]))
     _lib = L
     return L
+
+
+def source_hash():
+    """The digest pbr_build_id() would return for the sources next to this package (the Makefile's recipe: sorted csrc/*.hip and *.hpp,
+    include/pbr_hip.h, the Makefile), or None where the sources are not shipped."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.hpp")))
+    files += [os.path.join(_HERE, "..", "include", "pbr_hip.h"), os.path.join(csrc, "Makefile")]
+    if not files or not all(os.path.isfile(f) for f in files):
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_stamp() -> dict:
+    """What every evidence file says about the binary it measured: the commit (PBR_GIT_HEAD in the environment -- the GPU box has no
+    .git -- else `git rev-parse HEAD`), the library's own SHA-256, the digest of the sources it was built from (compiled in) and
+    whether that is still the digest of the sources on disk (`stale`: the library would not be what `make` builds now)."""
+    import hashlib
+    import subprocess
+    head = os.environ.get("PBR_GIT_HEAD")
+    if not head:
+        try:
+            root = os.path.dirname(_HERE)
+            head = subprocess.check_output(["git", "-C", root, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+            if subprocess.check_output(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], stderr=subprocess.DEVNULL).strip():
+                head += "+uncommitted"
+        except Exception:  # noqa: BLE001
+            head = "unknown"
+    with open(LIB_PATH, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()
+    built_from, now = lib().pbr_build_id().decode(), source_hash()
+    return {"git_head": head, "libpbr_hip_sha256": sha, "built_from_sources": built_from, "sources_on_disk": now,
+            "stale": now is not None and now != built_from}
 
 
 def error_string(code: int) -> str:

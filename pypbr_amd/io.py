@@ -42,6 +42,12 @@ def _open(path: str, map_type: str):
     return image if image.mode == "L" else image.convert("L")
 
 
+def _decoded(image):
+    """PIL opens lazily; `load()` runs the decoder now (in the calling thread)."""
+    image.load()
+    return image
+
+
 def select_material_class(loaded_maps: Dict[str, object], preferred_workflow: Optional[str] = None) -> Type[MaterialBase]:
     """io.py:132-186.  Pops the map of the workflow that is not chosen when both are present."""
     has_metallic, has_specular = "metallic" in loaded_maps, "specular" in loaded_maps
@@ -75,11 +81,18 @@ def load_material_from_folder(folder_path: str, map_names: Optional[Dict[str, Li
     """io.py:27-129: scan `folder_path` for <stem>.<ext> files, pick the workflow, build the material
     (maps are decoded on the CPU like the reference; `.to("cuda")` moves them)."""
     names = DEFAULT_MAP_NAMES if map_names is None else map_names
-    loaded = {}
-    for map_type, stems in names.items():
-        path = _find(folder_path, stems)
-        if path is not None:
-            loaded[map_type] = _open(path, map_type)
+    found = [(map_type, path) for map_type, path in ((t, _find(folder_path, stems)) for t, stems in names.items()) if path is not None]
+    # The files are decoded side by side: PIL's decoders release the interpreter lock, and PNG inflate is what this function spends its
+    # time on (five 1024^2 maps: 123 ms one after the other, the whole rest of examples/example_brdf.py 7 ms -- tools/example_bench.py).
+    # Same images, same dict order as the sequential loop of io.py:58-85.
+    if len(found) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        workers = min(len(found), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            images = list(pool.map(lambda tp: _decoded(_open(tp[1], tp[0])), found))
+    else:
+        images = [_decoded(_open(path, map_type)) for map_type, path in found]
+    loaded = {map_type: image for (map_type, _), image in zip(found, images)}
     cls = select_material_class(loaded, preferred_workflow)
     if issubclass(cls, BasecolorMetallicMaterial):
         albedo = loaded.get("basecolor")

@@ -7,7 +7,7 @@ import json
 import statistics
 import sys
 
-KERNEL = "cook_torrance_kernel<1, 0, float, float, 4, false, true>"
+KERNEL = "cook_torrance_kernel<1, 0, float, float, 4, false, true, false>"
 NAME = "ct_point_metallic_f32_f32_v4"
 PIXELS, BPP = 4096 * 4096, 44
 

@@ -70,16 +70,16 @@ lib = N.lib()
 if want("fwd_f32"):
     a, n, r, m, out = F.pack_maps(*synth_material(S, DEV, 1), reserve_output=True)
     p = F.plan_cook_torrance(a, n, r, m, out=out.unsqueeze(0), **PT)
-    report("fwd_f32: 1 x 4096^2 point metallic fp32 (bench.py workload)", "cook_torrance_kernel<1, 0, float, float, 4, false, true>",
+    report("fwd_f32: 1 x 4096^2 point metallic fp32 (bench.py workload)", "cook_torrance_kernel<1, 0, float, float, 4, false, true, false>",
            p.bytes_per_pixel * PX, timed(lambda: p.launch(stream), reps=max(REPS, 50), warm=20), reps=max(REPS, 50))
     del a, n, r, m, out, p
 if want("fwd_f16"):
     h = batch(4, S, torch.float16, 10)
     p = F.plan_cook_torrance(*h, **PT)
-    report("fwd_f16: 4 x 4096^2 point metallic, fp16 maps -> fp32", "cook_torrance_kernel<1, 0, __half, float, 8, false, true>",
+    report("fwd_f16: 4 x 4096^2 point metallic, fp16 maps -> fp32", "cook_torrance_kernel<1, 0, __half, float, 8, false, true, false>",
            p.bytes_per_pixel * 4 * PX, timed(lambda: p.launch(stream)))
     p2 = F.plan_cook_torrance(*h, out_dtype=torch.float16, **PT)
-    report("fwd_f16_f16: same, fp16 result", "cook_torrance_kernel<1, 0, __half, __half, 8, false, true>",
+    report("fwd_f16_f16: same, fp16 result", "cook_torrance_kernel<1, 0, __half, __half, 8, false, true, false>",
            p2.bytes_per_pixel * 4 * PX, timed(lambda: p2.launch(stream)))
     lights = [[math.cos(t), math.sin(t), 1.0] for t in [2 * math.pi * i / 16 for i in range(16)]]
     p16 = F.plan_cook_torrance(*h, view_dir=[0, 0, 1], light=lights, light_intensity=[[1.0 / 16] * 3] * 16, light_type="point", light_size=1.0)
@@ -123,13 +123,16 @@ if want("blend_fused"):
 if want("tiled"):
     maps = synth_material(2048, DEV, 31)
     p = F.plan_cook_torrance(*maps, tile=2, **PT)
-    report("tiled: 2048^2 maps, fused tile(2) -> 4096^2 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out)",
-           "cook_torrance_kernel<1, 0, float, float, 4, false, false>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
+    report("tiled: 2048^2 maps, fused tile(2) -> 4096^2 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out): repeat-inner kernel",
+           "cook_torrance_repeat_kernel<1, 0, float, float, false, true>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
+    p = F.plan_cook_torrance(*maps, tile=2, tuning={"tile_repeat": 0}, **PT)
+    report("tiled_wrap: the same launch in the wrap-around form (what row bands of a tiled output and several lights take), packed arithmetic",
+           "cook_torrance_kernel<1, 0, float, float, 4, false, false, true>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
     del maps, p
     maps = [t.half() for t in synth_material(2048, DEV, 32)]
     p = F.plan_cook_torrance(*maps, tile=2, **PT)
-    report("tiled_f16: 2048^2 fp16 maps, fused tile(2) -> 4096^2 fp32 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out)",
-           "cook_torrance_kernel<1, 0, __half, float, 8, false, false>", 16 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
+    report("tiled_f16: 2048^2 fp16 maps, fused tile(2) -> 4096^2 fp32 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out): repeat-inner kernel",
+           "cook_torrance_repeat_kernel<1, 0, __half, float, false, true>", 16 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
     del maps, p
 if want("map_ops"):
     g = torch.Generator(device=DEV).manual_seed(0)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tile(n) fused as wrap-around addressing, on random shapes: the image equals the one evaluated on the materialised repeat bit for bit, for
+"""tile(n) fused -- the repeat-inner kernel (whole output, one light) and wrap-around addressing (PBR_TUNE_TILE_REPEAT = 0, row bands, several lights) -- on random shapes: the image equals the one evaluated on the materialised repeat bit for bit, for
 every fold band (PBR_TUNE_TILE_FOLD) and workgroup order, row bands included.  python tools/tile_fuzz.py [cases] [seed]"""
 import os
 import random
@@ -37,7 +37,9 @@ def run(cases=60, seed=0, verbose=True):
             fold = rng.choice([-1, 0, 1, 2, 3, 5, 8])
             sched = rng.choice([N.SCHEDULE_AUTO, N.SCHEDULE_LINEAR, N.schedule_xcd(1), N.schedule_xcd(3), N.schedule_xcd(6)])
             lib.pbr_set_tuning(N.TUNE_TILE_FOLD, fold)
-            desc = f"case {i}: B={B} {h}x{w} tile=({ny},{nx}) {'f16' if half else 'f32'} lights={lights} fold={fold} schedule={sched}"
+            repeat = rng.choice([-1, -1, 0])
+            lib.pbr_set_tuning(N.TUNE_TILE_REPEAT, repeat)
+            desc = f"case {i}: B={B} {h}x{w} tile=({ny},{nx}) {'f16' if half else 'f32'} lights={lights} fold={fold} schedule={sched} repeat={repeat}"
             out = F.cook_torrance(a, n, r, m, tile=(ny, nx), schedule=sched, **kw)
             if not torch.equal(out, ref):
                 raise AssertionError(desc + f": differs from the materialised repeat by {float((out.float() - ref.float()).abs().max()):.2e}")
@@ -66,6 +68,7 @@ def run(cases=60, seed=0, verbose=True):
                 print(desc + ": ok", flush=True)
     finally:
         lib.pbr_set_tuning(N.TUNE_TILE_FOLD, -1)
+        lib.pbr_set_tuning(N.TUNE_TILE_REPEAT, -1)
     if verbose:
         print(f"{cases} cases passed")
 

@@ -13,5 +13,6 @@ for f in cook_torrance ct_batch ct_tiled ct_backward ct_blend ct_loss map_ops re
     pids+=($!)
 done
 for p in "${pids[@]}"; do wait "$p"; done
+g++ -O2 -fPIC -DPBR_SOURCE_HASH=\"alt:$NAME\" -c "$R/pypbr_amd/csrc/build_id.cpp" -o "$D/build_id.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$D/libpbr_hip.so" "$D"/*.o
 echo "$D/libpbr_hip.so"

@@ -129,11 +129,15 @@ def main(argv=None):
     assert torch.cuda.is_available(), "needs a ROCm device"
     cores = usable_cores()
     for example in (["brdf", "blend"] if args.example == "both" else [args.example]):
-        runs = [run_hip(example, args.size) for _ in range(args.repeat)]
-        color, rows, moved = runs[-1]
+        first_total = None
+        for _ in range(args.repeat):                       # a script runs once: results of earlier repeats are dropped like a finished script's
+            color = None
+            color, rows, moved = run_hip(example, args.size)
+            if first_total is None:
+                first_total = sum(ms for name, ms in rows[:-1])
         rec = {"example": example, "statements": "examples/example_%s.py" % example, "resize": args.size, "image": list(color.shape),
                "hip_ms": {name: round(ms, 3) for name, ms in rows}, "hip_total_ms": round(sum(ms for name, ms in rows[:-1]), 3),
-               "hip_total_ms_first_run": round(sum(ms for name, ms in runs[0][1][:-1]), 3), "transfers": moved}
+               "hip_total_ms_first_run": round(first_total, 3), "transfers": moved}
         if not args.no_cpu:
             ref, crow = run_oracle(example, args.size, cores)
             rec["cpu_oracle_ms"] = {name: round(ms, 3) for name, ms in crow}

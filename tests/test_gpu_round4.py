@@ -152,6 +152,26 @@ def test_repeat_inner_kernel_equals_the_materialised_repeat_and_the_wrap_around_
             assert torch.equal(out, want) and not big[:, :, 0].any() and not big[:, :, -1].any()
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_repeat_inner_kernel_at_full_size(dtype):
+    """2048^2 maps, tile(2) -> the 4096^2 image of the evidence set, bit-identical to evaluating the materialised repeat; a (3, 2) repeat of
+    a two-material batch as well (strided result planes of the second material)."""
+    from pypbr_amd import functional as F
+    import bench
+    maps = [t.to(dtype) for t in bench.synth_material(2048, torch.device("cuda", 0), 77)]
+    kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
+    plan = F.plan_cook_torrance(*maps, tile=2, **kw)
+    assert plan.kernel_name.startswith("ctr_point_metallic")
+    got = plan.launch()
+    want = F.cook_torrance(*[t.repeat(1, 2, 2) for t in maps], **kw)
+    assert got.shape == (3, 4096, 4096) and torch.equal(got, want)
+    del got, want, plan
+    two = [torch.stack([t[:, :1024, :1536], t[:, 1024:, :1536]]).contiguous() for t in maps]
+    got = F.cook_torrance(*two, tile=(3, 2), **kw)
+    want = F.cook_torrance(*[t.repeat(1, 1, 3, 2) for t in two], **kw)
+    assert got.shape == (2, 3, 3072, 3072) and torch.equal(got, want)
+
+
 def test_rendering_loss_differentiates_the_ground_truth_branch():
     """06_advanced.rst:101-105 renders BOTH materials under autograd: a light that is being fitted (requires grad, shared by both
     renderings) receives the gradient of both branches; ground-truth maps that require grad receive theirs.  Against float64

@@ -58,7 +58,7 @@ def build_case(case, rev, sets, dev):
         grads = [torch.empty(1, c, 4096, 4096, device=dev) for c in (3, 3, 1, 1)]
         ptrs = [t.data_ptr() for t in grads] + [None]
         fn = lib.pbr_cook_torrance_backward
-        return (lambda i: fn(ctypes.byref(plans[i % len(plans)].desc), g.data_ptr(), *ptrs, stream)), "backward:" + plans[0].kernel_name, 88 * 4096 * 4096
+        return (lambda i: fn(ctypes.byref(plans[i % len(plans)].desc), g.data_ptr(), *ptrs, stream)), "backward:" + plans[0].kernel_name, 76 * 4096 * 4096
     if case == "config4":
         kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
         plan = F.plan_cook_torrance(*sets["b64_1024"], **kw)

@@ -46,6 +46,7 @@ def _bench(*flags, gpus=1, timeout=900):
     assert run.returncode == 0, run.stderr[-3000:]
     lines = [l for l in run.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, run.stdout
+    assert run.stdout.strip() == lines[0], run.stdout          # ONE line and nothing else on stdout (RCCL's version banner goes to stderr)
     return json.loads(lines[0]), shared
 
 

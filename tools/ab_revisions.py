@@ -59,6 +59,21 @@ def build_case(case, rev, sets, dev):
         ptrs = [t.data_ptr() for t in grads] + [None]
         fn = lib.pbr_cook_torrance_backward
         return (lambda i: fn(ctypes.byref(plans[i % len(plans)].desc), g.data_ptr(), *ptrs, stream)), "backward:" + plans[0].kernel_name, 76 * 4096 * 4096
+    if case in ("backward_f16", "loss_f16"):              # the streamed kernels of the fp16-map family
+        kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
+        maps = [t.half() for t in sets["one4096"][0]]
+        plan = F.plan_cook_torrance(*maps, **kw)
+        g = torch.rand(1, 3, 4096, 4096, device=dev)
+        grads = [torch.empty(1, c, 4096, 4096, device=dev, dtype=torch.float16) for c in (3, 3, 1, 1)]
+        ptrs = [t.data_ptr() for t in grads] + [None]
+        keep = (maps, g, grads)
+        if case == "backward_f16":
+            fn = lib.pbr_cook_torrance_backward
+            return (lambda i, keep=keep: fn(ctypes.byref(plan.desc), g.data_ptr(), *ptrs, stream)), "backward fp16 maps", 44 * 4096 * 4096
+        loss = torch.empty((), device=dev)
+        ws = torch.empty(max(1, lib.pbr_mse_step_workspace_bytes(ctypes.byref(plan.desc)) // 4), device=dev)
+        fn = lib.pbr_cook_torrance_mse_step
+        return (lambda i, keep=keep: fn(ctypes.byref(plan.desc), g.data_ptr(), *ptrs, loss.data_ptr(), ws.data_ptr(), stream)), "loss step fp16 maps", 44 * 4096 * 4096
     if case == "config4":
         kw = dict(view_dir=[0, 0, 1], light=[0.1, 0.1, 1.0], light_intensity=[1, 1, 1], light_type="point", light_size=1.0)
         plan = F.plan_cook_torrance(*sets["b64_1024"], **kw)

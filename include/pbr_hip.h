@@ -89,7 +89,7 @@ enum {
     PBR_TUNE_BWD_WIDE = 13,             /* streamed backward with 16-byte memory instructions: -1 = rule (off), 0 = the 4-byte form, 1 = wherever legal */
     PBR_TUNE_RESIZE_UP2 = 14,           /* up-scales on both axes: the two-tap register kernel (1, default) or the strip kernel (0) */
     PBR_TUNE_TILE_FOLD = 15,            /* tiled maps, wrap-around form: log2 of the source rows per band of the fold order (all vertical repeats of a band back to back); -1 = rule, 0 = row order */
-    PBR_TUNE_RESIZE_BWD_FUSED = 16,     /* gradient of resize in one pass (1, default) or two passes through the workspace (0) */
+    PBR_TUNE_RESIZE_BWD_FUSED = 16,     /* gradient of resize: 1 (default) = one register-only pass (gather over the transposed tap tables; up-scales: the two-tap transpose), 2 = one pass through the LDS strip kernel, 0 = two passes through the workspace */
     PBR_TUNE_RESIZE_QUADS = 17,         /* strip kernel's width pass with four columns per lane and 16-byte stores: 1 = rule, 2 = wherever legal, 0 = never */
     PBR_TUNE_STREAM_SHAPE = 18,         /* launch shape of the streaming map kernels: -1 = each kernel's rule, 0 = 2048 walking workgroups of 256 lanes, 1 = one item per lane (256-lane groups), 2 = one-wave groups */
     PBR_TUNE_STREAM_LDS = 19,           /* unused dynamic LDS bytes per workgroup of those kernels (an occupancy cap); -1 = rule */

@@ -91,6 +91,7 @@ struct KArgs {
     LightU lights[PBR_MAX_LIGHTS];
     int32_t rep_y, rep_x;    // cook_torrance_repeat_kernel: the grid walks the SOURCE maps (H x W texels), every lane evaluates its texels at all rep_y * rep_x positions of the output
     int32_t out_W, out_Ht;   // ... whose rows are out_W pixels wide and whose point-light grid spans out_Ht x out_W
+    int32_t band_rows;       // ... of which `out` holds the rows [y_offset, y_offset + band_rows)
     uint64_t dev;            // pbr_render_desc.device_params (address of a DevParams block, 0 = none): when set, V and the light blocks are read from it (view_of / light_of)
 };
 
@@ -797,7 +798,8 @@ void cook_torrance_batch_kernel(const KArgs a) {
 // terms cost 1 / (rep_y rep_x) per output pixel; a directional light (position-independent) is evaluated ONCE and stored
 // rep_y x rep_x times.  Same functions in the same order per pixel as cook_torrance_kernel: bit-identical to evaluating the
 // materialised repeat.  One light, 4 texels per lane (fp16 maps: 8-byte loads -- loads are the minor stream here), packed
-// arithmetic; launches that are row bands of the tiled output, have several lights or ragged map widths keep the wrap-around form.
+// arithmetic; row bands of the tiled output (multi-GPU shards) are served when they hold at least one full period of the map's rows; thinner
+// bands, several lights and ragged map widths keep the wrap-around form.
 // NTL / NTS: the streaming hint on the loads / on the stores.
 template <int LIGHT, int WF, typename TI, typename TO, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
@@ -818,8 +820,11 @@ void cook_torrance_repeat_kernel(const KArgs a) {
     for (int g = 0; g < NG; ++g) material_terms<WF, VEC, R>(t, g, V, pt[g]);
 
     const uint32_t lane_out = (uint32_t)(p.y * a.out_W + p.x);              // inside the first repeat; < 2^30 when p.sb (fill_args)
+    // `out` holds the rows [y_offset, y_offset + band_rows) of the tiled image (all of it, or a multi-GPU shard's band): a repeat whose
+    // row falls outside is skipped; the others land y_offset rows higher.  (rep may be negative; rep + the lane's part never is.)
+    auto in_band = [&](int ry) { const int yy = p.y + ry * a.H - a.y_offset; return yy >= 0 && yy < a.band_rows; };
     auto store_at = [&](int ry, int rx, const R (&res)[3][NG]) {
-        const int64_t rep = (int64_t)ry * a.H * a.out_W + (int64_t)rx * a.W;
+        const int64_t rep = ((int64_t)ry * a.H - a.y_offset) * a.out_W + (int64_t)rx * a.W;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float o[VEC];
@@ -843,11 +848,14 @@ void cook_torrance_repeat_kernel(const KArgs a) {
         R res[3][NG];
         const R xs[NG] = {splat<R>(0.0f), splat<R>(0.0f)};
         shade(xs, 0.0f, res);
-        for (int ry = 0; ry < a.rep_y; ++ry)
+        for (int ry = 0; ry < a.rep_y; ++ry) {
+            if (!in_band(ry)) continue;
             for (int rx = 0; rx < a.rep_x; ++rx) store_at(ry, rx, res);
+        }
         return;
     }
     for (int ry = 0; ry < a.rep_y; ++ry) {
+        if (!in_band(ry)) continue;
         const float ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, p.y + ry * a.H);
         for (int rx = 0; rx < a.rep_x; ++rx) {
             R xs[NG], res[3][NG];

@@ -253,10 +253,12 @@ KernelFn pick_batch_kernel(const pbr_render_desc *d, int nb, bool nt);      // c
 KernelFn pick_repeat_kernel(const pbr_render_desc *d, int nt_knob);            // ct_tiled.hip
 void fill_repeat_args(const pbr_render_desc *d, KArgs &k);
 
-// Tiled maps evaluated by the repeat-inner kernel (ct_kernel.hpp: cook_torrance_repeat_kernel): the WHOLE tiled output of one light,
-// map rows a whole number of 4-texel lanes.  Row bands of a tiled output, several lights and ragged map widths take the wrap-around form.
+// Tiled maps evaluated by the repeat-inner kernel (ct_kernel.hpp: cook_torrance_repeat_kernel): one light, map rows a whole number of
+// 4-texel lanes, and an output -- the whole tiled image, or a row band of it (a multi-GPU shard) -- that holds at least one full period
+// of the map's rows: in a thinner band no texel row is used twice vertically, there is nothing for the kernel to share, and every source
+// row outside the band would be loaded for nothing.  Thin bands, several lights and ragged map widths take the wrap-around form.
 inline bool repeat_inner(const pbr_render_desc *d) {
-    return g_tile_repeat != 0 && is_tiled(d) && d->n_lights == 1 && d->y_offset == 0 && d->height == d->height_total &&
+    return g_tile_repeat != 0 && is_tiled(d) && d->n_lights == 1 && d->height >= d->map_height &&
            d->map_width % 4 == 0 && g_max_vec >= 4 && !g_interleave;
 }
 

@@ -42,10 +42,17 @@ struct AxisFilter {
     int n_in;
 };
 
-__device__ __forceinline__ void tap_window(const AxisFilter &f, int i, int &xmin, int &xsize, float &center) {
+__host__ __device__ __forceinline__ void tap_window(const AxisFilter &f, int i, int &xmin, int &xsize, float &center) {
     center = f.scale * ((float)i + 0.5f);
-    xmin = max(0, (int)(center - f.support + 0.5f));
-    xsize = min(f.n_in, (int)(center + f.support + 0.5f)) - xmin;
+    const int lo = (int)(center - f.support + 0.5f), hi = (int)(center + f.support + 0.5f);
+    xmin = lo > 0 ? lo : 0;
+    xsize = (hi < f.n_in ? hi : f.n_in) - xmin;
+}
+// first tap of output i (the window's start): what the gradient kernels bracket their contributors with; host and device agree bit for bit
+__host__ __device__ __forceinline__ int first_tap(const AxisFilter &f, int i) {
+    int xmin, n; float c;
+    tap_window(f, i, xmin, n, c);
+    return xmin;
 }
 
 __device__ __forceinline__ float tap_weight(const AxisFilter &f, int j, int xmin, float center) {
@@ -569,6 +576,227 @@ __global__ __launch_bounds__(64) void resize_up2_kernel(const float *__restrict_
     }
 }
 
+
+// ---- gradient of an up-scale: the transpose of resize_up2_kernel, registers only (round 4) ---------------------------------------
+// out[y][x] = sum over two rows and two columns of wy wx in[..]; the gradient g_in[ky][kx] gathers g_out over the outputs whose
+// two-tap windows hold (ky, kx).  Windows start at first_tap(i), which is monotone in i, so the outputs that touch gradient columns
+// k0 .. k0 + 3 are the contiguous range first_tap(i) in [k0 - 1, k0 + 3]: at most 5 / scale + 1 of them.  A lane owns FOUR consecutive
+// gradient columns of R rows: it finds the start of its range once (a short search around the closed-form estimate, with the forward's
+// own arithmetic), builds the 4 x W matrix of column weights in registers (W = 8 | 12 | 16 upstream columns; zero where an output
+// does not touch a column), then walks the upstream rows that touch its R gradient rows: W / 4 16-byte loads, 4 W fma for the width
+// sum, 4 R fma into the accumulators with the row's (wave-uniform) weights.  No tables, no LDS, no barriers -- the strip kernel with
+// transposed tables (resize_strip_kernel<true>) spends most of its time in per-tile set-up and between its barriers on these shapes
+// (0.52 of HBM).  A gather by gradient element with a fixed summation order: deterministic, no atomics.  The launcher checks on the
+// host (the same float arithmetic) that W and the row bound hold for every lane; other shapes keep the table-driven passes.
+template <int W, int R>
+__global__ __launch_bounds__(64) void resize_up2_backward_kernel(const float *__restrict__ gout, float *__restrict__ gin, int h_in, int w_in, int h_out,
+                                                                 int w_out, int groups_x, int groups_y, uint32_t xcd_groups, AxisFilter fw, AxisFilter fh) {
+    uint32_t wg = blockIdx.x;
+    if (wg < xcd_groups) {                                  // XCD x takes runs of 1 << kUpRunLog2 consecutive workgroups, as the forward
+        const uint32_t c = kUpRunLog2, xcd = wg & 7u, slot = wg >> 3;
+        wg = ((slot >> c) << (c + 3)) + (xcd << c) + (slot & ((1u << c) - 1u));
+    }
+    const uint32_t band = wg / (uint32_t)groups_x, gx = wg - band * (uint32_t)groups_x;
+    const int plane = (int)(band / (uint32_t)groups_y), r0 = (int)(band - (uint32_t)plane * (uint32_t)groups_y) * R;
+    const int k0 = ((int)gx * 64 + (int)threadIdx.x) * 4;
+    if (k0 >= w_in) return;
+    // ---- columns: the first output whose window reaches column k0 - 1 or beyond
+    int i_lo = 0;
+    if (k0 > 1) {
+        i_lo = (int)(((float)k0 - 0.5f) / fw.scale - 0.5f) - 1;
+        i_lo = i_lo < 0 ? 0 : (i_lo > w_out - 1 ? w_out - 1 : i_lo);
+        while (i_lo > 0 && first_tap(fw, i_lo - 1) >= k0 - 1) --i_lo;
+        while (i_lo < w_out - 1 && first_tap(fw, i_lo) < k0 - 1) ++i_lo;
+    }
+    const int i_base = i_lo < w_out - W ? i_lo : w_out - W;            // W upstream columns from here, inside the row (w_out >= W: the launcher)
+    float wx[4][W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+        int first; float wa, wb;
+        two_taps(fw, i_base + j, first, wa, wb);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wx[c][j] = (first == k0 + c ? wa : 0.0f) + (first + 1 == k0 + c ? wb : 0.0f);
+    }
+    // ---- rows: the upstream rows whose windows reach gradient rows r0 .. r0 + R - 1 (wave-uniform)
+    int y = 0;
+    if (r0 > 1) {
+        y = (int)(((float)r0 - 0.5f) / fh.scale - 0.5f) - 1;
+        y = y < 0 ? 0 : (y > h_out - 1 ? h_out - 1 : y);
+        while (y > 0 && first_tap(fh, y - 1) >= r0 - 1) --y;
+        while (y < h_out - 1 && first_tap(fh, y) < r0 - 1) ++y;
+    }
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+    const float *gp = gout + (int64_t)plane * h_out * w_out + i_base;
+    for (; y < h_out; ++y) {
+        int yf; float wy0, wy1;
+        two_taps(fh, y, yf, wy0, wy1);
+        if (yf > r0 + R - 1) break;
+        const int y1 = min(yf + 1, h_in - 1);               // the forward's second row (weight 0 when the window holds one tap)
+        const float *row = gp + (int64_t)y * w_out;
+        float g[W];
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) {
+            const rf4 v = *reinterpret_cast<const rf4 *>(row + 4 * q);       // cached: neighbouring lanes' and rows' windows overlap
+            g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        }
+        float t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = wx[c][0] * g[0];
+#pragma unroll
+            for (int j = 1; j < W; ++j) a = fmaf(wx[c][j], g[j], a);
+            t[c] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float cy = (yf == r0 + r ? wy0 : 0.0f) + (y1 == r0 + r ? wy1 : 0.0f);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(cy, t[c], acc[r][c]);
+        }
+    }
+    float *dp = gin + (int64_t)plane * h_in * w_in + k0;
+    const bool whole = k0 + 4 <= w_in;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r0 + r >= h_in) break;
+        float *q = dp + (int64_t)(r0 + r) * w_in;
+        if (whole) {
+            typedef float sf4 __attribute__((ext_vector_type(4), aligned(4)));
+            const sf4 v = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<sf4 *>(q));
+        } else {
+            for (int c = 0; c < w_in - k0; ++c) q[c] = acc[r][c];
+        }
+    }
+}
+
+// Host side of the kernel above: the largest number of outputs whose windows start in [k0 - 1, k0 + 3] over all lanes' k0 (multiples
+// of 4), computed with the kernel's own first_tap -- the kernel's W must cover it.
+static int up2_backward_window(const AxisFilter &f, int n_out) {
+    int worst = 0, lo = 0, hi = 0;                       // [lo, hi): outputs with first_tap in [k0 - 1, k0 + 3], both ends monotone in k0
+    for (int k0 = 0; k0 < f.n_in; k0 += 4) {
+        while (lo < n_out && first_tap(f, lo) < k0 - 1) ++lo;
+        if (hi < lo) hi = lo;
+        while (hi < n_out && first_tap(f, hi) <= k0 + 3) ++hi;
+        worst = hi - lo > worst ? hi - lo : worst;
+    }
+    return worst;
+}
+
+
+// ---- gradient of a down-scale, registers only (round 4): the two table-driven passes in one kernel without the LDS strip --------
+// With the transposed tap tables in global memory (resize_backward_tables_kernel: per gradient index k the first upstream index
+// lo[k] that read it, their number cnt[k] and the normalised weights w[j][k]) the gradient is a gather with short, contiguous ranges
+// on both axes.  A lane owns FOUR consecutive gradient columns of R rows.  Its columns' upstream ranges overlap and are monotone, so
+// their union is W <= 16 consecutive upstream columns: the lane builds the 4 x W matrix of column weights once (4 W table reads,
+// coalesced over the lanes), then walks the union of its rows' upstream rows: W / 4 16-byte loads, 4 W fma for the width sums, and per
+// gradient row one wave-uniform weight (scalar loads) times the four sums.  resize_strip_kernel<true> does the same work through a
+// tile of LDS with three barrier-separated phases and reaches 0.52 of HBM on 4096^2 <- 2048^2; this form has no set-up to amortise.
+// Gather by gradient element, fixed order: deterministic.  The launcher checks W on the host (same float arithmetic).
+template <int W, int R>
+__global__ __launch_bounds__(64) void resize_backward_gather_kernel(const float *__restrict__ gout, float *__restrict__ gin, int h_in, int w_in, int h_out,
+                                                                    int w_out, int groups_x, int groups_y, uint32_t xcd_groups, StripTables tb) {
+    uint32_t wg = blockIdx.x;
+    if (wg < xcd_groups) {
+        const uint32_t c = kUpRunLog2, xcd = wg & 7u, slot = wg >> 3;
+        wg = ((slot >> c) << (c + 3)) + (xcd << c) + (slot & ((1u << c) - 1u));
+    }
+    const uint32_t band = wg / (uint32_t)groups_x, gx = wg - band * (uint32_t)groups_x;
+    const int plane = (int)(band / (uint32_t)groups_y), r0 = (int)(band - (uint32_t)plane * (uint32_t)groups_y) * R;
+    const int k0 = ((int)gx * 64 + (int)threadIdx.x) * 4;
+    if (k0 >= w_in) return;
+    // ---- columns
+    int lo[4], n[4], i_lo = INT32_MAX;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = min(k0 + c, w_in - 1);
+        lo[c] = tb.lo_x[k]; n[c] = k0 + c < w_in ? min(tb.cnt_x[k], kBwdMaxTaps) : 0;
+        if (n[c] > 0) i_lo = min(i_lo, lo[c]);
+    }
+    if (i_lo == INT32_MAX) i_lo = 0;
+    const int i_base = i_lo < w_out - W ? i_lo : w_out - W;
+    float wx[4][W];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int k = min(k0 + c, w_in - 1);
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const int d = i_base + j - lo[c];
+            wx[c][j] = d >= 0 && d < n[c] ? tb.w_x[(size_t)d * tb.nx + k] : 0.0f;
+        }
+    }
+    // ---- rows (wave-uniform: scalar loads)
+    int ylo[R], yn[R], y_lo = INT32_MAX, y_hi = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int k = min(r0 + r, h_in - 1);
+        ylo[r] = tb.lo_y[k]; yn[r] = r0 + r < h_in ? min(tb.cnt_y[k], kBwdMaxTaps) : 0;
+        if (yn[r] > 0) { y_lo = min(y_lo, ylo[r]); y_hi = max(y_hi, ylo[r] + yn[r]); }
+    }
+    float acc[R][4];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
+    const float *gp = gout + (int64_t)plane * h_out * w_out + i_base;
+    for (int y = y_lo; y < y_hi; ++y) {
+        const float *row = gp + (int64_t)y * w_out;
+        float g[W];
+#pragma unroll
+        for (int q = 0; q < W / 4; ++q) {
+            const rf4 v = *reinterpret_cast<const rf4 *>(row + 4 * q);       // cached: neighbouring lanes' and rows' windows overlap
+            g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
+        }
+        float t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float a = wx[c][0] * g[0];
+#pragma unroll
+            for (int j = 1; j < W; ++j) a = fmaf(wx[c][j], g[j], a);
+            t[c] = a;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int d = y - ylo[r];
+            const float cy = d >= 0 && d < yn[r] ? tb.w_y[(size_t)d * tb.ny + min(r0 + r, h_in - 1)] : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(cy, t[c], acc[r][c]);
+        }
+    }
+    float *dp = gin + (int64_t)plane * h_in * w_in + k0;
+    const bool whole = k0 + 4 <= w_in;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (r0 + r >= h_in) break;
+        float *q = dp + (int64_t)(r0 + r) * w_in;
+        if (whole) {
+            typedef float sf4 __attribute__((ext_vector_type(4), aligned(4)));
+            const sf4 v = {acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            __builtin_nontemporal_store(v, reinterpret_cast<sf4 *>(q));
+        } else {
+            for (int c = 0; c < w_in - k0; ++c) q[c] = acc[r][c];
+        }
+    }
+}
+
+// Host side: the widest union of upstream columns over all lanes' four gradient columns, from the forward's own windows (an output's
+// window [xmin, xmin + size) is monotone in the output index at both ends): the outputs whose window meets [k0, k0 + 3].
+static int gather_window(const AxisFilter &f, int n_out) {
+    int worst = 0, lo = 0, hi = 0;
+    for (int k0 = 0; k0 < f.n_in; k0 += 4) {
+        int xmin, n; float c;
+        while (lo < n_out) { tap_window(f, lo, xmin, n, c); if (xmin + n > k0) break; ++lo; }
+        if (hi < lo) hi = lo;
+        while (hi < n_out) { tap_window(f, hi, xmin, n, c); if (xmin > k0 + 3) break; ++hi; }
+        worst = hi - lo > worst ? hi - lo : worst;
+    }
+    return worst;
+}
+
 static AxisFilter make_filter(int n_in, int n_out, bool antialias) {
     AxisFilter f;
     f.scale = (float)n_in / (float)n_out;            // area_pixel_compute_scale<float>, align_corners = False
@@ -687,6 +915,22 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
     int *lo_y = reinterpret_cast<int *>(wx + (size_t)kBwdMaxTaps * w_in), *cnt_y = lo_y + h_in, *lo_x = cnt_y + h_in, *cnt_x = lo_x + w_in;
     const auto g = static_cast<const float *>(grad_out);
     float *gi = static_cast<float *>(grad_in);
+    if (g_resize_up2 && g_resize_bwd_fused && fw.scale <= 1.0f && fh.scale <= 1.0f && fw.scale >= 0.34f && fh.scale >= 0.25f && w_out >= 16) {
+        // gradient of an up-scale (up to 3x across, 4x down the rows): the register-only transpose of the two-tap forward (round 4;
+        // tools/resize_bwd_probe.py).  W from the exact window count of THIS shape; rows per lane 4.
+        const int need = up2_backward_window(fw, w_out);
+        constexpr int R = 4;
+        const int64_t groups_x = (w_in + 255) / 256, groups_y = (h_in + R - 1) / R, n_groups = groups_x * groups_y * planes;
+        if (need <= 16 && n_groups <= INT32_MAX) {
+            const uint32_t span = 8u << kUpRunLog2;
+            const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
+            auto fn = need <= 8 ? resize_up2_backward_kernel<8, R> : (need <= 12 ? resize_up2_backward_kernel<12, R> : resize_up2_backward_kernel<16, R>);
+            hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(grad_out), static_cast<float *>(grad_in),
+                               (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)groups_x, (int)groups_y, xcd_groups, fw, fh);
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+        }
+    }
     auto fits = [](const AxisFilter &f) { return (int)((2.0f * f.support + 2.0f) / f.scale) + 2 <= kBwdMaxTaps; };
     const int64_t grid_rows = (int64_t)((w_out + 1023) / 1024) * planes * h_in;
     const int64_t grid_cols = (int64_t)((w_in + 255) / 256) * ((planes * h_in + kBwdRows - 1) / kBwdRows);
@@ -694,6 +938,22 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
         const int groups_y = (h_in + 255) / 256, groups_x = (w_in + 255) / 256;
         hipLaunchKernelGGL(resize_backward_tables_kernel, dim3(groups_y + groups_x), dim3(256), 0, s, lo_y, cnt_y, wy, (int)h_out, fh, lo_x, cnt_x, wx,
                            (int)w_out, fw, groups_y);
+        // Register-only gather over the tables (round 4, resize_backward_gather_kernel): 4 gradient columns x 8 rows per lane.
+        if (g_resize_bwd_fused == 1 && w_out >= 16) {
+            const int need = gather_window(fw, w_out);
+            const int R = g_resize_rows == 4 ? 4 : 8;                 // gradient rows per lane (A/B knob PBR_TUNE_RESIZE_ROWS)
+            const int64_t ggx = (w_in + 255) / 256, ggy = (h_in + R - 1) / R, n_groups = ggx * ggy * planes;
+            if (need <= 16 && n_groups <= INT32_MAX) {
+                const uint32_t span = 8u << kUpRunLog2;
+                const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
+                const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out};
+                auto fn = R == 4 ? (need <= 8 ? resize_backward_gather_kernel<8, 4> : (need <= 12 ? resize_backward_gather_kernel<12, 4> : resize_backward_gather_kernel<16, 4>))
+                                 : (need <= 8 ? resize_backward_gather_kernel<8, 8> : (need <= 12 ? resize_backward_gather_kernel<12, 8> : resize_backward_gather_kernel<16, 8>));
+                hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, g, gi, (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)ggx, (int)ggy, xcd_groups, tb);
+                const hipError_t e = hipGetLastError();
+                return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+            }
+        }
         // One pass: the strip kernel with the transposed tables (resize_strip_kernel<true>): a toh x 64 tile of the gradient, the
         // rows pass from global memory into the LDS strip, the columns pass out of it.  3 x 2048^2 gradient -> 4096^2: see DESIGN.md 3.8.
         const int kx = (int)((2.0f * fw.support + 2.0f) / fw.scale) + 2, ky = (int)((2.0f * fh.support + 2.0f) / fh.scale) + 2;     // <= kBwdMaxTaps

@@ -52,7 +52,7 @@ struct TuningScope {
 #define g_bwd_wide         (::pbr::knob(PBR_TUNE_BWD_WIDE))         // streamed backward with 16-byte memory instructions: -1 = rule (off), 0 off, 1 wherever legal
 #define g_resize_up2       (::pbr::knob(PBR_TUNE_RESIZE_UP2))       // resize.hip: two-tap register kernel for up-scales (1) or the strip kernel (0)
 #define g_tile_fold        (::pbr::knob(PBR_TUNE_TILE_FOLD))        // tiled maps, wrap-around form: log2 of the source rows per band of the fold order (-1 = rule, 0 = row order)
-#define g_resize_bwd_fused (::pbr::knob(PBR_TUNE_RESIZE_BWD_FUSED)) // resize.hip: gradient in one pass (1) or two passes through the workspace (0)
+#define g_resize_bwd_fused (::pbr::knob(PBR_TUNE_RESIZE_BWD_FUSED)) // resize.hip: gradient in registers (1), through the LDS strip (2) or in two passes through the workspace (0)
 #define g_resize_quads     (::pbr::knob(PBR_TUNE_RESIZE_QUADS))     // resize.hip: 16-byte stores in the strip kernel's width pass: 1 = rule, 2 = wherever legal, 0 = never
 #define g_stream_shape     (::pbr::knob(PBR_TUNE_STREAM_SHAPE))     // stream_shape.hpp: launch shape of the streaming map kernels (-1 = each launcher's rule)
 #define g_stream_lds       (::pbr::knob(PBR_TUNE_STREAM_LDS))       // stream_shape.hpp: unused dynamic LDS of those kernels (-1 = rule)

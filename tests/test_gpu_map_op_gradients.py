@@ -169,7 +169,8 @@ def test_resize_gradient_one_pass_equals_two_passes(shape, size, antialias):
     stream = torch.cuda.current_stream().cuda_stream
     got = {}
     try:
-        for fused, quads, rows in ((0, 1, 0), (1, 0, 0), (1, 2, 0), (1, 2, 16), (1, 1, 32)):
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 0)          # this test is about the strip kernel; the register-only gradient of up-scales has its own below
+        for fused, quads, rows in ((0, 1, 0), (2, 0, 0), (2, 2, 0), (2, 2, 16), (2, 1, 32)):       # 2 = the strip kernel (1 = the register gather, below)
             lib.pbr_set_tuning(N.TUNE_RESIZE_BWD_FUSED, fused)
             lib.pbr_set_tuning(N.TUNE_RESIZE_QUADS, quads)
             lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, rows)
@@ -180,13 +181,53 @@ def test_resize_gradient_one_pass_equals_two_passes(shape, size, antialias):
         lib.pbr_set_tuning(N.TUNE_RESIZE_BWD_FUSED, 1)
         lib.pbr_set_tuning(N.TUNE_RESIZE_QUADS, 1)
         lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, 0)
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
     ref = got[(0, 1, 0)]
     assert bool(torch.isfinite(ref).all())
     for key, val in got.items():
         assert torch.equal(val, ref), key
+    # the default since round 4: the register-only gather over the same tables (resize_backward_gather_kernel; up-scales: the
+    # two-tap transpose) -- the same products added in another order
+    gin = torch.full((3, h, w), float("nan"), device="cuda")
+    N.check(lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, h, w, ho, wo, int(antialias), ws.data_ptr(), stream))
+    assert bool(torch.isfinite(gin).all()) and (gin - ref).abs().max().item() <= 2e-6 * max(1.0, float(ref.abs().max()))
     x = torch.zeros(1, 3, h, w, dtype=torch.float64, requires_grad=True)
     (TF.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False, antialias=antialias)[0] * gout.cpu().double()).sum().backward()
     assert (ref.cpu().double() - x.grad[0]).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("shape,size", [((64, 96), (128, 192)), ((37, 53), (80, 97)), ((50, 70), (50, 70)), ((33, 130), (97, 131)), ((40, 44), (57, 128)),
+                                        ((9, 16), (10, 16)), ((128, 256), (300, 700)), ((5, 4), (11, 16)), ((24, 250), (31, 251))])
+def test_gradient_of_an_upscale_in_registers(shape, size):
+    """pbr_resize_bilinear_backward for up-scales (round 4: resize_up2_backward_kernel, the register-only transpose of the two-tap forward):
+    against float64 autograd of F.interpolate, and within rounding of the table-driven strip kernel it replaces on these shapes; exact 2x,
+    ragged and unaligned widths, 1:1, widths whose last lane is partial, a 3x up-scale across (16 upstream columns per lane)."""
+    from pypbr_amd import _native as N
+    lib = N.lib()
+    g = torch.Generator().manual_seed(15)
+    (h, w), (ho, wo) = shape, size
+    gout = (torch.rand(3, ho, wo, generator=g) - 0.5).cuda()
+    ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(3, h, w, ho, wo) // 4), device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    got = {}
+    try:
+        for up2 in (1, 0):
+            lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, up2)
+            gin = torch.full((3, h, w), float("nan"), device="cuda")
+            N.check(lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, h, w, ho, wo, 1, ws.data_ptr(), stream))
+            got[up2] = gin
+    finally:
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
+    x = torch.zeros(1, 3, h, w, dtype=torch.float64, requires_grad=True)
+    (TF.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False, antialias=True)[0] * gout.cpu().double()).sum().backward()
+    assert bool(torch.isfinite(got[1]).all())
+    assert (got[1].cpu().double() - x.grad[0]).abs().max().item() <= 3e-5      # float64 tap positions against float32 ones: the bound of the strip kernel's test
+    assert (got[1] - got[0]).abs().max().item() <= 2e-6
+    # the whole of an upstream gradient of ones comes back: every output's weights sum to one
+    ones = torch.ones(3, ho, wo, device="cuda")
+    gin = torch.empty(3, h, w, device="cuda")
+    N.check(lib.pbr_resize_bilinear_backward(ones.data_ptr(), gin.data_ptr(), 3, h, w, ho, wo, 1, ws.data_ptr(), stream))
+    assert abs(float(gin.double().sum()) - 3.0 * ho * wo) <= 1e-3 * ho * wo / 1000 + 1e-2
 
 
 def test_sigmoid_mask_gradient_and_height_blend_through_the_mask():

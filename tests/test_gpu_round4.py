@@ -116,7 +116,6 @@ def test_tile_zero_and_negative_follow_torch_repeat():
 def test_repeat_inner_kernel_equals_the_materialised_repeat_and_the_wrap_around_form(light_type, dtype):
     """tile(n) over the whole output runs cook_torrance_repeat_kernel (texels loaded and decoded once, evaluated at every repeat);
     bit-identical to evaluating the repeated maps and to the wrap-around kernel; bands / several lights keep the wrap-around form."""
-    import ctypes
     from pypbr_amd import _native as N, functional as F
     g = torch.Generator().manual_seed(11)
     lib = N.lib()
@@ -141,9 +140,15 @@ def test_repeat_inner_kernel_equals_the_materialised_repeat_and_the_wrap_around_
             assert torch.equal(wrap.launch(), want)
         finally:
             lib.pbr_set_tuning(N.TUNE_TILE_REPEAT, -1)
-        if ny * h > 4:                             # a row band of the tiled output: wrap-around addressing, same values
-            band = F.plan_cook_torrance(a, n, r, m, s, tile=(ny, nx), y_offset=3, rows=ny * h - 4, **kw)
-            assert not band.kernel_name.startswith("ctr_") and torch.equal(band.launch(), want[:, :, 3:ny * h - 1])
+        if ny * h > 4:                             # a row band of the tiled output (a multi-GPU shard): the repeat-inner kernel when the band
+            rows = ny * h - 4                      # holds a full period of the map's rows, wrap-around addressing when it is thinner; same values
+            band = F.plan_cook_torrance(a, n, r, m, s, tile=(ny, nx), y_offset=3, rows=rows, **kw)
+            assert band.kernel_name.startswith("ctr_") == (rows >= h) and torch.equal(band.launch(), want[:, :, 3:ny * h - 1])
+            thin = F.plan_cook_torrance(a, n, r, m, s, tile=(ny, nx), y_offset=ny * h - 3, rows=2, **kw)
+            assert not thin.kernel_name.startswith("ctr_") and torch.equal(thin.launch(), want[:, :, ny * h - 3:ny * h - 1])
+            if ny >= 2:                            # exactly one period, straddling a seam
+                mid = F.plan_cook_torrance(a, n, r, m, s, tile=(ny, nx), y_offset=h // 2 + 1, rows=h, **kw)
+                assert mid.kernel_name.startswith("ctr_") and torch.equal(mid.launch(), want[:, :, h // 2 + 1:h // 2 + 1 + h])
         # strided result planes (out= inside a larger allocation)
         big = torch.zeros(B, 3, ny * h + 2, nx * w, device="cuda")
         out = big[:, :, 1:ny * h + 1]

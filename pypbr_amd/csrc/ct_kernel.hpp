@@ -90,8 +90,8 @@ struct KArgs {
     int32_t grey_lights;     // every light's three intensities are equal: radiance * intensity once per light, not per channel
     LightU lights[PBR_MAX_LIGHTS];
     int32_t rep_y, rep_x;    // cook_torrance_repeat_kernel: the grid walks the SOURCE maps (H x W texels), every lane evaluates its texels at all rep_y * rep_x positions of the output
-    int32_t out_W, out_Ht;   // ... whose rows are out_W pixels wide and whose point-light grid spans out_Ht x out_W
-    int32_t band_rows;       // ... of which `out` holds the rows [y_offset, y_offset + band_rows)
+    int32_t out_W, out_Ht;   // ... whose rows are out_W pixels wide and whose point-light grid spans out_Ht x out_W; `out` holds the rows
+                             // [y_offset, y_offset + H_total) of it (the repeat kernel's H_total: the band's rows; it has no other use there)
     uint64_t dev;            // pbr_render_desc.device_params (address of a DevParams block, 0 = none): when set, V and the light blocks are read from it (view_of / light_of)
 };
 
@@ -820,9 +820,9 @@ void cook_torrance_repeat_kernel(const KArgs a) {
     for (int g = 0; g < NG; ++g) material_terms<WF, VEC, R>(t, g, V, pt[g]);
 
     const uint32_t lane_out = (uint32_t)(p.y * a.out_W + p.x);              // inside the first repeat; < 2^30 when p.sb (fill_args)
-    // `out` holds the rows [y_offset, y_offset + band_rows) of the tiled image (all of it, or a multi-GPU shard's band): a repeat whose
+    // `out` holds the rows [y_offset, y_offset + H_total) of the tiled image (all of it, or a multi-GPU shard's band): a repeat whose
     // row falls outside is skipped; the others land y_offset rows higher.  (rep may be negative; rep + the lane's part never is.)
-    auto in_band = [&](int ry) { const int yy = p.y + ry * a.H - a.y_offset; return yy >= 0 && yy < a.band_rows; };
+    auto in_band = [&](int ry) { const int yy = p.y + ry * a.H - a.y_offset; return yy >= 0 && yy < a.H_total; };
     auto store_at = [&](int ry, int rx, const R (&res)[3][NG]) {
         const int64_t rep = ((int64_t)ry * a.H - a.y_offset) * a.out_W + (int64_t)rx * a.W;
 #pragma unroll

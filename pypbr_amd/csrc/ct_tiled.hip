@@ -54,7 +54,7 @@ void fill_repeat_args(const pbr_render_desc *d, KArgs &k) {
     k.y0 = full.y0; k.y1 = full.y1; k.ystep = full.ystep;
     k.rep_y = d->height_total / d->map_height; k.rep_x = d->width / d->map_width;
     k.out_W = d->width; k.out_Ht = d->height_total;
-    k.y_offset = d->y_offset; k.band_rows = d->height;   // the rows [y_offset, y_offset + band_rows) of the tiled image are what `out` holds
+    k.y_offset = d->y_offset; k.H_total = d->height;     // the rows [y_offset, y_offset + H_total) of the tiled image are what `out` holds (KArgs: out_Ht)
     if (plane >= (1ll << 30)) k.sbase = 0;               // the lane's offset inside the result's first repeat must fit 32 bits of bytes
 }
 

@@ -123,19 +123,26 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--example", choices=["brdf", "blend", "both"], default="both")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--repeat", type=int, default=6)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args(argv)
     assert torch.cuda.is_available(), "needs a ROCm device"
     cores = usable_cores()
     for example in (["brdf", "blend"] if args.example == "both" else [args.example]):
-        first_total = None
+        import statistics
+        first_total, later = None, []
         for _ in range(args.repeat):                       # a script runs once: results of earlier repeats are dropped like a finished script's
             color = None
             color, rows, moved = run_hip(example, args.size)
             if first_total is None:
                 first_total = sum(ms for name, ms in rows[:-1])
-        rec = {"example": example, "statements": "examples/example_%s.py" % example, "resize": args.size, "image": list(color.shape),
+            else:
+                later.append(rows)
+        later = later or [rows]
+        # per statement the MEDIAN over the repeats after the first (the first run pays imports, HIP start-up and code-object loading and is
+        # reported by itself; single repeats jitter -- a busy host's PNG decode, a page-locking call -- by tens of milliseconds)
+        rows = [(name, statistics.median(r[i][1] for r in later)) for i, (name, _) in enumerate(later[0])]
+        rec = {"example": example, "statements": "examples/example_%s.py" % example, "resize": args.size, "image": list(color.shape), "repeats": args.repeat,
                "hip_ms": {name: round(ms, 3) for name, ms in rows}, "hip_total_ms": round(sum(ms for name, ms in rows[:-1]), 3),
                "hip_total_ms_first_run": round(first_total, 3), "transfers": moved}
         if not args.no_cpu:

@@ -349,6 +349,20 @@ int pbr_decode_normal(const void *src, void *dst, int32_t channels, int64_t pixe
                       void *workspace, void *stream);
 
 /*
+ * MaterialBase._to_tensor for PIL images, base.py:143-164, on the device: an image's own samples -- uint8 (`bits` 8; torchvision's
+ * to_tensor: (H,W,C) -> float32 (C,H,W) / 255) or uint16 (`bits` 16; base.py:146-152: / 65535.0) -- become the float32 planar map
+ * dst [channels][height][width] (dense).  The division is IEEE-exact: every one of the 256 / 65 536 possible samples gives the float
+ * the reference's CPU code gives.  `src` is addressed as src[c*stride_c + y*stride_h + x*stride_w] (strides in samples), so the
+ * (H,W,C) array PIL hands out travels as it is -- a quarter of the bytes of the float map on the host-to-device copy -- and needs
+ * no transposing on the host; channels 1..4.
+ * decode_normal != 0: the map is a normal map (channels 2 or 3) and base.py:191-242 `_process_normal_map` follows in the same pass --
+ * samples are never negative, so :212's "already signed?" is false by construction and the map is always decoded; dst has 3 planes,
+ * bit-identical to pbr_decode_normal of the float map.
+ */
+int pbr_unpack_image(const void *src, int32_t bits, int32_t channels, int32_t height, int32_t width, int64_t stride_c,
+                     int64_t stride_h, int64_t stride_w, float *dst, int32_t decode_normal, void *stream);
+
+/*
  * MaterialBase.resize, base.py:490-504 (torchvision resize of a float (C,H,W) map ==
  * F.interpolate(mode="bilinear", align_corners=False, antialias=...)).  fp32 planar
  * [planes][h_in][w_in] -> [planes][h_out][w_out]; `workspace` holds the width-pass

@@ -40,7 +40,7 @@ EXPORTS = (
     "pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
     "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
     "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward", "pbr_fold_gradient_typed",
-    "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar", "pbr_scale_list_by_device_scalar", "pbr_device_params_bytes", "pbr_prepare_device_params", "pbr_tuning_init", "pbr_build_id",
+    "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar", "pbr_scale_list_by_device_scalar", "pbr_device_params_bytes", "pbr_prepare_device_params", "pbr_tuning_init", "pbr_build_id", "pbr_unpack_image",
 )
 
 
@@ -176,6 +176,8 @@ def lib():
         getattr(L, name).restype = ctypes.c_int
     L.pbr_decode_normal.argtypes = [vp, vp, i32, i64, ctypes.c_int, vp, vp]
     L.pbr_decode_normal_backward.argtypes = [vp, vp, vp, i32, i64, vp, vp]
+    L.pbr_unpack_image.argtypes = [vp, i32, i32, i32, i32, i64, i64, i64, vp, i32, vp]
+    L.pbr_unpack_image.restype = ctypes.c_int
     L.pbr_decode_normal_backward.restype = ctypes.c_int
     for name in ("pbr_srgb_to_linear", "pbr_linear_to_srgb", "pbr_metallic_to_specular",
                  "pbr_specular_to_metallic", "pbr_decode_normal", "pbr_abi_version", "pbr_set_tuning",

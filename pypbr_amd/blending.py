@@ -188,8 +188,8 @@ def blend_with_mask(material1: MaterialBase, material2: MaterialBase, mask: torc
     if lazy or _LAZY:                    # only RECORDS the blend: the maps stay where they are, no device is needed yet
         for m in (material1, material2):
             m.materialize_blend()
-            if m.__dict__.get("_raw_normal"):
-                m._resident(keep=True)   # the fused kernel reads decoded normals
+            if m._has_pending():
+                m._resident(keep=True)   # the fused kernel reads float maps and decoded normals
         if _fusable(material1._raw, material2._raw, mask):
             blended.__dict__["_store"] = dict(material1._raw)
             blended.__dict__["_lazy_blend"] = (dict(material2._raw), mask)

@@ -19,6 +19,7 @@ Build extensions over the reference:
 """
 import ctypes
 import os
+import threading
 import weakref
 from typing import Optional, Sequence, Tuple, Union
 
@@ -1088,49 +1089,171 @@ def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool =
     return tuple(views)
 
 
-def upload_packed(tensors: Sequence[torch.Tensor], device, tail_planes: int = 0):
+# The page-locked staging area of upload_packed, one per thread, reused: allocating one is a hipHostMalloc (4 ms for 10 MB) and torch's
+# caching host allocator handed a recycled block back only some of the time -- the upload of examples/example_brdf.py's material took 0.8
+# or 4.5 ms by that alone (tools/example_bench.py, per-repeat times).  Grown geometrically; requests beyond the cap get a block of their own.
+UPLOAD_STAGE_CAP = int(os.environ.get("PBR_UPLOAD_STAGE_CAP", str(512 << 20)))
+_UPLOAD_STAGE = threading.local()
+
+
+def _upload_stage(nbytes: int):
+    """-> (`nbytes` of page-locked uint8 -- pageable where page-locking is refused: still one transfer --, the slot to leave the copy's
+    event in or None).  The previous copy out of the slot is waited for before its memory is handed out again."""
+    def fresh(n):
+        try:
+            return torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        except RuntimeError:
+            return torch.empty(n, dtype=torch.uint8)
+    if nbytes > UPLOAD_STAGE_CAP:
+        return fresh(nbytes), None
+    slot = getattr(_UPLOAD_STAGE, "slot", None)
+    if slot is None or slot[0].numel() < nbytes:
+        grown = max(nbytes, 2 * slot[0].numel() if slot is not None else 0)
+        slot = _UPLOAD_STAGE.slot = [fresh(min(grown, UPLOAD_STAGE_CAP)), None]
+    if slot[1] is not None:
+        slot[1].synchronize()
+        slot[1] = None
+    return slot[0][:nbytes], slot
+
+
+# Host tensor -> its place in the staging area.  Up to this many bytes per upload the copy is a plain memcpy on the calling thread, NOT
+# Tensor.copy_: ATen spreads a host copy over its whole OpenMP pool (128 threads on a GPU box's 256-core host), whose workers then spin
+# on every core -- inside the box's CPU quota (16 cores) that stalled this very thread for 70-170 ms at a time (CFS throttling: every other
+# upload of examples/example_brdf.py's 10 MB of samples), and each munmap that followed paid TLB shootdowns to all of them (2-5 ms to free
+# the samples).  Measured with tools/upload_phase_probe.py: 0.4-0.6 ms, every time, for the same bytes by memcpy.  Above the limit (a
+# 4096^2 float material is 537 MB) the pool's bandwidth is worth more than that risk.
+STAGE_MEMCPY_LIMIT = int(os.environ.get("PBR_STAGE_MEMCPY_LIMIT", str(128 << 20)))
+
+
+def _page_locked_range(samples):
+    """Dense sample arrays that all live in ONE page-locked storage, each dword-aligned, covering a range not much larger than their
+    bytes -> (address of the range's first byte, its length, the range as a uint8 tensor); None otherwise."""
+    first = samples[0]
+    storage = first.untyped_storage()
+    if not all(t.untyped_storage().data_ptr() == storage.data_ptr() for t in samples) or not first.is_pinned():
+        return None
+    lo = min(t.data_ptr() for t in samples)
+    hi = max(t.data_ptr() + t.numel() * t.element_size() for t in samples)
+    used = sum(t.numel() * t.element_size() for t in samples)
+    if any((t.data_ptr() - lo) % 4 for t in samples) or lo % 4 or hi - lo > 2 * used + 4096:
+        return None
+    whole = torch.empty(0, dtype=torch.uint8).set_(storage)
+    start = lo - storage.data_ptr()
+    return lo, hi - lo, whole[start:start + (hi - lo)]
+
+
+def _stage_copy(dst_bytes: torch.Tensor, src: torch.Tensor, upload_bytes: int):
+    if upload_bytes <= STAGE_MEMCPY_LIMIT and src.is_contiguous():
+        ctypes.memmove(dst_bytes.data_ptr(), src.data_ptr(), dst_bytes.numel())
+    else:
+        dst_bytes.view(src.dtype).view(src.shape).copy_(src)
+
+
+ENCODED_DTYPES = (torch.uint8, torch.uint16)       # an image's own samples (materials._image_to_tensor(..., defer=True)); float32 / 255 or / 65535 once decoded
+
+
+def is_encoded(t) -> bool:
+    return t is not None and t.dtype in ENCODED_DTYPES
+
+
+def _dense_samples(t: torch.Tensor):
+    """(C,H,W) view of image samples -> (the dense array behind it, (stride_c, stride_h, stride_w) in samples).  PIL's (H,W,C) array
+    seen as (C,H,W) travels as it is; anything that is not one dense block is copied to (C,H,W) order first."""
+    C, H, W = t.shape
+    hwc = t.permute(1, 2, 0)
+    if hwc.is_contiguous():
+        return hwc, (1, W * C, C)
+    t = t.contiguous()
+    return t, (H * W, W, 1)
+
+
+def unpack_image(samples: torch.Tensor, bits: int, strides, shape, out: torch.Tensor, decode_normal: bool = False) -> torch.Tensor:
+    """MaterialBase._to_tensor for PIL images (base.py:143-164) on the device: `bits`-wide samples (8 | 16) starting at `samples`'
+    first byte, resident on `out`'s device, addressed [c*strides[0] + y*strides[1] + x*strides[2]] -> float32 (C,H,W) `out` (dense);
+    with `decode_normal` base.py:191-242 follows in the same pass and `out` is (3,H,W) (pbr_unpack_image)."""
+    C, H, W = shape
+    if out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != ((3 if decode_normal else C), H, W) or samples.device != out.device:
+        raise ValueError("unpack_image: `out` must be a contiguous float32 (C,H,W) tensor on the samples' device")
+    with torch.cuda.device(out.device):
+        N.check(N.lib().pbr_unpack_image(samples.data_ptr(), bits, C, H, W, strides[0], strides[1], strides[2],
+                                         out.data_ptr(), 1 if decode_normal else 0, _stream_ptr(out.device)))
+    return out
+
+
+def upload_packed(tensors: Sequence[torch.Tensor], device, tail_planes: int = 0, encoded_normal: Optional[int] = None):
     """CPU tensors -> tensors on `device` with ONE host-to-device copy: the maps are laid out in a page-locked host arena exactly as
     they will sit in the device allocation, which then arrives as a single DMA transfer (five separate `t.to(device)` of pageable
     tensors are five transfers, each bounced through the runtime's own staging buffers).  Maps that share dtype and (H, W) -- a
-    material's maps as a rule -- are packed as DENSE planes in the order given, so that the whole material is one [P,H,W] block:
-    whole-material operations (MaterialBase.resize) then take one launch over all planes; `tail_planes` more planes of that shape are
-    left free behind them (the decoded normal map lands there).  Otherwise every map starts 256-byte aligned.  Returns
-    (views in the order given, the [P + tail_planes, H, W] block or None).  Pure data movement, no arithmetic."""
+    material's maps as a rule -- are packed as DENSE planes, so that the whole material is one [P,H,W] block: whole-material
+    operations (MaterialBase.resize) then take one launch over all planes; `tail_planes` more planes of that shape are left free
+    behind them (a float normal map's decoded form lands there).  Otherwise every map starts 256-byte aligned.
+
+    Maps that are still an image's samples (uint8 / uint16, `is_encoded`) travel AS SAMPLES -- a quarter / half of the bytes -- in a
+    staging area in front of the block and are turned into float32 on arrival (pbr_unpack_image, one launch per map; the map at index
+    `encoded_normal` is a normal map and is decoded on the way, base.py:191-242); their float planes sit behind the planes of the
+    maps that arrived as floats, so that the copy stays ONE contiguous transfer and the block stays dense.
+
+    Returns (views in the order given, the [P + tail_planes, H, W] block or None)."""
     dev = torch.device(device)
     ts = [t.detach() for t in tensors]
     if not ts:
         return [], None
-    same = all(t.dtype == ts[0].dtype and t.dim() == 3 and t.shape[-2:] == ts[0].shape[-2:] for t in ts)
-    esz = ts[0].element_size()
-    if same:
-        plane = ts[0].shape[-2] * ts[0].shape[-1] * esz
-        offs, off = [], 0
-        for t in ts:
-            offs.append(off)
-            off += t.shape[0] * plane
-        total, extra = off, tail_planes * plane
+    enc = [is_encoded(t) for t in ts]
+    out_dtype = [torch.float32 if e else t.dtype for t, e in zip(ts, enc)]
+    out_shape = [((3,) + tuple(t.shape[1:]) if i == encoded_normal else tuple(t.shape)) for i, t in enumerate(ts)]
+    same = all(d == out_dtype[0] and t.dim() == 3 and t.shape[-2:] == ts[0].shape[-2:] for t, d in zip(ts, out_dtype))
+
+    def slot_bytes(i):
+        n = out_dtype[i].itemsize
+        for e in out_shape[i]:
+            n *= e
+        return n if same else -(-n // 256) * 256
+
+    # staging area (samples), then the maps that arrive as floats, then the unpacked maps, then the tail
+    dense, stage_off, off = {}, {}, 0
+    for i, t in enumerate(ts):
+        if enc[i]:
+            dense[i] = _dense_samples(t)
+            stage_off[i] = off
+            off += -(-dense[i][0].numel() * t.element_size() // 256) * 256
+    # Samples the loader decoded straight into ONE page-locked block (io.load_material_from_folder) are already where a DMA transfer can
+    # read them, laid out for it: the block's used range goes up as it is -- no staging copy, and nothing to free but the block itself.
+    direct = _page_locked_range([dense[i][0] for i in range(len(ts))]) if all(enc) and dev.type == "cuda" else None
+    if direct is not None:
+        base, off = direct[0], -(-direct[1] // 256) * 256
+        stage_off = {i: dense[i][0].data_ptr() - base for i in range(len(ts))}
+    staged = off
+    offs = {}
+    for i in [i for i in range(len(ts)) if not enc[i]] + [i for i in range(len(ts)) if enc[i]]:
+        offs[i] = off
+        off += slot_bytes(i)
+    sent = staged + sum(slot_bytes(i) for i in range(len(ts)) if not enc[i])           # bytes of the one transfer
+    plane = ts[0].shape[-2] * ts[0].shape[-1] * out_dtype[0].itemsize
+    total = off + (tail_planes * plane if same else 0)
+    if direct is not None:
+        host, stage = direct[2], None
     else:
-        offs, off = [], 0
-        for t in ts:
-            offs.append(off)
-            off += -(-t.numel() * t.element_size() // 256) * 256
-        total, extra = off, 0
-    try:
-        host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
-    except RuntimeError:                   # page-locking refused: a pageable arena is still one transfer
-        host = torch.empty(total, dtype=torch.uint8)
-    for t, o in zip(ts, offs):
-        n = t.numel() * t.element_size()
-        host[o:o + n].view(t.dtype).view(t.shape).copy_(t)
-    arena = _aligned_arena(total + extra, dev)
-    arena[:total].copy_(host, non_blocking=True)
+        host, stage = _upload_stage(sent)
+        for i, t in enumerate(ts):
+            src, o = (dense[i][0], stage_off[i]) if enc[i] else (t, offs[i])
+            _stage_copy(host[o:o + src.numel() * src.element_size()], src, sent)
+    arena = _aligned_arena(total, dev)
+    arena[:host.numel()].copy_(host, non_blocking=True)
+    if stage is not None and dev.type == "cuda":
+        stage[1] = torch.cuda.Event()
+        stage[1].record(torch.cuda.current_stream(dev))
     views = []
-    for t, o in zip(ts, offs):
-        n = t.numel() * t.element_size()
-        views.append(arena[o:o + n].view(t.dtype).view(t.shape))
+    for i, t in enumerate(ts):
+        n = out_dtype[i].itemsize
+        for e in out_shape[i]:
+            n *= e
+        view = arena[offs[i]:offs[i] + n].view(out_dtype[i]).view(out_shape[i])
+        if enc[i]:
+            unpack_image(arena[stage_off[i]:], 8 * t.element_size(), dense[i][1], tuple(t.shape), view, decode_normal=(i == encoded_normal))
+        views.append(view)
     block = None
     if same:
-        block = arena.view(ts[0].dtype).view(-1, ts[0].shape[-2], ts[0].shape[-1])
+        block = arena[staged:].view(out_dtype[0]).view(-1, ts[0].shape[-2], ts[0].shape[-1])
     return views, block
 
 

@@ -52,7 +52,7 @@ class RenderingLoss(nn.Module):
                 rendered_gt = self.brdf(ground_truth_material, self.view_dir, self.light_dir, self.light_intensity, self.light_size)
         a, n, r, m, s = self._maps(predicted_material)
         fusable = (predicted_material.__dict__.get("_lazy_blend") is None and predicted_material.lazy_tile == (1, 1)
-                   and torch.device(predicted_material.device).type == "cuda" and not predicted_material.__dict__.get("_raw_normal")
+                   and torch.device(predicted_material.device).type == "cuda" and not predicted_material._has_pending()
                    and a is not None and r is not None and "normal" in predicted_material.__dict__.get("_store", {})
                    and (m is not None or s is not None) and all(t is None or t.is_cuda for t in (a, n, r, m, s))
                    and self.brdf.override_device is None)

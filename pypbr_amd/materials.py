@@ -60,17 +60,22 @@ def _is_image(value) -> bool:
 
 
 def _is_map_value(value) -> bool:
-    if value is None or isinstance(value, np.ndarray) or _is_image(value):
+    if value is None or isinstance(value, (np.ndarray, ImageMap)) or _is_image(value):
         return True
     return isinstance(value, torch.Tensor) and value.is_floating_point()
 
 
-def _image_to_tensor(image) -> torch.Tensor:
+def _image_to_tensor(image, defer: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PIL image -> (C,H,W) float32 in [0,1] (base.py:143-164: 16-bit modes / 65535,
-    mode F as is, RGBA -> RGB, everything else uint8 / 255)."""
+    mode F as is, RGBA -> RGB, everything else uint8 / 255).
+    `defer=True`: 8- and 16-bit images come back as their own SAMPLES -- a (C,H,W) uint8 / uint16 view of PIL's (H,W,C) array, no
+    transposing, no arithmetic -- and the division waits for `_samples_to_float` (host) or pbr_unpack_image (device).  `out`: a 1-D
+    uint8 tensor of exactly the samples' size (the loader passes a slice of its page-locked block): the samples are put there."""
     if image.mode in ("I", "I;16", "I;16B", "I;16L", "I;16N"):
-        arr = np.array(image, dtype=np.uint16).astype(np.float32)
-        return (torch.from_numpy(arr) / 65535.0).unsqueeze(0)
+        arr = np.array(image, dtype=np.uint16)
+        if defer:
+            return _samples_tensor(arr, out)
+        return (torch.from_numpy(arr.astype(np.float32)) / 65535.0).unsqueeze(0)
     if image.mode == "F":
         return torch.from_numpy(np.array(image, dtype=np.float32)).unsqueeze(0)
     if image.mode == "RGBA":
@@ -78,8 +83,45 @@ def _image_to_tensor(image) -> torch.Tensor:
     arr = np.array(image)
     if arr.ndim == 2:
         arr = arr[:, :, None]
+    if defer and arr.dtype == np.uint8:
+        return _samples_tensor(arr, out)
     t = torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1)))
     return t.to(torch.float32).div(255) if t.dtype == torch.uint8 else t.to(torch.float32)
+
+
+def _samples_tensor(arr: np.ndarray, out: Optional[torch.Tensor]) -> torch.Tensor:
+    """(H,W) or (H,W,C) samples -> the (C,H,W) VIEW of them as a tensor; copied into `out` first when it has their size."""
+    if out is not None and out.dtype == torch.uint8 and out.dim() == 1 and out.numel() == arr.nbytes and out.is_contiguous():
+        np.copyto(out.numpy().view(arr.dtype).reshape(arr.shape), arr)
+        t = out.view(torch.uint16 if arr.dtype == np.uint16 else torch.uint8).view(arr.shape)
+    else:
+        t = torch.from_numpy(arr)
+    return t.unsqueeze(0) if t.dim() == 2 else t.permute(2, 0, 1)
+
+
+def _samples_to_float(t: torch.Tensor) -> torch.Tensor:
+    """The arithmetic `_image_to_tensor(image, defer=True)` left out, on the host, exactly as base.py:143-164 would have done it."""
+    if t.dtype == torch.uint8:
+        return t.contiguous().to(torch.float32).div(255)
+    return t.to(torch.float32) / 65535.0
+
+
+class ImageMap:
+    """A PIL image the loader's worker threads already turned into a tensor (io.py): float (C,H,W), or -- conversion deferred --
+    the image's samples (`_image_to_tensor(image, defer=True)`).  Filed into a material like the image itself."""
+    __slots__ = ("tensor",)
+
+    def __init__(self, tensor: torch.Tensor):
+        self.tensor = tensor
+
+
+# Whether maps that come from image files stay as SAMPLES (and a normal map undecoded) until the first operation that needs floats:
+# None = when a ROCm device is there to do it on arrival; True / False force it (tests of the host side run with True).
+DEFER_IMAGE_DECODE: Optional[bool] = None
+
+
+def _defer_images() -> bool:
+    return torch.cuda.is_available() if DEFER_IMAGE_DECODE is None else bool(DEFER_IMAGE_DECODE)
 
 
 def _through_device(t: torch.Tensor, fn):
@@ -201,8 +243,20 @@ class MaterialBase:
         """A map of this material sits on another device than the one it is handed out on."""
         return any(t is not None and t.device != self.device for t in self._raw.values())
 
+    def _has_pending(self) -> bool:
+        """Some map is not yet what the reference's dict would hold: still an image's samples, or a normal map still undecoded."""
+        return bool(self.__dict__.get("_raw_normal")) or any(F_.is_encoded(t) for t in self._raw.values())
+
+    def _samples_on_host(self):
+        """Maps that are still an image's samples become float32 where they are (the host): base.py:143-164's arithmetic."""
+        store = self._raw
+        for name, t in store.items():
+            if F_.is_encoded(t):
+                store[name] = _samples_to_float(t)
+
     def _bring_home(self):
         store, home = self._raw, self.device
+        self._samples_on_host()
         if self.__dict__.get("_raw_normal"):
             self.__dict__["_raw_normal"] = False
             store["normal"] = self._process_normal_map(store["normal"])
@@ -211,11 +265,13 @@ class MaterialBase:
                 store[name] = F_.to_host(t, home) if home.type == "cpu" else t.to(home)
 
     def _resident(self, keep: bool = True) -> dict:
-        """name -> tensor on the compute device for every map that is present.  Maps that are still on the host travel in ONE
-        copy (functional.upload_packed; a deferred normal map first, its decoded form written behind the others so that the
-        material is one dense block of planes).  `keep=True`: the device tensors become the material's maps (the operation that
-        asked is about to replace them anyway); `keep=False` (CookTorranceBRDF): host maps stay the material's maps -- the
-        reference re-reads them every call -- except a deferred normal, whose decoded form is the map from now on."""
+        """name -> float tensor on the compute device for every map that is present.  Maps that are still on the host travel in ONE
+        copy (functional.upload_packed): maps that are still an image's samples go as samples and become float32 on arrival, the
+        normal map decoded in the same pass; a float normal map whose decode was deferred goes first, its decoded form written
+        behind the others -- either way the material ends up as one dense block of planes.  `keep=True`: the device tensors become
+        the material's maps (the operation that asked is about to replace them anyway); `keep=False` (CookTorranceBRDF): host maps
+        stay the material's maps -- the reference re-reads them every call -- except maps nobody can have seen yet (samples, a
+        deferred normal), whose float form on the device is the map from now on."""
         self.materialize_blend()
         d, store = self.__dict__, self._raw
         compute = _compute_device(self.device)
@@ -223,17 +279,23 @@ class MaterialBase:
         away = [k for k in names if store[k].device != compute]
         out = {k: store[k] for k in names}
         pending = bool(d.get("_raw_normal"))
+        unseen = [k for k in away if F_.is_encoded(store[k])]
         if away:
             grads = [k for k in away if store[k].requires_grad]
             for k in grads:
                 out[k] = store[k].to(compute)                    # differentiable copy, on its own
             plain = [k for k in away if k not in grads]
-            if pending and "normal" in plain:                    # raw normal first: everything behind it is one dense block
+            in_flight = pending and "normal" in plain
+            as_samples = in_flight and F_.is_encoded(store["normal"])
+            if in_flight and not as_samples:                     # raw float normal first: everything behind it is one dense block
                 plain = ["normal"] + [k for k in plain if k != "normal"]
             if plain:
-                views, block = F_.upload_packed([store[k] for k in plain], compute, tail_planes=3 if pending and "normal" in plain else 0)
+                views, block = F_.upload_packed([store[k] for k in plain], compute, tail_planes=3 if in_flight and not as_samples else 0,
+                                                encoded_normal=plain.index("normal") if as_samples else None)
                 out.update(zip(plain, views))
-                if pending and "normal" in plain and block is not None:
+                if as_samples:
+                    pending = False
+                elif in_flight and block is not None:
                     out["normal"] = F_._decode_normal_raw(out["normal"], out=block[-3:])[0]
                     pending = False
         if pending:
@@ -241,9 +303,8 @@ class MaterialBase:
         if d.get("_raw_normal"):
             d["_raw_normal"] = False
             store["normal"] = out["normal"]
-        if keep:
-            for k in away:
-                store[k] = out[k]
+        for k in (away if keep else unseen):
+            store[k] = out[k]
         return out
 
     def materialize_blend(self):
@@ -277,18 +338,24 @@ class MaterialBase:
             t = value.to(self.device)
         elif isinstance(value, np.ndarray):
             t = torch.from_numpy(value).float().to(self.device)
-        elif _is_image(value):
-            t = _image_to_tensor(value).to(self.device)
-            fresh = True
+        elif _is_image(value) or isinstance(value, ImageMap):
+            # base.py:143-164 converts and base.py:191-242 decodes at assignment.  A map that comes out of an image file lives on the
+            # host and nobody can look at it but through this material: it is stored as loaded -- the image's own samples, a normal map
+            # undecoded -- and becomes float32 on the device together with the first operation that uploads the material (a quarter of
+            # the bytes on the way, no conversion on the host), or on the host when somebody reads it first.
+            fresh = self.device.type == "cpu" and _defer_images()
+            t = value.tensor if isinstance(value, ImageMap) else _image_to_tensor(value, defer=fresh)
+            if F_.is_encoded(t) and not fresh:
+                t = _samples_to_float(t)
+            fresh = fresh and t.dim() == 3
+            if not F_.is_encoded(t):
+                t = t.to(self.device)
         else:  # pragma: no cover  (guarded by _is_map_value)
             raise TypeError(f"Unsupported image type: {type(value)}. Supported types are PIL.Image.Image, "
                             "np.ndarray, and torch.FloatTensor.")
         if name == "normal":
             self.__dict__["_raw_normal"] = False
-            if fresh and t.device.type == "cpu" and t.dim() == 3 and torch.cuda.is_available():
-                # base.py:191-242 decodes at assignment.  A map freshly decoded from an image file lives on the host and nobody
-                # can look at it but through this material: it is stored as loaded, and decoded on the device together with the
-                # first operation that uploads the material (or when somebody reads it) -- one transfer less in each direction.
+            if fresh:
                 if t.shape[0] not in (2, 3):
                     raise ValueError("Normal map must have 2 or 3 channels.")
                 self.__dict__["_raw_normal"] = True
@@ -419,12 +486,13 @@ class MaterialBase:
         repeat likewise."""
         if num_tiles <= 0:                 # upstream: map.repeat(1, 0, 0) -> empty maps; a negative count is torch's RuntimeError
             self.materialize_tile()
+            self._samples_on_host()
             store = self._raw
             for name, t in store.items():
                 if t is not None:
                     store[name] = t.repeat(*((1,) * (t.dim() - 2) + (num_tiles, num_tiles)))
             return self
-        if lazy or self._is_away():
+        if lazy or self._is_away() or self._has_pending():      # maps nobody has seen yet: the repeat waits with them
             ny, nx = self.lazy_tile
             object.__setattr__(self, "_lazy_tile", (ny * num_tiles, nx * num_tiles))
             return self
@@ -447,6 +515,7 @@ class MaterialBase:
         if (ny, nx) != (1, 1):
             object.__setattr__(self, "_lazy_tile", (1, 1))
             self.materialize_blend()
+            self._samples_on_host()
             if self.__dict__.get("_raw_normal"):
                 self._bring_home_normal()
             store = self._raw
@@ -458,6 +527,7 @@ class MaterialBase:
     def clone(self):
         """Deep copy: tensors cloned, flags copied (base.py:880-912)."""
         self.materialize_blend()          # a pending lazy blend is carried out first: the copy must not blend again
+        self._samples_on_host()
         if self.__dict__.get("_raw_normal"):
             self._bring_home_normal()
         new = copy.copy(self)

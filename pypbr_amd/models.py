@@ -141,9 +141,10 @@ class CookTorranceBRDF(BRDFModel):
             # package is read through its raw store: attribute access would materialise a pending tile(n, lazy=True),
             # which this call hands to the kernel as wrap-around addressing instead.
             store = material.__dict__.get("_store") if isinstance(material, MaterialBase) else None
-            if store is not None and material.__dict__.get("_raw_normal"):
-                # a normal map whose decode was deferred (materials.py, _ingest): the whole material goes up in one transfer and the
-                # normal is decoded on arrival; its decoded form stays the material's map, the others are re-read next call as ever
+            if store is not None and material._has_pending():
+                # maps nobody has seen yet (materials.py, _ingest: an image's samples, a normal map undecoded): the whole material goes up
+                # in one transfer and becomes float / decoded on arrival; those forms stay the material's maps, the others are re-read
+                # next call as ever
                 store = {**store, **material._resident(keep=False)}
 
             def probe(name):

@@ -623,3 +623,34 @@ def test_upload_packed_layout_on_the_host():
     mixed, none = F.upload_packed([a, torch.rand(1, 3, 5, generator=g).half()], "cpu")
     assert none is None and mixed[1].dtype == torch.float16 and mixed[1].data_ptr() % 256 == 0 and torch.equal(mixed[0], a)
     assert F.upload_packed([], "cpu") == ([], None)
+
+
+def test_image_maps_kept_as_samples_decode_on_the_host_exactly_like_upstream(monkeypatch):
+    """materials.DEFER_IMAGE_DECODE: a map that comes out of an image keeps the image's own samples (a (C,H,W) view of PIL's (H,W,C) array)
+    until somebody needs floats; read on the host, it is base.py:143-164's arithmetic, bit for bit -- all 256 / 65 536 sample values."""
+    from PIL import Image
+    import pypbr_amd.materials as M
+    rng = np.random.default_rng(11)
+    rgb = np.arange(256, dtype=np.uint8).repeat(3 * 12).reshape(-1)[rng.permutation(256 * 36)].reshape(32, 96, 3)
+    deep = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    grey = rng.integers(0, 256, size=(32, 96), dtype=np.uint8)
+    images = dict(albedo=Image.fromarray(rgb, "RGB"), roughness=Image.fromarray(grey, "L"), height=Image.fromarray(deep))
+    want = {k: M._image_to_tensor(v) for k, v in images.items()}
+    assert torch.equal(want["albedo"], torch.from_numpy(rgb.transpose(2, 0, 1).copy()).float() / 255)
+    assert torch.equal(want["height"], (torch.from_numpy(deep.astype(np.float32)) / 65535.0).unsqueeze(0))
+    monkeypatch.setattr(M, "DEFER_IMAGE_DECODE", True)
+    m = M.BasecolorMetallicMaterial(albedo=images["albedo"], roughness=images["roughness"])
+    m.height = M.ImageMap(M._image_to_tensor(images["height"], defer=True))            # what the loader's worker threads hand over
+    assert m._has_pending() and {k: v.dtype for k, v in m._raw.items()} == {"albedo": torch.uint8, "roughness": torch.uint8, "height": torch.uint16}
+    assert m.size == (32, 96) and m._raw["albedo"].shape == (3, 32, 96) and not m._is_away()
+    m.tile(2)
+    assert m.lazy_tile == (2, 2) and m._has_pending()          # nobody has seen the maps: the repeat waits with them
+    maps = m._maps
+    assert not m._has_pending() and m.lazy_tile == (1, 1)
+    assert torch.equal(maps["albedo"], want["albedo"].repeat(1, 2, 2)) and torch.equal(maps["roughness"], want["roughness"].repeat(1, 2, 2))
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in maps.values())
+    c = M.BasecolorMetallicMaterial(albedo=images["albedo"], height=images["height"]).clone()
+    assert not c._has_pending() and torch.equal(c._raw["height"], want["height"]) and torch.equal(c._raw["albedo"], want["albedo"])
+    monkeypatch.setattr(M, "DEFER_IMAGE_DECODE", False)        # no deferral: floats at assignment, as before
+    e = M.BasecolorMetallicMaterial(albedo=images["albedo"], height=M.ImageMap(M._image_to_tensor(images["height"], defer=True)))
+    assert not e._has_pending() and torch.equal(e._raw["albedo"], want["albedo"]) and torch.equal(e._raw["height"], want["height"])

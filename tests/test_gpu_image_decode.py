@@ -1,0 +1,244 @@
+"""Maps that come out of image files travel to the device as the image's own SAMPLES and become float32 there (pbr_unpack_image;
+/root/reference/pypbr/materials/base.py:143-164 `_to_tensor`, and :191-242 behind it for a normal map).  The bar is bit-exactness:
+every possible sample value, every layout, against the host arithmetic the reference performs -- and the materials built either way
+must render the same image bit for bit."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+VIEW, LIGHT, INTEN = torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0])
+
+
+def _host_float(samples: torch.Tensor) -> torch.Tensor:
+    """base.py:143-164 on a (C,H,W) tensor of samples: torchvision's to_tensor (/ 255) or the 16-bit branch (/ 65535.0)."""
+    if samples.dtype == torch.uint8:
+        return samples.contiguous().to(torch.float32).div(255)
+    return torch.from_numpy(samples.numpy().astype(np.float32)) / 65535.0
+
+
+def _unpack(samples_chw: torch.Tensor, decode_normal=False):
+    """Through the C ABI the way upload_packed does it: the dense array behind the view goes up as bytes, strides in samples."""
+    from pypbr_amd import functional as F
+    dense, strides = F._dense_samples(samples_chw)
+    dev = dense.cuda()
+    C, H, W = samples_chw.shape
+    out = torch.empty((3 if decode_normal else C, H, W), dtype=torch.float32, device="cuda")
+    return F.unpack_image(dev, 8 * samples_chw.element_size(), strides, (C, H, W), out, decode_normal=decode_normal)
+
+
+@pytest.mark.parametrize("channels,width,layout", [(1, 256, "hwc"), (3, 256, "hwc"), (3, 250, "hwc"), (2, 64, "hwc"), (4, 64, "hwc"),
+                                                   (3, 256, "chw"), (1, 37, "chw")])
+def test_every_uint8_sample_value_in_every_layout(channels, width, layout):
+    g = torch.Generator().manual_seed(channels * 1000 + width)
+    height = 24
+    base = torch.arange(256, dtype=torch.uint8).repeat(-(-channels * height * width // 256))[:channels * height * width]
+    base = base[torch.randperm(base.numel(), generator=g)]
+    if layout == "hwc":
+        samples = base.view(height, width, channels).permute(2, 0, 1)            # what _image_to_tensor(defer=True) returns
+    else:
+        samples = base.view(channels, height, width)
+    assert len(torch.unique(samples)) == 256
+    got = _unpack(samples).cpu()
+    assert torch.equal(got, _host_float(samples))
+
+
+@pytest.mark.parametrize("width", [256, 255])
+def test_every_uint16_sample_value(width):
+    arr = np.arange(65536, dtype=np.uint16)
+    arr = np.concatenate([arr, arr[:(-65536) % width]]).reshape(-1, width)
+    samples = torch.from_numpy(arr).unsqueeze(0)
+    got = _unpack(samples).cpu()
+    assert torch.equal(got, _host_float(samples))
+    assert got.max().item() == 1.0 and got.min().item() == 0.0
+
+
+@pytest.mark.parametrize("channels,width,dtype", [(3, 128, np.uint8), (3, 126, np.uint8), (2, 128, np.uint8), (2, 50, np.uint8), (3, 64, np.uint16)])
+def test_normal_map_decoded_in_the_same_pass_equals_decode_of_the_float_map(channels, width, dtype):
+    """base.py:191-242 behind the conversion: the same bits as pbr_decode_normal of the float map the host would have made (samples
+    are never negative: always decoded).  Includes the degenerate samples: (0,0,0), mid-grey 127/128, (255,255,255)."""
+    from pypbr_amd import functional as F
+    rng = np.random.default_rng(channels * 7 + width)
+    hi = np.iinfo(dtype).max
+    arr = rng.integers(0, hi + 1, size=(40, width, channels)).astype(dtype)
+    arr[0, :4] = 0
+    arr[0, 4:8] = hi
+    arr[1, :4] = hi // 2
+    arr[1, 4:8] = hi // 2 + 1
+    samples = torch.from_numpy(arr).permute(2, 0, 1)
+    got = _unpack(samples, decode_normal=True).cpu()
+    want = F.decode_normal(_host_float(samples).cuda()).cpu()
+    assert got.shape == (3, 40, width) and torch.equal(got, want)
+    assert torch.isfinite(got).all()
+
+
+def _load(defer, folder="tiles"):
+    import pypbr_amd.materials as M
+    from pypbr_amd.io import load_material_from_folder
+    before = M.DEFER_IMAGE_DECODE
+    M.DEFER_IMAGE_DECODE = defer
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return load_material_from_folder(os.path.join(GOLDEN, folder), preferred_workflow="metallic")
+    finally:
+        M.DEFER_IMAGE_DECODE = before
+
+
+def _maps_eagerly(folder="tiles"):
+    """The maps as base.py:143-164 + :191-242 make them at assignment: float conversion on the host, the normal map decoded (staged through
+    the device, float in / float out)."""
+    import pypbr_amd.materials as M
+    from pypbr_amd.io import load_material_from_folder
+    before = M.DEFER_IMAGE_DECODE
+    M.DEFER_IMAGE_DECODE = False
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            material = load_material_from_folder(os.path.join(GOLDEN, folder), preferred_workflow="metallic")
+        assert not material._has_pending() and all(t.dtype == torch.float32 and t.device.type == "cpu" for t in material._raw.values())
+        return material
+    finally:
+        M.DEFER_IMAGE_DECODE = before
+
+
+def test_loaded_material_holds_samples_until_needed_and_arrives_bit_identical(monkeypatch):
+    from pypbr_amd import functional as F
+    eager = _maps_eagerly()
+    material = _load(None)                                     # the default on a box with a device: deferred
+    raw = material._raw
+    assert material.device.type == "cpu" and material._has_pending()
+    assert {k: v.dtype for k, v in raw.items()} == {"albedo": torch.uint8, "normal": torch.uint8, "roughness": torch.uint8,
+                                                     "height": torch.uint16, "metallic": torch.uint8}
+    sent = []
+    up = F.upload_packed
+    monkeypatch.setattr(F, "upload_packed", lambda ts, *a, **k: (sent.append(sum(t.numel() * t.element_size() for t in ts)), up(ts, *a, **k))[1])
+    resident = material._resident(keep=True)
+    assert sent == [1024 * 1024 * (3 + 3 + 1 + 2 + 1)]         # ONE transfer of 10 bytes per texel (floats: 36)
+    assert not material._has_pending() and all(t.is_cuda and t.dtype == torch.float32 for t in material._raw.values())
+    assert len({t.untyped_storage().data_ptr() for t in resident.values()}) == 1
+    planes = sorted((t.data_ptr(), t.shape[0]) for t in resident.values())
+    assert all(a + 4 * 1024 * 1024 * n == b for (a, n), (b, _) in zip(planes, planes[1:]))        # one dense block of planes
+    for k, v in eager._raw.items():
+        assert torch.equal(resident[k].cpu(), v), k
+
+
+def test_example_statements_render_the_same_bits_either_way(golden):
+    from pypbr_amd.models import CookTorranceBRDF
+    brdf = CookTorranceBRDF(light_type="point")
+    images = []
+    for material in (_maps_eagerly(), _load(True)):
+        material.resize((512, 512)).tile(2)
+        images.append(brdf(material, VIEW, LIGHT, INTEN, 1.0))
+    assert torch.equal(images[0], images[1])
+    z = golden("example")
+    assert np.abs(images[1][:, 448:576, 448:576].numpy() - z["example_crop"]).max() <= 1e-5
+
+
+def test_render_straight_after_load_and_tile_without_a_resize():
+    """No resize in between: the repeat is recorded with the samples, the BRDF uploads once, and the float forms stay the maps."""
+    from pypbr_amd import functional as F
+    from pypbr_amd.models import CookTorranceBRDF
+    brdf = CookTorranceBRDF(light_type="directional")
+    eager = _maps_eagerly()
+    want = brdf(eager.tile(2), VIEW, LIGHT, INTEN)
+    material = _load(True).tile(2)
+    assert material._has_pending() and material.lazy_tile == (2, 2) and material.size == (2048, 2048)
+    got = brdf(material, VIEW, LIGHT, INTEN)
+    assert torch.equal(got, want)
+    assert not material._has_pending() and all(t.is_cuda for t in material._raw.values()) and material.lazy_tile == (2, 2)
+    calls = []
+    up = F.upload_packed
+    F.upload_packed = lambda *a, **k: (calls.append(1), up(*a, **k))[1]
+    try:
+        assert torch.equal(brdf(material, VIEW, LIGHT, INTEN), want)
+    finally:
+        F.upload_packed = up
+    assert calls == []                                          # the second evaluation reads the device-resident maps in place
+
+
+def test_reading_a_map_first_converts_on_the_host_like_upstream():
+    eager = _maps_eagerly()
+    material = _load(True)
+    albedo = material.albedo                                    # somebody looks: everything comes out as base.py would hold it
+    assert albedo.dtype == torch.float32 and albedo.device.type == "cpu" and albedo.is_contiguous() and not material._has_pending()
+    for k, v in eager._raw.items():
+        assert torch.equal(material._maps[k], v), k
+    clone = _load(True).clone()
+    assert not clone._has_pending() and all(torch.equal(clone._maps[k], v) for k, v in eager._raw.items())
+
+
+def test_image_assigned_next_to_float_maps_travels_with_them_in_one_copy(monkeypatch):
+    """A mixed material: two float tensors and three PIL images.  Still one transfer, one dense block, the same bits."""
+    import pypbr_amd.materials as M
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    rough, metal = torch.rand(1, 64, 96, generator=g), torch.rand(1, 64, 96, generator=g)
+    rng = np.random.default_rng(3)
+    pil = {k: Image.fromarray(rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8), "RGB") for k in ("albedo", "normal")}
+    height = Image.fromarray(rng.integers(0, 65536, size=(64, 96)).astype(np.uint16))
+    assert height.mode in ("I;16", "I;16L", "I;16N", "I;16B")
+    monkeypatch.setattr(M, "DEFER_IMAGE_DECODE", True)
+    material = M.BasecolorMetallicMaterial(albedo=pil["albedo"], normal=pil["normal"], roughness=rough, metallic=metal, height=height)
+    assert material._has_pending() and material._raw["height"].dtype == torch.uint16
+    calls = []
+    up = F.upload_packed
+    monkeypatch.setattr(F, "upload_packed", lambda *a, **k: (calls.append(1), up(*a, **k))[1])
+    resident = material._resident(keep=True)
+    assert calls == [1] and len({t.untyped_storage().data_ptr() for t in resident.values()}) == 1
+    assert torch.equal(resident["roughness"].cpu(), rough) and torch.equal(resident["metallic"].cpu(), metal)
+    assert torch.equal(resident["albedo"].cpu(), M._image_to_tensor(pil["albedo"]))
+    assert torch.equal(resident["height"].cpu(), M._image_to_tensor(height))
+    assert torch.equal(resident["normal"].cpu(), F.decode_normal(M._image_to_tensor(pil["normal"]).cuda()).cpu())
+    out = material.resize((32, 48))
+    assert all(t.shape[-2:] == (32, 48) and t.is_cuda for t in out._raw.values())
+
+
+def test_blend_example_with_sample_maps_equals_the_eager_path():
+    """examples/example_blend.py:14-32 with both materials arriving as samples."""
+    from pypbr_amd import blending as B
+    from pypbr_amd.models import CookTorranceBRDF
+    brdf = CookTorranceBRDF(light_type="point")
+    images = []
+    for load in (_maps_eagerly, lambda folder: _load(True, folder)):
+        m1, m2 = load("tiles"), load("rocks")
+        blended, mask = B.HeightBlend(blend_width=0.1, shift=-0.5)(m1, m2)
+        blended.resize((256, 256)).tile(2)
+        images.append((brdf(blended, VIEW, LIGHT, INTEN, 1.0), mask))
+    assert torch.equal(images[0][0], images[1][0]) and torch.equal(images[0][1], images[1][1])
+
+
+def test_loader_decodes_into_one_page_locked_block_that_goes_up_as_it_is(monkeypatch):
+    """io.load_material_from_folder: the workflow is chosen from the file names, only its maps are decoded, and their samples sit in ONE
+    page-locked allocation laid out for the transfer -- upload_packed sends that block without a staging copy."""
+    from pypbr_amd import functional as F
+    eager = _maps_eagerly()
+    material = _load(True)
+    raw = material._raw
+    assert set(raw) == {"albedo", "normal", "roughness", "height", "metallic"}          # diffuse.png / specular.png: not this workflow's
+    assert len({t.untyped_storage().data_ptr() for t in raw.values()}) == 1 and all(t.is_pinned() for t in raw.values())
+    assert raw["albedo"].untyped_storage().nbytes() == 1024 * 1024 * (3 + 3 + 1 + 2 + 1)
+    copies, sent = [], []
+    stage_copy, arena = F._stage_copy, F._aligned_arena
+    monkeypatch.setattr(F, "_stage_copy", lambda *a, **k: (copies.append(1), stage_copy(*a, **k))[1])
+    monkeypatch.setattr(F, "_aligned_arena", lambda n, d: (sent.append(n), arena(n, d))[1])
+    resident = material._resident(keep=True)
+    assert copies == [] and sent == [1024 * 1024 * (10 + 4 * 9)]                        # samples + nine float planes, nothing else
+    for k, v in eager._raw.items():
+        assert torch.equal(resident[k].cpu(), v), k
+    # the specular workflow of the same folder: the other albedo, the other second map
+    import pypbr_amd.materials as M
+    from pypbr_amd.io import load_material_from_folder
+    monkeypatch.setattr(M, "DEFER_IMAGE_DECODE", True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        spec = load_material_from_folder(os.path.join(GOLDEN, "tiles"), preferred_workflow="specular")
+    assert type(spec).__name__ == "DiffuseSpecularMaterial" and set(spec._raw) == {"albedo", "normal", "roughness", "height", "specular"}
+    got = spec._resident(keep=True)
+    assert torch.equal(got["specular"].cpu(), M._image_to_tensor(Image.open(os.path.join(GOLDEN, "tiles", "specular.png")).convert("RGB")))
+    assert torch.equal(got["albedo"].cpu(), M._image_to_tensor(Image.open(os.path.join(GOLDEN, "tiles", "diffuse.png")).convert("RGB")))

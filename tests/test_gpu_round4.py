@@ -60,8 +60,10 @@ def test_example_brdf_statements_are_one_upload_and_one_download(golden, monkeyp
 
 
 def test_loaded_material_without_any_operation_renders_with_one_upload(monkeypatch):
-    """load -> render: the deferred normal decode rides on the render's own upload; the decoded normal stays on the device,
-    the other maps are re-read from the host on every call as the reference re-reads them."""
+    """load -> render: the maps nobody has seen yet (an image's samples, the normal map undecoded) ride on the render's own upload and
+    their float / decoded forms stay on the device; host maps somebody may have edited are re-read on every call, as the reference
+    re-reads them."""
+    import pypbr_amd.materials as M
     from pypbr_amd import functional as F
     from pypbr_amd.materials import BasecolorMetallicMaterial
     from pypbr_amd.models import CookTorranceBRDF
@@ -69,15 +71,24 @@ def test_loaded_material_without_any_operation_renders_with_one_upload(monkeypat
     up = F.upload_packed
     monkeypatch.setattr(F, "upload_packed", lambda ts, *a, **k: (ups.append(len(ts)), up(ts, *a, **k))[1])
     material = _load("rocks")
+    assert material._has_pending()
     brdf = CookTorranceBRDF("point")
     first = brdf(material, VIEW, LIGHT, INTEN, 1.0)
-    assert ups == [len(material._raw)] and material._raw["normal"].is_cuda and not material._raw["albedo"].is_cuda
+    assert ups == [len(material._raw)] and all(t.is_cuda and t.dtype == torch.float32 for t in material._raw.values()) and not material._has_pending()
     second = brdf(material, VIEW, LIGHT, INTEN, 1.0)
-    assert ups[1] == 3 and torch.equal(first, second)       # albedo, roughness, metallic (what the evaluation reads); height is not uploaded
-    # the same maps assigned as tensors (decoded at assignment, as upstream) give the same image
+    assert len(ups) == 1 and torch.equal(first, second)     # read in place
+    # the same maps assigned as tensors (decoded at assignment, as upstream) give the same image, and are uploaded on every call:
+    # albedo, normal, roughness, metallic -- what the evaluation reads
     eager = BasecolorMetallicMaterial(albedo=material.albedo, normal=material.normal, roughness=material.roughness, metallic=material.metallic)
     assert (brdf(eager, VIEW, LIGHT, INTEN, 1.0) - first).abs().max().item() <= 2e-6
+    assert (brdf(eager, VIEW, LIGHT, INTEN, 1.0) - first).abs().max().item() <= 2e-6
+    assert ups[1:] == [4, 4] and all(t.device.type == "cpu" for t in eager._raw.values())
     assert material.normal.device.type == "cpu" and abs(float(material.normal.norm(dim=0).mean()) - 1.0) < 1e-5
+    # a loaded material whose images were converted at assignment (no deferral): its float normal map was decoded then
+    monkeypatch.setattr(M, "DEFER_IMAGE_DECODE", False)
+    plain = _load("rocks")
+    assert not plain._has_pending() and all(t.device.type == "cpu" and t.dtype == torch.float32 for t in plain._raw.values())
+    assert torch.equal(brdf(plain, VIEW, LIGHT, INTEN, 1.0), first)
 
 
 def test_results_of_material_operations_stay_on_the_device_until_read():

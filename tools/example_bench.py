@@ -144,6 +144,7 @@ def main(argv=None):
         rows = [(name, statistics.median(r[i][1] for r in later)) for i, (name, _) in enumerate(later[0])]
         rec = {"example": example, "statements": "examples/example_%s.py" % example, "resize": args.size, "image": list(color.shape), "repeats": args.repeat,
                "hip_ms": {name: round(ms, 3) for name, ms in rows}, "hip_total_ms": round(sum(ms for name, ms in rows[:-1]), 3),
+               "hip_ms_each_repeat": {name: [round(r[i][1], 3) for r in later] for i, (name, _) in enumerate(later[0])},
                "hip_total_ms_first_run": round(first_total, 3), "transfers": moved}
         if not args.no_cpu:
             ref, crow = run_oracle(example, args.size, cores)

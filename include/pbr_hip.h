@@ -83,7 +83,7 @@ enum {
     PBR_TUNE_INTERLEAVE = 7,            /* experiment: materials of a batch interleaved workgroup by workgroup */
     PBR_TUNE_SCALAR_BASE = 8,           /* scalar plane addresses: 0 never, 1 rule (single materials), 2 whenever the launch allows them */
     PBR_TUNE_MAX_VEC = 9,               /* at most this many pixels per lane (8 default; 1 = the one-pixel kernels everywhere) */
-    PBR_TUNE_RESIZE_ROWS = 10,          /* output rows per workgroup of the resize kernels (0 = rule) */
+    PBR_TUNE_RESIZE_ROWS = 10,          /* output rows per workgroup of the resize kernels (0 = rule); the gradient's register gather: 4 = four rows per lane, 7 = eight rows with the rows' weights looked up one by one instead of read from the per-band matrices */
     PBR_TUNE_BWD_RUN = 11,              /* rounds of the streamed backward kernel for fp16 maps with one light (-1 = rule, 0 = the one-tile kernels) */
     PBR_TUNE_RESIZE_XCD = 12,           /* tile order of the resize kernel: 1 = XCD-contiguous chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many */
     PBR_TUNE_BWD_WIDE = 13,             /* streamed backward with 16-byte memory instructions: -1 = rule (off), 0 = the 4-byte form, 1 = wherever legal */

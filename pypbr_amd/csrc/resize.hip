@@ -290,7 +290,7 @@ __device__ __forceinline__ void width_to_global_quads(const float *mid, float *d
 // index k the first upstream index that reads it, their number and the normalised weights, as resize_backward_tables_kernel
 // wrote them to global memory -- instead of derived from the filter: "dst" is the gradient of the resize's input, "src" the
 // upstream gradient.  Phase 0 copies the tile's slices of the tables into the same LDS arrays; phases 1 and 2 do not change.
-struct StripTables { const int *lo_x, *cnt_x, *lo_y, *cnt_y; const float *w_x, *w_y; int nx, ny, h_src; };
+struct StripTables { const int *lo_x, *cnt_x, *lo_y, *cnt_y; const float *w_x, *w_y; int nx, ny, h_src; const float *band; };
 
 template <bool TABLES, bool QUADS>
 __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_out,
@@ -438,11 +438,38 @@ __device__ __forceinline__ void backward_table_entry(int *__restrict__ lo_out, i
 }
 
 // both axes in one launch: workgroups [0, groups_y) write the row tables, the others the column tables
+// `band` != nullptr: besides, per BAND of kBandRows consecutive gradient rows (what one wave of resize_backward_gather_kernel owns), the
+// rows' weights as a dense matrix over the band's union of upstream rows -- record of kBandWords words: [0] first upstream row,
+// [1] number of upstream rows (<= kBandMaxRows), [8 + 8 j + r] weight of upstream row first + j in gradient row r -- so that the
+// gather kernel reads eight wave-uniform weights with one scalar load instead of looking each up through lo / cnt (the look-ups made
+// it scalar-bound: 953 scalar against 752 vector instructions per wave).  A lane reads back only the entries of its own row k; the
+// band's first / last upstream row come from its eight lanes by shuffles.
+constexpr int kBandRows = 8, kBandMaxRows = 16, kBandWords = 8 + kBandRows * kBandMaxRows;
 __global__ __launch_bounds__(256) void resize_backward_tables_kernel(int *__restrict__ lo_y, int *__restrict__ cnt_y, float *__restrict__ wy, int h_out,
                                                                      AxisFilter fh, int *__restrict__ lo_x, int *__restrict__ cnt_x,
-                                                                     float *__restrict__ wx, int w_out, AxisFilter fw, int groups_y) {
-    if ((int)blockIdx.x < groups_y) backward_table_entry(lo_y, cnt_y, wy, h_out, fh, blockIdx.x * 256 + threadIdx.x);
-    else backward_table_entry(lo_x, cnt_x, wx, w_out, fw, (blockIdx.x - groups_y) * 256 + threadIdx.x);
+                                                                     float *__restrict__ wx, int w_out, AxisFilter fw, int groups_y,
+                                                                     float *__restrict__ band) {
+    if ((int)blockIdx.x >= groups_y) {
+        backward_table_entry(lo_x, cnt_x, wx, w_out, fw, (blockIdx.x - groups_y) * 256 + threadIdx.x);
+        return;
+    }
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    backward_table_entry(lo_y, cnt_y, wy, h_out, fh, k);
+    if (band == nullptr) return;
+    const bool live = k < fh.n_in;
+    const int first = live ? lo_y[k] : 0, n = live ? cnt_y[k] : 0;
+    int lo = n > 0 ? first : INT32_MAX, hi = n > 0 ? first + n : 0;
+    for (int o = 1; o < kBandRows; o <<= 1) { lo = min(lo, __shfl_xor(lo, o, 64)); hi = max(hi, __shfl_xor(hi, o, 64)); }
+    if (lo == INT32_MAX) lo = 0;
+    const int rows = min(max(hi - lo, 0), kBandMaxRows);
+    if (k - (int)(threadIdx.x & (kBandRows - 1)) >= fh.n_in) return;        // a band past the last row
+    float *rec = band + (size_t)(k / kBandRows) * kBandWords;
+    const int r = threadIdx.x & (kBandRows - 1);
+    if (r == 0) { reinterpret_cast<int *>(rec)[0] = lo; reinterpret_cast<int *>(rec)[1] = rows; }
+    for (int j = 0; j < kBandMaxRows; ++j) {
+        const int d = lo + j - first;
+        rec[8 + kBandRows * j + r] = d >= 0 && d < n ? wy[(size_t)d * fh.n_in + k] : 0.0f;
+    }
 }
 
 // rows pass: tmp[plane][k][x] = sum_j wy[j][k] g[plane][lo[k] + j][x].  One input row k per workgroup row: lo / cnt / weights are
@@ -697,7 +724,7 @@ static int up2_backward_window(const AxisFilter &f, int n_out) {
 // gradient row one wave-uniform weight (scalar loads) times the four sums.  resize_strip_kernel<true> does the same work through a
 // tile of LDS with three barrier-separated phases and reaches 0.52 of HBM on 4096^2 <- 2048^2; this form has no set-up to amortise.
 // Gather by gradient element, fixed order: deterministic.  The launcher checks W on the host (same float arithmetic).
-template <int W, int R>
+template <int W, int R, bool BAND>
 __global__ __launch_bounds__(64) void resize_backward_gather_kernel(const float *__restrict__ gout, float *__restrict__ gin, int h_in, int w_in, int h_out,
                                                                     int w_out, int groups_x, int groups_y, uint32_t xcd_groups, StripTables tb) {
     uint32_t wg = blockIdx.x;
@@ -730,28 +757,21 @@ __global__ __launch_bounds__(64) void resize_backward_gather_kernel(const float 
         }
     }
     // ---- rows (wave-uniform: scalar loads)
-    int ylo[R], yn[R], y_lo = INT32_MAX, y_hi = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-        const int k = min(r0 + r, h_in - 1);
-        ylo[r] = tb.lo_y[k]; yn[r] = r0 + r < h_in ? min(tb.cnt_y[k], kBwdMaxTaps) : 0;
-        if (yn[r] > 0) { y_lo = min(y_lo, ylo[r]); y_hi = max(y_hi, ylo[r] + yn[r]); }
-    }
     float acc[R][4];
 #pragma unroll
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[r][c] = 0.0f;
     const float *gp = gout + (int64_t)plane * h_out * w_out + i_base;
-    for (int y = y_lo; y < y_hi; ++y) {
+    auto load_row = [&](int y, float g[W]) {
         const float *row = gp + (int64_t)y * w_out;
-        float g[W];
 #pragma unroll
         for (int q = 0; q < W / 4; ++q) {
             const rf4 v = *reinterpret_cast<const rf4 *>(row + 4 * q);       // cached: neighbouring lanes' and rows' windows overlap
             g[4 * q] = v.x; g[4 * q + 1] = v.y; g[4 * q + 2] = v.z; g[4 * q + 3] = v.w;
         }
-        float t[4];
+    };
+    auto width_sums = [&](const float g[W], float t[4]) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float a = wx[c][0] * g[0];
@@ -759,12 +779,43 @@ __global__ __launch_bounds__(64) void resize_backward_gather_kernel(const float 
             for (int j = 1; j < W; ++j) a = fmaf(wx[c][j], g[j], a);
             t[c] = a;
         }
+    };
+    if (BAND) {
+        // the band's record (resize_backward_tables_kernel): first upstream row, their number, eight weights per upstream row
+        static_assert(!BAND || R == kBandRows, "a band is what one wave owns");
+        const float *rec = tb.band + (size_t)(r0 / R) * kBandWords;
+        const int y_lo = reinterpret_cast<const int *>(rec)[0], y_n = reinterpret_cast<const int *>(rec)[1];
+        for (int j = 0; j < y_n; ++j) {
+            float g[W], t[4];
+            load_row(y_lo + j, g);
+            width_sums(g, t);
+            const float *cw = rec + 8 + kBandRows * j;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float cy = cw[r];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(cy, t[c], acc[r][c]);
+            }
+        }
+    } else {
+        int ylo[R], yn[R], y_lo = INT32_MAX, y_hi = 0;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int d = y - ylo[r];
-            const float cy = d >= 0 && d < yn[r] ? tb.w_y[(size_t)d * tb.ny + min(r0 + r, h_in - 1)] : 0.0f;
+            const int k = min(r0 + r, h_in - 1);
+            ylo[r] = tb.lo_y[k]; yn[r] = r0 + r < h_in ? min(tb.cnt_y[k], kBwdMaxTaps) : 0;
+            if (yn[r] > 0) { y_lo = min(y_lo, ylo[r]); y_hi = max(y_hi, ylo[r] + yn[r]); }
+        }
+        for (int y = y_lo; y < y_hi; ++y) {
+            float g[W], t[4];
+            load_row(y, g);
+            width_sums(g, t);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(cy, t[c], acc[r][c]);
+            for (int r = 0; r < R; ++r) {
+                const int d = y - ylo[r];
+                const float cy = d >= 0 && d < yn[r] ? tb.w_y[(size_t)d * tb.ny + min(r0 + r, h_in - 1)] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(cy, t[c], acc[r][c]);
+            }
         }
     }
     float *dp = gin + (int64_t)plane * h_in * w_in + k0;
@@ -792,6 +843,19 @@ static int gather_window(const AxisFilter &f, int n_out) {
         while (lo < n_out) { tap_window(f, lo, xmin, n, c); if (xmin + n > k0) break; ++lo; }
         if (hi < lo) hi = lo;
         while (hi < n_out) { tap_window(f, hi, xmin, n, c); if (xmin > k0 + 3) break; ++hi; }
+        worst = hi - lo > worst ? hi - lo : worst;
+    }
+    return worst;
+}
+
+// The same for the rows of a band: the most upstream rows any kBandRows consecutive gradient rows (starting at a multiple) gather from.
+static int band_window(const AxisFilter &f, int n_out, int rows) {
+    int worst = 0, lo = 0, hi = 0;
+    for (int k0 = 0; k0 < f.n_in; k0 += rows) {
+        int xmin, n; float c;
+        while (lo < n_out) { tap_window(f, lo, xmin, n, c); if (xmin + n > k0) break; ++lo; }
+        if (hi < lo) hi = lo;
+        while (hi < n_out) { tap_window(f, hi, xmin, n, c); if (xmin > k0 + rows - 1) break; ++hi; }
         worst = hi - lo > worst ? hi - lo : worst;
     }
     return worst;
@@ -936,23 +1000,27 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
     const int64_t grid_cols = (int64_t)((w_in + 255) / 256) * ((planes * h_in + kBwdRows - 1) / kBwdRows);
     if (fits(fw) && fits(fh) && grid_rows <= INT32_MAX && grid_cols <= INT32_MAX) {          // table-driven
         const int groups_y = (h_in + 255) / 256, groups_x = (w_in + 255) / 256;
+        // Register-only gather over the tables (round 4, resize_backward_gather_kernel): 4 gradient columns x 8 rows per lane; the rows'
+        // weights from the per-band matrices the tables kernel leaves in the (otherwise unused) pass-to-pass area of the workspace.
+        const bool gather = g_resize_bwd_fused == 1 && w_out >= 16;
+        const int need = gather ? gather_window(fw, w_out) : 0;
+        const int R = g_resize_rows == 4 ? 4 : 8;                     // gradient rows per lane (A/B knob PBR_TUNE_RESIZE_ROWS; 7 = 8 rows, weights looked up per row)
+        const int64_t ggx = (w_in + 255) / 256, ggy = (h_in + R - 1) / R, n_groups = ggx * ggy * planes;
+        const bool gather_ok = gather && need <= 16 && n_groups <= INT32_MAX;
+        const bool banded = gather_ok && R == kBandRows && g_resize_rows != 7 && band_window(fh, h_out, kBandRows) <= kBandMaxRows &&
+                            (size_t)((h_in + kBandRows - 1) / kBandRows) * kBandWords <= (size_t)planes * h_in * w_out;
         hipLaunchKernelGGL(resize_backward_tables_kernel, dim3(groups_y + groups_x), dim3(256), 0, s, lo_y, cnt_y, wy, (int)h_out, fh, lo_x, cnt_x, wx,
-                           (int)w_out, fw, groups_y);
-        // Register-only gather over the tables (round 4, resize_backward_gather_kernel): 4 gradient columns x 8 rows per lane.
-        if (g_resize_bwd_fused == 1 && w_out >= 16) {
-            const int need = gather_window(fw, w_out);
-            const int R = g_resize_rows == 4 ? 4 : 8;                 // gradient rows per lane (A/B knob PBR_TUNE_RESIZE_ROWS)
-            const int64_t ggx = (w_in + 255) / 256, ggy = (h_in + R - 1) / R, n_groups = ggx * ggy * planes;
-            if (need <= 16 && n_groups <= INT32_MAX) {
-                const uint32_t span = 8u << kUpRunLog2;
-                const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
-                const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out};
-                auto fn = R == 4 ? (need <= 8 ? resize_backward_gather_kernel<8, 4> : (need <= 12 ? resize_backward_gather_kernel<12, 4> : resize_backward_gather_kernel<16, 4>))
-                                 : (need <= 8 ? resize_backward_gather_kernel<8, 8> : (need <= 12 ? resize_backward_gather_kernel<12, 8> : resize_backward_gather_kernel<16, 8>));
-                hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, g, gi, (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)ggx, (int)ggy, xcd_groups, tb);
-                const hipError_t e = hipGetLastError();
-                return e == hipSuccess ? PBR_OK : 1000 + (int)e;
-            }
+                           (int)w_out, fw, groups_y, banded ? tmp : static_cast<float *>(nullptr));
+        if (gather_ok) {
+            const uint32_t span = 8u << kUpRunLog2;
+            const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
+            const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out, banded ? tmp : static_cast<const float *>(nullptr)};
+            auto fn = R == 4 ? (need <= 8 ? resize_backward_gather_kernel<8, 4, false> : (need <= 12 ? resize_backward_gather_kernel<12, 4, false> : resize_backward_gather_kernel<16, 4, false>))
+                    : banded ? (need <= 8 ? resize_backward_gather_kernel<8, 8, true> : (need <= 12 ? resize_backward_gather_kernel<12, 8, true> : resize_backward_gather_kernel<16, 8, true>))
+                             : (need <= 8 ? resize_backward_gather_kernel<8, 8, false> : (need <= 12 ? resize_backward_gather_kernel<12, 8, false> : resize_backward_gather_kernel<16, 8, false>));
+            hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, g, gi, (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)ggx, (int)ggy, xcd_groups, tb);
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? PBR_OK : 1000 + (int)e;
         }
         // One pass: the strip kernel with the transposed tables (resize_strip_kernel<true>): a toh x 64 tile of the gradient, the
         // rows pass from global memory into the LDS strip, the columns pass out of it.  3 x 2048^2 gradient -> 4096^2: see DESIGN.md 3.8.
@@ -980,7 +1048,7 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
             const int quads = (g_resize_quads == 2 || (g_resize_quads == 1 && (int64_t)h_in * w_in >= 2 * (int64_t)h_out * w_out)) && w_in % 4 == 0 &&
                               (reinterpret_cast<uintptr_t>(grad_in) & 15u) == 0;
             const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0), quads};
-            const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out};
+            const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out, nullptr};
             auto strip = quads ? resize_strip_kernel<true, true> : resize_strip_kernel<true, false>;
             hipLaunchKernelGGL(strip, dim3((unsigned)n_tiles), dim3(256), lds, s, g, gi, (int)h_in, (int)w_in, (int)w_out, tg, fw, fh, tb);
         } else {                                                                              // two passes through the workspace

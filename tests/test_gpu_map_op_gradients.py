@@ -191,6 +191,15 @@ def test_resize_gradient_one_pass_equals_two_passes(shape, size, antialias):
     gin = torch.full((3, h, w), float("nan"), device="cuda")
     N.check(lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, h, w, ho, wo, int(antialias), ws.data_ptr(), stream))
     assert bool(torch.isfinite(gin).all()) and (gin - ref).abs().max().item() <= 2e-6 * max(1.0, float(ref.abs().max()))
+    # its rows' weights come from per-band matrices the tables kernel prepares (one scalar load per upstream row); looked up per row
+    # instead (PBR_TUNE_RESIZE_ROWS = 7) the sums are the same, bit for bit
+    try:
+        lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, 7)
+        looked_up = torch.full((3, h, w), float("nan"), device="cuda")
+        N.check(lib.pbr_resize_bilinear_backward(gout.data_ptr(), looked_up.data_ptr(), 3, h, w, ho, wo, int(antialias), ws.data_ptr(), stream))
+    finally:
+        lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, 0)
+    assert torch.equal(looked_up, gin)
     x = torch.zeros(1, 3, h, w, dtype=torch.float64, requires_grad=True)
     (TF.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False, antialias=antialias)[0] * gout.cpu().double()).sum().backward()
     assert (ref.cpu().double() - x.grad[0]).abs().max().item() <= 2e-5

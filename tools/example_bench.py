@@ -70,11 +70,11 @@ def run_hip(example, size):
         st = Stages(torch.cuda.synchronize)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            material = st("load (PIL decode, host)", lambda: load_material_from_folder(os.path.join(GOLDEN, "tiles"), preferred_workflow="metallic"))
+            material = st("load (PNG inflate on the host, samples into one page-locked block)", lambda: load_material_from_folder(os.path.join(GOLDEN, "tiles"), preferred_workflow="metallic"))
             if example == "blend":
-                material2 = st("load 2 (PIL decode, host)", lambda: load_material_from_folder(os.path.join(GOLDEN, "rocks"), preferred_workflow="metallic"))
+                material2 = st("load 2 (PNG inflate on the host)", lambda: load_material_from_folder(os.path.join(GOLDEN, "rocks"), preferred_workflow="metallic"))
                 material, mask = st("HeightBlend (2 uploads, mask, blend; mask handed out)", lambda: B.HeightBlend(blend_width=0.1, shift=-0.5)(material, material2))
-        st("resize (upload, normal decode, one launch)" if example == "brdf" else "resize (one launch)", lambda: material.resize((size, size)))
+        st("resize (samples uploaded, unpacked, normal decoded; one resize launch)" if example == "brdf" else "resize (one launch)", lambda: material.resize((size, size)))
         st("tile(2) (recorded)", lambda: material.tile(2))
         brdf = CookTorranceBRDF(light_type="point")
         color = st("render + download of the image", lambda: brdf(material, VIEW, LIGHT, INTEN, 1.0))

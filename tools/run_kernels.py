@@ -164,6 +164,12 @@ if want("map_ops"):
            timed(lambda: lib.pbr_decode_normal(n_late.data_ptr(), o3.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
     report("map_ops decode_normal in place (the map is signed after the first call: the probe settles the flag, the flag pass leaves at once, the transform copies 3 planes in, 3 out)", "decode_normal_kernel", 24 * PX,
            timed(lambda: lib.pbr_decode_normal(n_inplace.data_ptr(), n_inplace.data_ptr(), 3, PX, N.F32, flag.data_ptr(), stream)))
+    # round 4: maps that come out of image files arrive as samples (3 bytes per texel in, 12 out)
+    rgb = torch.randint(0, 256, (S, S, 3), dtype=torch.uint8, device=DEV, generator=g)
+    report("unpack_image 4096^2 RGB uint8 samples -> 3 float32 planes (3 B in, 12 B out per texel)", "unpack_dense_kernel<unsigned char, 3, false>", 15 * PX,
+           timed(lambda: lib.pbr_unpack_image(rgb.data_ptr(), 8, 3, S, S, 1, 3 * S, 3, o3.data_ptr(), 0, stream)))
+    report("unpack_image 4096^2 RGB uint8 normal map -> decoded unit normals (base.py:191-242 in the same pass)", "unpack_dense_kernel<unsigned char, 3, true>", 15 * PX,
+           timed(lambda: lib.pbr_unpack_image(rgb.data_ptr(), 8, 3, S, S, 1, 3 * S, 3, o3.data_ptr(), 1, stream)))
     report("blend_maps 3 ch 4096^2 (7 planes in, 3 out)", "blend_kernel<false>", 40 * PX,
            timed(lambda: lib.pbr_blend_maps(a.data_ptr(), n.data_ptr(), m.data_ptr(), o3.data_ptr(), 3, PX, 0, stream)))
     report("blend_maps normals 4096^2 (7 planes in, 3 out)", "blend_kernel<true>", 40 * PX,

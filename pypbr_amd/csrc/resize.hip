@@ -290,7 +290,7 @@ __device__ __forceinline__ void width_to_global_quads(const float *mid, float *d
 // index k the first upstream index that reads it, their number and the normalised weights, as resize_backward_tables_kernel
 // wrote them to global memory -- instead of derived from the filter: "dst" is the gradient of the resize's input, "src" the
 // upstream gradient.  Phase 0 copies the tile's slices of the tables into the same LDS arrays; phases 1 and 2 do not change.
-struct StripTables { const int *lo_x, *cnt_x, *lo_y, *cnt_y; const float *w_x, *w_y; int nx, ny, h_src; const float *band; };
+struct StripTables { const int *lo_x, *cnt_x, *lo_y, *cnt_y; const float *w_x, *w_y; int nx, ny, h_src; const float *band; const int *col_base; const float *col_w; };
 
 template <bool TABLES, bool QUADS>
 __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_out,
@@ -448,9 +448,27 @@ constexpr int kBandRows = 8, kBandMaxRows = 16, kBandWords = 8 + kBandRows * kBa
 __global__ __launch_bounds__(256) void resize_backward_tables_kernel(int *__restrict__ lo_y, int *__restrict__ cnt_y, float *__restrict__ wy, int h_out,
                                                                      AxisFilter fh, int *__restrict__ lo_x, int *__restrict__ cnt_x,
                                                                      float *__restrict__ wx, int w_out, AxisFilter fw, int groups_y,
-                                                                     float *__restrict__ band) {
+                                                                     float *__restrict__ band, int *__restrict__ col_base, float *__restrict__ col_w,
+                                                                     int col_window) {
     if ((int)blockIdx.x >= groups_y) {
-        backward_table_entry(lo_x, cnt_x, wx, w_out, fw, (blockIdx.x - groups_y) * 256 + threadIdx.x);
+        // ... and per GROUP of four consecutive gradient columns (what one lane of the gather kernel owns): the first upstream column of
+        // the group's window, col_base[group], and the 4 x col_window matrix of column weights over that window, col_w[(c W + j) groups +
+        // group] -- group-minor, so that the gather kernel's lanes read each entry coalesced, with no look-up through lo / cnt in between.
+        const int k = (blockIdx.x - groups_y) * 256 + threadIdx.x;
+        backward_table_entry(lo_x, cnt_x, wx, w_out, fw, k);
+        if (col_w == nullptr) return;
+        const bool live = k < fw.n_in;
+        const int first = live ? lo_x[k] : 0, n = live ? cnt_x[k] : 0;
+        int lo = n > 0 ? first : INT32_MAX;
+        lo = min(lo, __shfl_xor(lo, 1, 64)); lo = min(lo, __shfl_xor(lo, 2, 64));
+        if (lo == INT32_MAX) lo = 0;
+        const int base = lo < w_out - col_window ? lo : w_out - col_window, group = k >> 2, c = k & 3, groups = (fw.n_in + 3) >> 2;
+        if (group >= groups) return;
+        if (c == 0) col_base[group] = base;
+        for (int j = 0; j < col_window; ++j) {
+            const int d = base + j - first;
+            col_w[(size_t)(c * col_window + j) * groups + group] = d >= 0 && d < n ? wx[(size_t)d * fw.n_in + k] : 0.0f;
+        }
         return;
     }
     const int k = blockIdx.x * 256 + threadIdx.x;
@@ -737,23 +755,33 @@ __global__ __launch_bounds__(64) void resize_backward_gather_kernel(const float 
     const int k0 = ((int)gx * 64 + (int)threadIdx.x) * 4;
     if (k0 >= w_in) return;
     // ---- columns
-    int lo[4], n[4], i_lo = INT32_MAX;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int k = min(k0 + c, w_in - 1);
-        lo[c] = tb.lo_x[k]; n[c] = k0 + c < w_in ? min(tb.cnt_x[k], kBwdMaxTaps) : 0;
-        if (n[c] > 0) i_lo = min(i_lo, lo[c]);
-    }
-    if (i_lo == INT32_MAX) i_lo = 0;
-    const int i_base = i_lo < w_out - W ? i_lo : w_out - W;
     float wx[4][W];
+    int i_base;
+    if (BAND) {                                  // the group's record (resize_backward_tables_kernel): 1 + 4 W coalesced loads, none waits for another
+        const int group = k0 >> 2, groups = (w_in + 3) >> 2;
+        i_base = tb.col_base[group];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int k = min(k0 + c, w_in - 1);
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-            const int d = i_base + j - lo[c];
-            wx[c][j] = d >= 0 && d < n[c] ? tb.w_x[(size_t)d * tb.nx + k] : 0.0f;
+            for (int j = 0; j < W; ++j) wx[c][j] = tb.col_w[(size_t)(c * W + j) * groups + group];
+    } else {
+        int lo[4], n[4], i_lo = INT32_MAX;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = min(k0 + c, w_in - 1);
+            lo[c] = tb.lo_x[k]; n[c] = k0 + c < w_in ? min(tb.cnt_x[k], kBwdMaxTaps) : 0;
+            if (n[c] > 0) i_lo = min(i_lo, lo[c]);
+        }
+        if (i_lo == INT32_MAX) i_lo = 0;
+        i_base = i_lo < w_out - W ? i_lo : w_out - W;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int k = min(k0 + c, w_in - 1);
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const int d = i_base + j - lo[c];
+                wx[c][j] = d >= 0 && d < n[c] ? tb.w_x[(size_t)d * tb.nx + k] : 0.0f;
+            }
         }
     }
     // ---- rows (wave-uniform: scalar loads)
@@ -1007,14 +1035,18 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
         const int R = g_resize_rows == 4 ? 4 : 8;                     // gradient rows per lane (A/B knob PBR_TUNE_RESIZE_ROWS; 7 = 8 rows, weights looked up per row)
         const int64_t ggx = (w_in + 255) / 256, ggy = (h_in + R - 1) / R, n_groups = ggx * ggy * planes;
         const bool gather_ok = gather && need <= 16 && n_groups <= INT32_MAX;
+        const int window = need <= 8 ? 8 : (need <= 12 ? 12 : 16);    // the gather kernel's W
+        const size_t band_words = (size_t)((h_in + kBandRows - 1) / kBandRows) * kBandWords, col_groups = (size_t)(w_in + 3) / 4;
         const bool banded = gather_ok && R == kBandRows && g_resize_rows != 7 && band_window(fh, h_out, kBandRows) <= kBandMaxRows &&
-                            (size_t)((h_in + kBandRows - 1) / kBandRows) * kBandWords <= (size_t)planes * h_in * w_out;
+                            band_words + col_groups * (1 + 4 * (size_t)window) <= (size_t)planes * h_in * w_out;
+        float *band = banded ? tmp : nullptr, *col_w = banded ? tmp + band_words + col_groups : nullptr;
+        int *col_base = banded ? reinterpret_cast<int *>(tmp + band_words) : nullptr;
         hipLaunchKernelGGL(resize_backward_tables_kernel, dim3(groups_y + groups_x), dim3(256), 0, s, lo_y, cnt_y, wy, (int)h_out, fh, lo_x, cnt_x, wx,
-                           (int)w_out, fw, groups_y, banded ? tmp : static_cast<float *>(nullptr));
+                           (int)w_out, fw, groups_y, band, col_base, col_w, window);
         if (gather_ok) {
             const uint32_t span = 8u << kUpRunLog2;
             const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
-            const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out, banded ? tmp : static_cast<const float *>(nullptr)};
+            const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out, band, col_base, col_w};
             auto fn = R == 4 ? (need <= 8 ? resize_backward_gather_kernel<8, 4, false> : (need <= 12 ? resize_backward_gather_kernel<12, 4, false> : resize_backward_gather_kernel<16, 4, false>))
                     : banded ? (need <= 8 ? resize_backward_gather_kernel<8, 8, true> : (need <= 12 ? resize_backward_gather_kernel<12, 8, true> : resize_backward_gather_kernel<16, 8, true>))
                              : (need <= 8 ? resize_backward_gather_kernel<8, 8, false> : (need <= 12 ? resize_backward_gather_kernel<12, 8, false> : resize_backward_gather_kernel<16, 8, false>));
@@ -1048,7 +1080,7 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
             const int quads = (g_resize_quads == 2 || (g_resize_quads == 1 && (int64_t)h_in * w_in >= 2 * (int64_t)h_out * w_out)) && w_in % 4 == 0 &&
                               (reinterpret_cast<uintptr_t>(grad_in) & 15u) == 0;
             const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0), quads};
-            const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out, nullptr};
+            const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out, nullptr, nullptr, nullptr};
             auto strip = quads ? resize_strip_kernel<true, true> : resize_strip_kernel<true, false>;
             hipLaunchKernelGGL(strip, dim3((unsigned)n_tiles), dim3(256), lds, s, g, gi, (int)h_in, (int)w_in, (int)w_out, tg, fw, fh, tb);
         } else {                                                                              // two passes through the workspace

@@ -65,7 +65,10 @@ except OSError:
 
 
 def cases_of(name):
-    return [cs for cs in cases if name.startswith(cs["kernel"])] or [cs for cs in cases if cs["kernel"] in name + "("]
+    """A case names its kernel by a prefix of the rocprof name, by a substring, or -- a template that has grown a parameter since the
+    case was written -- by the name up to its closing bracket."""
+    return ([cs for cs in cases if name.startswith(cs["kernel"])] or [cs for cs in cases if cs["kernel"] in name + "("]
+            or [cs for cs in cases if cs["kernel"].endswith(">") and name.startswith(cs["kernel"][:-1] + ",")])
 
 # one kernel, several cases, each with its own grid (the resize shapes): the n-th grid to appear belongs to the n-th case
 by_order = {}

@@ -234,7 +234,7 @@ if want("resize_bwd"):
     ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(3, S, S, ho, ho) // 4), device=DEV)
     us = timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, S, S, ho, ho, 1, ws.data_ptr(), stream))
     # one pass: the register gather over the transposed tap tables (plus the small kernel that writes the tables); `us` is the whole call
-    report("resize backward 3 x 2048^2 gradient -> 4096^2 (gradient of a 2x down-scale: 3 planes of 2048^2 in, 3 of 4096^2 out)", "resize_backward_gather_kernel<8, 8>", 12 * (ho * ho + PX), us,
+    report("resize backward 3 x 2048^2 gradient -> 4096^2 (gradient of a 2x down-scale: 3 planes of 2048^2 in, 3 of 4096^2 out)", "resize_backward_gather_kernel<8, 8, true>", 12 * (ho * ho + PX), us,
            whole_call_us=round(us, 1))
     del gout, gin, ws
     gout = torch.rand(3, S, S, device=DEV, generator=g)

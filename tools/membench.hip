@@ -167,6 +167,33 @@ void oneshot_fwd16(const f4 *__restrict__ in, f4 *__restrict__ out, size_t npx, 
     }
 }
 
+// the repeat-inner kernel's pattern (MaterialBase.tile(2) fused, ct_tiled.hip): 8 source planes of (S/2)^2 read once -- 16 bytes per
+// lane and plane for fp32 maps, 8 for fp16 (HALF) --, 3 result planes of S^2 written: every lane's four pixels go to the four repeats
+// (two across, two down).  One-wave workgroups, source order, stores non-temporal (the kernel's rule).  268 / 335 MB per launch at
+// S = 4096, three quarters / three fifths of them writes.
+template <bool HALF, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, 8)))
+void oneshot_repeat(const float *__restrict__ in, f4 *__restrict__ out, int src, size_t src_plane) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const size_t q = (size_t)blockIdx.x * 64 + threadIdx.x;                 // quad of the source
+    const int qx = src / 4, y = (int)(q / qx), x = (int)(q - (size_t)y * qx) * 4;
+    if (y >= src) return;
+    f4 r = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (HALF) { const f2 v = *reinterpret_cast<const f2 *>(in + (c * src_plane + (size_t)y * src + x) / 2); r += f4{v.x, v.y, v.x, v.y}; }
+        else r += *reinterpret_cast<const f4 *>(in + c * src_plane + (size_t)y * src + x);
+    }
+    const size_t W = 2 * (size_t)src, plane = W * W;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry)
+#pragma unroll
+            for (int rx = 0; rx < 2; ++rx)
+                __builtin_nontemporal_store(r + (float)c, out + (c * plane + ((size_t)ry * src + y) * W + (size_t)rx * src + x) / 4);
+}
+
 // BASELINE config 3's layout: B materials as five [B][C][S^2] tensors (albedo 3, normal 3, roughness 1, metallic 1 -> result 3),
 // 11 streams whose plane strides are all multiples of 16 MiB at S = 2048.  RUNS: XCD x takes runs of 64 consecutive tiles
 // (tile_of_workgroup's remap); else the identity order.  One-wave groups, 3 waves per SIMD, as the fused kernel.
@@ -322,6 +349,14 @@ int main(int argc, char **argv) {
 #define FWD16(WPE) report("fp16 forward pattern 4 x S^2, 8 px per lane, waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_fwd16<WPE>), dim3((unsigned)((p4 / 8 + 63) / 64)), dim3(64), 0, 0, fi, fo, p4, p4); }, iters), 28.0 * p4)
         FWD16(2); FWD16(3); FWD16(4); FWD16(3);
         CHECK(hipFree(fi)); CHECK(hipFree(fo));
+    }
+    {   // repeat-inner pattern: (S/2)^2 source, tile(2) -> S^2
+        const int src = (int)(S / 2);
+        const size_t sp = (size_t)src * src;
+#define REPEAT(HALF, WPE) report(HALF ? "repeat pattern, fp16 source, waves/SIMD>=" #WPE : "repeat pattern, fp32 source, waves/SIMD>=" #WPE, time_us([&](int i) { \
+            hipLaunchKernelGGL((oneshot_repeat<HALF, WPE>), dim3((unsigned)(sp / 4 / 64)), dim3(64), 0, 0, (const float *)in[i % NSETS], out[i % NSETS], src, sp); }, iters), \
+            (HALF ? 16.0 : 32.0) * sp + 12.0 * px)
+        REPEAT(false, 4); REPEAT(true, 4); REPEAT(false, 2); REPEAT(true, 2); REPEAT(false, 8); REPEAT(true, 8); REPEAT(false, 4); REPEAT(true, 4);
     }
     {   // fused blend + render pattern: 17 planes in, 3 out
         f4 *mk = nullptr; CHECK(hipMalloc(&mk, px * 4)); CHECK(hipMemset(mk, 0x3c, px * 4));

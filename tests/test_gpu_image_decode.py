@@ -266,3 +266,47 @@ def test_float_normal_map_from_an_image_is_decoded_on_arrival_behind_the_other_p
     # read on the host first instead: decoded there (staged through the device), as at assignment upstream
     other = M.BasecolorMetallicMaterial(albedo=M.ImageMap(albedo), normal=M.ImageMap(normal))
     assert torch.equal(other.normal, F.decode_normal(normal.cuda()).cpu()) and not other._has_pending()
+
+
+def test_full_size_unpack_and_decode_index_every_texel_once():
+    """4096 x 4096 RGB (the bench workload's extent, 50 MB of samples -> 201 MB of planes): bit-equal to the host conversion, and -- read as
+    a normal map -- to pbr_decode_normal of the float map; every output element written (NaN-filled destination)."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(77)
+    samples = torch.randint(0, 256, (4096, 4096, 3), dtype=torch.uint8, generator=g)
+    chw = samples.permute(2, 0, 1)
+    dev = samples.cuda()
+    out = torch.full((3, 4096, 4096), float("nan"), device="cuda")
+    F.unpack_image(dev, 8, (1, 3 * 4096, 3), (3, 4096, 4096), out)
+    want = chw.contiguous().to(torch.float32).div(255)
+    assert torch.equal(out.cpu(), want)
+    out.fill_(float("nan"))
+    F.unpack_image(dev, 8, (1, 3 * 4096, 3), (3, 4096, 4096), out, decode_normal=True)
+    assert torch.equal(out, F.decode_normal(want.cuda()))
+    assert abs(float(out.square().sum(dim=0).mean()) - 1.0) < 1e-5
+
+
+def test_jpeg_and_palette_images_take_the_same_path(tmp_path):
+    """Whatever PIL decodes: a JPEG (lossy: the samples are what PIL's decoder gives) and a palette PNG loaded as a colour map."""
+    import pypbr_amd.materials as M
+    from pypbr_amd.io import load_material_from_folder
+    rng = np.random.default_rng(21)
+    rgb = rng.integers(0, 256, size=(64, 96, 3), dtype=np.uint8)
+    Image.fromarray(rgb, "RGB").save(tmp_path / "basecolor.jpg", quality=90)
+    Image.fromarray(rgb, "RGB").convert("P", palette=Image.ADAPTIVE, colors=64).save(tmp_path / "normal.png")
+    Image.fromarray(rng.integers(0, 256, size=(64, 96), dtype=np.uint8), "L").save(tmp_path / "roughness.bmp")
+    Image.fromarray(rng.integers(0, 256, size=(64, 96), dtype=np.uint8), "L").save(tmp_path / "metallic.tiff")
+    before = M.DEFER_IMAGE_DECODE
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            M.DEFER_IMAGE_DECODE = False
+            eager = load_material_from_folder(str(tmp_path))
+            M.DEFER_IMAGE_DECODE = True
+            lazy = load_material_from_folder(str(tmp_path))
+    finally:
+        M.DEFER_IMAGE_DECODE = before
+    assert lazy._has_pending() and set(lazy._raw) == {"albedo", "normal", "roughness", "metallic"}
+    resident = lazy._resident(keep=True)
+    for k, v in eager._raw.items():
+        assert torch.equal(resident[k].cpu(), v), k

@@ -234,6 +234,29 @@ void oneshot_blend(const f4 *__restrict__ a, const f4 *__restrict__ b, const f4 
     st<true>(out + i, work<FMAS>(s0, s1, s2)); st<true>(out + plane + i, work<FMAS>(s1, s2, s0)); st<true>(out + 2 * plane + i, work<FMAS>(s2, s0, s1));
 }
 
+// the fused blend + render BACKWARD pattern: both materials (8 planes each), the mask and 3 upstream-gradient planes in, the gradients of both
+// materials and of the mask out (20 in / 17 out, 148 B per pixel, 37 streams), PX pixels per lane (the kernel: 2 -> 8-byte accesses).
+template <int WPE, int PX>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void oneshot_blend_bwd(const float *__restrict__ a, const float *__restrict__ b, const float *__restrict__ mask, const float *__restrict__ gout,
+                       float *__restrict__ ga, float *__restrict__ gb, float *__restrict__ gm, size_t npx) {
+    typedef float vf __attribute__((ext_vector_type(PX)));
+    const size_t i = ((size_t)blockIdx.x * 64 + threadIdx.x) * PX;
+    if (i >= npx) return;
+    auto L = [&](const float *p, size_t c) { return __builtin_nontemporal_load(reinterpret_cast<const vf *>(p + c * npx + i)); };
+    vf s = L(mask, 0);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += L(a, c) - L(b, c);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s += L(gout, c);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        __builtin_nontemporal_store(s + (float)c, reinterpret_cast<vf *>(ga + c * npx + i));
+        __builtin_nontemporal_store(s - (float)c, reinterpret_cast<vf *>(gb + c * npx + i));
+    }
+    __builtin_nontemporal_store(s, reinterpret_cast<vf *>(gm + i));
+}
+
 // two 1 KiB pieces per plane and wave (lane l: pieces l and l + 64 of a 2 KiB run): 16 loads in flight per lane, every
 // instruction still covers a contiguous 1 KiB.  WPE waves per SIMD.
 template <bool NT, int FMAS, int WPE>
@@ -363,6 +386,15 @@ int main(int argc, char **argv) {
 #define BLEND(WPE, F) report("blend+render pattern 17 in / 3 out, valu/px=" #F " waves/SIMD=" #WPE, time_us([&](int i) { hipLaunchKernelGGL((oneshot_blend<WPE, F>), dim3((nv + 63) / 64), dim3(64), 0, 0, in[0], in[1], mk, out[i % NSETS], nv, plane); }, iters), 80.0 * px)
         BLEND(2, 0); BLEND(3, 0); BLEND(2, 60); BLEND(3, 60); BLEND(2, 0);
         CHECK(hipFree(mk));
+    }
+    {   // fused blend + render backward pattern: 20 planes in, 17 out
+        float *mk, *go, *ga, *gb, *gm;
+        CHECK(hipMalloc(&mk, px * 4)); CHECK(hipMalloc(&go, 3 * px * 4)); CHECK(hipMalloc(&ga, 8 * px * 4)); CHECK(hipMalloc(&gb, 8 * px * 4)); CHECK(hipMalloc(&gm, px * 4));
+        CHECK(hipMemset(mk, 0x3c, px * 4)); CHECK(hipMemset(go, 0x3c, 3 * px * 4));
+#define BLENDBWD(WPE, PX) report("blend+render backward pattern 20 in / 17 out, " #PX " px per lane, waves/SIMD=" #WPE, time_us([&](int i) { \
+            hipLaunchKernelGGL((oneshot_blend_bwd<WPE, PX>), dim3((unsigned)((px / PX + 63) / 64)), dim3(64), 0, 0, (const float *)in[0], (const float *)in[1], mk, go, ga, gb, gm, px); }, 10), 148.0 * px)
+        BLENDBWD(2, 2); BLENDBWD(3, 2); BLENDBWD(4, 2); BLENDBWD(2, 4); BLENDBWD(3, 4); BLENDBWD(2, 2);
+        CHECK(hipFree(mk)); CHECK(hipFree(go)); CHECK(hipFree(ga)); CHECK(hipFree(gb)); CHECK(hipFree(gm));
     }
     for (int cfg = 0; cfg < 2; ++cfg) {   // config 3 (64 x 2048^2) and config 4's share (64 x 1024^2): the batch layout's own ceiling, both orders
         const size_t s = cfg == 0 ? 2048 : 1024, B = 64, pp = s * s / 4;          // plane in f4 units

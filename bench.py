@@ -358,6 +358,9 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer exchange between ranks fails with
+    # `hipIpcGetMemHandle: invalid argument` (the image exports it; a launcher that builds its own environment may not)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

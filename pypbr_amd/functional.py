@@ -1092,7 +1092,7 @@ def pack_maps(*maps: Optional[torch.Tensor], device=None, reserve_output: bool =
 # The page-locked staging area of upload_packed, one per thread, reused: allocating one is a hipHostMalloc (4 ms for 10 MB) and torch's
 # caching host allocator handed a recycled block back only some of the time -- the upload of examples/example_brdf.py's material took 0.8
 # or 4.5 ms by that alone (tools/example_bench.py, per-repeat times).  Grown geometrically; requests beyond the cap get a block of their own.
-UPLOAD_STAGE_CAP = int(os.environ.get("PBR_UPLOAD_STAGE_CAP", str(512 << 20)))
+UPLOAD_STAGE_CAP = int(os.environ.get("PBR_UPLOAD_STAGE_CAP", str(256 << 20)))
 _UPLOAD_STAGE = threading.local()
 
 

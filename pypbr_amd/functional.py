@@ -788,7 +788,8 @@ class _MseStepFn(torch.autograd.Function):
         present = (True, bool(d.normal.data), True, bool(d.metallic.data), bool(d.specular.data))
         wanted = [bool(ctx.needs_input_grad[i] and present[i] and maps[i] is not None) for i in range(5)]
         loss, bufs = _MseStepFn._launch(plan, target, maps, wanted)
-        ctx.plan, ctx.wanted, ctx.grads = plan, wanted, bufs
+        # the plan (descriptor + strong references to every map) is NOT kept: a second backward rebuilds it from the saved tensors
+        ctx.kwargs, ctx.wanted, ctx.grads = kwargs, wanted, bufs
         ctx.present = [t is not None for t in maps]
         ctx.save_for_backward(*[t for t in maps if t is not None], target)
         return loss
@@ -803,7 +804,9 @@ class _MseStepFn(torch.autograd.Function):
             # evaluated once more for fresh ones -- the common single backward never pays for a copy
             it = iter(saved[:-1])
             maps = [next(it) if p else None for p in ctx.present]
-            _, grads = _MseStepFn._launch(ctx.plan, saved[-1], maps, ctx.wanted)
+            plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **ctx.kwargs)
+            plan.out = None
+            _, grads = _MseStepFn._launch(plan, saved[-1], maps, ctx.wanted)
         live = [b for b in grads if b is not None]
         if live:                                            # all gradients scaled in ONE launch (they share a dtype and a device)
             k = grad_loss.detach().to(live[0].device, torch.float32).reshape(1).contiguous()
@@ -1116,6 +1119,17 @@ def _upload_stage(nbytes: int):
     return slot[0][:nbytes], slot
 
 
+def release_upload_stage():
+    """Drops the CALLING thread's page-locked staging block (up to UPLOAD_STAGE_CAP bytes stay pinned per uploading thread otherwise:
+    loader pools and server threads that are done uploading call this, or set PBR_UPLOAD_STAGE_CAP lower).  The copy still in flight
+    out of it is waited for first."""
+    slot = getattr(_UPLOAD_STAGE, "slot", None)
+    if slot is not None:
+        if slot[1] is not None:
+            slot[1].synchronize()
+        _UPLOAD_STAGE.slot = None
+
+
 # Host tensor -> its place in the staging area.  Up to this many bytes per upload the copy is a plain memcpy on the calling thread, NOT
 # Tensor.copy_: ATen spreads a host copy over its whole OpenMP pool (128 threads on a GPU box's 256-core host), whose workers then spin
 # on every core -- inside the box's CPU quota (16 cores) that stalled this very thread for 70-170 ms at a time (CFS throttling: every other
@@ -1143,7 +1157,9 @@ def _page_locked_range(samples):
 
 
 def _stage_copy(dst_bytes: torch.Tensor, src: torch.Tensor, upload_bytes: int):
-    if upload_bytes <= STAGE_MEMCPY_LIMIT and src.is_contiguous():
+    # a host memcpy: only a HOST source may take it (a device pointer here would be read by the CPU, unordered against the kernels
+    # still queued on that device); anything else goes through copy_, which knows about devices and streams
+    if upload_bytes <= STAGE_MEMCPY_LIMIT and src.device.type == "cpu" and src.is_contiguous():
         ctypes.memmove(dst_bytes.data_ptr(), src.data_ptr(), dst_bytes.numel())
     else:
         dst_bytes.view(src.dtype).view(src.shape).copy_(src)

@@ -128,32 +128,34 @@ def load_material_from_folder(folder_path: str, map_names: Optional[Dict[str, Li
     # sequential loop of io.py:58-85.
     defer = _defer_images()                # the material is built on the CPU (the ctor's default), like upstream
     from PIL import Image
-    loaded = {map_type: Image.open(path) for map_type, path in found}           # headers only: nothing is decoded yet
-    # The workflow is decided by WHICH maps are there (io.py:132-186), so it is decided before the decoders run: the maps the chosen
-    # workflow does not take (the other workflow's albedo and specular / metallic map) are opened -- a file that is no image raises as
-    # upstream -- but not decoded, and the samples of the others sit back to back in one block.
-    cls = select_material_class(loaded, preferred_workflow)
-    if issubclass(cls, BasecolorMetallicMaterial):
-        albedo_key = "basecolor"
-        if "basecolor" not in loaded:
-            warnings.warn("Basecolor map not found for metallic workflow. Looking for 'albedo' or 'basecolor' maps.")
-    else:
-        albedo_key = "diffuse"
-        if "diffuse" not in loaded:
-            warnings.warn("Diffuse map not found for specular workflow. Looking for 'diffuse' map.")
-    wanted = [(t, im) for t, im in loaded.items() if t not in ("basecolor", "diffuse") or t == albedo_key]
-    for t, im in loaded.items():
-        if t in ("basecolor", "diffuse") and t != albedo_key:
+    opened = {map_type: Image.open(path) for map_type, path in found}           # headers only: nothing is decoded yet
+    try:
+        # The workflow is decided by WHICH maps are there (io.py:132-186), so it is decided before the decoders run: the maps the chosen
+        # workflow does not take (the other workflow's albedo and specular / metallic map) are opened -- a file that is no image raises as
+        # upstream -- but not decoded, and the samples of the others sit back to back in one block.
+        loaded = dict(opened)
+        cls = select_material_class(loaded, preferred_workflow)       # pops the map of the workflow not chosen
+        if issubclass(cls, BasecolorMetallicMaterial):
+            albedo_key = "basecolor"
+            if "basecolor" not in loaded:
+                warnings.warn("Basecolor map not found for metallic workflow. Looking for 'albedo' or 'basecolor' maps.")
+        else:
+            albedo_key = "diffuse"
+            if "diffuse" not in loaded:
+                warnings.warn("Diffuse map not found for specular workflow. Looking for 'diffuse' map.")
+        wanted = [(t, im) for t, im in loaded.items() if t not in ("basecolor", "diffuse") or t == albedo_key]
+        slots = _sample_block([_sample_bytes(im, t) for t, im in wanted]) if defer else [None] * len(wanted)
+        jobs = [(im, t, defer, slot) for (t, im), slot in zip(wanted, slots)]
+        if len(jobs) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            workers = min(len(jobs), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
+            with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+                images = list(pool.map(lambda job: _decoded(*job), jobs))
+        else:
+            images = [_decoded(*job) for job in jobs]
+    finally:
+        for im in opened.values():         # every file handle, decoded or not, whatever a decoder raised (close() is idempotent)
             im.close()
-    slots = _sample_block([_sample_bytes(im, t) for t, im in wanted]) if defer else [None] * len(wanted)
-    jobs = [(im, t, defer, slot) for (t, im), slot in zip(wanted, slots)]
-    if len(jobs) > 1:
-        from concurrent.futures import ThreadPoolExecutor
-        workers = min(len(jobs), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 4)
-        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
-            images = list(pool.map(lambda job: _decoded(*job), jobs))
-    else:
-        images = [_decoded(*job) for job in jobs]
     loaded = {t: image for (t, _), image in zip(wanted, images)}
     albedo = loaded.get(albedo_key)
     kwargs = {k: v for k, v in loaded.items() if k not in ("basecolor", "diffuse")}

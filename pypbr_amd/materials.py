@@ -205,6 +205,9 @@ class MaterialBase:
             object.__setattr__(self, name, value)
         elif _is_map_value(value):
             self.materialize_blend()                       # an assignment to a lazily blended material lands on blended maps
+            if self.__dict__.get("_lazy_tile", (1, 1)) != (1, 1):
+                self.materialize_tile()                    # ... and one to a material with a recorded tile(n) on REPEATED maps: the
+                                                           # new map is not repeated again on read (base.py:524-537 tiles what is there)
             self._raw[name] = self._ingest(name, value)
         else:
             object.__setattr__(self, name, value)
@@ -281,10 +284,12 @@ class MaterialBase:
         pending = bool(d.get("_raw_normal"))
         unseen = [k for k in away if F_.is_encoded(store[k])]
         if away:
-            grads = [k for k in away if store[k].requires_grad]
-            for k in grads:
-                out[k] = store[k].to(compute)                    # differentiable copy, on its own
-            plain = [k for k in away if k not in grads]
+            # only HOST maps ride the packed upload (its staging is a host memcpy); a map that requires grad takes the differentiable
+            # copy, a map on ANOTHER GPU (material.to("cuda:1") from cuda:0) the device-to-device copy, ordered on its stream
+            alone = [k for k in away if store[k].requires_grad or store[k].device.type != "cpu"]
+            for k in alone:
+                out[k] = store[k].to(compute)
+            plain = [k for k in away if k not in alone]
             in_flight = pending and "normal" in plain
             as_samples = in_flight and F_.is_encoded(store["normal"])
             if in_flight and not as_samples:                     # raw float normal first: everything behind it is one dense block

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBR_HIP_ABI_VERSION 6      /* 6: pbr_render_desc.tuning (per-call schedule knobs; pbr_set_tuning demoted to a process-global test hook); 5: pbr_render_desc.device_params (view / light / intensity read from device memory); 4: light_size follows Python truthiness, gradients of the map ops */
+#define PBR_HIP_ABI_VERSION 7      /* 7: folded gradients of tiled maps (pbr_cook_torrance_backward_folded), the loss step over tiled maps, 12 schedule knobs (was 23); 6: pbr_render_desc.tuning (per-call schedule knobs; pbr_set_tuning demoted to a process-global test hook); 5: pbr_render_desc.device_params (view / light / intensity read from device memory); 4: light_size follows Python truthiness, gradients of the map ops */
 #define PBR_MAX_LIGHTS 16
 
 /* ---- status codes (negative = caller error, positive = HIP runtime error code + 1000) */
@@ -77,27 +77,19 @@ enum {
     PBR_TUNE_BLOCK_LOG2 = 1,            /* workgroup = 1 << value lanes (6..8); 0 = rule */
     PBR_TUNE_F16_VEC = 2,               /* pixels per lane for fp16 maps (4 | 8) */
     PBR_TUNE_LDS_BYTES = 3,             /* unused dynamic LDS per workgroup of the render kernel: an occupancy governor (-1 = rule) */
-    PBR_TUNE_XCD_LOG2 = 4,              /* consecutive tiles per XCD = 1 << value (the workgroup -> tile order); -1 = the descriptor's schedule */
-    PBR_TUNE_BWD_VEC = 5,               /* pixels per lane of the backward kernels (2 | 4 force; 0 = rule) */
-    PBR_TUNE_BATCH_INNER = 6,           /* several lights: materials per lane of the batch-inner kernel (-1 = rule, 0 = one-material kernel) */
-    PBR_TUNE_INTERLEAVE = 7,            /* experiment: materials of a batch interleaved workgroup by workgroup */
-    PBR_TUNE_SCALAR_BASE = 8,           /* scalar plane addresses: 0 never, 1 rule (single materials), 2 whenever the launch allows them */
-    PBR_TUNE_MAX_VEC = 9,               /* at most this many pixels per lane (8 default; 1 = the one-pixel kernels everywhere) */
-    PBR_TUNE_RESIZE_ROWS = 10,          /* output rows per workgroup of the resize kernels (0 = rule); the gradient's register gather: 4 = four rows per lane, 7 = eight rows with the rows' weights looked up one by one instead of read from the per-band matrices */
-    PBR_TUNE_BWD_RUN = 11,              /* rounds of the streamed backward kernel for fp16 maps with one light (-1 = rule, 0 = the one-tile kernels) */
-    PBR_TUNE_RESIZE_XCD = 12,           /* tile order of the resize kernel: 1 = XCD-contiguous chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = chunks of that many */
-    PBR_TUNE_BWD_WIDE = 13,             /* streamed backward with 16-byte memory instructions: -1 = rule (off), 0 = the 4-byte form, 1 = wherever legal */
-    PBR_TUNE_RESIZE_UP2 = 14,           /* up-scales on both axes: the two-tap register kernel (1, default) or the strip kernel (0) */
-    PBR_TUNE_TILE_FOLD = 15,            /* tiled maps, wrap-around form: log2 of the source rows per band of the fold order (all vertical repeats of a band back to back); -1 = rule, 0 = row order */
-    PBR_TUNE_RESIZE_BWD_FUSED = 16,     /* gradient of resize: 1 (default) = one register-only pass (gather over the transposed tap tables; up-scales: the two-tap transpose), 2 = one pass through the LDS strip kernel, 0 = two passes through the workspace */
-    PBR_TUNE_RESIZE_QUADS = 17,         /* strip kernel's width pass with four columns per lane and 16-byte stores: 1 = rule, 2 = wherever legal, 0 = never */
-    PBR_TUNE_STREAM_SHAPE = 18,         /* launch shape of the streaming map kernels: -1 = each kernel's rule, 0 = 2048 walking workgroups of 256 lanes, 1 = one item per lane (256-lane groups), 2 = one-wave groups */
-    PBR_TUNE_STREAM_LDS = 19,           /* unused dynamic LDS bytes per workgroup of those kernels (an occupancy cap); -1 = rule */
-    PBR_TUNE_MSE_STREAM = 20,           /* rendering-loss step for fp16 maps with one light: the streamed kernel (1, default) or the one-tile kernels (0) */
-    PBR_TUNE_PACK_SINGLE = 21,          /* one light over fp32 maps: packed (two pixels per instruction) arithmetic: -1 = rule (wrap-around launches over tiled maps, which are VALU-bound), 0 = never, 1 = always */
-    PBR_TUNE_TILE_REPEAT = 22,          /* tiled maps, whole output, one light: every texel loaded and decoded once and evaluated at all its repeats (-1 = rule: on, 0 = wrap-around addressing) */
-    PBR_TUNE_COUNT = 23
+    PBR_TUNE_BWD_VEC = 4,               /* pixels per lane of the backward kernels (2 | 4 force; 0 = rule) */
+    PBR_TUNE_BATCH_INNER = 5,           /* several lights: materials per lane of the batch-inner kernel (-1 = rule, 0 = one-material kernel) */
+    PBR_TUNE_SCALAR_BASE = 6,           /* scalar plane addresses: 0 never, 1 rule (single materials), 2 whenever the launch allows them */
+    PBR_TUNE_MAX_VEC = 7,               /* at most this many pixels per lane (8 default; 1 = the one-pixel kernels everywhere) */
+    PBR_TUNE_BWD_RUN = 8,               /* rounds of the streamed backward kernel for fp16 maps with one light (-1 = rule, 0 = the one-tile kernels) */
+    PBR_TUNE_MSE_STREAM = 9,            /* rendering-loss step for fp16 maps with one light: the streamed kernel (1, default) or the one-tile kernels (0) */
+    PBR_TUNE_TILE_REPEAT = 10,          /* tiled maps: every texel loaded and decoded once and evaluated / differentiated at all its repeats (-1 = rule: on, 0 = wrap-around addressing, gradients folded by a second kernel) */
+    PBR_TUNE_RESIZE_UP2 = 11,           /* up-scales on both axes: the two-tap register kernels (1, default) or the strip kernels (0) */
+    PBR_TUNE_COUNT = 12
 };
+/* (ABI 6 carried 23 knobs; the 11 whose experiments are closed -- workgroup interleave, 16-byte streamed backward, the resize
+ * kernels' row / tile-order / quad-store / gradient-form switches, the map kernels' launch shape, the wrap-around fold order, packed
+ * one-light arithmetic, the XCD run length that pbr_render_desc.schedule already carries -- are rules now: profiles/EXPERIMENTS.md.) */
 #define PBR_TUNE_UNSET INT32_MIN
 #define PBR_TUNE_SLOTS 32               /* room for knobs of later versions: a pbr_tuning never changes size */
 typedef struct pbr_tuning {
@@ -227,13 +219,31 @@ int pbr_cook_torrance_blend_backward(const pbr_render_desc *desc, const pbr_blen
  * Each non-NULL g_* receives a contiguous gradient in the maps' storage type, shaped like its map
  * ([B][3|1][H][W]); NULL skips it.  Same sub-gradient conventions as torch (clamp passes on the
  * closed interval).  With tiled maps (map_height/map_width) the g_* are OUTPUT-sized: one value per
- * output pixel; the gradient of a texel is the sum over its repeats, which is left to the caller.
+ * output pixel; the gradient of a texel is the sum over its repeats -- pbr_cook_torrance_backward_folded hands that out directly.
  * fp16 maps with one light, rows of a whole number of 128 pixels and 4-byte-aligned planes take a streamed kernel (persistent
  * waves, the next tile prefetched global -> LDS); every other launch the one-tile kernels -- same values either way.
  */
 int pbr_cook_torrance_backward(const pbr_render_desc *desc, const void *grad_out, void *g_albedo,
                                void *g_normal, void *g_roughness, void *g_metallic, void *g_specular,
                                void *stream);
+
+/*
+ * Gradient w.r.t. TILED maps, folded: MaterialBase.tile (base.py:524-537) is map.repeat(1, n, n), so autograd gives a texel the SUM of
+ * the gradients of its repeats (the reference's example material is resize(512).tile(2), examples/example_brdf.py:11; its documented
+ * ML use a rendering loss over such a material, docs/source/tutorials/06_advanced.rst:73-107).  Arguments as pbr_cook_torrance_backward,
+ * but every non-NULL g_* is shaped like its MAP -- [B][3|1][map_height][map_width], contiguous, the maps' storage type -- and receives
+ * the sum over the map's repeats inside the output the descriptor describes (the whole tiled image, or a row band of it that holds
+ * at least one full period of the map's rows: a multi-GPU shard, whose partial sums the caller adds up across ranks).
+ * One light, map rows a whole number of 4-texel groups: ONE kernel walks the maps, re-evaluates each texel's light-independent terms
+ * once, visits its repeats and accumulates in registers (12 B per output pixel + 64 B per texel); `workspace` may be NULL.  Other
+ * launches (several lights, ragged map widths) run pbr_cook_torrance_backward into `workspace`
+ * (pbr_backward_folded_workspace_bytes(desc) bytes of device memory, 0 when the one-kernel form serves the descriptor) followed by
+ * pbr_fold_gradient_typed per map: same values for fp32 maps bit for bit; fp16 gradients are rounded once instead of per repeat.
+ * Untiled descriptors are passed on to pbr_cook_torrance_backward.
+ */
+size_t pbr_backward_folded_workspace_bytes(const pbr_render_desc *desc);
+int pbr_cook_torrance_backward_folded(const pbr_render_desc *desc, const void *grad_out, void *g_albedo, void *g_normal,
+                                      void *g_roughness, void *g_metallic, void *g_specular, void *workspace, void *stream);
 
 /*
  * The same, plus the gradient w.r.t. the view / light parameters: the reference's forward is plain torch ops on
@@ -254,7 +264,7 @@ int pbr_cook_torrance_backward_params(const pbr_render_desc *desc, const void *g
  * The rendering-loss step of docs/source/tutorials/06_advanced.rst:73-107 for the PREDICTED material, as one pass:
  *     loss = nn.MSELoss()(CookTorranceBRDF(...)(predicted_material, ...), target);  loss.backward()
  * `desc` describes the predicted material and the evaluation exactly as for pbr_cook_torrance (its `out` is ignored; out_dtype
- * PBR_F32; fp32 or fp16 maps; any workflow, light type and light count; untiled); `target` is the reference rendering
+ * PBR_F32; fp32 or fp16 maps; any workflow, light type and light count); `target` is the reference rendering
  * [B][3][H][W] fp32 contiguous (e.g. pbr_cook_torrance of the ground-truth material, computed once).  Writes *loss (a DEVICE
  * float) = mean((out - target)^2) over all B*3*H*W values and, into every non-NULL g_*, d loss / d map -- contiguous, shaped
  * like the map, in the maps' storage type -- with torch's sub-gradient conventions, as pbr_cook_torrance_backward.  The
@@ -262,6 +272,10 @@ int pbr_cook_torrance_backward_params(const pbr_render_desc *desc, const void *g
  * `workspace`: pbr_mse_step_workspace_bytes(desc) bytes of device memory (one partial sum per workgroup, added in fp64 in a
  * fixed order by a second small kernel on `stream`: deterministic).  An upstream gradient other than 1 (loss * k) is applied
  * afterwards with pbr_scale_by_device_scalar, which returns at once when the scalar is 1.
+ * Tiled maps (map_height / map_width, the whole output): the g_* are MAP-sized and receive the sum over the repeats, as from
+ * pbr_cook_torrance_backward_folded, out of one pass over the maps and the target (12 B per output pixel + 64 B per texel); served
+ * for one light and map rows of a whole number of 4-texel groups, PBR_ERR_UNSUPPORTED otherwise (pbr_mse_step_workspace_bytes
+ * returns 0 then): the caller evaluates, compares and calls pbr_cook_torrance_backward_folded.
  */
 size_t pbr_mse_step_workspace_bytes(const pbr_render_desc *desc);
 int pbr_cook_torrance_mse_step(const pbr_render_desc *desc, const void *target, void *g_albedo, void *g_normal, void *g_roughness,

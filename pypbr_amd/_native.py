@@ -9,20 +9,19 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBR_HIP_LIB") or os.path.join(_HERE, "libpbr_hip.so")   # env override: A/B of two builds
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_LIGHTS = 16
 
 F32, F16 = 0, 1
 LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 WORKFLOW_METALLIC, WORKFLOW_SPECULAR, WORKFLOW_CONVERTED = 0, 1, 2
-TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, TUNE_XCD_LOG2, TUNE_BWD_VEC, TUNE_BATCH_INNER, TUNE_INTERLEAVE, TUNE_SCALAR_BASE, TUNE_MAX_VEC, TUNE_RESIZE_ROWS, TUNE_BWD_RUN, TUNE_RESIZE_XCD, TUNE_BWD_WIDE, TUNE_RESIZE_UP2, TUNE_TILE_FOLD, TUNE_RESIZE_BWD_FUSED, TUNE_RESIZE_QUADS, TUNE_STREAM_SHAPE, TUNE_STREAM_LDS, TUNE_MSE_STREAM, TUNE_PACK_SINGLE, TUNE_TILE_REPEAT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22
+(TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, TUNE_BWD_VEC, TUNE_BATCH_INNER, TUNE_SCALAR_BASE, TUNE_MAX_VEC, TUNE_BWD_RUN,
+ TUNE_MSE_STREAM, TUNE_TILE_REPEAT, TUNE_RESIZE_UP2) = range(12)
 
-TUNE_COUNT, TUNE_SLOTS, TUNE_UNSET = 23, 32, -2 ** 31
-TUNE_NAMES = {"nontemporal": TUNE_NONTEMPORAL, "block_log2": TUNE_BLOCK_LOG2, "f16_vec": TUNE_F16_VEC, "lds_bytes": TUNE_LDS_BYTES, "xcd_log2": TUNE_XCD_LOG2,
-              "bwd_vec": TUNE_BWD_VEC, "batch_inner": TUNE_BATCH_INNER, "interleave": TUNE_INTERLEAVE, "scalar_base": TUNE_SCALAR_BASE, "max_vec": TUNE_MAX_VEC,
-              "resize_rows": TUNE_RESIZE_ROWS, "bwd_run": TUNE_BWD_RUN, "resize_xcd": TUNE_RESIZE_XCD, "bwd_wide": TUNE_BWD_WIDE, "resize_up2": TUNE_RESIZE_UP2,
-              "tile_fold": TUNE_TILE_FOLD, "resize_bwd_fused": TUNE_RESIZE_BWD_FUSED, "resize_quads": TUNE_RESIZE_QUADS, "stream_shape": TUNE_STREAM_SHAPE,
-              "stream_lds": TUNE_STREAM_LDS, "mse_stream": TUNE_MSE_STREAM, "pack_single": TUNE_PACK_SINGLE, "tile_repeat": TUNE_TILE_REPEAT}
+TUNE_COUNT, TUNE_SLOTS, TUNE_UNSET = 12, 32, -2 ** 31
+TUNE_NAMES = {"nontemporal": TUNE_NONTEMPORAL, "block_log2": TUNE_BLOCK_LOG2, "f16_vec": TUNE_F16_VEC, "lds_bytes": TUNE_LDS_BYTES,
+              "bwd_vec": TUNE_BWD_VEC, "batch_inner": TUNE_BATCH_INNER, "scalar_base": TUNE_SCALAR_BASE, "max_vec": TUNE_MAX_VEC,
+              "bwd_run": TUNE_BWD_RUN, "mse_stream": TUNE_MSE_STREAM, "tile_repeat": TUNE_TILE_REPEAT, "resize_up2": TUNE_RESIZE_UP2}
 
 OK = 0
 ERR_NULL_MAP, ERR_WORKFLOW, ERR_LIGHT_TYPE, ERR_SHAPE, ERR_DTYPE, ERR_CHANNELS, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6, -7
@@ -41,6 +40,7 @@ EXPORTS = (
     "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
     "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward", "pbr_fold_gradient_typed",
     "pbr_mse_step_workspace_bytes", "pbr_cook_torrance_mse_step", "pbr_scale_by_device_scalar", "pbr_scale_list_by_device_scalar", "pbr_device_params_bytes", "pbr_prepare_device_params", "pbr_tuning_init", "pbr_build_id", "pbr_unpack_image",
+    "pbr_backward_folded_workspace_bytes", "pbr_cook_torrance_backward_folded",
 )
 
 
@@ -160,6 +160,10 @@ def lib():
     L.pbr_fold_gradient_typed.restype = ctypes.c_int
     L.pbr_cook_torrance_backward.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp]
     L.pbr_cook_torrance_backward.restype = ctypes.c_int
+    L.pbr_backward_folded_workspace_bytes.argtypes = [ctypes.POINTER(RenderDesc)]
+    L.pbr_backward_folded_workspace_bytes.restype = ctypes.c_size_t
+    L.pbr_cook_torrance_backward_folded.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pbr_cook_torrance_backward_folded.restype = ctypes.c_int
     L.pbr_srgb_to_linear.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     L.pbr_linear_to_srgb.argtypes = [vp, vp, sz, ctypes.c_int, vp]
     L.pbr_metallic_to_specular.argtypes = [vp, vp, vp, vp, i32, i64, ctypes.c_int, ctypes.c_int, vp]
@@ -212,8 +216,7 @@ def lib():
                                  % (L.pbr_render_desc_size(), ctypes.sizeof(RenderDesc)))
     if L.pbr_abi_version() != ABI_VERSION:
         raise NativeLibraryError("libpbr_hip.so ABI %d, binding expects %d" % (L.pbr_abi_version(), ABI_VERSION))
-    for env, knob in (("PBR_TUNE_LDS_BYTES", TUNE_LDS_BYTES), ("PBR_TUNE_NONTEMPORAL", TUNE_NONTEMPORAL),
-                      ("PBR_TUNE_BLOCK_LOG2", TUNE_BLOCK_LOG2), ("PBR_TUNE_XCD_LOG2", TUNE_XCD_LOG2), ("PBR_TUNE_BWD_VEC", TUNE_BWD_VEC), ("PBR_TUNE_BATCH_INNER", TUNE_BATCH_INNER), ("PBR_TUNE_SCALAR_BASE", TUNE_SCALAR_BASE), ("PBR_TUNE_MAX_VEC", TUNE_MAX_VEC), ("PBR_TUNE_RESIZE_ROWS", TUNE_RESIZE_ROWS), ("PBR_TUNE_BWD_RUN", TUNE_BWD_RUN), ("PBR_TUNE_RESIZE_XCD", TUNE_RESIZE_XCD), ("PBR_TUNE_BWD_WIDE", TUNE_BWD_WIDE), ("PBR_TUNE_RESIZE_UP2", TUNE_RESIZE_UP2), ("PBR_TUNE_TILE_FOLD", TUNE_TILE_FOLD), ("PBR_TUNE_RESIZE_BWD_FUSED", TUNE_RESIZE_BWD_FUSED), ("PBR_TUNE_RESIZE_QUADS", TUNE_RESIZE_QUADS), ("PBR_TUNE_STREAM_SHAPE", TUNE_STREAM_SHAPE), ("PBR_TUNE_STREAM_LDS", TUNE_STREAM_LDS), ("PBR_TUNE_MSE_STREAM", TUNE_MSE_STREAM), ("PBR_TUNE_PACK_SINGLE", TUNE_PACK_SINGLE), ("PBR_TUNE_TILE_REPEAT", TUNE_TILE_REPEAT)):      # profiling runs: knobs from the environment
+    for env, knob in tuple(("PBR_TUNE_" + name.upper(), index) for name, index in TUNE_NAMES.items()):      # profiling runs: knobs from the environment
         if os.environ.get(env, "") != "":
             L.pbr_set_tuning(knob, int(os.environ[env]))
     _lib = L

@@ -30,14 +30,11 @@ namespace pbr {
 
 // The process-wide values of the schedule knobs (tuning.hpp), initialised to the rules.  Indexed by PBR_TUNE_*.
 static constexpr int kKnobRules[PBR_TUNE_COUNT] = {
-    /* NONTEMPORAL */ 1, /* BLOCK_LOG2 */ 0, /* F16_VEC */ 8, /* LDS_BYTES */ -1, /* XCD_LOG2 */ -1, /* BWD_VEC */ 0, /* BATCH_INNER */ -1,
-    /* INTERLEAVE */ 0, /* SCALAR_BASE */ 1, /* MAX_VEC */ 8, /* RESIZE_ROWS */ 0, /* BWD_RUN */ -1, /* RESIZE_XCD */ 1, /* BWD_WIDE */ -1,
-    /* RESIZE_UP2 */ 1, /* TILE_FOLD */ -1, /* RESIZE_BWD_FUSED */ 1, /* RESIZE_QUADS */ 1, /* STREAM_SHAPE */ -1, /* STREAM_LDS */ -1,
-    /* MSE_STREAM */ 1, /* PACK_SINGLE */ -1, /* TILE_REPEAT */ -1};
+    /* NONTEMPORAL */ 1, /* BLOCK_LOG2 */ 0, /* F16_VEC */ 8, /* LDS_BYTES */ -1, /* BWD_VEC */ 0, /* BATCH_INNER */ -1,
+    /* SCALAR_BASE */ 1, /* MAX_VEC */ 8, /* BWD_RUN */ -1, /* MSE_STREAM */ 1, /* TILE_REPEAT */ -1, /* RESIZE_UP2 */ 1};
 std::atomic<int> g_knobs[PBR_TUNE_COUNT] = {
     {kKnobRules[0]}, {kKnobRules[1]}, {kKnobRules[2]}, {kKnobRules[3]}, {kKnobRules[4]}, {kKnobRules[5]}, {kKnobRules[6]}, {kKnobRules[7]},
-    {kKnobRules[8]}, {kKnobRules[9]}, {kKnobRules[10]}, {kKnobRules[11]}, {kKnobRules[12]}, {kKnobRules[13]}, {kKnobRules[14]}, {kKnobRules[15]},
-    {kKnobRules[16]}, {kKnobRules[17]}, {kKnobRules[18]}, {kKnobRules[19]}, {kKnobRules[20]}, {kKnobRules[21]}, {kKnobRules[22]}};
+    {kKnobRules[8]}, {kKnobRules[9]}, {kKnobRules[10]}, {kKnobRules[11]}};
 thread_local const pbr_tuning *t_tuning = nullptr;
 
 struct KernelEntry { KernelFn fn; const char *name; };
@@ -86,7 +83,7 @@ static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
         return KernelEntry{pick_repeat_kernel(d, g_nontemporal), name};
     }
     // packed arithmetic for ONE light over fp32 maps: the rule is tiled launches only (ct_kernel.hpp: PACK1)
-    const bool pack1 = idt == PBR_F32 && !multi && vec == 4 && (g_pack_single == 1 || (g_pack_single < 0 && is_tiled(d)));
+    const bool pack1 = idt == PBR_F32 && !multi && vec == 4 && is_tiled(d);
     if (nb) {
         std::snprintf(name, sizeof(name), "ctb_%s_%s_%s_%s_v2_b%d", point ? "point" : "directional", wf_names[d->workflow],
                       idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", nb);

@@ -45,21 +45,6 @@ static BwdStreamFn pick_bwd_stream(const pbr_render_desc *d, bool full) {
 #undef PBR_BWDS
 }
 
-using BwdStream16Fn = void (*)(const KArgs, const BArgs, int);
-static BwdStream16Fn pick_bwd_stream16(const pbr_render_desc *d) {
-    const bool point = d->light_type == PBR_LIGHT_POINT;
-#define PBR_BWDS16(L, W) return cook_torrance_backward_stream16_kernel<L, W>
-    switch ((point ? 3 : 0) + d->workflow) {
-        case 0: PBR_BWDS16(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC);
-        case 1: PBR_BWDS16(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR);
-        case 2: PBR_BWDS16(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED);
-        case 3: PBR_BWDS16(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC);
-        case 4: PBR_BWDS16(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR);
-        default: PBR_BWDS16(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED);
-    }
-#undef PBR_BWDS16
-}
-
 // Rounds of the streamed backward kernel (ct_backward.hpp: its grid is rounds x the waves the chip holds at once), or 0 when
 // the launch does not qualify: fp16 maps, one light, untiled, rows a whole number of 128-pixel tiles, 4-byte aligned planes
 // with even strides (its loads and stores move two fp16 values per lane).  g_bwd_run: -1 = rule, 0 = never, N = N rounds (A/B).
@@ -131,22 +116,7 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
         int64_t per_material = (slots + d->batch - 1) / d->batch;
         if (per_material > tiles) per_material = tiles;
         if (per_material < 1) per_material = 1;
-        // 16-byte memory instructions (cook_torrance_backward_stream16_kernel): every plane 16-byte aligned with strides that keep
-        // it so, the FULL case only.  g_bwd_wide: -1 = rule, 0 = the 4-byte form, 1 = forced where legal (A/B).  Measured on a
-        // 4096^2 material (tools/bwd_wide_ab.py, alternating in one process, round 3): 143.5 us against 142.9 us for the 4-byte
-        // form (metallic), 169.4 against 170.0 (specular) -- 4 + 2 vector-memory instructions per tile instead of 14 + 8 change
-        // nothing: the kernel is not limited by how its memory requests are shaped.  The rule is therefore "off".
-        auto al16 = [](const pbr_map &m) {
-            return !m.data || ((reinterpret_cast<uintptr_t>(m.data) & 15u) == 0 && m.batch_stride % 8 == 0 && m.channel_stride % 8 == 0);
-        };
-        bool wide = full && g_bwd_wide > 0 && al16(d->albedo) && al16(d->normal) && al16(d->roughness) && al16(d->metallic) && al16(d->specular) &&
-                    (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0 && k.o_cs % 8 == 0;
-        for (int i = 0; i < 5 && wide; ++i) wide = (reinterpret_cast<uintptr_t>(gs[i]) & 15u) == 0;
-        if (wide)
-            hipLaunchKernelGGL(pick_bwd_stream16(d), dim3((unsigned)per_material, (unsigned)d->batch, 1), dim3(64, 1, 1), 0,
-                               static_cast<hipStream_t>(stream), k, b, tiles);
-        else
-            hipLaunchKernelGGL(pick_bwd_stream(d, full), dim3((unsigned)per_material, (unsigned)d->batch, 1), dim3(64, 1, 1), 0,
+        hipLaunchKernelGGL(pick_bwd_stream(d, full), dim3((unsigned)per_material, (unsigned)d->batch, 1), dim3(64, 1, 1), 0,
                                static_cast<hipStream_t>(stream), k, b, tiles, n_stores);
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? PBR_OK : 1000 + (int)e;

@@ -659,170 +659,8 @@ void cook_torrance_backward_stream_kernel(const KArgs a, const BArgs b, const in
     backward_stream_body<LIGHT, WF, FULL>(a, b, tiles_per_material, n_stores, buf, none);
 }
 
-// ------------------------------------------------------------------ streamed form with 16-byte memory instructions (round 3)
-// The same schedule as cook_torrance_backward_stream_kernel<.., FULL = true> with FOUR vector-memory loads and TWO (three)
-// stores per tile instead of 14 (16) and 8 (10): every instruction moves 1 KiB.
-//   loads   global_load_lds_dwordx4: lane l's 16 bytes land at LDS byte  j * 1024 + 16 l  of the tile buffer, i.e. in plane
-//           4 j + (l >> 4) of the buffer's 256-byte planes at byte 16 (l & 15) -- so lane l fetches THAT plane's bytes of the
-//           tile: a per-lane 64-bit address, formed once per wave (plane base, lane offset, the instruction's offset bias),
-//           plus tile * (256 | 512) bytes per tile (one v_mad_u64_u32).  Same buffer layout as the 4-byte form, so the
-//           hand-written ds_reads are unchanged.
-//   stores  the lane's fp16 gradient pairs go through a second LDS block (ds_write_b32 per plane, ds_read_b128 back transposed:
-//           lane l gets 16 bytes of plane 4 k + (l >> 4)), then ONE global_store_dwordx4 per four planes.
-// Everything that touches LDS is hand-written (the compiler would wait for every vector-memory operation before an LDS access
-// it can see, the buffer being a DMA target); tools/check_isa.py pins the instruction counts the waits assume.
-constexpr int kStream16StoreWords = 12 * 64;                              // up to 12 planes x 256 bytes (3 store instructions)
-
-template <int LIGHT, int WF>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PBR_BWD_STREAM_WAVES)))
-void cook_torrance_backward_stream16_kernel(const KArgs a, const BArgs b, const int tiles_per_material) {
-    __shared__ uint32_t buf[kStreamLdsWords + kStream16StoreWords];
-    constexpr bool SPEC = WF == PBR_WORKFLOW_SPECULAR;
-    constexpr int NP = SPEC ? 10 : 8;                                     // map planes = gradient planes
-    constexpr int NS = (NP + 3) / 4;                                      // store instructions per tile
-    const int lane = threadIdx.x, mat = blockIdx.y;
-    const int t0 = blockIdx.x, t1 = tiles_per_material, step = gridDim.x;
-    __builtin_assume(a.albedo_srgb != 0); __builtin_assume(a.out_srgb != 0); __builtin_assume(a.has_normal != 0);
-    __builtin_assume(b.g_albedo != nullptr); __builtin_assume(b.g_normal != nullptr); __builtin_assume(b.g_rough != nullptr);
-    if (WF != PBR_WORKFLOW_METALLIC) __builtin_assume(a.spec_srgb != 0);
-    if (SPEC) __builtin_assume(b.g_spec != nullptr); else __builtin_assume(b.g_metal != nullptr);
-    // ---- per-lane plane addresses, once per wave
-    const int sub = lane >> 4, at16 = 16 * (lane & 15);
-    auto map_plane = [&](int q) -> uint64_t {                             // byte address of map plane q of this material
-        const _Float16 *p;
-        if (q < 3) p = static_cast<const _Float16 *>(a.albedo) + mat * a.a_bs + q * a.a_cs;
-        else if (q < 6) p = static_cast<const _Float16 *>(a.normal) + mat * a.n_bs + (q - 3) * a.n_cs;
-        else if (q == 6) p = static_cast<const _Float16 *>(a.rough) + mat * a.r_bs;
-        else if (!SPEC) p = static_cast<const _Float16 *>(a.metal) + mat * a.m_bs;
-        else p = static_cast<const _Float16 *>(a.spec) + mat * a.s_bs + (q - 7) * a.s_cs;
-        return reinterpret_cast<uint64_t>(p);
-    };
-    auto grad_plane = [&](int q) -> uint64_t {                            // byte address of gradient plane q (dense [B][C][H*W])
-        _Float16 *p;
-        if (q < 3) p = static_cast<_Float16 *>(b.g_albedo) + ((int64_t)mat * 3 + q) * a.o_cs;
-        else if (q < 6) p = static_cast<_Float16 *>(b.g_normal) + ((int64_t)mat * 3 + (q - 3)) * a.o_cs;
-        else if (q == 6) p = static_cast<_Float16 *>(b.g_rough) + (int64_t)mat * a.o_cs;
-        else if (!SPEC) p = static_cast<_Float16 *>(b.g_metal) + (int64_t)mat * a.o_cs;
-        else p = static_cast<_Float16 *>(b.g_spec) + ((int64_t)mat * 3 + (q - 7)) * a.o_cs;
-        return reinterpret_cast<uint64_t>(p);
-    };
-    // plane (q0 + sub) of this lane, without a per-lane indirect access: four scalar addresses, selected
-    auto pick_map = [&](int q0) -> uint64_t {
-        const uint64_t v0 = map_plane(q0), v1 = map_plane(q0 + 1), v2 = map_plane(q0 + 2), v3 = map_plane(q0 + 3);
-        return sub == 0 ? v0 : (sub == 1 ? v1 : (sub == 2 ? v2 : v3));
-    };
-    auto pick_grad = [&](int q0) -> uint64_t {
-        const int q1 = q0 + 1 < NP ? q0 + 1 : q0, q2 = q0 + 2 < NP ? q0 + 2 : q0, q3 = q0 + 3 < NP ? q0 + 3 : q0;
-        const uint64_t v0 = grad_plane(q0), v1 = grad_plane(q1), v2 = grad_plane(q2), v3 = grad_plane(q3);
-        return sub == 0 ? v0 : (sub == 1 ? v1 : (sub == 2 ? v2 : v3));
-    };
-    // loads: instruction j covers LDS bytes [1024 j, 1024 j + 1024).  j = 0, 1: map planes 0-7.  The upstream gradient's three
-    // 512-byte planes sit at byte 2560 (behind the 10 map-plane slots): j = 2 covers slots 8, 9 (specular maps only) and
-    // gradient plane 0, j = 3 gradient planes 1 and 2.  Lanes without a source (metallic: lanes 0-31 of j = 2) are masked off.
-    const uint64_t gout0 = reinterpret_cast<uint64_t>(static_cast<const float *>(b.gout) + mat * a.o_bs);
-    const uint64_t cs4 = (uint64_t)a.o_cs * 4u;
-    uint64_t ld[4];
-    uint32_t stride[4];
-    ld[0] = pick_map(0) + at16;            stride[0] = 256u;
-    ld[1] = pick_map(4) + at16 - 1024u;    stride[1] = 256u;
-    {   // j = 2: lanes 0-31 -> map planes 8, 9 (SPEC) ; lanes 32-63 -> gradient plane 0 (16 bytes per lane: 32 lanes = 512 bytes)
-        const uint64_t m8 = SPEC ? (sub == 0 ? map_plane(8) : map_plane(9)) + at16 : 0;
-        ld[2] = (lane < 32 ? m8 : gout0 + 16u * (lane - 32)) - 2048u;
-        stride[2] = lane < 32 ? 256u : 512u;
-        ld[3] = gout0 + cs4 * (lane < 32 ? 1u : 2u) + 16u * (lane & 31) - 3072u;
-        stride[3] = 512u;
-    }
-    uint64_t st[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) st[k] = pick_grad(4 * k) + at16;
-    // The last store of the specular form holds 2 planes (32 lanes' worth).  No lane may sit it out -- a store under an exec mask
-    // is a branch around a vector-memory instruction the hand-counted vmcnt relies on -- so lanes 32-63 repeat lanes 0-31: the same
-    // 16 bytes to the same address.
-    const bool mirror = NP % 4 != 0;
-    if (mirror) st[NS - 1] = ((lane & 16) ? grad_plane(NP - 1) : grad_plane(NP - 2)) + at16;
-    auto issue = [&](int t) {
-        const uint32_t tt = (uint32_t)t;
-#define PBR_DMA16(J) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ld[J] + (uint64_t)tt * stride[J]), \
-                                                      (lds_ptr)buf, 16, (J) * 1024, 2)
-        PBR_DMA16(0);
-        PBR_DMA16(1);
-        if (SPEC || lane >= 32) PBR_DMA16(2);
-        PBR_DMA16(3);
-#undef PBR_DMA16
-    };
-    const uint32_t lds0 = (uint32_t)(size_t)(lds_ptr)buf;
-    const uint32_t at4 = lds0 + 4u * lane, at8 = lds0 + kStreamMapPlanes * 256u + 8u * lane;
-    const uint32_t sb4 = lds0 + 4u * kStreamLdsWords + 4u * lane, sb16 = lds0 + 4u * kStreamLdsWords + 16u * lane;
-    const uint32_t sb16_last = mirror ? lds0 + 4u * kStreamLdsWords + 16u * (lane & 31) : sb16;
-    issue(t0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    for (int t = t0; t < t1; t += step) {
-        // the tile's loads were issued BEFORE the previous tile's NS stores: vmcnt retires in order
-        if (NS == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        uint32_t w[kStreamMapPlanes];
-        float2 g2[3];
-#pragma unroll
-        for (int q = 0; q < kStreamMapPlanes; ++q) {
-            w[q] = 0u;
-            if (q < NP) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(w[q]) : "v"(at4), "i"(q * 256) : "memory");
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(g2[c]) : "v"(at8), "i"(c * 512) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]), "+v"(w[8]), "+v"(w[9]),
-                       "+v"(g2[0]), "+v"(g2[1]), "+v"(g2[2]) :: "memory");
-        Texels<2> tx;
-        float go[3][2];
-        auto halves = [&](int plane, float v[2]) {
-            const f16x2 h = __builtin_bit_cast(f16x2, w[plane]);
-            v[0] = (float)h.x; v[1] = (float)h.y;
-        };
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { halves(c, tx.al[c]); halves(3 + c, tx.nm[c]); }
-        halves(6, tx.ro);
-        if (!SPEC) {
-            halves(7, tx.me);
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) halves(7 + c, tx.sp[c]);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { go[c][0] = g2[c].x; go[c][1] = g2[c].y; }
-        if (t + step < t1) issue(t + step);
-        const int ty = (int)a.div_tx.div((uint32_t)t);
-        LanePos p;
-        p.b = p.b0 = mat; p.y = ty; p.x = (t - ty * a.tiles_x) * 128 + 2 * lane;
-        p.pix = p.src = (int64_t)t * 128 + 2 * lane;
-        p.valid = true; p.sb = true; p.dup = 0;
-        backward_body_to<LIGHT, WF, 2, false, __half, false>(a, b, p, tx, go, nullptr, 0,
-            [&](float (&ga)[3][2], float (&gn)[3][2], float (&gr)[2], float (&gm)[2], float (&gs)[3][2]) {
-                auto pack = [](const float v[2]) { return __builtin_bit_cast(uint32_t, f16x2{(_Float16)v[0], (_Float16)v[1]}); };
-                uint32_t o[NP];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) { o[c] = pack(ga[c]); o[3 + c] = pack(gn[c]); }
-                o[6] = pack(gr);
-                if (!SPEC) {
-                    o[7] = pack(gm);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) o[7 + c] = pack(gs[c]);
-                }
-#pragma unroll
-                for (int q = 0; q < NP; ++q) asm volatile("ds_write_b32 %0, %1 offset:%2" :: "v"(sb4), "v"(o[q]), "i"(q * 256) : "memory");
-                f32x4 r[NS];
-#pragma unroll
-                for (int k = 0; k < NS; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r[k]) : "v"(k + 1 < NS ? sb16 : sb16_last), "i"(k * 1024) : "memory");
-                if (NS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]) :: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[NS - 1]) :: "memory");
-                const uint64_t off = (uint64_t)(uint32_t)t * 256u;
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    typedef __attribute__((address_space(1))) f32x4 *global_f32x4;          // a GLOBAL store (flat_store would also count in lgkmcnt)
-                    __builtin_nontemporal_store(r[k], (global_f32x4)(st[k] + off));
-                }
-            });
-    }
-}
+// (A form of this kernel with 16-byte memory instructions -- 4 + 2 vector-memory instructions per tile instead of 14 + 8 -- was built in round 3
+// and measured level, 143.5 against 142.9 us: the kernel is not limited by how its requests are shaped.  Removed in round 5; profiles/EXPERIMENTS.md.)
 
 #ifdef PBR_PARAM_GRAD_KERNELS      // the two reduction kernels are not templates: defined in ct_backward.hip only (the header is shared)
 // Adds up the per-workgroup rows of the PGRAD kernels (fp64 sums, fixed order: deterministic) and applies the part of

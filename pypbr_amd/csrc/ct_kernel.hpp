@@ -71,7 +71,6 @@ struct KArgs {
     int32_t n_tiles;         // tiles_x * ceil(rows / tile rows)
     int32_t xcd_log2;        // workgroup -> tile remap: each XCD takes runs of (1 << xcd_log2) consecutive tiles (0 = identity)
     int32_t xcd_tiles;       // tiles covered by the remap: n_tiles rounded down to a multiple of 8 << xcd_log2
-    int32_t ilv_b, ilv_tiles;// experiment (PBR_TUNE_INTERLEAVE): consecutive workgroups walk ilv_b materials round-robin, ilv_tiles tiles each
     int32_t fold_log2, fold_reps;   // tiled maps: rows visited in bands of (1 << fold_log2) source rows, all fold_reps vertical repeats of a band back to back (0 = off)
     FastDiv div_reps;        // band visit / fold_reps
     int32_t xpose;           // 8-pixel lanes, fp32 result: exchange the lanes' 16-byte pieces through LDS before storing
@@ -103,13 +102,10 @@ struct KArgs {
 typedef const __attribute__((address_space(4))) DevParams *DevParamsPtr;
 __device__ __forceinline__ DevParamsPtr dev_params(uint64_t address) { return (DevParamsPtr)address; }
 __device__ __forceinline__ Vec3 view_of(const KArgs &a) {
-#ifndef PBR_NO_DEV_PARAMS           // build-time A/B switch: the kernels as they were before ABI 5
     if (a.dev) { const DevParamsPtr d = dev_params(a.dev); return Vec3{d->V[0], d->V[1], d->V[2]}; }
-#endif
     return Vec3{a.V[0], a.V[1], a.V[2]};
 }
 __device__ __forceinline__ LightU light_of(const KArgs &a, int l) {
-#ifndef PBR_NO_DEV_PARAMS
     if (a.dev) {
         const DevParamsPtr d = dev_params(a.dev);
         LightU u;
@@ -118,7 +114,6 @@ __device__ __forceinline__ LightU light_of(const KArgs &a, int l) {
         u.rhh = d->lights[l].rhh; u.p5 = d->lights[l].p5;
         return u;
     }
-#endif
     return a.lights[l];
 }
 __device__ __forceinline__ bool grey_lights_of(const KArgs &a) { return a.dev ? dev_params(a.dev)->grey != 0 : a.grey_lights != 0; }
@@ -255,10 +250,6 @@ __device__ __forceinline__ float linspace_at(float a, float b, float step, int n
 // [x << c, (x + 1) << c) of every block of 8 << c tiles, i.e. (1 KiB << c)-contiguous runs per XCD, while the chip-wide
 // front stays one compact window.  Scalar arithmetic only.
 __device__ __forceinline__ uint32_t tile_of_workgroup(const KArgs &a, uint32_t wg) {
-    if (a.ilv_b > 1) {
-        const uint32_t t = wg / (uint32_t)a.ilv_b, b = wg - t * (uint32_t)a.ilv_b;
-        return b * (uint32_t)a.ilv_tiles + t;
-    }
     uint32_t s = wg;
     if (a.xcd_log2 != 0 && wg < (uint32_t)a.xcd_tiles) {
         const uint32_t c = (uint32_t)a.xcd_log2, xcd = wg & 7u, slot = wg >> 3;
@@ -671,7 +662,7 @@ __device__ __forceinline__ void shade_and_store(const KArgs &a, const LanePos &p
 //   PACK1: the one-light fp32 body with packed arithmetic too.  Streaming launches lose with it (see RealOf above), but a
 //        launch over TILED maps (MaterialBase.tile fused as wrap-around addressing) re-reads its texels from L2 / the
 //        memory-side cache and is VALU-bound on the scalar body (valu_busy 0.885, profiles/r03_kernels.json): there the
-//        packed body is the faster one (cook_torrance.hip: pick_kernel, PBR_TUNE_PACK_SINGLE).
+//        packed body is the faster one (cook_torrance.hip: pick_kernel).
 // 1-D grid, one tile per workgroup, tiles ordered x fastest.
 template <int LIGHT, int WF, typename TI, typename TO, int VEC, bool MULTI, bool NT, bool PACK1 = false>
 // Occupancy: the one-light kernels are HBM-bound and want exactly 3 waves per SIMD (12 per CU): fewer cannot
@@ -690,11 +681,7 @@ void cook_torrance_kernel(const KArgs a) {
     if (!p.valid) return;
     Texels<VEC> t;
     load_texels<WF, TI, VEC, NT>(a, a.has_normal != 0, p, t);
-#ifdef PBR_PACK_SINGLE   // build-time experiment switch: packed math for the one-light fp32 kernels too
-    shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, true>(a, p, t);
-#else
     shade_and_store<LIGHT, WF, TO, VEC, MULTI, NT, (MULTI || sizeof(TI) == 2 || PACK1)>(a, p, t);
-#endif
 }
 
 // ------------------------------------------------------------------ batch-inner kernel (several lights)

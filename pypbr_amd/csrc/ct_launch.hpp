@@ -131,7 +131,6 @@ inline int pick_vec(const pbr_render_desc *d) {
 // 8 / 16 MiB plane strides (2048^2, 4096x1024: -2..12 %).  AUTO encodes exactly that; pbr_cook_torrance_autotune
 // measures instead of guessing.
 inline int schedule_xcd_log2(const pbr_render_desc *d, int vec) {
-    if (g_xcd_log2 >= 0) return g_xcd_log2 > 12 ? 12 : g_xcd_log2;
     if (d->schedule >= PBR_SCHEDULE_LINEAR) return d->schedule - PBR_SCHEDULE_LINEAR;
     const int64_t esz = d->map_dtype == PBR_F32 ? 4 : 2;
     const int64_t row_bytes = (int64_t)d->width * esz, tile_bytes = 64 * (int64_t)vec * esz;
@@ -174,7 +173,6 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log
     k.n_tiles = tiles > INT32_MAX ? -1 : (int32_t)tiles;      // -1: more tiles than a 1-D grid holds, rejected by the callers
     k.xcd_log2 = schedule_xcd_log2(d, vec);
     k.xcd_tiles = k.n_tiles < 0 ? 0 : (k.n_tiles >> (k.xcd_log2 + 3)) << (k.xcd_log2 + 3);
-    if (g_interleave && by == 1 && d->batch > 1 && k.n_tiles > 0) { k.ilv_b = d->batch; k.ilv_tiles = k.n_tiles / d->batch; }
     // 8-pixel lanes with an fp32 result swap 16-byte pieces between the lanes of a row before storing (ct_kernel.hpp)
     k.xpose = vec == 8 && d->out_dtype == PBR_F32;
     // Scalar plane addresses (ct_kernel.hpp, plane_at) need every workgroup inside one material -- tile rows divide the
@@ -185,7 +183,7 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log
     // turns it on for those too.
     const int64_t plane_px = (int64_t)d->height * d->width;
     const int64_t map_px = is_tiled(d) ? (int64_t)d->map_height * d->map_width : plane_px;
-    const bool sb_allowed = (d->batch == 1 || d->height % by == 0) && plane_px < (1ll << 30) && map_px < (1ll << 30) && !k.ilv_b;
+    const bool sb_allowed = (d->batch == 1 || d->height % by == 0) && plane_px < (1ll << 30) && map_px < (1ll << 30);
     k.sbase = sb_allowed && (g_scalar_base == 2 || (g_scalar_base == 1 && d->batch == 1));
     k.div_h.init((uint32_t)d->height);
     k.div_tx.init((uint32_t)k.tiles_x);
@@ -198,15 +196,15 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log
     // the source (PMC) -- and costs fp32 maps 8-17 % of time whatever the band (78-82 us in row order, 87-98 us folded, with or
     // without the streaming hint): in row order the second visit is served by the 256 MB memory-side cache, and the launch is
     // VALU-bound either way.  fp16 maps run level (65-69 us both).  The rule therefore folds fp16 maps only.
-    const bool fold_wanted = g_tile_fold > 0 || (g_tile_fold < 0 && d->map_dtype == PBR_F16);
-    if (k.tiled && fold_wanted && by == 1 && d->batch == 1 && d->y_offset == 0 && d->height == d->height_total && !k.ilv_b &&
+    const bool fold_wanted = d->map_dtype == PBR_F16;
+    if (k.tiled && fold_wanted && by == 1 && d->batch == 1 && d->y_offset == 0 && d->height == d->height_total &&
         d->height_total > d->map_height && k.n_tiles > 0) {
         // rows per band: the band's texels (all planes) within ~2 MiB -- 1/8 of it per XCD, beside the result streams in a 4 MiB
         // L2 -- a power of two that divides map_h, the band a whole number of XCD periods (tools/tile_probe.py: "fold").
         const int64_t esz = d->map_dtype == PBR_F32 ? 4 : 2;
         const int64_t row_bytes = (int64_t)d->map_width * esz * (3 + (d->normal.data ? 3 : 0) + 1 + (d->workflow == PBR_WORKFLOW_SPECULAR ? 3 : 1));
-        int fl = g_tile_fold > 0 ? g_tile_fold : 0;
-        if (g_tile_fold < 0) while (fl < 12 && (row_bytes << (fl + 1)) <= (2ll << 20)) ++fl;
+        int fl = 0;
+        while (fl < 12 && (row_bytes << (fl + 1)) <= (2ll << 20)) ++fl;
         const int64_t period = 8ll << k.xcd_log2;
         while (fl > 0 && (d->map_height % (1 << fl) || (((int64_t)k.tiles_x << fl) % period))) --fl;
         if (fl > 0) { k.fold_log2 = fl; k.fold_reps = d->height_total / d->map_height; k.div_reps.init((uint32_t)k.fold_reps); }
@@ -252,6 +250,11 @@ using KernelFn = void (*)(const KArgs);
 KernelFn pick_batch_kernel(const pbr_render_desc *d, int nb, bool nt);      // ct_batch.hip
 KernelFn pick_repeat_kernel(const pbr_render_desc *d, int nt_knob);            // ct_tiled.hip
 void fill_repeat_args(const pbr_render_desc *d, KArgs &k);
+// ct_repeat_backward.hip: gradients of TILED maps folded in registers (and, with `loss`, the rendering-loss step over tiled maps)
+bool repeat_backward_serves(const pbr_render_desc *d);
+int64_t repeat_backward_tiles(const pbr_render_desc *d);
+int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void *g_albedo, void *g_normal, void *g_roughness, void *g_metallic,
+                           void *g_specular, bool loss, float scale, float *partials, hipStream_t st);
 
 // Tiled maps evaluated by the repeat-inner kernel (ct_kernel.hpp: cook_torrance_repeat_kernel): one light, map rows a whole number of
 // 4-texel lanes, and an output -- the whole tiled image, or a row band of it (a multi-GPU shard) -- that holds at least one full period
@@ -259,7 +262,7 @@ void fill_repeat_args(const pbr_render_desc *d, KArgs &k);
 // row outside the band would be loaded for nothing.  Thin bands, several lights and ragged map widths take the wrap-around form.
 inline bool repeat_inner(const pbr_render_desc *d) {
     return g_tile_repeat != 0 && is_tiled(d) && d->n_lights == 1 && d->height >= d->map_height &&
-           d->map_width % 4 == 0 && g_max_vec >= 4 && !g_interleave;
+           d->map_width % 4 == 0 && g_max_vec >= 4;
 }
 
 // Materials per lane for this launch, or 0 for the one-material kernels.  Several lights make the launch VALU-bound, and

@@ -189,8 +189,10 @@ extern "C" {
 
 size_t pbr_mse_step_workspace_bytes(const pbr_render_desc *d) {
     const pbr::TuningScope tuning(d);
-    if (pbr::validate(d) != PBR_OK || pbr::is_tiled(d)) return 0;
-    const int64_t tiles = pbr::mse_tiles(d, 1);            // one pixel per lane: the most workgroups any launch of this descriptor has
+    if (pbr::validate(d) != PBR_OK) return 0;
+    if (pbr::is_tiled(d) && !pbr::repeat_backward_serves(d)) return 0;
+    // tiled maps: one partial sum per workgroup of the repeat-inner kernel; else one pixel per lane: the most workgroups any launch of this descriptor has
+    const int64_t tiles = pbr::is_tiled(d) ? pbr::repeat_backward_tiles(d) : pbr::mse_tiles(d, 1);
     return tiles < 0 ? 0 : pbr::mse_stage_offset((size_t)tiles) + (size_t)pbr::kMseStageGroups * sizeof(double);
 }
 
@@ -202,11 +204,30 @@ int pbr_cook_torrance_mse_step(const pbr_render_desc *d, const void *target, voi
     if (rc != PBR_OK) return rc;
     if (!target || !loss || !workspace) return PBR_ERR_NULL_MAP;
     if (d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;        // the target image and the colour it is compared with are fp32
-    if (is_tiled(d) || nan_light_size(d)) return PBR_ERR_UNSUPPORTED;
+    if (nan_light_size(d)) return PBR_ERR_UNSUPPORTED;
     const int vec = mse_vec(d);
     KArgs k;
     const double count = 3.0 * (double)d->batch * (double)d->height * (double)d->width;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (is_tiled(d)) {
+        // MaterialBase.tile fused (base.py:524-537): the repeat-inner kernel walks the maps, compares every repeat with the target and leaves
+        // MAP-sized gradients (ct_repeat_backward.hpp); launches it does not serve are the caller's to split (render, loss, folded backward)
+        if (!repeat_backward_serves(d)) return PBR_ERR_UNSUPPORTED;
+        const int64_t tiles = repeat_backward_tiles(d);
+        if (tiles < 0) return PBR_ERR_SHAPE;
+        const int e = launch_repeat_backward(d, target, g_albedo, g_normal, g_roughness, g_metallic, g_specular, true, (float)(2.0 / count),
+                                             static_cast<float *>(workspace), st);
+        if (e != PBR_OK) return e;
+        if (tiles <= kMseSmall) {
+            hipLaunchKernelGGL(mse_reduce_small_kernel, dim3(1), dim3(256), 0, st, static_cast<const float *>(workspace), (int)tiles, 1.0 / count, static_cast<float *>(loss));
+        } else {
+            double *stage = reinterpret_cast<double *>(static_cast<char *>(workspace) + mse_stage_offset((size_t)tiles));
+            hipLaunchKernelGGL(mse_stage_kernel, dim3(kMseStageGroups), dim3(256), 0, st, static_cast<const float *>(workspace), (int)tiles, stage);
+            hipLaunchKernelGGL(mse_finish_kernel, dim3(1), dim3(256), 0, st, stage, 1.0 / count, static_cast<float *>(loss));
+        }
+        const hipError_t err = hipGetLastError();
+        return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+    }
     void *const gs[5] = {g_albedo, g_normal, g_roughness, g_metallic, g_specular};
     if (const int rounds = g_mse_stream ? stream_run(d, target, gs) : 0) {      // fp16 maps, one light: the streamed form
         fill_args(d, 2, k, 6);

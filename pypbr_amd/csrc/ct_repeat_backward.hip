@@ -1,0 +1,122 @@
+// ct_repeat_backward.hip -- instantiations and launch of the repeat-inner backward kernel (ct_repeat_backward.hpp), and the C ABI
+// entry that hands out FOLDED gradients of tiled maps: pbr_cook_torrance_backward_folded.  The rendering-loss step over tiled maps
+// (pbr_cook_torrance_mse_step, ct_loss.hip) launches the same kernel with the loss policy through launch_repeat_backward.
+#include "ct_repeat_backward.hpp"
+#include "ct_launch.hpp"
+
+namespace pbr {
+
+using RepBwdFn = void (*)(const KArgs, const BArgs, const RBArgs);
+
+template <int L, int W>
+static RepBwdFn repeat_bwd_types(bool half_maps, bool loss) {
+    if (half_maps) return loss ? cook_torrance_repeat_backward_kernel<L, W, __half, true> : cook_torrance_repeat_backward_kernel<L, W, __half, false>;
+    return loss ? cook_torrance_repeat_backward_kernel<L, W, float, true> : cook_torrance_repeat_backward_kernel<L, W, float, false>;
+}
+
+static RepBwdFn pick_repeat_bwd(const pbr_render_desc *d, bool loss) {
+    const bool point = d->light_type == PBR_LIGHT_POINT, half_maps = d->map_dtype == PBR_F16;
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: return repeat_bwd_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(half_maps, loss);
+        case 1: return repeat_bwd_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(half_maps, loss);
+        case 2: return repeat_bwd_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(half_maps, loss);
+        case 3: return repeat_bwd_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(half_maps, loss);
+        case 4: return repeat_bwd_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(half_maps, loss);
+        default: return repeat_bwd_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(half_maps, loss);
+    }
+}
+
+// The launches the repeat-inner backward serves: what the forward's repeat-inner kernel serves (one light, map rows a whole number of
+// 4-texel lanes, an output band that holds a full period of the map's rows) with planes small enough for its 32-bit lane offsets
+// when it addresses them through a scalar base.  fp32 result / upstream gradient only (as every backward entry).
+bool repeat_backward_serves(const pbr_render_desc *d) {
+    return repeat_inner(d) && d->out_dtype == PBR_F32 && g_max_vec >= 2;
+}
+
+// Workgroups of the launch for this descriptor (one partial sum each under the loss policy), -1 when it does not fit a 1-D grid.
+int64_t repeat_backward_tiles(const pbr_render_desc *d) {
+    KArgs k;
+    pbr_render_desc g = *d;
+    g.height = g.height_total = d->map_height; g.width = d->map_width; g.map_height = g.map_width = 0; g.y_offset = 0;
+    fill_args(&g, 2, k, 6);
+    return k.n_tiles;
+}
+
+// `upstream`: the gradient w.r.t. the output, or (loss != nullptr) the target image; [B][3][d->height][d->width] fp32 contiguous.
+// g_*: MAP-sized ([B][C][map_height][map_width], dense), in the maps' storage type.
+int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void *g_albedo, void *g_normal, void *g_roughness, void *g_metallic,
+                           void *g_specular, bool loss, float scale, float *partials, hipStream_t st) {
+    KArgs full, k;
+    fill_args(d, 4, full);                               // the output's point-light grid, view, light, flags
+    pbr_render_desc g = *d;
+    g.height = g.height_total = d->map_height; g.width = d->map_width; g.map_height = g.map_width = 0; g.y_offset = 0;
+    g.out_batch_stride = g.out_channel_stride = 0;
+    fill_args(&g, 2, k, 6);                              // one-wave workgroups over the source maps, two texels per lane
+    if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+    k.x0 = full.x0; k.x1 = full.x1; k.xstep = full.xstep;
+    k.y0 = full.y0; k.y1 = full.y1; k.ystep = full.ystep;
+    k.rep_y = d->height_total / d->map_height; k.rep_x = d->width / d->map_width;
+    k.out_W = d->width; k.out_Ht = d->height_total;
+    k.y_offset = d->y_offset; k.H_total = d->height;     // `upstream` holds the rows [y_offset, y_offset + height) of the tiled image
+    k.o_cs = (int64_t)d->map_height * d->map_width; k.o_bs = 3 * k.o_cs;      // the gradient planes: dense, map-sized
+    const int64_t out_plane = (int64_t)d->height * d->width;
+    if (out_plane >= (1ll << 30)) k.sbase = 0;           // the lane's offset inside the output's first repeat must fit 32 bits of bytes
+    const BArgs b = {nullptr, g_albedo, g_normal, g_roughness, g_metallic, g_specular, nullptr};
+    const RBArgs rb = {static_cast<const float *>(upstream), out_plane, scale, partials};
+    hipLaunchKernelGGL(pick_repeat_bwd(d, loss), dim3((unsigned)k.n_tiles, 1, 1), dim3(64, 1, 1), 0, st, k, b, rb);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+}
+
+static size_t folded_fallback_bytes(const pbr_render_desc *d) {
+    // output-sized gradients of every map the descriptor holds, in the maps' storage type (the two-kernel form's intermediate)
+    const size_t esz = d->map_dtype == PBR_F32 ? 4 : 2;
+    const size_t planes = 3 + (d->normal.data ? 3 : 0) + 1 + (d->workflow == PBR_WORKFLOW_SPECULAR ? 3 : 1);
+    return planes * (size_t)d->batch * (size_t)d->height * (size_t)d->width * esz;
+}
+
+}  // namespace pbr
+
+extern "C" {
+
+size_t pbr_backward_folded_workspace_bytes(const pbr_render_desc *d) {
+    const pbr::TuningScope tuning(d);
+    if (pbr::validate(d) != PBR_OK || !pbr::is_tiled(d)) return 0;
+    return pbr::repeat_backward_serves(d) ? 0 : pbr::folded_fallback_bytes(d);
+}
+
+int pbr_cook_torrance_backward_folded(const pbr_render_desc *d, const void *grad_out, void *g_albedo, void *g_normal, void *g_roughness,
+                                      void *g_metallic, void *g_specular, void *workspace, void *stream) {
+    const pbr::TuningScope tuning(d);
+    using namespace pbr;
+    const int rc = validate(d);
+    if (rc != PBR_OK) return rc;
+    if (!grad_out) return PBR_ERR_NULL_MAP;
+    if (d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;
+    if (!is_tiled(d))                                         // nothing to fold: the gradients are map-sized as they come
+        return pbr_cook_torrance_backward(d, grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, stream);
+    if (d->height != d->height_total && d->height < d->map_height) return PBR_ERR_UNSUPPORTED;   // a band thinner than one period of the map
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (repeat_backward_serves(d))
+        return launch_repeat_backward(d, grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, false, 0.0f, nullptr, st);
+    // the two-kernel form: per-output-pixel gradients into the workspace, then the sums (whole outputs only: a band's repeats are not whole)
+    if (!workspace) return PBR_ERR_NULL_MAP;
+    if (d->height != d->height_total) return PBR_ERR_UNSUPPORTED;
+    const size_t esz = d->map_dtype == PBR_F32 ? 4 : 2;
+    const size_t plane = (size_t)d->batch * d->height * d->width * esz;
+    char *w = static_cast<char *>(workspace);
+    void *const wanted[5] = {g_albedo, d->normal.data ? g_normal : nullptr, g_roughness,
+                             d->workflow == PBR_WORKFLOW_SPECULAR ? nullptr : g_metallic, d->workflow == PBR_WORKFLOW_SPECULAR ? g_specular : nullptr};
+    const int channels[5] = {3, 3, 1, 1, 3};
+    void *big[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    for (int i = 0; i < 5; ++i)
+        if (wanted[i]) { big[i] = w; w += (size_t)channels[i] * plane; }
+    int e = pbr_cook_torrance_backward(d, grad_out, big[0], big[1], big[2], big[3], big[4], stream);
+    for (int i = 0; i < 5 && e == PBR_OK; ++i)
+        if (wanted[i])
+            e = pbr_fold_gradient_typed(big[i], wanted[i], d->batch, channels[i], d->map_height, d->map_width, d->height / d->map_height,
+                                        d->width / d->map_width, 0, d->map_dtype, stream);
+    return e;
+}
+
+}  // extern "C"

@@ -1,0 +1,235 @@
+// ct_repeat_backward.hpp -- gradient of the fused evaluation w.r.t. TILED maps, folded in registers (round 5).
+//
+// material.tile(n) (/root/reference/pypbr/materials/base.py:524-537) is `map.repeat(1, n, n)`: autograd gives a texel the SUM of
+// the gradients of its n x n repeats.  The reference's example material is `resize(512).tile(2)` (examples/example_brdf.py:11) and
+// its documented ML use a rendering loss over such a material (docs/source/tutorials/06_advanced.rst:73-107).  Until round 4 the
+// backward kernel wrote one gradient per OUTPUT pixel (32 B x n^2 per texel) and pbr_fold_gradient read them back and summed.
+// Here the grid walks the SOURCE maps, like cook_torrance_repeat_kernel in the forward direction: a lane loads its texels once,
+// re-evaluates the light-independent forward terms once (colour decode and its slope, F0, normal, the PixelTerms), then visits the
+// rep_y x rep_x output positions of its texels -- upstream gradient in (12 B per output pixel), light geometry, the chain rule of
+// ct_backward.hpp (eval_light / backprop_light), the light-independent tail -- and adds each position's gradient to register
+// accumulators in the order pbr_fold_gradient adds them (repeat rows outer, repeat columns inner).  Map-sized gradients are
+// written once: 12 B per output pixel + 64 B per texel instead of 76 + 32 (fold reads) + 32/n^2 per output pixel.
+//
+// Same functions, same statements per position as backward_body_to: for fp32 maps the result is BIT-IDENTICAL to
+// pbr_cook_torrance_backward + pbr_fold_gradient (tests/test_gpu_round5.py); for fp16 maps the per-position gradients are summed
+// unrounded in fp32 and rounded once (the two-kernel form rounds every position's gradient to fp16 first).
+//
+// With the MseLoss policy the upstream gradient is formed in the kernel from the target image (the rendering-loss step for tiled
+// maps: pbr_cook_torrance_mse_step lifts its "untiled" restriction through this kernel).
+//
+// One packed pair (2 texels) per lane: the texel state that must stay live across the repeat loop (PixelTerms, colour slopes,
+// 8-10 accumulators) plus one position's working set is ~150 VGPRs per pair; two pairs would leave one wave per SIMD.
+#pragma once
+#include "ct_backward.hpp"
+
+namespace pbr {
+
+// Forward decode of one pixel group, as the chain rule needs it again (cooktorrance.py:99-118 and the conversions it calls):
+// the statements of backward_body_to's "forward: decoded colours and their derivatives" block.
+template <class R> struct BwdTexelT {
+    R base[3], dbase[3], f0[3], df0[3], alin[3];
+    R m, om, kd_scale, rough;
+    Vec3T<R> nraw;
+    PixelTermsT<R> pt;
+};
+
+template <int WF, int VEC, class R>
+__device__ __forceinline__ void bwd_decode(const KArgs &a, const Texels<VEC> &t, int g, const Vec3 &V, BwdTexelT<R> &x) {
+    x.kd_scale = splat<R>(1.0f);
+    x.m = WF != PBR_WORKFLOW_SPECULAR ? gather<R>(t.me, g) : splat<R>(0.0f);
+    x.om = splat<R>(1.0f) - x.m;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const R al = gather<R>(t.al[c], g);
+        x.alin[c] = x.base[c] = al; x.dbase[c] = splat<R>(1.0f);
+        if (a.albedo_srgb) srgb_to_linear_and_grad(al, x.base[c], x.dbase[c]);
+        x.alin[c] = x.base[c];
+        if (WF == PBR_WORKFLOW_METALLIC) {
+            x.f0[c] = fma_(x.m, x.base[c], x.om * kDielectricF0);                  // lerp(0.04, base, m) :107
+            x.df0[c] = splat<R>(0.0f);
+        } else if (WF == PBR_WORKFLOW_SPECULAR) {
+            const R sp = gather<R>(t.sp[c], g);
+            x.f0[c] = sp; x.df0[c] = splat<R>(1.0f);
+            if (a.spec_srgb) srgb_to_linear_and_grad(sp, x.f0[c], x.df0[c]);
+        } else {   // CONVERTED: to_diffuse_specular_material (metallic.py:98-108), then the specular workflow
+            const R sp = fma_(x.alin[c], x.m, x.om * kDielectricF0);
+            x.base[c] = x.alin[c] * x.om;
+            x.f0[c] = sp; x.df0[c] = splat<R>(1.0f);
+            if (a.spec_srgb) srgb_to_linear_and_grad(sp, x.f0[c], x.df0[c]);
+        }
+    }
+    if (WF == PBR_WORKFLOW_METALLIC) x.kd_scale = x.om;
+    x.nraw = {gather<R>(t.nm[0], g), gather<R>(t.nm[1], g), gather<R>(t.nm[2], g)};
+    x.rough = gather<R>(t.ro, g);
+    pixel_terms(x.nraw, V, x.rough, x.base, x.f0, x.kd_scale, x.pt);
+}
+
+// The light-independent tail of the chain rule (backward_body_to's last block): adjoints of kb / f0 / a2 / k / N.V / the unit
+// normal -> gradients w.r.t. the stored texels of the group.
+template <int WF, class R>
+__device__ __forceinline__ void bwd_tail(const BwdTexelT<R> &x, const PixelAdjointT<R> &adj, const Vec3 &V, R (&ga)[3], R (&gn)[3], R &gr, R &gm,
+                                         R (&gs)[3]) {
+    // kb = kd_scale * base / pi ; kd_scale = 1 - m  (:169-174)
+    R g_m = splat<R>(0.0f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        R g_base = adj.g_kb[c] * (x.kd_scale * kInvPi);
+        gs[c] = splat<R>(0.0f);
+        if (WF == PBR_WORKFLOW_METALLIC) {                               // kd_scale = 1 - m; lerp(0.04, base, m)  (:107)
+            g_m = fma_(adj.g_kb[c], x.base[c] * (-kInvPi), g_m);
+            g_base = fma_(adj.g_f0[c], x.m, g_base);
+            g_m = fma_(adj.g_f0[c], x.base[c] - kDielectricF0, g_m);
+        } else if (WF == PBR_WORKFLOW_SPECULAR) {
+            gs[c] = adj.g_f0[c] * x.df0[c];
+        } else {   // diffuse = a (1-m) ; specular = 0.04 (1-m) + a m
+            const R g_sp = adj.g_f0[c] * x.df0[c], g_diff = adj.g_kb[c] * kInvPi;
+            g_base = fma_(g_diff, x.om, g_sp * x.m);
+            g_m = fma_(g_sp, x.alin[c] - kDielectricF0, fma_(-g_diff, x.alin[c], g_m));
+        }
+        ga[c] = g_base * x.dbase[c];
+    }
+    gm = g_m;
+    gr = fma_(adj.g_k, (x.rough + 1.0f) * 0.25f, adj.g_a2 * (x.rough * 2.0f));   // k = (r+1)^2/8, a2 = r^2
+    // N.V clamp, then F.normalize: g_n = (g - n (n.g)) / |n|
+    const R gv = masked(in_unit(x.pt.ndv_raw, x.pt.ndv), adj.g_ndv);
+    const Vec3T<R> gnh = {fma_(gv, splat<R>(V.x), adj.g_n.x), fma_(gv, splat<R>(V.y), adj.g_n.y), fma_(gv, splat<R>(V.z), adj.g_n.z)};
+    const R rn = rsq(dot_plus(x.nraw, x.nraw, 1e-24f));
+    const R radial = dot(x.pt.n, gnh);
+    gn[0] = (gnh.x - x.pt.n.x * radial) * rn;
+    gn[1] = (gnh.y - x.pt.n.y * radial) * rn;
+    gn[2] = (gnh.z - x.pt.n.z * radial) * rn;
+}
+
+// Extra kernel arguments: where the upstream gradient (or the target image) of the OUTPUT lives.
+struct RBArgs {
+    const float *gout;          // upstream gradient, or with the loss policy the target image: [B][3][band rows][out_W] fp32 contiguous
+    int64_t gout_cs;            // elements between its channel planes (band rows * out_W); materials are 3 of them apart
+    float scale;                // loss: 2 / N
+    float *partials;            // loss: one sum of squared differences per workgroup
+};
+
+//   LIGHT / WF: as everywhere.  TM: storage type of the maps and of their gradients.  LOSS: the rendering-loss step.
+// KArgs as fill_repeat_args leaves them (the grid of an untiled launch over the source maps; rep_y / rep_x / out_W / out_Ht /
+// y_offset / H_total describe the output) with o_cs = the MAP's plane (the gradient planes are dense [B][C][map_h * map_w]).
+template <int LIGHT, int WF, typename TM, bool LOSS>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RBArgs rb) {
+    constexpr int VEC = 2;
+    using R = f32x2;
+    const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
+    const int ty = (int)a.div_tx.div(tile);
+    const LanePos p = lane_pos<VEC, LOSS>(a, (int)tile - ty * a.tiles_x, ty);      // over the SOURCE maps; LOSS: every lane reaches the wave sum
+    if (!LOSS && !p.valid) return;
+    Texels<VEC> t;
+    if constexpr (sizeof(TM) == 4) {
+        load_texels<WF, TM, VEC, true>(a, a.has_normal != 0, p, t);
+    } else if (p.sb) {
+        if (a.has_normal) load_texels_fixed<WF, TM, VEC, true, true, true>(a, p, t); else load_texels_fixed<WF, TM, VEC, true, true, false>(a, p, t);
+    } else {
+        if (a.has_normal) load_texels_fixed<WF, TM, VEC, true, false, true>(a, p, t); else load_texels_fixed<WF, TM, VEC, true, false, false>(a, p, t);
+    }
+    // Positions k = ry * rep_x + rx in pbr_fold_gradient's order; (ry, rx) are wave-uniform (scalar plane addresses need that), whether
+    // a repeat's row lies inside the band `gout` holds -- rows [y_offset, y_offset + H_total) of the tiled image -- is the lane's own test.
+    const int n_pos = a.rep_y * a.rep_x;
+    const uint32_t lane_out = (uint32_t)(p.y * a.out_W + p.x);                  // inside the first repeat; < 2^30 when p.sb (launch_repeat_backward)
+    auto in_band = [&](int ry) { const int yy = p.y + ry * a.H - a.y_offset; return yy >= 0 && yy < a.H_total; };
+    auto load_upstream = [&](int k, float (&go)[3][VEC]) {
+        const int ry = k / a.rep_x, rx = k - ry * a.rep_x;
+        if (!in_band(ry)) return;
+        const int64_t rep = ((int64_t)ry * a.H - a.y_offset) * a.out_W + (int64_t)rx * a.W;      // may be negative; rep + the lane's part never is
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (p.sb) Ld<float, VEC>::template load<true>(plane_at<float>(rb.gout, (p.b0 * 3 + c) * rb.gout_cs + rep, lane_out), 0, go[c]);
+            else Ld<float, VEC>::template load<true>(rb.gout, ((int64_t)p.b * 3 + c) * rb.gout_cs + rep + (int64_t)p.y * a.out_W + p.x, go[c]);
+        }
+    };
+    float go[3][VEC] = {}, go_next[3][VEC] = {};
+    load_upstream(0, go);
+
+    if (!a.has_normal) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { t.nm[0][j] = 0.0f; t.nm[1][j] = 0.0f; t.nm[2][j] = 1.0f; }
+    }
+    const Vec3 V = view_of(a);
+    const LightU lu = light_of(a, 0);
+    BwdTexelT<R> x;
+    bwd_decode<WF, VEC, R>(a, t, 0, V, x);
+
+    R acc_a[3], acc_n[3], acc_s[3], acc_r = splat<R>(0.0f), acc_m = splat<R>(0.0f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { acc_a[c] = splat<R>(0.0f); acc_n[c] = splat<R>(0.0f); acc_s[c] = splat<R>(0.0f); }
+    float sq = 0.0f;
+
+    for (int k = 0; k < n_pos; ++k) {
+        if (k + 1 < n_pos) load_upstream(k + 1, go_next);                       // the next position's 12 B per pixel travel under this one's arithmetic
+        const int ry = k / a.rep_x, rx = k - ry * a.rep_x;
+        if (!in_band(ry)) {                                                     // a repeat outside this rank's band: nothing to add
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
+            continue;
+        }
+        float ys = 0.0f;
+        R xs[1] = {splat<R>(0.0f)};
+        if (LIGHT == PBR_LIGHT_POINT) {
+            ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, p.y + ry * a.H);
+            x_grid_w<R, 1, VEC>(a, a.out_W, p.x + rx * a.W, xs);
+        }
+        const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[0], ys);
+        LightEvalT<R> e;
+        eval_light(x.pt, lg, lu.inten, e);
+        R gout_c[3], g_col[3];
+        if constexpr (LOSS) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const R out = a.out_srgb ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180
+                const R d = out - gather<R>(go[c], 0);
+                if (p.valid) sq += hsum(d * d);
+                gout_c[c] = d * rb.scale;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
+        PixelAdjointT<R> adj;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { adj.g_kb[c] = splat<R>(0.0f); adj.g_f0[c] = splat<R>(0.0f); }
+        adj.g_a2 = adj.g_k = adj.g_ndv = splat<R>(0.0f);
+        adj.g_n = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
+        LightParamAdjT<R> pa;
+        backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
+        R ga[3], gn[3], gs[3], gr, gm;
+        bwd_tail<WF, R>(x, adj, V, ga, gn, gr, gm, gs);
+        // one statement per sum: the position's gradient is a rounded value BEFORE it is added (no fused multiply-add across the
+        // two), which is what makes the sum equal pbr_fold_gradient's over the stored per-position gradients
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc_a[c] = acc_a[c] + ga[c];
+            acc_n[c] = acc_n[c] + gn[c];
+            acc_s[c] = acc_s[c] + gs[c];
+        }
+        acc_r = acc_r + gr;
+        acc_m = acc_m + gm;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
+    }
+    if constexpr (LOSS) {
+        const float total = wave_sum(sq);
+        if (threadIdx.x == 0) rb.partials[blockIdx.x] = total;
+        if (!p.valid) return;
+    }
+    float oa[3][VEC], on[3][VEC], os[3][VEC], orr[VEC], om[VEC];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { scatter(oa[c], 0, acc_a[c]); scatter(on[c], 0, acc_n[c]); scatter(os[c], 0, acc_s[c]); }
+    scatter(orr, 0, acc_r); scatter(om, 0, acc_m);
+    store_gradients<WF, VEC, TM>(a, b, p, oa, on, orr, om, os);
+}
+
+}  // namespace pbr

@@ -925,13 +925,13 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
         // Output rows per lane.  Measured (tools/resize_up_ab.py, 3 planes, us, rows 2 / 4 / 8; strip kernel for scale):
         //   4096^2 -> 6144^2  131.4 / 121.6 / 110.8 (157)    -> 8192^2  215.3 / 195.5 / 184.7 (270)    2048^2 -> 4096^2  59.0 / 53.6 / 53.0 (64)
         //   4096^2 -> 4608^2   79.1 /  70.0 /  73.1 (101)    -> 4096^2   63.7 /  61.2 /  66.0 (95)
-        // 8 from 1.25x up (the column taps' share shrinks as the rows grow), 4 below.  A/B knob PBR_TUNE_RESIZE_ROWS (2 | 4 | 8).
-        const int rows = g_resize_rows == 2 || g_resize_rows == 4 || g_resize_rows == 8 ? g_resize_rows : (fh.scale <= 0.8f ? 8 : 4);
+        // 8 from 1.25x up (the column taps' share shrinks as the rows grow), 4 below.
+        const int rows = fh.scale <= 0.8f ? 8 : 4;
         const int64_t groups_x = (w_out + 255) / 256, groups_y = (h_out + rows - 1) / rows, n_groups = groups_x * groups_y * planes;
         if (n_groups <= INT32_MAX) {
             const uint32_t span = 8u << kUpRunLog2;
-            const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
-            auto fn = rows == 2 ? resize_up2_kernel<2> : (rows == 8 ? resize_up2_kernel<8> : resize_up2_kernel<4>);
+            const uint32_t xcd_groups = (uint32_t)(n_groups / span) * span;
+            auto fn = rows == 8 ? resize_up2_kernel<8> : resize_up2_kernel<4>;
             hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(src), static_cast<float *>(dst),
                                (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)groups_x, (int)groups_y, xcd_groups, fw, fh);
             const hipError_t e = hipGetLastError();
@@ -953,7 +953,6 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
             int toh = 8;
             for (int rows : {128, 64, 32, 16})
                 if (lds_for(rows) <= 24 * 1024) { toh = rows; break; }
-            if (g_resize_rows > 0) toh = g_resize_rows;
             const size_t lds = lds_for(toh);
             const int64_t tx = (w_out + kTileW - 1) / kTileW, tyy = (h_out + toh - 1) / toh;
             if (lds <= 64 * 1024 && planes * tx * tyy <= INT32_MAX) {
@@ -963,11 +962,11 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
                 // -> 6144^2 163.5 -> 158.1, -> 8192^2 269.1 -> 271.5; HBM reads 301.5 -> 201.7 MB for the 2x down-scale (the input is
                 // 201.3 MB), 399.7 -> 201.7 MB for the 1.5x up-scale.  One chunk per XCD (an eighth of all tiles each) is as good for
                 // down-scales but 4 % slower for large up-scales (eight write fronts far apart); 32 ... 1024 tiles are within 2 %.
-                int64_t chunk = g_resize_xcd == 0 ? 0 : (g_resize_xcd >= 8 ? g_resize_xcd : (g_resize_xcd == 2 ? n_tiles / 8 : 64));
+                int64_t chunk = 64;
                 if (chunk > n_tiles / 8) chunk = n_tiles / 8;
-                const int quads = g_resize_quads == 2 && w_out % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;      // forward down-scales: 62.7 against 54.0 us with them (4096^2 -> 2048^2), so only on demand
+                const int quads = 0;      // 16-byte stores in the forward width pass: 62.7 against 54.0 us with them (4096^2 -> 2048^2): never
                 const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0), quads};
-                auto strip = quads ? resize_strip_kernel<false, true> : resize_strip_kernel<false, false>;
+                auto strip = resize_strip_kernel<false, false>;
                 hipLaunchKernelGGL(strip, dim3((unsigned)(planes * tx * tyy)), dim3(256), lds, s,
                                    static_cast<const float *>(src), static_cast<float *>(dst), (int)h_out, (int)w_out, (int)w_in, tg, fw, fh, StripTables{});
                 const hipError_t e = hipGetLastError();
@@ -1007,7 +1006,7 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
     int *lo_y = reinterpret_cast<int *>(wx + (size_t)kBwdMaxTaps * w_in), *cnt_y = lo_y + h_in, *lo_x = cnt_y + h_in, *cnt_x = lo_x + w_in;
     const auto g = static_cast<const float *>(grad_out);
     float *gi = static_cast<float *>(grad_in);
-    if (g_resize_up2 && g_resize_bwd_fused && fw.scale <= 1.0f && fh.scale <= 1.0f && fw.scale >= 0.34f && fh.scale >= 0.25f && w_out >= 16) {
+    if (g_resize_up2 && fw.scale <= 1.0f && fh.scale <= 1.0f && fw.scale >= 0.34f && fh.scale >= 0.25f && w_out >= 16) {
         // gradient of an up-scale (up to 3x across, 4x down the rows): the register-only transpose of the two-tap forward (round 4;
         // tools/resize_bwd_probe.py).  W from the exact window count of THIS shape; rows per lane 4.
         const int need = up2_backward_window(fw, w_out);
@@ -1015,7 +1014,7 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
         const int64_t groups_x = (w_in + 255) / 256, groups_y = (h_in + R - 1) / R, n_groups = groups_x * groups_y * planes;
         if (need <= 16 && n_groups <= INT32_MAX) {
             const uint32_t span = 8u << kUpRunLog2;
-            const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
+            const uint32_t xcd_groups = (uint32_t)(n_groups / span) * span;
             auto fn = need <= 8 ? resize_up2_backward_kernel<8, R> : (need <= 12 ? resize_up2_backward_kernel<12, R> : resize_up2_backward_kernel<16, R>);
             hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(grad_out), static_cast<float *>(grad_in),
                                (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)groups_x, (int)groups_y, xcd_groups, fw, fh);
@@ -1030,14 +1029,14 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
         const int groups_y = (h_in + 255) / 256, groups_x = (w_in + 255) / 256;
         // Register-only gather over the tables (round 4, resize_backward_gather_kernel): 4 gradient columns x 8 rows per lane; the rows'
         // weights from the per-band matrices the tables kernel leaves in the (otherwise unused) pass-to-pass area of the workspace.
-        const bool gather = g_resize_bwd_fused == 1 && w_out >= 16;
+        const bool gather = w_out >= 16;
         const int need = gather ? gather_window(fw, w_out) : 0;
-        const int R = g_resize_rows == 4 ? 4 : 8;                     // gradient rows per lane (A/B knob PBR_TUNE_RESIZE_ROWS; 7 = 8 rows, weights looked up per row)
+        constexpr int R = 8;                                          // gradient rows per lane
         const int64_t ggx = (w_in + 255) / 256, ggy = (h_in + R - 1) / R, n_groups = ggx * ggy * planes;
         const bool gather_ok = gather && need <= 16 && n_groups <= INT32_MAX;
         const int window = need <= 8 ? 8 : (need <= 12 ? 12 : 16);    // the gather kernel's W
         const size_t band_words = (size_t)((h_in + kBandRows - 1) / kBandRows) * kBandWords, col_groups = (size_t)(w_in + 3) / 4;
-        const bool banded = gather_ok && R == kBandRows && g_resize_rows != 7 && band_window(fh, h_out, kBandRows) <= kBandMaxRows &&
+        const bool banded = gather_ok && R == kBandRows && band_window(fh, h_out, kBandRows) <= kBandMaxRows &&
                             band_words + col_groups * (1 + 4 * (size_t)window) <= (size_t)planes * h_in * w_out;
         float *band = banded ? tmp : nullptr, *col_w = banded ? tmp + band_words + col_groups : nullptr;
         int *col_base = banded ? reinterpret_cast<int *>(tmp + band_words) : nullptr;
@@ -1045,10 +1044,9 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
                            (int)w_out, fw, groups_y, band, col_base, col_w, window);
         if (gather_ok) {
             const uint32_t span = 8u << kUpRunLog2;
-            const uint32_t xcd_groups = g_resize_xcd ? (uint32_t)(n_groups / span) * span : 0u;
+            const uint32_t xcd_groups = (uint32_t)(n_groups / span) * span;
             const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out, band, col_base, col_w};
-            auto fn = R == 4 ? (need <= 8 ? resize_backward_gather_kernel<8, 4, false> : (need <= 12 ? resize_backward_gather_kernel<12, 4, false> : resize_backward_gather_kernel<16, 4, false>))
-                    : banded ? (need <= 8 ? resize_backward_gather_kernel<8, 8, true> : (need <= 12 ? resize_backward_gather_kernel<12, 8, true> : resize_backward_gather_kernel<16, 8, true>))
+            auto fn = banded ? (need <= 8 ? resize_backward_gather_kernel<8, 8, true> : (need <= 12 ? resize_backward_gather_kernel<12, 8, true> : resize_backward_gather_kernel<16, 8, true>))
                              : (need <= 8 ? resize_backward_gather_kernel<8, 8, false> : (need <= 12 ? resize_backward_gather_kernel<12, 8, false> : resize_backward_gather_kernel<16, 8, false>));
             hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, g, gi, (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)ggx, (int)ggy, xcd_groups, tb);
             const hipError_t e = hipGetLastError();
@@ -1069,15 +1067,14 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
         int toh = 8;
         for (int rows : {128, 64, 32, 16})
             if (lds_for(rows) <= 48 * 1024) { toh = rows; break; }
-        if (g_resize_rows > 0) toh = g_resize_rows;
         const size_t lds = lds_for(toh);
         const int64_t tx = (w_in + kTileW - 1) / kTileW, tyy = (h_in + toh - 1) / toh, n_tiles = planes * tx * tyy;
-        if (g_resize_bwd_fused && lds <= 64 * 1024 && n_tiles <= INT32_MAX) {
-            int64_t chunk = g_resize_xcd == 0 ? 0 : (g_resize_xcd >= 8 ? g_resize_xcd : (g_resize_xcd == 2 ? n_tiles / 8 : 64));
+        if (lds <= 64 * 1024 && n_tiles <= INT32_MAX) {
+            int64_t chunk = 64;
             if (chunk > n_tiles / 8) chunk = n_tiles / 8;
             // 16-byte stores where the gradient is at least twice its upstream (2048^2 -> 4096^2: 66.7 against 69.3 us; the other way,
             // 4096^2 -> 2048^2, 70.6 against 59.4: a quarter of the lanes then walk the LDS strip)
-            const int quads = (g_resize_quads == 2 || (g_resize_quads == 1 && (int64_t)h_in * w_in >= 2 * (int64_t)h_out * w_out)) && w_in % 4 == 0 &&
+            const int quads = (int64_t)h_in * w_in >= 2 * (int64_t)h_out * w_out && w_in % 4 == 0 &&
                               (reinterpret_cast<uintptr_t>(grad_in) & 15u) == 0;
             const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0), quads};
             const StripTables tb = {lo_x, cnt_x, lo_y, cnt_y, wx, wy, (int)w_in, (int)h_in, (int)h_out, nullptr, nullptr, nullptr};

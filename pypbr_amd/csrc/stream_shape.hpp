@@ -9,12 +9,12 @@ namespace pbr {
 // Launch shape of the streaming map kernels (map_ops.hip, blend.hip): all of them are grid-stride loops over blockDim-agnostic
 // indices, so the shape is the launcher's choice.  shape 0 = 2048 workgroups of 256 lanes walking the data, 1 = one item per lane in
 // 256-lane workgroups, 2 = one item per lane in one-wave workgroups; lds = unused dynamic LDS per workgroup, which caps the resident
-// waves the way the render kernel's occupancy governor does.  Each launcher names its rule; PBR_TUNE_STREAM_SHAPE / _LDS override
-// it (-1 = rule) for A/B runs (tools/stream_shape_probe.py).
+// waves the way the render kernel's occupancy governor does.  Each launcher names its rule (measured below; the override knobs of
+// ABI 6 went with their experiment: profiles/EXPERIMENTS.md).
 struct StreamRule { int shape, lds; };
 struct StreamShape { unsigned grid, block; size_t lds; };
 inline StreamShape stream_shape(size_t work_items, StreamRule rule) {
-    const int shape = g_stream_shape >= 0 ? g_stream_shape : rule.shape, lds = g_stream_lds >= 0 ? g_stream_lds : rule.lds;
+    const int shape = rule.shape, lds = rule.lds;
     const unsigned block = shape == 2 ? 64u : 256u;
     size_t blocks = (work_items + block - 1) / block;
     if (shape == 0 && blocks > 256 * 8) blocks = 256 * 8;

@@ -40,22 +40,11 @@ struct TuningScope {
 #define g_block_log2       (::pbr::knob(PBR_TUNE_BLOCK_LOG2))       // workgroup size: 64 (6), 128 (7) or 256 (8) lanes; 0 = rule (64; 256 for the one-pixel kernels)
 #define g_f16_vec          (::pbr::knob(PBR_TUNE_F16_VEC))          // pixels per lane for fp16 maps with one light: 8 (16-byte loads) or 4
 #define g_lds_bytes        (::pbr::knob(PBR_TUNE_LDS_BYTES))        // unused dynamic LDS per one-wave workgroup: an occupancy governor (-1 = rule, ct_launch.hpp)
-#define g_xcd_log2         (::pbr::knob(PBR_TUNE_XCD_LOG2))         // >= 0 overrides the descriptor's schedule: tiles per XCD run = 1 << value
 #define g_bwd_vec          (::pbr::knob(PBR_TUNE_BWD_VEC))          // pixels per lane of the backward kernels: 0 = rule, 2 | 4 = forced
 #define g_batch_inner      (::pbr::knob(PBR_TUNE_BATCH_INNER))      // materials per lane of the several-lights kernels: -1 = rule (4 | 2 | off), 0 = off, 2 | 4 = forced
-#define g_interleave       (::pbr::knob(PBR_TUNE_INTERLEAVE))       // experiment: materials of a batch interleaved workgroup by workgroup
 #define g_scalar_base      (::pbr::knob(PBR_TUNE_SCALAR_BASE))      // scalar plane addresses: 0 never, 1 = rule (single materials), 2 = whenever the launch allows them
 #define g_max_vec          (::pbr::knob(PBR_TUNE_MAX_VEC))          // at most this many pixels per lane (1 = the one-pixel kernels everywhere)
-#define g_resize_rows      (::pbr::knob(PBR_TUNE_RESIZE_ROWS))      // resize.hip: output rows per tile of the strip form: 0 = rule
 #define g_bwd_run          (::pbr::knob(PBR_TUNE_BWD_RUN))          // tiles per wave of the streamed backward kernel (fp16 maps, one light): -1 = rule, 0 = off
-#define g_resize_xcd       (::pbr::knob(PBR_TUNE_RESIZE_XCD))       // resize.hip: XCD-contiguous tile order: 1 = chunks of 64 tiles, 0 = identity, 2 = one chunk per XCD, >= 8 = that many
-#define g_bwd_wide         (::pbr::knob(PBR_TUNE_BWD_WIDE))         // streamed backward with 16-byte memory instructions: -1 = rule (off), 0 off, 1 wherever legal
-#define g_resize_up2       (::pbr::knob(PBR_TUNE_RESIZE_UP2))       // resize.hip: two-tap register kernel for up-scales (1) or the strip kernel (0)
-#define g_tile_fold        (::pbr::knob(PBR_TUNE_TILE_FOLD))        // tiled maps, wrap-around form: log2 of the source rows per band of the fold order (-1 = rule, 0 = row order)
-#define g_resize_bwd_fused (::pbr::knob(PBR_TUNE_RESIZE_BWD_FUSED)) // resize.hip: gradient in registers (1), through the LDS strip (2) or in two passes through the workspace (0)
-#define g_resize_quads     (::pbr::knob(PBR_TUNE_RESIZE_QUADS))     // resize.hip: 16-byte stores in the strip kernel's width pass: 1 = rule, 2 = wherever legal, 0 = never
-#define g_stream_shape     (::pbr::knob(PBR_TUNE_STREAM_SHAPE))     // stream_shape.hpp: launch shape of the streaming map kernels (-1 = each launcher's rule)
-#define g_stream_lds       (::pbr::knob(PBR_TUNE_STREAM_LDS))       // stream_shape.hpp: unused dynamic LDS of those kernels (-1 = rule)
 #define g_mse_stream       (::pbr::knob(PBR_TUNE_MSE_STREAM))       // ct_loss.hip: streamed loss step for fp16 maps with one light (1) or the one-tile kernels (0)
-#define g_pack_single      (::pbr::knob(PBR_TUNE_PACK_SINGLE))      // packed arithmetic in the one-light fp32 kernels: -1 = rule (tiled launches in the wrap-around form), 0 never, 1 always
-#define g_tile_repeat      (::pbr::knob(PBR_TUNE_TILE_REPEAT))      // tiled maps, whole output, one light: the repeat-inner kernel (-1 = rule: on, 0 = the wrap-around form)
+#define g_tile_repeat      (::pbr::knob(PBR_TUNE_TILE_REPEAT))      // tiled maps: the repeat-inner kernels, forward and backward (-1 = rule: on, 0 = the wrap-around form)
+#define g_resize_up2       (::pbr::knob(PBR_TUNE_RESIZE_UP2))       // resize.hip: two-tap register kernels for up-scales (1) or the strip kernels (0)

@@ -708,14 +708,27 @@ class _CookTorranceFn(torch.autograd.Function):
         g = grad_out.reshape(B, 3, H, W).to(torch.float32).contiguous()
         channels = (3, 3, 1, 1, 3)
         present = (True, bool(d.normal.data), True, bool(d.metallic.data), bool(d.specular.data))
-        bufs = []
         gdtype = torch.float32 if d.map_dtype == N.F32 else torch.float16      # gradients in the maps' storage type
-        for i in range(5):
-            want = ctx.needs_input_grad[i] and present[i] and ctx.in_shapes[i] is not None
-            bufs.append(torch.empty((B, channels[i], H, W), dtype=gdtype, device=g.device) if want else None)
-        ptrs = [None if b is None else b.data_ptr() for b in bufs]
         want_params = any(ctx.needs_input_grad[5:8])
+        wanted = [bool(ctx.needs_input_grad[i] and present[i] and ctx.in_shapes[i] is not None) for i in range(5)]
+        tiled = bool(d.map_height) and (d.map_height, d.map_width) != (d.height_total, W)
+        shared = [wanted[i] and B > 1 and (len(ctx.in_shapes[i]) == 3 or ctx.in_shapes[i][0] == 1) for i in range(5)]
         lib = N.lib()
+        if tiled and not want_params and not any(shared):
+            # MaterialBase.tile (base.py:524-537) under autograd: a texel owns the SUM over its repeats.  pbr_cook_torrance_backward_folded
+            # hands out MAP-sized gradients -- one kernel that walks the maps and accumulates over the repeats in registers where it serves
+            # the launch (one light, map rows of whole 4-texel groups), else backward + fold through its workspace
+            h, w = d.map_height, d.map_width
+            bufs = [torch.empty((B, channels[i], h, w), dtype=gdtype, device=g.device) if wanted[i] else None for i in range(5)]
+            ws_bytes = lib.pbr_backward_folded_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=g.device) if ws_bytes else None
+            with torch.cuda.device(g.device):
+                N.check(lib.pbr_cook_torrance_backward_folded(ctypes.byref(d), g.data_ptr(), *[None if b is None else b.data_ptr() for b in bufs],
+                                                              None if ws is None else ws.data_ptr(), _stream_ptr(g.device)))
+            grads = [None if b is None else b.reshape(shape) for b, shape in zip(bufs, ctx.in_shapes)]
+            return (*grads, None, None, None, None)
+        bufs = [torch.empty((B, channels[i], H, W), dtype=gdtype, device=g.device) if wanted[i] else None for i in range(5)]
+        ptrs = [None if b is None else b.data_ptr() for b in bufs]
         with torch.cuda.device(g.device):
             if want_params:
                 L = d.n_lights
@@ -726,21 +739,19 @@ class _CookTorranceFn(torch.autograd.Function):
             else:
                 N.check(lib.pbr_cook_torrance_backward(ctypes.byref(d), g.data_ptr(), *ptrs, _stream_ptr(g.device)))
         grads = []
-        for b, shape in zip(bufs, ctx.in_shapes):
+        for i, (b, shape) in enumerate(zip(bufs, ctx.in_shapes)):
             if b is None:
                 grads.append(None)
                 continue
             # a map repeated by a fused tile(), or shared by the whole batch, owns the SUM of the per-output-pixel gradients
-            tiled = bool(d.map_height) and (d.map_height, d.map_width) != (H, W)
             if tiled and H != d.height_total:
-                raise NotImplementedError("gradients of a tiled evaluation need the whole output, not a row band")
-            shared = B > 1 and (len(shape) == 3 or shape[0] == 1)
-            if tiled or shared:
+                raise NotImplementedError("gradients of a tiled evaluation with light / view gradients or batch-shared maps need the whole output, not a row band")
+            if tiled or shared[i]:
                 h, w = (d.map_height, d.map_width) if tiled else (H, W)
-                folded = torch.empty((1 if shared else B, b.shape[1], h, w), dtype=gdtype, device=b.device)
+                folded = torch.empty((1 if shared[i] else B, b.shape[1], h, w), dtype=gdtype, device=b.device)
                 with torch.cuda.device(b.device):      # fp16 gradients: summed in fp32, rounded once
                     N.check(N.lib().pbr_fold_gradient_typed(b.data_ptr(), folded.data_ptr(), B, b.shape[1], h, w, H // h, W // w,
-                                                            int(shared), _DTYPES[gdtype], _stream_ptr(b.device)))
+                                                            int(shared[i]), _DTYPES[gdtype], _stream_ptr(b.device)))
                 b = folded
             grads.append(b.reshape(shape))
         pgrads = [None, None, None]
@@ -754,6 +765,10 @@ class _CookTorranceFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ the rendering-loss step as one kernel
+class _StepNotServed(Exception):
+    """pbr_cook_torrance_mse_step does not serve this descriptor as one pass (raised before anything is launched)."""
+
+
 class _MseStepFn(torch.autograd.Function):
     """loss = mean((cook_torrance(maps) - target)^2) with its gradients from ONE kernel (pbr_cook_torrance_mse_step): forward
     evaluates, compares and differentiates in a single pass over the maps (32 + 12 bytes read, 32 written per pixel) and keeps
@@ -766,14 +781,17 @@ class _MseStepFn(torch.autograd.Function):
         d = plan.desc
         B, H, W = d.batch, d.height, d.width
         dev = plan.device                                   # the maps' device: a target handed over on the CPU, or on another GPU, is brought here
-        tgt = target.detach().to(dev, torch.float32).reshape(B, 3, H, W).contiguous()
+        tgt = target.detach().to(dev, torch.float32).reshape(B, 3, H, W).contiguous()       # H x W: the OUTPUT (tiled maps: all repeats)
         gdtype = torch.float32 if d.map_dtype == N.F32 else torch.float16
         # in the map's OWN shape ([C,H,W] or [B,C,H,W]: the same memory layout), so that backward returns the buffer itself, not a view of
         # it -- autograd takes ownership of such a gradient instead of cloning it (a 4096^2 fp16 albedo: 73 us per step)
         bufs = [torch.empty(tuple(maps[i].shape), dtype=gdtype, device=dev) if wanted[i] else None for i in range(5)]
         loss = torch.empty((), dtype=torch.float32, device=dev)
         lib = N.lib()
-        ws = torch.empty(max(1, lib.pbr_mse_step_workspace_bytes(ctypes.byref(d)) // 4), dtype=torch.float32, device=dev)
+        ws_bytes = lib.pbr_mse_step_workspace_bytes(ctypes.byref(d))
+        if ws_bytes == 0:                                   # e.g. tiled maps with several lights or ragged map rows: not one pass (pbr_hip.h)
+            raise _StepNotServed()
+        ws = torch.empty(max(1, ws_bytes // 4), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             N.check(lib.pbr_cook_torrance_mse_step(ctypes.byref(d), tgt.data_ptr(), *[None if b is None else b.data_ptr() for b in bufs],
                                                    loss.data_ptr(), ws.data_ptr(), _stream_ptr(dev)))
@@ -832,10 +850,15 @@ def rendering_loss_mse(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
     B = albedo.shape[0] if albedo.dim() == 4 else 1
     shared = any(t is not None and B > 1 and (t.dim() == 3 or t.shape[0] == 1) for t in maps)
     plain = all(kwargs.get(k) in (None, d) for k, d in (("out", None), ("blend", None), ("out_dtype", torch.float32))) and \
-        kwargs.get("tile", 1) in (1, (1, 1)) and not kwargs.get("autotune")
+        kwargs.get("rows") is None and not kwargs.get("autotune")
     if grad_maps and not grad_other and plain and not shared and albedo.is_cuda:
-        kw = {k: v for k, v in kwargs.items() if k not in ("out", "blend", "out_dtype", "tile", "autotune")}
-        return _MseStepFn.apply(albedo, normal, roughness, metallic, specular, target, kw)
+        # tiled maps (tile=n: MaterialBase.tile fused) take the one pass too -- the repeat-inner kernel leaves map-sized gradients -- where
+        # the library serves them (one light, map rows of whole 4-texel groups); otherwise the three steps below
+        kw = {k: v for k, v in kwargs.items() if k not in ("out", "blend", "out_dtype", "autotune", "rows")}
+        try:
+            return _MseStepFn.apply(albedo, normal, roughness, metallic, specular, target, kw)
+        except _StepNotServed:
+            pass
     out = cook_torrance(albedo, normal, roughness, metallic, specular, **kwargs)
     return torch.nn.functional.mse_loss(out.float(), target.to(out.device, torch.float32).reshape(out.shape))
 

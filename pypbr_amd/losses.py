@@ -51,7 +51,7 @@ class RenderingLoss(nn.Module):
             with torch.enable_grad() if differentiable else torch.no_grad():
                 rendered_gt = self.brdf(ground_truth_material, self.view_dir, self.light_dir, self.light_intensity, self.light_size)
         a, n, r, m, s = self._maps(predicted_material)
-        fusable = (predicted_material.__dict__.get("_lazy_blend") is None and predicted_material.lazy_tile == (1, 1)
+        fusable = (predicted_material.__dict__.get("_lazy_blend") is None
                    and torch.device(predicted_material.device).type == "cuda" and not predicted_material._has_pending()
                    and a is not None and r is not None and "normal" in predicted_material.__dict__.get("_store", {})
                    and (m is not None or s is not None) and all(t is None or t.is_cuda for t in (a, n, r, m, s))
@@ -63,5 +63,6 @@ class RenderingLoss(nn.Module):
             s = None
         return F_.rendering_loss_mse(a, n, r, m, s, target=rendered_gt.to(a.device), view_dir=self.view_dir, light=self.light_dir,
                                      light_intensity=self.light_intensity, light_type=self.brdf.light_type, light_size=self.light_size,
+                                     tile=predicted_material.lazy_tile,      # a recorded tile(n): evaluated and differentiated at every repeat
                                      albedo_is_srgb=bool(predicted_material.albedo_is_srgb),
                                      specular_is_srgb=bool(getattr(predicted_material, "specular_is_srgb", True)))

@@ -487,8 +487,8 @@ class MaterialBase:
         """Repeat every map num_tiles x num_tiles (base.py:524-537).  `lazy=True` (build extension) only records
         the repeat: the maps stay as they are, `CookTorranceBRDF` hands the count to the kernel, which evaluates every texel at
         all its repeats -- each texel then leaves HBM once instead of num_tiles^2 times and no copy is made; whoever else looks at
-        the maps sees the repeated ones.  A material whose maps are waiting on the compute device (module docstring) records the
-        repeat likewise."""
+        the maps sees the repeated ones.  A material whose maps are waiting on the compute device (module docstring), or live there,
+        records the repeat likewise."""
         if num_tiles <= 0:                 # upstream: map.repeat(1, 0, 0) -> empty maps; a negative count is torch's RuntimeError
             self.materialize_tile()
             self._samples_on_host()
@@ -497,7 +497,12 @@ class MaterialBase:
                 if t is not None:
                     store[name] = t.repeat(*((1,) * (t.dim() - 2) + (num_tiles, num_tiles)))
             return self
-        if lazy or self._is_away() or self._has_pending():      # maps nobody has seen yet: the repeat waits with them
+        on_device = [t.is_cuda for t in self._raw.values() if t is not None]
+        if lazy or self._is_away() or self._has_pending() or (on_device and all(on_device)):
+            # maps nobody has seen yet, or maps that live on the compute device: the repeat is recorded and the kernels evaluate (and
+            # differentiate) every texel at all its repeats -- the example's `material.resize(512).tile(2)` inside a rendering loss
+            # (06_advanced.rst:73-107) then moves a quarter of the map bytes and no repeated copy exists; whoever LOOKS at the maps
+            # (`_maps`, attribute access, `as_dict`, `clone`, another map operation) gets the repeated ones, as upstream
             ny, nx = self.lazy_tile
             object.__setattr__(self, "_lazy_tile", (ny * num_tiles, nx * num_tiles))
             return self

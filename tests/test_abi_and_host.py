@@ -486,7 +486,8 @@ def test_tuning_knob_numbers_match_the_header():
     header = open(os.path.join(ROOT, "include", "pbr_hip.h")).read()
     knobs = {m.group(1): int(m.group(2)) for m in re.finditer(r"PBR_TUNE_(\w+)\s*=\s*(\d+)", header)}
     count = knobs.pop("COUNT")
-    assert len(knobs) >= 13 and sorted(knobs.values()) == list(range(len(knobs))) and count == len(knobs) == N.TUNE_COUNT
+    assert len(knobs) <= 12 and sorted(knobs.values())      # ABI 7: the boundary lists no closed experiment
+    assert sorted(knobs.values()) == list(range(len(knobs))) and count == len(knobs) == N.TUNE_COUNT
     assert sorted(N.TUNE_NAMES.values()) == list(range(count)) and {k.upper() for k in N.TUNE_NAMES} == set(knobs)
     lib = N.lib()
     for name, number in knobs.items():
@@ -553,8 +554,7 @@ def test_isa_assumptions_of_the_hand_scheduled_kernels_hold_and_the_checker_can_
             subprocess.check_call(["make", "-s", "-j4", "-C", C.CSRC])
             break
     report = C.check()
-    assert len(report) == 43 and sum("backward_stream<" in r for r in report) == 12 and sum("backward_stream16<" in r for r in report) == 6 and \
-        sum("mse_stream<" in r for r in report) == 12
+    assert len(report) == 37 and sum("backward_stream<" in r for r in report) == 12 and sum("mse_stream<" in r for r in report) == 12
 
     import tempfile
     tmp = tempfile.mkdtemp()
@@ -577,15 +577,6 @@ def test_isa_assumptions_of_the_hand_scheduled_kernels_hold_and_the_checker_can_
     for what, insts in doctored.items():
         assert C.check_stream_kernel(sym, insts, meta[sym])[1], what
     assert C.check_stream_kernel(sym, good, dict(meta[sym], private_segment_fixed_size=16))[1]
-    sym16 = next(s for s in fns if "cook_torrance_backward_stream16_kernelILi1ELi0E" in s)       # point, metallic, 16-byte form
-    good16 = fns[sym16]
-    assert C.check_stream16_kernel(sym16, good16, meta[sym16])[1] == []
-    st = next(i for i, (m, _) in enumerate(good16) if m.startswith("global_store"))
-    for what, insts in {"flat store": good16[:st] + [("flat_store_dwordx4", "v[26:27], v[18:21] nt")] + good16[st + 1:],
-                        "extra store": good16[:st] + [("global_store_dword", "v78, v1, s[2:3] nt")] + good16[st:],
-                        "compiler wait": good16[:st] + [("s_waitcnt", "vmcnt(1)")] + good16[st:],
-                        "lds write": good16[:st] + [("ds_write_b64", "v2, v[8:9]")] + good16[st:]}.items():
-        assert C.check_stream16_kernel(sym16, insts, meta[sym16])[1], what
     co = C._code_object(os.path.join(C.CSRC, "cook_torrance.o"), tmp)
     fns, meta = C._functions(co), C._metadata(co)
     sym = next(s for s in fns if "cook_torrance_kernelILi1ELi0E6__halffLi8ELb0ELb1E" in s)

@@ -430,17 +430,14 @@ def test_streamed_backward_is_bit_identical_to_the_one_tile_kernels():
     try:
         for name, mp, kw, extra in cases:
             want = grads(mp, kw, 0, **extra)                  # the one-tile kernels
-            for wide in (0, 1):                  # 4-byte and 16-byte memory instructions (the latter: the usual launch, aligned planes)
-                lib.pbr_set_tuning(N.TUNE_BWD_WIDE, wide)
-                for run in (1, 2, 7, 1000):          # rounds: grid = run x the waves the chip holds; 1000 = one tile per wave
-                    got = grads(mp, kw, run, **extra)
-                    for x, y in zip(want, got):
-                        assert (x is None) == (y is None), (name, run, wide)
-                        if x is not None:
-                            assert torch.equal(x, y), (name, run, wide, float((x.float() - y.float()).abs().max()))
+            for run in (1, 2, 7, 1000):          # rounds: grid = run x the waves the chip holds; 1000 = one tile per wave
+                got = grads(mp, kw, run, **extra)
+                for x, y in zip(want, got):
+                    assert (x is None) == (y is None), (name, run)
+                    if x is not None:
+                        assert torch.equal(x, y), (name, run, float((x.float() - y.float()).abs().max()))
     finally:
         lib.pbr_set_tuning(N.TUNE_BWD_RUN, -1)
-        lib.pbr_set_tuning(N.TUNE_BWD_WIDE, -1)
 
 
 @pytest.mark.parametrize("binding", ["torch_op", "ctypes"])

@@ -187,16 +187,13 @@ def test_streamed_backward_full_shape_2x4096_fp16():
         return [t.grad for t in leaves]
     try:
         want = grads(0)
-        for wide in (0, 1):
-            lib.pbr_set_tuning(N.TUNE_BWD_WIDE, wide)
-            for rounds in (-1, 1, 3):
-                got = grads(rounds)
-                for name, x, y in zip(("albedo", "normal", "roughness", "metallic"), want, got):
-                    assert torch.equal(x, y), (wide, rounds, name)
-                del got
+        for rounds in (-1, 1, 3):
+            got = grads(rounds)
+            for name, x, y in zip(("albedo", "normal", "roughness", "metallic"), want, got):
+                assert torch.equal(x, y), (rounds, name)
+            del got
     finally:
         lib.pbr_set_tuning(N.TUNE_BWD_RUN, -1)
-        lib.pbr_set_tuning(N.TUNE_BWD_WIDE, -1)
     assert all(bool(torch.isfinite(x).all()) for x in want)
     # last rows of the last material against float64 autograd of the oracle
     b, y0, h = B - 1, H - 8, 8

@@ -156,10 +156,13 @@ def test_resize_gradient_full_size_adjoint():
 
 
 @pytest.mark.parametrize("shape,size,antialias", [((37, 53), (20, 31), True), ((64, 256), (32, 128), True), ((200, 260), (67, 90), True),
-                                                  ((40, 64), (100, 160), False), ((130, 131), (129, 64), True), ((256, 512), (128, 256), True)])
-def test_resize_gradient_one_pass_equals_two_passes(shape, size, antialias):
-    """pbr_resize_bilinear_backward in one pass (the strip kernel with the transposed tap tables, 4-byte and 16-byte stores) forms the
-    same sums in the same order as its two passes through the workspace: bit-identical, ragged tiles and unaligned rows included."""
+                                                  ((40, 64), (100, 160), False), ((130, 131), (129, 64), True), ((256, 512), (128, 256), True),
+                                                  ((40, 64), (9, 12), True), ((200, 260), (20, 26), True), ((24, 40), (60, 13), True)])
+def test_resize_gradient_forms_agree_with_float64_autograd(shape, size, antialias):
+    """pbr_resize_bilinear_backward picks its form by shape (ABI 7: the A/B knobs of round 4 are gone, profiles/EXPERIMENTS.md): the
+    register gather over the transposed tap tables (banded and looked-up rows), the two-tap transpose for up-scales, the LDS strip
+    kernel (outputs narrower than 16 columns), the generic two passes (more than 16 taps).  Every form against float64 autograd of
+    F.interpolate, and -- the up-scale forms -- the register kernel against the strip kernel (PBR_TUNE_RESIZE_UP2 = 0)."""
     from pypbr_amd import _native as N
     lib = N.lib()
     g = torch.Generator().manual_seed(14)
@@ -169,40 +172,19 @@ def test_resize_gradient_one_pass_equals_two_passes(shape, size, antialias):
     stream = torch.cuda.current_stream().cuda_stream
     got = {}
     try:
-        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 0)          # this test is about the strip kernel; the register-only gradient of up-scales has its own below
-        for fused, quads, rows in ((0, 1, 0), (2, 0, 0), (2, 2, 0), (2, 2, 16), (2, 1, 32)):       # 2 = the strip kernel (1 = the register gather, below)
-            lib.pbr_set_tuning(N.TUNE_RESIZE_BWD_FUSED, fused)
-            lib.pbr_set_tuning(N.TUNE_RESIZE_QUADS, quads)
-            lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, rows)
+        for up2 in (1, 0):
+            lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, up2)
             gin = torch.full((3, h, w), float("nan"), device="cuda")
             N.check(lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, h, w, ho, wo, int(antialias), ws.data_ptr(), stream))
-            got[(fused, quads, rows)] = gin
+            got[up2] = gin
     finally:
-        lib.pbr_set_tuning(N.TUNE_RESIZE_BWD_FUSED, 1)
-        lib.pbr_set_tuning(N.TUNE_RESIZE_QUADS, 1)
-        lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, 0)
         lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
-    ref = got[(0, 1, 0)]
-    assert bool(torch.isfinite(ref).all())
-    for key, val in got.items():
-        assert torch.equal(val, ref), key
-    # the default since round 4: the register-only gather over the same tables (resize_backward_gather_kernel; up-scales: the
-    # two-tap transpose) -- the same products added in another order
-    gin = torch.full((3, h, w), float("nan"), device="cuda")
-    N.check(lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, h, w, ho, wo, int(antialias), ws.data_ptr(), stream))
-    assert bool(torch.isfinite(gin).all()) and (gin - ref).abs().max().item() <= 2e-6 * max(1.0, float(ref.abs().max()))
-    # its rows' weights come from per-band matrices the tables kernel prepares (one scalar load per upstream row); looked up per row
-    # instead (PBR_TUNE_RESIZE_ROWS = 7) the sums are the same, bit for bit
-    try:
-        lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, 7)
-        looked_up = torch.full((3, h, w), float("nan"), device="cuda")
-        N.check(lib.pbr_resize_bilinear_backward(gout.data_ptr(), looked_up.data_ptr(), 3, h, w, ho, wo, int(antialias), ws.data_ptr(), stream))
-    finally:
-        lib.pbr_set_tuning(N.TUNE_RESIZE_ROWS, 0)
-    assert torch.equal(looked_up, gin)
     x = torch.zeros(1, 3, h, w, dtype=torch.float64, requires_grad=True)
     (TF.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False, antialias=antialias)[0] * gout.cpu().double()).sum().backward()
-    assert (ref.cpu().double() - x.grad[0]).abs().max().item() <= 2e-5
+    for up2, gin in got.items():
+        assert bool(torch.isfinite(gin).all()), up2
+        assert (gin.cpu().double() - x.grad[0]).abs().max().item() <= 2e-5, up2
+    assert (got[1] - got[0]).abs().max().item() <= 2e-6 * max(1.0, float(got[0].abs().max()))
 
 
 @pytest.mark.parametrize("shape,size", [((64, 96), (128, 192)), ((37, 53), (80, 97)), ((50, 70), (50, 70)), ((33, 130), (97, 131)), ((40, 44), (57, 128)),

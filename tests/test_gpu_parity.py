@@ -692,19 +692,18 @@ def test_fused_tile_fold_order_is_bit_identical(dtype, h, w, tile):
     gout = torch.rand(ref.shape, generator=g).cuda()
     leaves0 = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
     try:
-        N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, 0)
+        # the wrap-around form (PBR_TUNE_TILE_REPEAT = 0: fp16 maps take its fold order by rule) under every workgroup order
+        N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, 0)
         (F.cook_torrance(*leaves0, tile=tile, **kw) * gout).sum().backward()
-        for fold in (-1, 1, 2, 3, 4, 8):
-            N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, fold)
-            for sched in (N.SCHEDULE_AUTO, N.SCHEDULE_LINEAR, N.schedule_xcd(1), N.schedule_xcd(3)):
-                out = F.cook_torrance(a, n, r, m, tile=tile, schedule=sched, **kw)
-                assert torch.equal(out, ref), (fold, sched)
-            leaves = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
-            (F.cook_torrance(*leaves, tile=tile, schedule=N.SCHEDULE_LINEAR, **kw) * gout).sum().backward()
-            for x, y in zip(leaves, leaves0):
-                assert torch.equal(x.grad, y.grad), fold
+        for sched in (N.SCHEDULE_AUTO, N.SCHEDULE_LINEAR, N.schedule_xcd(1), N.schedule_xcd(3)):
+            out = F.cook_torrance(a, n, r, m, tile=tile, schedule=sched, **kw)
+            assert torch.equal(out, ref), sched
+        leaves = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
+        (F.cook_torrance(*leaves, tile=tile, schedule=N.SCHEDULE_LINEAR, **kw) * gout).sum().backward()
+        for x, y in zip(leaves, leaves0):
+            assert torch.equal(x.grad, y.grad)
     finally:
-        N.lib().pbr_set_tuning(N.TUNE_TILE_FOLD, -1)
+        N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, -1)
 
 
 def test_fused_tile_gradients_and_material_api():
@@ -913,28 +912,18 @@ def test_resize_guard_bands_and_random_shapes():
         assert (got - ref).abs().max().item() <= 1e-5, (trial, c, hi, wi, ho, wo, aa, float((got - ref).abs().max()))
 
 
-def test_resize_tile_orders_are_bit_identical():
-    """pbr_resize_bilinear walks its tiles in XCD-contiguous chunks (every XCD takes its own chunk of each block of 8 chunks, so
-    the tiles that share halo rows and boundary lines meet in one L2).  The order only changes WHERE a tile runs: identity order,
-    chunks of 64 (default), one chunk per XCD and chunks of 8 tiles must agree bit for bit -- on tile counts that are not a
-    multiple of a block, down- and up-scaling -- and with ATen."""
-    from pypbr_amd import _native as N, functional as F
-    lib = N.lib()
+def test_resize_in_xcd_contiguous_chunks_matches_aten_on_ragged_tile_counts():
+    """pbr_resize_bilinear walks its tiles in XCD-contiguous chunks of 64 (every XCD takes its own chunk of each block of 8 chunks, so
+    the tiles that share halo rows and boundary lines meet in one L2; the other orders of round 3's A/B went with their knob).  Tile
+    counts that are not a multiple of a block, down- and up-scaling, against ATen."""
+    from pypbr_amd import functional as F
     g = torch.Generator().manual_seed(77)
-    try:
-        for shape, size, aa in (((3, 1000, 1400), (700, 900), True), ((2, 520, 1096), (1210, 1500), False), ((5, 777, 640), (300, 333), True)):
-            x = torch.rand(*shape, generator=g)
-            ref = torch.nn.functional.interpolate(x[None], size=size, mode="bilinear", align_corners=False, antialias=aa)[0]
-            outs = []
-            for knob in (0, 1, 2, 8):
-                lib.pbr_set_tuning(N.TUNE_RESIZE_XCD, knob)
-                outs.append(F.resize(x.cuda(), size, antialias=aa))
-            for o in outs[1:]:
-                assert torch.equal(outs[0], o), (shape, size)
-            # source coordinates of a 1 500-pixel axis carry ~1e-5 of fp32 rounding, and ATen rounds them at other points (see the test above)
-            assert (outs[0].cpu() - ref).abs().max().item() <= 3e-5, (shape, size)
-    finally:
-        lib.pbr_set_tuning(N.TUNE_RESIZE_XCD, 1)
+    for shape, size, aa in (((3, 1000, 1400), (700, 900), True), ((2, 520, 1096), (1210, 1500), False), ((5, 777, 640), (300, 333), True)):
+        x = torch.rand(*shape, generator=g)
+        ref = torch.nn.functional.interpolate(x[None], size=size, mode="bilinear", align_corners=False, antialias=aa)[0]
+        out = F.resize(x.cuda(), size, antialias=aa)
+        # source coordinates of a 1 500-pixel axis carry ~1e-5 of fp32 rounding, and ATen rounds them at other points (see the test above)
+        assert (out.cpu() - ref).abs().max().item() <= 3e-5, (shape, size)
 
 
 def test_random_shapes_workflows_flags_and_lights_against_the_oracle():

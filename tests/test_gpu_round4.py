@@ -287,7 +287,7 @@ def test_plan_launched_on_another_stream_folds_its_device_parameters_there():
 
 
 def test_per_call_tuning_changes_the_schedule_not_the_bits():
-    """ABI 6: knobs passed with the plan (pbr_render_desc.tuning) pick other schedules -- streaming hint off, XCD runs, no occupancy
+    """ABI 6: knobs passed with the plan (pbr_render_desc.tuning) pick other schedules -- streaming hint off, no occupancy
     governor, one-pixel lanes, the wrap-around form of a tiled launch -- with bit-identical results, and leave no trace for the next call."""
     from pypbr_amd import functional as F
     g = torch.Generator().manual_seed(4)
@@ -296,12 +296,12 @@ def test_per_call_tuning_changes_the_schedule_not_the_bits():
     n = TF.normalize(torch.cat([torch.rand(2, H, W, generator=g) - 0.5, torch.ones(1, H, W)], 0), dim=0).cuda()
     kw = dict(view_dir=VIEW, light=LIGHT, light_intensity=INTEN, light_type="point", light_size=1.0)
     want = F.plan_cook_torrance(a, n, r, m, **kw).launch().clone()
-    for knobs in (dict(nontemporal=0), dict(xcd_log2=6, lds_bytes=0), dict(block_log2=8, scalar_base=0), dict(max_vec=1)):
+    for knobs in (dict(nontemporal=0), dict(lds_bytes=0), dict(block_log2=8, scalar_base=0), dict(max_vec=1)):
         plan = F.plan_cook_torrance(a, n, r, m, tuning=knobs, **kw)
         assert torch.equal(plan.launch(), want), knobs
     one_pixel = F.plan_cook_torrance(a, n, r, m, tuning=dict(max_vec=1), **kw)
     assert one_pixel.kernel_name.endswith("_v1") and F.plan_cook_torrance(a, n, r, m, **kw).kernel_name.endswith("_v4")      # nothing stuck
     tiled = F.plan_cook_torrance(a, n, r, m, tile=2, **kw)
-    wrap = F.plan_cook_torrance(a, n, r, m, tile=2, tuning=dict(tile_repeat=0, tile_fold=3), **kw)
+    wrap = F.plan_cook_torrance(a, n, r, m, tile=2, tuning=dict(tile_repeat=0), **kw)
     assert tiled.kernel_name.startswith("ctr_") and wrap.kernel_name.endswith("_pk") and torch.equal(tiled.launch(), wrap.launch())
     assert wrap.set_tuning().kernel_name.startswith("ctr_")               # back to the rules

@@ -48,3 +48,209 @@ def test_map_assigned_after_tile_on_a_device_material_keeps_its_size():
     brdf = CookTorranceBRDF("point")
     got, want = brdf(m, *ARGS), brdf(ref, *ARGS)
     assert got.shape == (3, 32, 48) and torch.allclose(got, want, atol=2e-6)
+
+
+# ---------------------------------------------------------------- the repeat-inner backward
+import torch.nn.functional as TF
+
+import torch_oracle as O
+
+
+def _leaf_maps(g, H, W, workflow, dtype=torch.float32, B=None):
+    lead = () if B is None else (B,)
+    a = torch.rand(*lead, 3, H, W, generator=g)
+    n = torch.cat([(torch.rand(*lead, 2, H, W, generator=g) - 0.5) * 1.4, torch.ones(*lead, 1, H, W)], -3)      # un-normalised on purpose
+    r = torch.rand(*lead, 1, H, W, generator=g) * 0.7 + 0.25
+    m = torch.rand(*lead, 1, H, W, generator=g) if workflow != "specular" else None
+    s = torch.rand(*lead, 3, H, W, generator=g) * 0.6 if workflow == "specular" else None
+    return [None if t is None else t.to(dtype) for t in (a, n, r, m, s)]
+
+
+REPEAT_CASES = [
+    # workflow, light_type, (h, w), (ny, nx), dtype, batch
+    ("metallic", "point", (24, 48), (2, 2), torch.float32, None),
+    ("metallic", "directional", (16, 64), (3, 2), torch.float32, None),
+    ("specular", "point", (20, 40), (2, 3), torch.float32, None),
+    ("converted", "directional", (12, 36), (2, 2), torch.float32, None),
+    ("converted", "point", (10, 128), (4, 1), torch.float32, None),
+    ("metallic", "point", (7, 260), (1, 2), torch.float32, 2),           # ragged tiles (130 lanes a row), a batch
+    ("specular", "directional", (9, 24), (2, 2), torch.float32, 3),
+    ("metallic", "point", (16, 64), (2, 2), torch.float16, None),
+    ("specular", "point", (12, 48), (3, 1), torch.float16, 2),
+]
+
+
+def _tiled_grads(F, maps, kw, tile, gout, knob):
+    from pypbr_amd import _native as N
+    leaves = [None if t is None else t.detach().clone().cuda().requires_grad_(True) for t in maps]
+    try:
+        N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, knob)
+        out = F.cook_torrance(*leaves, tile=tile, **kw)
+        (out * gout).sum().backward()
+    finally:
+        N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, -1)
+    return out.detach(), [None if t is None else t.grad for t in leaves]
+
+
+@pytest.mark.parametrize("workflow,light_type,hw,tile,dtype,B", REPEAT_CASES)
+def test_repeat_inner_backward_equals_backward_plus_fold_and_float64_autograd(workflow, light_type, hw, tile, dtype, B):
+    """pbr_cook_torrance_backward_folded: ONE kernel walks the maps and accumulates every texel's gradient over its repeats in
+    registers.  fp32 maps: bit-identical to pbr_cook_torrance_backward + pbr_fold_gradient (PBR_TUNE_TILE_REPEAT = 0 is that form);
+    fp16 maps: the sum is rounded once instead of per repeat.  And against float64 autograd of the reference's ops through
+    map.repeat(1, ny, nx) (MaterialBase.tile, base.py:524-537)."""
+    from pypbr_amd import functional as F
+    (h, w), (ny, nx) = hw, tile
+    g = torch.Generator().manual_seed(31 * h + w + ny)
+    maps = _leaf_maps(g, h, w, workflow, dtype, B)
+    view = torch.tensor([0.05, 0.1, 0.9])
+    light = torch.tensor([0.1, 0.1, 1.0]) if light_type == "point" else torch.tensor([0.3, -0.2, 1.0])
+    inten = torch.tensor([1.0, 0.9, 0.8])
+    size = 1.5 if light_type == "point" else None
+    kw = dict(view_dir=view, light=light, light_intensity=inten, light_type=light_type, light_size=size,
+              convert_to_diffuse_specular=(workflow == "converted"))
+    lead = () if B is None else (B,)
+    gout = (torch.rand(*lead, 3, ny * h, nx * w, generator=g) - 0.3).cuda()
+    out1, one = _tiled_grads(F, maps, kw, tile, gout, -1)
+    out0, two = _tiled_grads(F, maps, kw, tile, gout, 0)
+    assert torch.equal(out1, out0)
+    for name, x, y in zip(("albedo", "normal", "roughness", "metallic", "specular"), one, two):
+        if x is None:
+            assert y is None
+            continue
+        assert x.shape == y.shape and x.dtype == dtype and bool(torch.isfinite(x.float()).all()), name
+        if dtype == torch.float32:
+            assert torch.equal(x, y), (name, float((x - y).abs().max()))
+        else:
+            assert (x.float() - y.float()).abs().max().item() <= 2e-3 * (float(y.float().abs().max()) + 1e-12) + 1e-6, name
+    # float64 autograd through repeat()
+    rep = (1,) * (len(lead) + 1) + (ny, nx)
+    leaves = [None if t is None else t.float().double().requires_grad_(True) for t in maps]
+    outs = []
+    for b in range(B or 1):
+        args = [None if t is None else (t if B is None else t[b]).repeat(1, ny, nx) for t in leaves]
+        okw = dict(view=view.double(), light=light.double(), intensity=inten.double(), light_type=light_type, light_size=size)
+        if workflow == "converted":
+            outs.append(O.cook_torrance_converted(args[0], args[1], args[2], args[3], **okw))
+        else:
+            outs.append(O.cook_torrance(*args, **okw))
+    ref = torch.stack(outs) if B is not None else outs[0]
+    (ref * gout.cpu().double()).sum().backward()
+    for name, x, y in zip(("albedo", "normal", "roughness", "metallic", "specular"), one, leaves):
+        if x is None:
+            continue
+        err = (x.float().cpu().double() - y.grad).abs()
+        tol = (2e-5 if dtype == torch.float32 else 2e-3) * (1 + y.grad.abs())
+        assert bool((err <= tol).all()), (name, float(err.max()))
+    del rep
+
+
+def test_repeat_inner_backward_dispatch_and_fallbacks():
+    """Which launches the one-kernel form serves is the library's decision (pbr_backward_folded_workspace_bytes == 0): one light and map
+    rows of whole 4-texel groups.  Several lights and ragged map widths go through the workspace -- same gradients as autograd of the
+    materialised repeat."""
+    from pypbr_amd import functional as F, _native as N
+    import ctypes
+    g = torch.Generator().manual_seed(9)
+    lib = N.lib()
+    for (h, w), lights, served in (((8, 32), 1, True), ((8, 30), 1, False), ((8, 32), 2, False)):
+        a, n, r, m, _ = [None if t is None else t.cuda() for t in _leaf_maps(g, h, w, "metallic")]
+        L = [[0.1, 0.1, 1.0], [-0.3, 0.2, 0.8]][:lights]
+        I = [[1.0, 0.9, 0.8], [0.5, 0.5, 0.5]][:lights]
+        kw = dict(view_dir=[0.0, 0.1, 1.0], light=L if lights > 1 else L[0], light_intensity=I if lights > 1 else I[0], light_type="point", light_size=1.0)
+        plan = F.plan_cook_torrance(a, n, r, m, tile=2, **kw)
+        ws = lib.pbr_backward_folded_workspace_bytes(ctypes.byref(plan.desc))
+        assert (ws == 0) == served, ((h, w), lights, ws)
+        if not served:
+            assert ws == 8 * 4 * (2 * h) * (2 * w)              # output-sized gradients of 8 planes, fp32
+        leaves = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
+        gout = torch.rand(3, 2 * h, 2 * w, generator=g).cuda()
+        (F.cook_torrance(*leaves, tile=2, **kw) * gout).sum().backward()
+        mats = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
+        (F.cook_torrance(*[t.repeat(1, 2, 2) for t in mats], **kw) * gout).sum().backward()
+        for x, y in zip(leaves, mats):
+            assert x.grad.shape == x.shape
+            assert (x.grad - y.grad).abs().max().item() <= 1e-5 * (float(y.grad.abs().max()) + 1e-12) + 1e-9
+
+
+@pytest.mark.parametrize("workflow,light_type,hw,tile,dtype", [("metallic", "point", (24, 48), (2, 2), torch.float32),
+                                                             ("specular", "directional", (16, 40), (2, 3), torch.float32),
+                                                             ("converted", "point", (10, 64), (3, 1), torch.float32),
+                                                             ("metallic", "point", (7, 260), (2, 2), torch.float32),
+                                                             ("metallic", "point", (16, 64), (2, 2), torch.float16)])
+def test_loss_step_over_tiled_maps_is_one_pass(workflow, light_type, hw, tile, dtype):
+    """pbr_cook_torrance_mse_step with tiled maps (ABI 7): loss and MAP-sized gradients from one pass over the maps and the target --
+    against float64 autograd of MSELoss(brdf(material.tile(n)), target) (06_advanced.rst:73-107 over examples/example_brdf.py:11's
+    material) and against the three-step path (evaluate, torch's MSE, folded backward)."""
+    from pypbr_amd import functional as F
+    (h, w), (ny, nx) = hw, tile
+    g = torch.Generator().manual_seed(77 + h + w)
+    maps = _leaf_maps(g, h, w, workflow, dtype)
+    target = torch.rand(3, ny * h, nx * w, generator=g)
+    view = torch.tensor([0.05, 0.1, 0.9])
+    light = torch.tensor([0.1, 0.1, 1.0]) if light_type == "point" else torch.tensor([0.3, -0.2, 1.0])
+    inten = torch.tensor([1.0, 0.9, 0.8])
+    size = 1.5 if light_type == "point" else None
+    kw = dict(view_dir=view, light=light, light_intensity=inten, light_type=light_type, light_size=size,
+              convert_to_diffuse_specular=(workflow == "converted"))
+    leaves = [None if t is None else t.cuda().requires_grad_(True) for t in maps]
+    loss = F.rendering_loss_mse(*leaves, target=target.cuda(), tile=tile, **kw)
+    assert loss.shape == () and type(loss.grad_fn).__name__ == "_MseStepFnBackward"
+    loss.backward()
+    ref_leaves = [None if t is None else t.float().double().requires_grad_(True) for t in maps]
+    args = [None if t is None else t.repeat(1, ny, nx) for t in ref_leaves]
+    okw = dict(view=view.double(), light=light.double(), intensity=inten.double(), light_type=light_type, light_size=size)
+    ref = O.cook_torrance_converted(args[0], args[1], args[2], args[3], **okw) if workflow == "converted" else O.cook_torrance(*args, **okw)
+    want = TF.mse_loss(ref, target.double())
+    want.backward()
+    assert abs(loss.item() - want.item()) <= 1e-6 * (1 + want.item())
+    for name, x, y in zip(("albedo", "normal", "roughness", "metallic", "specular"), leaves, ref_leaves):
+        if x is None:
+            continue
+        assert x.grad.dtype == dtype and x.grad.shape == x.shape
+        err = (x.grad.float().cpu().double() - y.grad).abs()
+        scale = float(y.grad.abs().max())
+        assert float(err.max()) <= (2e-5 if dtype == torch.float32 else 2e-3) * (scale + 1e-12) + 1e-9, (name, float(err.max()), scale)
+    again = [None if t is None else t.detach().clone().requires_grad_(True) for t in leaves]
+    unfused = TF.mse_loss(F.cook_torrance(*again, tile=tile, **kw), target.cuda())
+    unfused.backward()
+    assert abs(unfused.item() - loss.item()) <= 2e-6 * (1 + loss.item())
+    for x, y in zip(leaves, again):
+        if x is not None:
+            d = (x.grad.float() - y.grad.float()).abs().max().item()
+            assert d <= (2e-5 if dtype == torch.float32 else 2e-3) * (float(y.grad.float().abs().max()) + 1e-12) + 1e-9
+    # several lights: not one pass, same numbers through the three steps
+    multi = dict(kw, light=torch.stack([light, light * 0.8 + 0.1]), light_intensity=torch.stack([inten, inten * 0.5]))
+    more = [None if t is None else t.detach().clone().requires_grad_(True) for t in leaves]
+    l2 = F.rendering_loss_mse(*more, target=target.cuda(), tile=tile, **multi)
+    assert type(l2.grad_fn).__name__ != "_MseStepFnBackward"
+    l2.backward()
+    assert all(t is None or bool(torch.isfinite(t.grad.float()).all()) for t in more)
+
+
+def test_rendering_loss_on_the_examples_material_takes_the_one_pass_path():
+    """examples/example_brdf.py:11's material -- resize(512).tile(2) -- inside docs/source/tutorials/06_advanced.rst:73-107's loss: the
+    recorded tile reaches the loss step, whose gradients are map-sized and equal float64 autograd through the materialised repeat."""
+    from pypbr_amd.losses import RenderingLoss
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    g = torch.Generator().manual_seed(3)
+    h = w = 64
+    a, n, r, m, _ = _leaf_maps(g, h, w, "metallic")
+    leaves = [t.cuda().requires_grad_(True) for t in (a, n, r, m)]
+    pred = BasecolorMetallicMaterial(albedo=leaves[0], roughness=leaves[2], metallic=leaves[3], device="cuda")
+    pred._raw["normal"] = leaves[1]
+    pred.tile(2)
+    assert pred.lazy_tile == (2, 2) and pred.size == (128, 128)
+    target = torch.rand(3, 2 * h, 2 * w, generator=g).cuda()
+    crit = RenderingLoss(light_type="point", light_size=1.0)
+    loss = crit(pred, target)
+    assert type(loss.grad_fn).__name__ == "_MseStepFnBackward"
+    loss.backward()
+    ref_leaves = [t.double().requires_grad_(True) for t in (a, n, r, m)]
+    ref = O.cook_torrance(*[t.repeat(1, 2, 2) for t in ref_leaves], None, view=torch.tensor([0.0, 0.0, 1.0]).double(),
+                          light=torch.tensor([0.1, 0.1, 1.0]).double(), intensity=torch.ones(3).double(), light_type="point", light_size=1.0)
+    want = TF.mse_loss(ref, target.cpu().double())
+    want.backward()
+    assert abs(loss.item() - want.item()) <= 1e-6 * (1 + want.item())
+    for x, y in zip(leaves, ref_leaves):
+        assert x.grad.shape == x.shape
+        assert (x.grad.cpu().double() - y.grad).abs().max().item() <= 2e-5 * (float(y.grad.abs().max()) + 1e-12) + 1e-9

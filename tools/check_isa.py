@@ -177,54 +177,6 @@ def check_stream_kernel(sym, insts, meta):
     return summary, ["%s: %s" % (what, f) for f in fail]
 
 
-def check_stream16_kernel(sym, insts, meta):
-    """cook_torrance_backward_stream16_kernel<LIGHT, WF>: the streamed backward kernel with 16-byte memory instructions."""
-    m = re.search(r"stream16_kernelILi(\d)ELi(\d)E", sym)
-    light, wf = int(m.group(1)), int(m.group(2))
-    what = "backward_stream16<%s,%s>" % ("point" if light else "directional", WF_NAMES[wf])
-    n_maps = 10 if wf == 1 else 8
-    n_stores = (n_maps + 3) // 4                     # one global_store_dwordx4 per four gradient planes
-    ops = [mn for mn, _ in insts]
-    fail = []
-    if meta.get("private_segment_fixed_size", -1) != 0:
-        fail.append("scratch: private_segment_fixed_size = %s" % meta.get("private_segment_fixed_size"))
-    for bad in ("scratch_", "buffer_", "flat_"):
-        n = sum(1 for o in ops if o.startswith(bad))
-        if n:
-            fail.append("%d %s* instructions" % (n, bad))
-    if sum(1 for o in ops if o.startswith("global_load") and o != "global_load_lds_dwordx4"):
-        fail.append("vector-memory loads other than global_load_lds_dwordx4")
-    dma = [t for mn, t in insts if mn == "global_load_lds_dwordx4"]
-    stores = [mn for mn in ops if mn.startswith("global_store")]
-    waits = [int(re.search(r"vmcnt\((\d+)\)", t).group(1)) for mn, t in insts if mn == "s_waitcnt" and "vmcnt(" in t]
-
-    def offsets(texts):
-        return sorted(int(re.search(r"offset:(\d+)", t).group(1)) if "offset:" in t else 0 for t in texts)
-    if offsets(dma) != sorted([0, 1024, 2048, 3072] * 2):
-        fail.append("DMA loads at LDS offsets %s, expected [0, 1024, 2048, 3072] twice (first tile + loop)" % offsets(dma))
-    if stores != ["global_store_dwordx4"] * n_stores:
-        fail.append("stores %s, the hand-counted wait assumes %d global_store_dwordx4 per tile" % (stores, n_stores))
-    if sorted(waits) != [0, n_stores]:
-        fail.append("s_waitcnt vmcnt(...) values %s, expected exactly [0, %d]" % (sorted(waits), n_stores))
-    r32 = offsets(t for mn, t in insts if mn == "ds_read_b32")
-    r64 = offsets(t for mn, t in insts if mn == "ds_read_b64")
-    w32 = offsets(t for mn, t in insts if mn == "ds_write_b32")
-    r128 = offsets(t for mn, t in insts if mn == "ds_read_b128")
-    if r32 != [256 * q for q in range(n_maps)] or r64 != [0, 512, 1024]:
-        fail.append("LDS reads of the DMA buffer b32 %s / b64 %s: not exactly the hand-written ones" % (r32, r64))
-    if w32 != [256 * q for q in range(n_maps)] or r128 != [1024 * k for k in range(n_stores)]:
-        fail.append("store exchange ds_write_b32 %s / ds_read_b128 %s: not exactly the hand-written ones" % (w32, r128))
-    other_ds = sorted({o for o in ops if o.startswith("ds_") and o not in ("ds_read_b32", "ds_read_b64", "ds_write_b32", "ds_read_b128")})
-    if other_ds:
-        fail.append("unexpected LDS instructions %s" % other_ds)
-    order = _stores_follow_loads(insts, lambda mn: mn == "global_load_lds_dwordx4", lambda mn: mn.startswith("global_store"))
-    if order:
-        fail.append(order)
-    summary = "%-48s vgpr %3d  scratch %d  dma16 %d  store16 %d  ds_read %2d+%d  exchange %d->%d  vmcnt waits %s" % (
-        what, meta.get("vgpr_count", -1), meta.get("private_segment_fixed_size", -1), len(dma), len(stores), len(r32), len(r64), len(w32), len(r128), sorted(waits))
-    return summary, ["%s: %s" % (what, f) for f in fail]
-
-
 def check_xpose_kernel(sym, insts, meta):
     """cook_torrance_kernel<.., __half, float, 8, ..>: the piece exchange of shade_and_store."""
     fail = []
@@ -306,13 +258,6 @@ def check(verbose=False):
     try:
         co = _code_object(objs["ct_backward"], tmp)
         fns, meta = _functions(co), _metadata(co)
-        wide = sorted(s for s in fns if "cook_torrance_backward_stream16_kernel" in s)
-        if len(wide) != 6:
-            failures.append("expected 6 instantiations of cook_torrance_backward_stream16_kernel, found %d" % len(wide))
-        for s16 in wide:
-            line, bad = check_stream16_kernel(s16, fns[s16], meta.get(s16, {}))
-            report.append(line)
-            failures += bad
         stream = sorted(s for s in fns if "cook_torrance_backward_stream_kernel" in s)
         if len(stream) != 12:
             failures.append("expected 12 instantiations of cook_torrance_backward_stream_kernel, found %d" % len(stream))

@@ -29,10 +29,16 @@ Timing protocol.  Two timed regions, both K steps bracketed by barrier + synchro
   steady  `--settle` further untimed launches (default: 300 for config 2, else what fills ~40 ms) so that power
           management has settled the clocks (tools/transient_probe.py), then K timed steps -> `ms_per_step`, `value`:
           the sustained rate.
+  slope   2K more steps, timed the same way: (wall(2K) - wall(K)) / K is the per-step time without the fixed cost of entering and
+          leaving a region (~80 us: 4 us per step of a 20-step region) -> `ms_per_step_slope`, beside the literal `ms_per_step`.
+`warmup` echoes the argument; `launches_before_value` says how many launches really preceded the region `value` is taken from.
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
   roofline     -- achieved algorithmic HBM GB/s of the kernel (bytes per pixel x this rank's pixels per launch / average
-                  launch duration from HIP events on the launch stream over ALL 2K timed launches, cold + steady: the figure a
-                  rocprofv3 --kernel-trace average of the same command reproduces) vs 8 TB/s; for N > 1 the slowest rank's
+                  launch duration from HIP events on the launch stream over the STEADY region -- the K steps `value` is quoted on;
+                  rounds 2-4 averaged the cold region in, which alone moved `frac` by 4 %: profiles/r05_driver_line_ab.md) vs 8 TB/s;
+                  for N > 1 the slowest rank's.  Config 2 also runs the BARE access pattern of the kernel (tools/boxcal.hip: the same
+                  planes, the same bytes per lane, no arithmetic) on the same buffers right behind the steady region:
+                  `box_pattern_us`, `kernel_over_box_pattern` -- a slow line with a ratio near 1 is a slow box, not a slow binary
   roofline_valu-- config 5 only: the launch is VALU-bound; vector instructions issued per second against the chip's issue rate
   per_rank     -- kernel_us of every rank (steady region), its shard, and the latency of the light-block broadcast
   parity       -- bands of the timed output of this run against the float64 C oracle and the ATen restatement
@@ -182,7 +188,7 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, budget_s=15.0):
+def cpu_baseline(cfg, budget_s=30.0):
     """SURVEY.md 8d / BASELINE.md 4: the ATen restatement of the reference's CPU path with torch.set_num_threads(n) for
     n = 1 and n = the cores this process can really use (affinity mask and cgroup quota: `usable_cores`; `host_cores` =
     os.cpu_count() is reported beside it, and no leg runs more threads than are usable), at 256^2 (the size BASELINE configs[0]
@@ -195,11 +201,13 @@ def cpu_baseline(cfg, budget_s=15.0):
     t_start = time.perf_counter()
     table, skipped = [], []
     legs = ((256, 5), (1024, 2), (2048, 1)) if len(cfg["light"]) == 1 else ((256, 2), (512, 1), (1024, 1))
+    # the size the metric is quoted on (SURVEY.md 8d "256^2, 1024^2, 4096^2"): one pass at ONE thread (8-9 s) when the budget allows
+    metric_leg = (4096, 1) if cfg["size"] >= 4096 and len(cfg["light"]) == 1 else None
     _oracle_eval(cfg, synth_material(128, "cpu", 98))               # cold first call of the process (~1 s), untimed
     for threads in sorted({1, usable}):
         torch.set_num_threads(threads)
         per_pixel = None
-        for size, passes in legs:
+        for size, passes in legs + ((metric_leg,) if metric_leg and threads == 1 else ()):
             left = budget_s - (time.perf_counter() - t_start)
             if left <= 0 or (per_pixel is not None and per_pixel * size * size * passes > left):
                 skipped.append(f"{size}^2 x {threads} threads")
@@ -214,13 +222,13 @@ def cpu_baseline(cfg, budget_s=15.0):
     torch.set_num_threads(saved)
     rec = {"value": None, "unit": "Mpixels/s", "cores": None, "usable_cores": usable, "host_cores": host, "kind": "port", "cpu_model": cpu_model(),
            "table": table}
-    legs_txt = " / ".join(f"{sz}^2 ({p} passes)" for sz, p in legs)
+    legs_txt = " / ".join(f"{sz}^2 ({p} passes)" for sz, p in legs) + (f" and, at 1 thread, {metric_leg[0]}^2 (1 pass: the metric's own size)" if metric_leg else "")
     if not table:                                                   # e.g. --cpu-budget 0: a skipped baseline, not a lost bench line
         rec["sample"] = f"nothing measured within the {budget_s:.0f} s budget; skipped: {skipped}"
         return rec
     biggest = max(e["size"] for e in table)
     best = max((e for e in table if e["size"] == biggest), key=lambda e: e["Mpixels_per_s"])
-    rec.update(value=best["Mpixels_per_s"], cores=best["threads"])
+    rec.update(value=best["Mpixels_per_s"], cores=best["threads"], value_at=f"{biggest}^2")
     rec["sample"] = (f"oracle/torch_oracle.py (the reference's ATen ops, bit-equal to it in the dev container), this configuration's light and flags, "
                      f"one material of {legs_txt} at 1 and {usable} threads (the cores this process may use; the host has {host}), "
                      f"{time.perf_counter() - t_start:.1f} s in all; value = the fastest thread count at {biggest}^2" +
@@ -285,6 +293,41 @@ def recorded_traffic(kernel_name):
         return None, None
 
 
+class BoxPattern:
+    """tools/boxcal.hip on the buffers of one plan of config 2 (fp32 metallic maps, one material): `.launch(stream)` enqueues the bare
+    8-in / 3-out access pattern over the plan's own planes.  Bench-side helper; None when the helper library is not built."""
+
+    def __init__(self, lib, maps, out):
+        import ctypes
+        self.lib, self.ctypes = lib, ctypes
+        planes = []
+        for t in maps:                                   # [1,C,H,W] fp32, rows dense
+            for c in range(t.shape[1]):
+                planes.append(t.data_ptr() + c * t.stride(1) * 4)
+        outs = [out.data_ptr() + c * out.stride(1) * 4 for c in range(3)]
+        assert len(planes) == 8 and all(p % 16 == 0 for p in planes + outs)
+        self.inp = (ctypes.c_void_p * 8)(*planes)
+        self.out = (ctypes.c_void_p * 3)(*outs)
+        self.pixels = maps[0].shape[-2] * maps[0].shape[-1]
+        self.keep = (maps, out)
+
+    def launch(self, stream):
+        rc = self.lib.boxcal_forward_pattern(self.inp, self.out, self.ctypes.c_uint64(self.pixels), self.ctypes.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError("boxcal_forward_pattern: %d" % rc)
+
+
+def load_boxcal():
+    import ctypes
+    path = os.path.join(ROOT, "tools", "libboxcal.so")
+    if not os.path.exists(path):
+        return None
+    lib = ctypes.CDLL(path)
+    lib.boxcal_forward_pattern.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint64, ctypes.c_void_p]
+    lib.boxcal_forward_pattern.restype = ctypes.c_int
+    return lib
+
+
 SHARE_GPU = os.environ.get("PBR_BENCH_SHARE_GPU") == "1"     # test hook: N ranks on fewer GPUs (rank r on device r mod count), the
                                                               # small collectives over gloo -- exercises the N > 1 code path on a 1-GPU box
 
@@ -292,7 +335,7 @@ SHARE_GPU = os.environ.get("PBR_BENCH_SHARE_GPU") == "1"     # test hook: N rank
 def launch_ranks(n):
     """`python bench.py --gpus N`, N > 1, typed as it stands: this process has not touched the GPU (and never will);
     the N ranks run under torch.distributed.run as a CHILD process, and its exit code becomes ours."""
-    if torch.cuda.device_count() < n and not SHARE_GPU:          # counting devices does not initialise HIP
+    if torch.cuda.device_count() < n and not SHARE_GPU:          # (on ROCm wheels without amdsmi this count CAN initialise the runtime: harmless, the ranks are a CHILD)
         raise SystemExit(f"bench.py --gpus {n}: only {torch.cuda.device_count()} ROCm device(s) visible")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -336,7 +379,7 @@ def main():
     ap.add_argument("--layout", choices=("separate", "arena"), default="arena",
                     help="config 2.  arena (default): the material's maps and result in one allocation, as Material.to(device) lays "
                          "them out (F.pack_maps); separate: five tensors as torch's allocator places them")
-    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds the cpu_baseline leg may take (legs predicted to overrun are skipped and named)")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds the cpu_baseline leg may take (legs predicted to overrun are skipped and named)")
     ap.add_argument("--spawn", action="store_true", help="start the ranks through torch.distributed.run even for --gpus 1")
     ap.add_argument("--no-rccl", action="store_true", help="--gpus 1 started plainly: do not form the one-rank RCCL group (no collectives at all)")
     ap.add_argument("--example", choices=("brdf", "blend", "both"), default=None,
@@ -471,8 +514,20 @@ def main():
     for i in range(settle):
         plans[i % len(plans)].launch(stream)
     elapsed, kernel_ms = timed_region(plans, steps, stream, barrier)
+    # ---- slope: 2K more steps; (wall(2K) - wall(K)) / K is a step without the region's fixed entry / exit cost
+    elapsed2k, kernel2k_ms = timed_region(plans, 2 * steps, stream, barrier)
 
     extras = {}
+    box_ms = None
+    if args.config == 2 and cfg["dtype"] == torch.float32:
+        boxlib = load_boxcal()
+        if boxlib is not None:                     # the bare access pattern on the same buffers, same rotation, same protocol
+            boxes = [BoxPattern(boxlib, ms, pl.out) for ms, pl in zip(map_sets, plans)]
+            for i in range(10):
+                boxes[i % len(boxes)].launch(stream)
+            _, box_ms = timed_region(boxes, steps, stream, barrier)
+            for pl in plans:                       # the pattern wrote sums into the result planes: evaluate again (the parity leg reads plans[0].out)
+                pl.launch(stream)
     if share_plan is not None:
         _, share_ms = timed_region([share_plan], max(5, steps), stream, barrier)
         k = cfg["batch"] // 8
@@ -513,9 +568,9 @@ def main():
     per_rank_all = [0.5 * (kernel_ms + cold_kernel_ms) * 1e3]
     shards = [tuple(shard)]
     if distributed:
-        t = torch.tensor([elapsed, cold_s], device=coll, dtype=torch.float64)
+        t = torch.tensor([elapsed, cold_s, elapsed2k], device=coll, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, cold_s = float(t[0].item()), float(t[1].item())
+        elapsed, cold_s, elapsed2k = float(t[0].item()), float(t[1].item()), float(t[2].item())
         mine = torch.tensor([kernel_ms * 1e3, 0.5 * (kernel_ms + cold_kernel_ms) * 1e3, float(local_pixels)] + [float(v) for v in shard],
                             device=coll, dtype=torch.float64)
         gathered = [torch.zeros_like(mine) for _ in range(world)]
@@ -529,9 +584,9 @@ def main():
 
     if rank == 0:
         value = global_pixels * steps / elapsed / 1e6
-        slow = max(range(world), key=lambda i: per_rank_all[i])       # the rank every timed launch of which took longest:
-        kernel_all_ms = per_rank_all[slow] * 1e-3                     # K cold + K steady launches, what a rocprofv3 --kernel-trace
-        achieved = bpp * per_rank_px[slow] / (kernel_all_ms * 1e-3) / 1e9   # average of the same command shows
+        slow = max(range(world), key=lambda i: per_rank_us[i])        # the rank whose launches of the STEADY region -- the K steps `value`
+        kernel_all_ms = per_rank_all[slow] * 1e-3                     # is quoted on -- took longest; (kernel_all: cold + steady, rounds 2-4's basis)
+        achieved = bpp * per_rank_px[slow] / (per_rank_us[slow] * 1e-6) / 1e9
         traffic, traffic_run = recorded_traffic(kernel) if args.config == 2 and S == 4096 else (None, None)
         line = {
             "metric": "Mpixels/s Cook-Torrance eval, 4K maps" if args.config == 2 else
@@ -540,6 +595,9 @@ def main():
             "ms_per_step": round(elapsed / steps * 1e3, 5), "higher_is_better": True, "scaling": cfg["scaling"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ms_per_step_cold": round(cold_s / steps * 1e3, 5),
+            "ms_per_step_slope": round((elapsed2k - elapsed) / steps * 1e3, 5),
+            "value_slope": round(global_pixels * steps / max(elapsed2k - elapsed, 1e-9) / 1e6, 1),
+            "launches_before_value": warmup + steps + settle,
             "value_cold": round(global_pixels * steps / cold_s / 1e6, 1),
             "config": {"workload": cfg["name"].format(S=S, B=cfg["batch"]), "config": args.config,
                        "kernel": kernel, "global_batch": world if args.config == 2 else cfg["batch"], "map_size": [S, S],
@@ -548,13 +606,17 @@ def main():
                        "parallelism": (f"material-sharded x{world}: " + ("one material per rank (weak)" if args.config == 2 else
                                        "pypbr_amd.distributed.partition over the batch, every rank generates and owns its slice (strong)"))
                                       + (" (TEST HOOK: ranks share GPUs, collectives over gloo)" if SHARE_GPU else ""),
-                       "timing": f"value/ms_per_step: {steps} steps after {warmup} warm-up + {steps} cold-timed + "
-                                 f"{settle} clock-settle launches (sustained rate); value_cold/ms_per_step_cold: the "
-                                 f"{steps} steps right after the {warmup} warm-up launches",
+                       "timing": f"value/ms_per_step: wall time of {steps} steps after {warmup} warm-up + {steps} cold-timed + "
+                                 f"{settle} clock-settle launches = {warmup + steps + settle} launches (sustained rate; `warmup` echoes the argument); "
+                                 f"value_cold/ms_per_step_cold: the {steps} steps right after the {warmup} warm-up launches; "
+                                 f"value_slope/ms_per_step_slope: (wall of {2 * steps} further steps - wall of the {steps}) / {steps}, i.e. "
+                                 f"without the ~{max(0.0, (2 * elapsed - elapsed2k)) * 1e6:.0f} us a region costs to enter and leave",
                        "clock_settle_launches": settle},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_run,
-                         "kernel_us": round(kernel_all_ms * 1e3, 2), "kernel_us_steady": round(per_rank_us[slow], 2),
+                         "kernel_us": round(per_rank_us[slow], 2), "kernel_us_steady": round(per_rank_us[slow], 2),
+                         "kernel_us_cold_and_steady": round(kernel_all_ms * 1e3, 2),
+                         "basis": "HIP events on the launch stream around the steady region's launches (the region `value` is quoted on)",
                          "pixels_per_launch": per_rank_px[slow], "rank": slow},
             "per_rank": {"kernel_us": [round(u, 2) for u in per_rank_us], "pixels_per_launch": per_rank_px,
                          "shard_batch_rows": shards, "backend": backend, "ranks_seen": ranks_seen,
@@ -565,6 +627,13 @@ def main():
                                         "(pypbr_amd.functional.pack_maps, what Material.to(device) does)" if args.layout == "arena" else
                                         "separate: albedo, normal, roughness, metallic and the result as five tensors wherever torch's allocator put them")
             line["roofline"]["kernel_us_cold"] = round(cold_kernel_ms * 1e3, 2)
+            line["roofline"]["kernel_us_2k_region"] = round(kernel2k_ms * 1e3, 2)
+            if box_ms is not None:
+                # the bare 8-in / 3-out access pattern (tools/boxcal.hip) on the same buffers right behind the steady region: what THIS box
+                # gives any kernel with this access pattern.  kernel_over_box_pattern ~ 1: the kernel is at its pattern's ceiling on this box
+                line["roofline"]["box_pattern_us"] = round(box_ms * 1e3, 2)
+                line["roofline"]["box_pattern_frac"] = round(bpp * per_rank_px[0] / (box_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                line["roofline"]["kernel_over_box_pattern"] = round(per_rank_us[0] / (box_ms * 1e3), 4)
         if len(cfg["light"]) > 1:
             L = len(cfg["light"])
             per_pl, valu_src = recorded_valu()

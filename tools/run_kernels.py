@@ -134,6 +134,25 @@ if want("tiled"):
     report("tiled_f16: 2048^2 fp16 maps, fused tile(2) -> 4096^2 fp32 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out): repeat-inner kernel",
            "cook_torrance_repeat_kernel<1, 0, __half, float, false, true>", 16 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
     del maps, p
+if want("tiled_bwd"):
+    # round 5: gradients of tiled maps folded in registers (pbr_cook_torrance_backward_folded) and the loss step over tiled maps
+    for dtype, tag in ((torch.float32, "f32"), (torch.float16, "f16")):
+        maps = F.pack_maps(*[t.to(dtype) for t in synth_material(2048, DEV, 41)])
+        plan = F.plan_cook_torrance(*maps, tile=2, **PT)
+        gout = torch.rand(1, 3, S, S, device=DEV)
+        grads = [torch.empty_like(t) for t in maps]
+        es = maps[0].element_size()
+        tm = "float" if dtype == torch.float32 else "__half"
+        report(f"tiled_bwd_{tag}: folded gradient of 2048^2 maps under tile(2) -> 4096^2 ({dtype}): 8 map planes + 3 upstream planes of 4096^2 in, 8 gradient planes of 2048^2 out",
+               f"cook_torrance_repeat_backward_kernel<1, 0, {tm}, false>", 12 * PX + 16 * es * 2048 * 2048,
+               timed(lambda: N.check(lib.pbr_cook_torrance_backward_folded(ctypes.byref(plan.desc), gout.data_ptr(), *[t.data_ptr() for t in grads], None, None, stream))))
+        loss = torch.empty((), device=DEV)
+        ws = torch.empty(max(1, lib.pbr_mse_step_workspace_bytes(ctypes.byref(plan.desc)) // 4), device=DEV)
+        report(f"tiled_bwd_loss_{tag}: rendering-loss step over the same tiled maps: 8 map planes + target image of 4096^2 in, 8 gradient planes of 2048^2 out",
+               f"cook_torrance_repeat_backward_kernel<1, 0, {tm}, true>", 12 * PX + 16 * es * 2048 * 2048,
+               timed(lambda: N.check(lib.pbr_cook_torrance_mse_step(ctypes.byref(plan.desc), gout.data_ptr(), *[t.data_ptr() for t in grads], None,
+                                                                    loss.data_ptr(), ws.data_ptr(), stream))))
+        del maps, plan, gout, grads, ws
 if want("map_ops"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)

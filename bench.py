@@ -246,7 +246,7 @@ def parity_of_timed_output(cfg, out, maps, shard, band_rows):
     S, h = cfg["size"], shard.row_stop - shard.row_start
     nb = shard.batch_stop - shard.batch_start
     picks = sorted({(0, 0), (nb // 2, max(0, (h - band_rows) // 2)), (nb - 1, max(0, h - band_rows))})
-    worst64 = worst32 = ref_gap = 0.0
+    worst64 = worst32 = ref_gap = rough_needed = 0.0
     over = ref_over = values = 0
     fp16_out = out.dtype == torch.float16
     for i, y0 in picks:
@@ -264,6 +264,8 @@ def parity_of_timed_output(cfg, out, maps, shard, band_rows):
         d32 = np.abs(got - ref32)
         worst32 = max(worst32, float(d32.max()))
         over += int((d32 > 1e-5).sum())
+        if (d32 > 1e-5).any():                                                       # the roughness above which every value of the sample is within 1e-5
+            rough_needed = max(rough_needed, float(np.broadcast_to(crop[2].numpy(), d32.shape)[d32 > 1e-5].max()))
         r = np.abs(ref32 - ref64)                                                     # the reference's own fp32 rounding against its float64 evaluation
         ref_gap = max(ref_gap, float(r.max()))
         ref_over += int((r > 1e-5).sum())
@@ -271,6 +273,10 @@ def parity_of_timed_output(cfg, out, maps, shard, band_rows):
     return {"max_abs_err_vs_fp64_oracle": worst64, "max_abs_err_vs_reference_fp32": worst32,
             "values_over_1e-5_vs_reference_fp32": over, "values": values,
             "reference_fp32_max_abs_err_vs_its_fp64": ref_gap, "reference_fp32_values_over_1e-5_vs_its_fp64": ref_over,
+            # count <= 2e-5 N -- a statement about the build only where the reference's own fp32 run meets it
+            "count_bound_2e-5_N": round(2e-5 * values, 1), "count_within_bound": over <= 2e-5 * values,
+            "reference_count_within_bound": ref_over <= 2e-5 * values,
+            "roughness_above_which_every_value_is_within_tolerance": round(rough_needed, 4),
             "tolerance": 4.9e-4 if fp16_out else 1e-5,
             "sample": f"{len(picks)} bands of {band_rows} rows x {S} columns (local material, first row) = "
                       f"{[(shard.batch_start + i, shard.row_start + y) for i, y in picks]} of the output written by rank 0's timed launches; "

@@ -78,8 +78,8 @@ static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
     const int idt = d->map_dtype, odt = d->out_dtype;
     const int nb = batch_group(d, vec);
     if (repeat_inner(d)) {
-        std::snprintf(name, sizeof(name), "ctr_%s_%s_%s_%s_v4", point ? "point" : "directional", wf_names[d->workflow],
-                      idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16");
+        std::snprintf(name, sizeof(name), "ctr_%s_%s_%s_%s_v4%s", point ? "point" : "directional", wf_names[d->workflow],
+                      idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", multi ? "_multi" : "");
         return KernelEntry{pick_repeat_kernel(d, g_nontemporal), name};
     }
     // packed arithmetic for ONE light over fp32 maps: the rule is tiled launches only (ct_kernel.hpp: PACK1)
@@ -167,7 +167,7 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
     // Tiled maps are re-read from L2 / Infinity Cache, so their loads must not carry the streaming hint, and the
     // launch is then VALU-bound and wants every wave it can get (2048^2 tile(2): 81 us vs 122 us with the streaming
-    // settings, 120 us for the materialised 4096^2 maps; tools/tile_probe.py).
+    // settings, 120 us for the materialised 4096^2 maps; tile_probe.py (a probe of its round, removed with its knob: git 9ce0718:tools/)).
     const bool tiled = k.tiled != 0;
     const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0 && (!tiled || g_nontemporal == 2));
     // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane

@@ -788,7 +788,11 @@ void cook_torrance_batch_kernel(const KArgs a) {
 // arithmetic; row bands of the tiled output (multi-GPU shards) are served when they hold at least one full period of the map's rows; thinner
 // bands, several lights and ragged map widths keep the wrap-around form.
 // NTL / NTS: the streaming hint on the loads / on the stores.
-template <int LIGHT, int WF, typename TI, typename TO, bool NTL, bool NTS>
+// MULTI (round 5): several lights -- the light loop sits INSIDE the position loop (a position's lights are summed, clamped and encoded as
+// cook_torrance_kernel<.., MULTI = true> does: per-light clamp, sum, clamp, encode), so texels are still loaded, decoded and turned into
+// pixel terms once for all repeats and all lights.  The launch is VALU-bound; what the walk saves is the second read of every texel
+// (the wrap-around form: 1.40 x the maps from HBM) and 1 - 1/(rep_y rep_x) of the decode.
+template <int LIGHT, int WF, typename TI, typename TO, bool NTL, bool NTS, bool MULTI = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void cook_torrance_repeat_kernel(const KArgs a) {
     constexpr int VEC = 4, NG = 2;
@@ -822,13 +826,39 @@ void cook_torrance_repeat_kernel(const KArgs a) {
         }
     };
     auto shade = [&](const R (&xs)[NG], float ys, R (&res)[3][NG]) {
+        if constexpr (MULTI) {            // lights outer (uniform), the lane's pixel groups inside: shade_and_store's order, its sums
+            R sum[3][NG];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[g], ys);
-            R col[3];
-            shade_light(pt[g], lg, lu.inten, col);
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) res[c][g] = a.out_srgb ? linear_to_srgb_unit(col[c]) : col[c];      // :179-180
+                for (int g = 0; g < NG; ++g) sum[c][g] = splat<R>(0.0f);
+            for (int l = 0; l < a.n_lights; ++l) {
+                const LightU ll = light_of(a, l);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const LightGeomT<R> lg = light_geom<LIGHT, R>(ll, V, xs[g], ys);
+                    R col[3];
+                    shade_light(pt[g], lg, ll.inten, col);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) sum[c][g] += col[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const R lin = clamp01(sum[c][g]);                                                     // sum of per-light clamped terms, clamped
+                    res[c][g] = a.out_srgb ? linear_to_srgb_unit(lin) : lin;                              // :179-180
+                }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[g], ys);
+                R col[3];
+                shade_light(pt[g], lg, lu.inten, col);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) res[c][g] = a.out_srgb ? linear_to_srgb_unit(col[c]) : col[c];      // :179-180
+            }
         }
     };
     if (LIGHT == PBR_LIGHT_DIRECTIONAL) {                                   // the light does not know where the pixel is (:125-127)

@@ -192,7 +192,7 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log
     k.div_mh.init((uint32_t)k.map_h); k.div_mw.init((uint32_t)k.map_w);
     k.y_offset = d->y_offset; k.H_total = d->height_total;
     k.div_reps.init(1);
-    // Measured (tools/tile_probe.py, 2048^2 maps, tile(2), MI355X): the fold order brings the read traffic from 2.0 x to 1.0002 x
+    // Measured (tile_probe.py (a probe of its round, removed with its knob: git 9ce0718:tools/), 2048^2 maps, tile(2), MI355X): the fold order brings the read traffic from 2.0 x to 1.0002 x
     // the source (PMC) -- and costs fp32 maps 8-17 % of time whatever the band (78-82 us in row order, 87-98 us folded, with or
     // without the streaming hint): in row order the second visit is served by the 256 MB memory-side cache, and the launch is
     // VALU-bound either way.  fp16 maps run level (65-69 us both).  The rule therefore folds fp16 maps only.
@@ -200,7 +200,7 @@ inline void fill_args(const pbr_render_desc *d, int vec, KArgs &k, int block_log
     if (k.tiled && fold_wanted && by == 1 && d->batch == 1 && d->y_offset == 0 && d->height == d->height_total &&
         d->height_total > d->map_height && k.n_tiles > 0) {
         // rows per band: the band's texels (all planes) within ~2 MiB -- 1/8 of it per XCD, beside the result streams in a 4 MiB
-        // L2 -- a power of two that divides map_h, the band a whole number of XCD periods (tools/tile_probe.py: "fold").
+        // L2 -- a power of two that divides map_h, the band a whole number of XCD periods (tile_probe.py (a probe of its round, removed with its knob: git 9ce0718:tools/): "fold").
         const int64_t esz = d->map_dtype == PBR_F32 ? 4 : 2;
         const int64_t row_bytes = (int64_t)d->map_width * esz * (3 + (d->normal.data ? 3 : 0) + 1 + (d->workflow == PBR_WORKFLOW_SPECULAR ? 3 : 1));
         int fl = 0;
@@ -256,12 +256,12 @@ int64_t repeat_backward_tiles(const pbr_render_desc *d);
 int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void *g_albedo, void *g_normal, void *g_roughness, void *g_metallic,
                            void *g_specular, bool loss, float scale, float *partials, hipStream_t st);
 
-// Tiled maps evaluated by the repeat-inner kernel (ct_kernel.hpp: cook_torrance_repeat_kernel): one light, map rows a whole number of
+// Tiled maps evaluated by the repeat-inner kernel (ct_kernel.hpp: cook_torrance_repeat_kernel): map rows a whole number of
 // 4-texel lanes, and an output -- the whole tiled image, or a row band of it (a multi-GPU shard) -- that holds at least one full period
 // of the map's rows: in a thinner band no texel row is used twice vertically, there is nothing for the kernel to share, and every source
-// row outside the band would be loaded for nothing.  Thin bands, several lights and ragged map widths take the wrap-around form.
+// row outside the band would be loaded for nothing.  Thin bands and ragged map widths take the wrap-around form.
 inline bool repeat_inner(const pbr_render_desc *d) {
-    return g_tile_repeat != 0 && is_tiled(d) && d->n_lights == 1 && d->height >= d->map_height &&
+    return g_tile_repeat != 0 && is_tiled(d) && d->height >= d->map_height &&
            d->map_width % 4 == 0 && g_max_vec >= 4;
 }
 

@@ -30,7 +30,7 @@ static RepBwdFn pick_repeat_bwd(const pbr_render_desc *d, bool loss) {
 // 4-texel lanes, an output band that holds a full period of the map's rows) with planes small enough for its 32-bit lane offsets
 // when it addresses them through a scalar base.  fp32 result / upstream gradient only (as every backward entry).
 bool repeat_backward_serves(const pbr_render_desc *d) {
-    return repeat_inner(d) && d->out_dtype == PBR_F32 && g_max_vec >= 2;
+    return repeat_inner(d) && d->n_lights == 1 && d->out_dtype == PBR_F32 && g_max_vec >= 2;
 }
 
 // Workgroups of the launch for this descriptor (one partial sum each under the loss policy), -1 when it does not fit a 1-D grid.

@@ -18,7 +18,7 @@
 // and only the height-reduced strip of a tile goes through LDS for the width pass.  Tap weights are normalised once per
 // tile (as ATen does) instead of per output.  4096^2 -> 2048^2, 3 planes, antialiased: 450 MB of HBM traffic for two
 // passes through a workspace -> 252 MB.
-// History of the schedule (tools/resize_sweep.py, 3 x 4096^2 -> 2048^2 | 1024^2 | 6144^2 up-scale, us): two kernels through the
+// History of the schedule (resize_sweep.py (a probe of its round, removed with its knob: git 9ce0718:tools/), 3 x 4096^2 -> 2048^2 | 1024^2 | 6144^2 up-scale, us): two kernels through the
 // workspace 89 | 94 | 412; the whole raw window of a tile in LDS, width pass LDS -> LDS, height pass LDS -> output
 // 81.5 | 95.8 | 232 -- counters: LDS pipe 65-80 % busy (13.5 cycles per LDS instruction, ~28 bytes per clock: the width pass
 // reads dwords `scale` floats apart, a bank conflict for even scales), VALUs 40 %, global loads fully hidden; this form
@@ -921,8 +921,8 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
     float *tmp = static_cast<float *>(workspace);
     const AxisFilter fw = make_filter(w_in, w_out, antialias != 0), fh = make_filter(h_in, h_out, antialias != 0);
     if (g_resize_up2 && fw.scale <= 1.0f && fh.scale <= 1.0f && w_in >= 6) {
-        // up-scaling (or 1:1) on both axes: the two-tap register form.  3 x 4096^2 -> 6144^2 (tools/resize_sweep.py, round 3).
-        // Output rows per lane.  Measured (tools/resize_up_ab.py, 3 planes, us, rows 2 / 4 / 8; strip kernel for scale):
+        // up-scaling (or 1:1) on both axes: the two-tap register form.  3 x 4096^2 -> 6144^2 (resize_sweep.py (a probe of its round, removed with its knob: git 9ce0718:tools/), round 3).
+        // Output rows per lane.  Measured (resize_up_ab.py (a probe of its round, removed with its knob: git 9ce0718:tools/), 3 planes, us, rows 2 / 4 / 8; strip kernel for scale):
         //   4096^2 -> 6144^2  131.4 / 121.6 / 110.8 (157)    -> 8192^2  215.3 / 195.5 / 184.7 (270)    2048^2 -> 4096^2  59.0 / 53.6 / 53.0 (64)
         //   4096^2 -> 4608^2   79.1 /  70.0 /  73.1 (101)    -> 4096^2   63.7 /  61.2 /  66.0 (95)
         // 8 from 1.25x up (the column taps' share shrinks as the rows grow), 4 below.
@@ -949,7 +949,7 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
             };
             // Output rows per workgroup: as many as keep the workgroup's LDS within 24 KiB (6 workgroups per CU).  More rows
             // amortise the tables and re-read fewer input rows; more resident workgroups overlap the phases
-            // (tools/resize_sweep.py: 2x down 32-64 rows, 3-4x down 16, up-scales 64-128).
+            // (resize_sweep.py (a probe of its round, removed with its knob: git 9ce0718:tools/): 2x down 32-64 rows, 3-4x down 16, up-scales 64-128).
             int toh = 8;
             for (int rows : {128, 64, 32, 16})
                 if (lds_for(rows) <= 24 * 1024) { toh = rows; break; }
@@ -1008,7 +1008,7 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
     float *gi = static_cast<float *>(grad_in);
     if (g_resize_up2 && fw.scale <= 1.0f && fh.scale <= 1.0f && fw.scale >= 0.34f && fh.scale >= 0.25f && w_out >= 16) {
         // gradient of an up-scale (up to 3x across, 4x down the rows): the register-only transpose of the two-tap forward (round 4;
-        // tools/resize_bwd_probe.py).  W from the exact window count of THIS shape; rows per lane 4.
+        // resize_bwd_probe.py (a probe of its round, removed with its knob: git 9ce0718:tools/)).  W from the exact window count of THIS shape; rows per lane 4.
         const int need = up2_backward_window(fw, w_out);
         constexpr int R = 4;
         const int64_t groups_x = (w_in + 255) / 256, groups_y = (h_in + R - 1) / R, n_groups = groups_x * groups_y * planes;
@@ -1061,7 +1061,7 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
         auto lds_for = [&](int rows) {
             return sizeof(float) * ((size_t)kx * kTileW + (size_t)ky * rows + 2 * (kTileW + rows) + (size_t)rows * pitch + 16);
         };
-        // Rows per tile: here more rows win up to ~48 KiB of LDS (tools/resize_bwd_probe.py, us at 32 / 64 / 128 rows: 2048^2 -> 4096^2
+        // Rows per tile: here more rows win up to ~48 KiB of LDS (resize_bwd_probe.py (a probe of its round, removed with its knob: git 9ce0718:tools/), us at 32 / 64 / 128 rows: 2048^2 -> 4096^2
         // 123 / 79 / 67, 3000^2 -> 4096^2 138 / 98 / 84, 6144^2 -> 4096^2 184 / 150 / -, 4096^2 -> 2048^2 59 / 60 / 115): the strip's
         // halo rows are re-read per tile, and a gradient tile reads few bytes for what it writes.
         int toh = 8;

@@ -46,7 +46,7 @@ def test_light_size_follows_python_truthiness(golden, manifest, binding):
                                             light=torch.tensor([0.1, 0.1, 1.0], dtype=torch.float64),
                                             intensity=torch.tensor(manifest["intensity1"], dtype=torch.float64), light_type="point",
                                             light_size=size, return_srgb=(cs == "srgb")).numpy()
-                    rep = parity_report(got, z[f"out_{kind}_{tag}_{cs}"], ref64, z["in_roughness"], what=(kind, tag, cs))
+                    rep = parity_report(got, z[f"out_{kind}_{tag}_{cs}"], ref64, z["in_roughness"], what=(kind, tag, cs), set_name="edge_golden")
                     worst = max(worst, rep["max32"])
             # the mirrored grid is not the default grid: the build must not fold a negative size into "not given"
             neg = F.cook_torrance(a, n, r, m, s, view_dir=manifest["view1"], light=[0.1, 0.1, 1.0], light_intensity=manifest["intensity1"],

@@ -5,7 +5,8 @@ Criterion (DESIGN.md "Parity criterion").  TOL = 1e-5
 tolerance BASELINE.json's north_star states.  ref32 = the reference's own fp32 output (golden vectors; on seeded
 inputs the ATen restatement, pinned bit-equal to it), ref64 = the same reference code run in float64.
   (i)   |hip - ref32| <= TOL on EVERY value of: crops of the reference's own PNG fixtures (tiles, rocks), both example
-        scripts, and synthetic maps wherever roughness >= ROUGH_OK.
+        scripts, and synthetic maps wherever roughness lies above the set's threshold -- a MEASURED output of the suite, recorded per
+        set in tests/golden/parity_thresholds.json and not allowed to rise (tests/test_gpu_zz_parity_table.py).
   (ii)  Below that roughness the reference's OWN fp32 output is not reproducible to 1e-5 by anything that is not
         bit-identical to ATen: its GGX denominator NdotH^2 (a^2-1) + 1 cancels, and its fp32 run is up to 5.6e-5 away
         from its own float64 run on these very fixtures.  There, on every value of every variant:
@@ -14,9 +15,9 @@ inputs the ATen restatement, pinned bit-equal to it), ref64 = the same reference
         (b) |hip - ref32| <= |ref32 - ref64| + TOL -- every difference above TOL lies inside the reference's own fp32
             rounding envelope;
         (c) count(|hip - ref32| > TOL) <= count(|ref32 - ref64| > TOL - TRACK): the build exceeds TOL against ref32 on
-            no more values than the reference exceeds it against its own float64 run.  (SURVEY.md's absolute bound
-            2e-5 * N is printed next to it; the reference itself misses it on low-roughness sets: 3.4e-5 * N on rand64,
-            1.4e-4 * N on real48.)
+            no more values than the reference exceeds it against its own float64 run.  SURVEY.md's absolute bound
+            count <= 2e-5 * N is ASSERTED per set wherever the reference's own count meets it (the closing test of the suite);
+            the reference itself misses it on low-roughness sets: 3.4e-5 * N on rand64, 1.4e-4 * N on real48.
         No blanket bound: variants whose float64 twin is not in the fixtures get it from the pinned oracle's float64
         mode (tests/test_oracle_pin.py checks that mode bit-equal to the committed float64 runs).
 """
@@ -28,13 +29,20 @@ from conftest import RANDOM_SETS, oracle_render, parse_case, render_keys
 
 pytestmark = pytest.mark.gpu
 
+from conftest import PARITY_SETS, parity_threshold
+
 TOL = 1e-5
 TRACK = 2e-6          # |hip - ref64|: what the cancellation-free kernel is held to (measured 5.4e-7)
-ROUGH_OK = 0.185      # smallest roughness from which (i) holds on every fixture and on the 4096^2 map (measured: 0.180, printed per test)
+ROUGH_OK = 0.185      # where seeded test inputs start their roughness range when they want criterion (i) on every value; the threshold the
+                      # suite ASSERTS is per set and measured: tests/golden/parity_thresholds.json (conftest.parity_threshold)
 
 
-def parity_report(got, ref32, ref64, rough=None, what=""):
-    """Asserts criterion (i) where `rough` >= ROUGH_OK and (ii a-c) everywhere; returns the numbers for the log."""
+def parity_report(got, ref32, ref64, rough=None, what="", set_name=None):
+    """Asserts criterion (i) where `rough` > the set's recorded threshold and (ii a-c) everywhere; returns the numbers for the log and
+    adds them to the set's row of the suite's parity table (conftest.PARITY_SETS; closed by tests/test_gpu_zz_parity_table.py: SURVEY 8c's
+    count bound 2e-5 N wherever the reference itself meets it, and the measured threshold must not have risen)."""
+    set_name = set_name or (str(what[0]) if isinstance(what, tuple) and what else str(what))
+    thr = parity_threshold(set_name)
     got64 = got.astype(np.float64)
     err, e64 = np.abs(got64 - ref32), np.abs(got64 - ref64)
     env = np.abs(ref32.astype(np.float64) - ref64)
@@ -44,12 +52,16 @@ def parity_report(got, ref32, ref64, rough=None, what=""):
     assert n_hip <= n_ref, (what, "more values over TOL than the reference has against its own float64 run", n_hip, n_ref)
     need = 0.0
     if rough is not None:
-        well = np.broadcast_to(rough >= ROUGH_OK, err.shape)
+        well = np.broadcast_to(rough > thr, err.shape)
         if well.any():
-            assert err[well].max() <= TOL, (what, "roughness >= %.2f" % ROUGH_OK, float(err[well].max()))
+            assert err[well].max() <= TOL, (what, "roughness > %.4f (the set's recorded threshold)" % thr, float(err[well].max()))
         bad = err > TOL
         if bad.any():
             need = float(np.broadcast_to(rough, err.shape)[bad].max())
+    row = PARITY_SETS.setdefault(set_name, dict(n=0, n_hip=0, n_ref=0, rough_needed=0.0, max32=0.0, max64=0.0, with_roughness=False))
+    row["n"] += err.size; row["n_hip"] += n_hip; row["n_ref"] += n_ref
+    row["rough_needed"] = max(row["rough_needed"], need); row["max32"] = max(row["max32"], float(err.max())); row["max64"] = max(row["max64"], float(e64.max()))
+    row["with_roughness"] = row["with_roughness"] or rough is not None
     return dict(max32=float(err.max()), max64=float(e64.max()), n_hip=n_hip, n_ref=n_ref, n=err.size, rough_needed=need)
 
 
@@ -94,7 +106,7 @@ def test_golden_random_sets(name, golden, manifest):
             tot[k] += rep[k]
     print(f"\n[{name}] {tot['n']} values: max|hip-ref32| {tot['max32']:.2e}, max|hip-ref64| {tot['max64']:.2e}; values > {TOL:g} vs ref32: "
           f"{tot['n_hip']} (reference vs its own float64 run: {tot['n_ref']}; 2e-5*N = {2e-5 * tot['n']:.1f}); "
-          f"criterion (i) holds from roughness {tot['rough_needed']:.3f} up (asserted from {ROUGH_OK})")
+          f"criterion (i) holds above roughness {tot['rough_needed']:.4f} (asserted above {parity_threshold(name):.4f})")
 
 
 @pytest.mark.parametrize("name", ["tiles96", "rocks96"])

@@ -254,3 +254,30 @@ def test_rendering_loss_on_the_examples_material_takes_the_one_pass_path():
     for x, y in zip(leaves, ref_leaves):
         assert x.grad.shape == x.shape
         assert (x.grad.cpu().double() - y.grad).abs().max().item() <= 2e-5 * (float(y.grad.abs().max()) + 1e-12) + 1e-9
+
+
+# ---------------------------------------------------------------- the repeat-inner walk with several lights
+@pytest.mark.parametrize("workflow,light_type,hw,tile,dtype,out_dtype", [("metallic", "point", (24, 64), (2, 2), torch.float32, torch.float32),
+                                                                       ("specular", "directional", (16, 40), (3, 2), torch.float32, torch.float32),
+                                                                       ("converted", "point", (10, 128), (2, 3), torch.float16, torch.float32),
+                                                                       ("metallic", "point", (12, 48), (2, 2), torch.float16, torch.float16)])
+def test_repeat_inner_walk_serves_several_lights_bit_identically(workflow, light_type, hw, tile, dtype, out_dtype):
+    """Several lights over tiled maps used to take the wrap-around form (every texel read and decoded once per repeat, the second
+    read past L2: 1.40 x the maps from HBM).  The repeat-inner kernel now loops the lights inside each position: same bits as the
+    wrap-around form (PBR_TUNE_TILE_REPEAT = 0) and as the materialised repeat (MaterialBase.tile, base.py:524-537)."""
+    from pypbr_amd import functional as F
+    (h, w), (ny, nx) = hw, tile
+    g = torch.Generator().manual_seed(5 * h + w)
+    maps = [None if t is None else t.cuda() for t in _leaf_maps(g, h, w, workflow, dtype)]
+    L = torch.tensor([[0.1, 0.1, 1.0], [-0.4, 0.2, 0.7], [0.3, -0.3, 0.9]])
+    I = torch.tensor([[1.0, 0.9, 0.8], [0.4, 0.5, 0.6], [0.3, 0.3, 0.3]])
+    kw = dict(view_dir=[0.05, 0.1, 0.9], light=L, light_intensity=I, light_type=light_type, light_size=1.5 if light_type == "point" else None,
+              convert_to_diffuse_specular=(workflow == "converted"), out_dtype=out_dtype)
+    plan = F.plan_cook_torrance(*maps, tile=tile, **kw)
+    assert plan.kernel_name.startswith("ctr_") and plan.kernel_name.endswith("_multi")
+    got = plan.launch().clone()
+    wrap = F.plan_cook_torrance(*maps, tile=tile, tuning=dict(tile_repeat=0), **kw)
+    assert not wrap.kernel_name.startswith("ctr_")
+    assert torch.equal(got, wrap.launch())
+    full = F.cook_torrance(*[None if t is None else t.repeat(1, ny, nx) for t in maps], **kw)
+    assert torch.equal(got.reshape(full.shape), full)

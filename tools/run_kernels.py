@@ -134,6 +134,18 @@ if want("tiled"):
     report("tiled_f16: 2048^2 fp16 maps, fused tile(2) -> 4096^2 fp32 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out): repeat-inner kernel",
            "cook_torrance_repeat_kernel<1, 0, __half, float, false, true>", 16 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
     del maps, p
+if want("tiled_multi"):
+    # round 5: several lights over tiled maps take the repeat-inner walk too (texels read and decoded once); beside it the wrap-around form
+    lights4 = [[math.cos(t), math.sin(t), 1.0] for t in [2 * math.pi * i / 4 for i in range(4)]]
+    kw4 = dict(view_dir=[0, 0, 1], light=lights4, light_intensity=[[0.25] * 3] * 4, light_type="point", light_size=1.0)
+    maps = F.pack_maps(*synth_material(2048, DEV, 31))
+    p = F.plan_cook_torrance(*maps, tile=2, **kw4)
+    report("tiled_multi: 2048^2 maps, tile(2) -> 4096^2, 4 point lights: repeat-inner kernel (8 planes of 2048^2 in once, 3 planes of 4096^2 out)",
+           "cook_torrance_repeat_kernel<1, 0, float, float, false, true, true>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
+    p = F.plan_cook_torrance(*maps, tile=2, tuning={"tile_repeat": 0}, **kw4)
+    report("tiled_multi_wrap: the same launch in the wrap-around form (what it took until round 4)",
+           "cook_torrance_kernel<1, 0, float, float, 4, true, false, false>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
+    del maps, p
 if want("tiled_bwd"):
     # round 5: gradients of tiled maps folded in registers (pbr_cook_torrance_backward_folded) and the loss step over tiled maps
     for dtype, tag in ((torch.float32, "f32"), (torch.float16, "f16")):

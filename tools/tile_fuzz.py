@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tile(n) fused -- the repeat-inner kernel (whole output, one light) and wrap-around addressing (PBR_TUNE_TILE_REPEAT = 0, row bands, several lights) -- on random shapes: the image equals the one evaluated on the materialised repeat bit for bit, for
-every fold band (PBR_TUNE_TILE_FOLD) and workgroup order, row bands included.  python tools/tile_fuzz.py [cases] [seed]"""
+every workgroup order, row bands included; gradients through the folded backward (one kernel, or backward + fold).  python tools/tile_fuzz.py [cases] [seed]"""
 import os
 import random
 import sys
@@ -32,14 +32,12 @@ def run(cases=60, seed=0, verbose=True):
             kw = dict(view_dir=[0.1, 0, 1], light=L if lights > 1 else L[0], light_intensity=[[1, 0.9, 0.8]] * lights if lights > 1 else [1, 0.9, 0.8],
                       light_type=rng.choice(["point", "directional"]), light_size=2.0)
             rep = lambda t: t.repeat(1, 1, ny, nx)
-            lib.pbr_set_tuning(N.TUNE_TILE_FOLD, 0)
             ref = F.cook_torrance(rep(a), rep(n), rep(r), rep(m), **kw)
-            fold = rng.choice([-1, 0, 1, 2, 3, 5, 8])
+            rng.choice([-1, 0, 1, 2, 3, 5, 8])                      # (the fold knob's draw of round 4: kept so that the cases stay the same)
             sched = rng.choice([N.SCHEDULE_AUTO, N.SCHEDULE_LINEAR, N.schedule_xcd(1), N.schedule_xcd(3), N.schedule_xcd(6)])
-            lib.pbr_set_tuning(N.TUNE_TILE_FOLD, fold)
             repeat = rng.choice([-1, -1, 0])
             lib.pbr_set_tuning(N.TUNE_TILE_REPEAT, repeat)
-            desc = f"case {i}: B={B} {h}x{w} tile=({ny},{nx}) {'f16' if half else 'f32'} lights={lights} fold={fold} schedule={sched} repeat={repeat}"
+            desc = f"case {i}: B={B} {h}x{w} tile=({ny},{nx}) {'f16' if half else 'f32'} lights={lights} schedule={sched} repeat={repeat}"
             out = F.cook_torrance(a, n, r, m, tile=(ny, nx), schedule=sched, **kw)
             if not torch.equal(out, ref):
                 raise AssertionError(desc + f": differs from the materialised repeat by {float((out.float() - ref.float()).abs().max()):.2e}")
@@ -67,7 +65,6 @@ def run(cases=60, seed=0, verbose=True):
             if verbose and i % 10 == 0:
                 print(desc + ": ok", flush=True)
     finally:
-        lib.pbr_set_tuning(N.TUNE_TILE_FOLD, -1)
         lib.pbr_set_tuning(N.TUNE_TILE_REPEAT, -1)
     if verbose:
         print(f"{cases} cases passed")

@@ -16,8 +16,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import synth_material  # noqa: E402
 from pypbr_amd import _native as N, functional as F  # noqa: E402
 
-KNOBS = {"nt": 0, "blk": 1, "f16vec": 2, "lds": 3, "xcd": 4, "bwdvec": 5, "nb": 6, "ilv": 7, "sb": 8, "maxvec": 9}
-DEFAULTS = {"nt": 1, "blk": 6, "lds": -1, "xcd": -1, "nb": -1, "ilv": 0, "sb": 1, "maxvec": 8}
+KNOBS = {"nt": 0, "blk": 1, "f16vec": 2, "lds": 3, "bwdvec": 4, "nb": 5, "sb": 6, "maxvec": 7}      # PBR_TUNE_* of ABI 7 (the workgroup order is the descriptor's `schedule`)
+DEFAULTS = {"nt": 1, "blk": 6, "lds": -1, "nb": -1, "sb": 1, "maxvec": 8}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)

@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of fused Cook-Torrance evaluation on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|4|5] [--size S] [--batch B] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4|5] [--size S] [--batch B] [--no-cpu-baseline]
                   [--layout arena|separate] [--settle L] [--cpu-budget SECONDS]
 
 `--config` selects the workload by SURVEY.md 8d's numbering (= BASELINE.json configs[config - 1]); a "step" is one pass of
 the hot path over this rank's batch = ONE launch of the fused kernel through the C ABI, inputs already resident in HBM:
+  1  BASELINE.json configs[0] on the GPU: ONE 256x256 material through CookTorranceBRDF.__call__ -- device-resident (eager, and captured
+     into a HIP graph) and CPU-resident (upload, evaluate, image back) -- with the host / launch / kernel split (`latency_us`) and the
+     CPU oracle's time for the same call beside it (run_config1);
   2 (default, the configuration the metric is quoted on)  one 4096x4096 BasecolorMetallicMaterial PER GPU (albedo sRGB,
      decoded normal, roughness, metallic; fp32 planar), point light, sRGB out.  WEAK scaling: every rank owns its own
      material;
@@ -372,10 +375,121 @@ def timed_region(plans, steps, stream, barrier, offset=0):
     return elapsed, ev0.elapsed_time(ev1) / steps
 
 
+def run_config1(args, real_stdout):
+    """BASELINE.json configs[0] on the GPU: ONE 256x256 BasecolorMetallicMaterial, point light, through the reference-shaped callable
+    `CookTorranceBRDF.__call__` (examples/example_brdf.py:14-23) -- where the cost is the host layer and the launch, not the kernel.
+    Legs (median of `--steps` repeats of 200 calls each): device-resident material, eager and captured into a HIP graph; CPU-resident
+    material (the reference's default: upload, evaluate, image back), eager; the bare plan launch; the kernel by HIP events; and the CPU
+    oracle's time for the same call on this host (34.4 ms on the survey's 8 cores)."""
+    import statistics
+    from pypbr_amd import functional as F
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    from pypbr_amd.models import CookTorranceBRDF
+    S = args.size or 256
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    view, light, inten = torch.tensor(VIEW), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0])
+    host_maps = synth_material(S, "cpu", 0)
+    brdf = CookTorranceBRDF(light_type="point")
+    on_dev = BasecolorMetallicMaterial(albedo=host_maps[0], roughness=host_maps[2], metallic=host_maps[3])
+    on_dev._raw["normal"] = host_maps[1]
+    on_dev.to(dev)
+    on_cpu = BasecolorMetallicMaterial(albedo=host_maps[0], roughness=host_maps[2], metallic=host_maps[3])
+    on_cpu._raw["normal"] = host_maps[1]
+    calls, reps = 200, max(3, args.steps or 7)
+
+    def per_call(fn, sync_each=False):
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
+        issue, drained = [], []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for _ in range(calls):
+                fn()
+                if sync_each:
+                    torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            issue.append((t1 - t0) / calls * 1e6)
+            drained.append((t2 - t0) / calls * 1e6)
+        return round(statistics.median(issue), 2), round(statistics.median(drained), 2)
+
+    eager_issue, eager = per_call(lambda: brdf(on_dev, view, light, inten, 1.0))
+    _, eager_sync = per_call(lambda: brdf(on_dev, view, light, inten, 1.0), sync_each=True)          # a caller that looks at every image
+    _, cpu_resident = per_call(lambda: brdf(on_cpu, view, light, inten, 1.0))                        # returns a host tensor: synchronous by nature
+    store = on_dev._raw
+    plan = F.plan_cook_torrance(store["albedo"], store["normal"], store["roughness"], store["metallic"], view_dir=VIEW, light=[0.1, 0.1, 1.0],
+                                light_intensity=[1.0, 1.0, 1.0], light_type="point", light_size=1.0)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    plan_issue, plan_drained = per_call(lambda: plan.launch(stream))
+    _, kernel_ms = timed_region([plan], 2000, stream, lambda: None)
+    # the same call captured into a HIP graph (a render loop over a fixed material: replay costs one graph launch)
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            brdf(on_dev, view, light, inten, 1.0)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured_out = brdf(on_dev, view, light, inten, 1.0)
+    graph_issue, graph_drained = per_call(graph.replay)
+    eager_out = brdf(on_dev, view, light, inten, 1.0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured_out, eager_out)
+    line = {
+        "metric": "Mpixels/s Cook-Torrance eval, BASELINE.json configs[0] (one 256x256 material through CookTorranceBRDF.__call__)",
+        "value": round(S * S / eager, 3), "unit": "Mpixels/s", "n_gpus": 1, "steps": reps, "warmup": 20,
+        "ms_per_step": round(eager * 1e-3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"Single {S}x{S} BasecolorMetallicMaterial, point light, CookTorranceBRDF.__call__ on a device-resident material, eager "
+                               "(BASELINE.json configs[0]; examples/example_brdf.py path)", "config": 1, "kernel": plan.kernel_name,
+                   "pixels_per_step": S * S, "bytes_per_pixel": plan.bytes_per_pixel, "lights": 1, "map_dtype": "f32",
+                   "timing": f"a step = one call; medians over {reps} repeats of {calls} back-to-back calls, GPU drained at the end of each repeat"},
+        "latency_us": {
+            "eager_device_resident": eager, "eager_device_resident_host_issue": eager_issue, "eager_device_resident_sync_every_call": eager_sync,
+            "graph_replay_device_resident": graph_drained, "graph_replay_host_issue": graph_issue,
+            "eager_cpu_resident_upload_evaluate_download": cpu_resident,
+            "plan_launch": plan_drained, "plan_launch_host_issue": plan_issue, "kernel_hip_events": round(kernel_ms * 1e3, 2),
+            "eager_over_graph": round(eager / graph_drained, 2),
+            "note": "host layer = eager - plan_launch; launch = plan_launch - kernel; the kernel itself is launch-latency-sized at 256^2"},
+        "roofline": {"bound": "hbm", "achieved": round(plan.bytes_per_pixel * S * S / (kernel_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(plan.bytes_per_pixel * S * S / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel_us": round(kernel_ms * 1e3, 2), "note": "2.9 MB per launch: 0.36 us at peak -- this configuration measures latency, not bandwidth"},
+    }
+    from pypbr_amd import _native
+    line["build"] = _native.build_stamp()
+    if not args.no_cpu_baseline:
+        _oracle_path()
+        import torch_oracle as O
+        a, n, r, m = host_maps
+        ref = O.cook_torrance(a, n, r, m, None, view=view, light=light, intensity=inten, light_type="point", light_size=1.0)
+        line["parity"] = {"max_abs_err_vs_reference_fp32": float((eager_out.cpu() - ref).abs().max()), "values": ref.numel(), "tolerance": 1e-5,
+                          "sample": "the whole image against oracle/torch_oracle.py (the reference's ATen ops)"}
+        table = []
+        saved = torch.get_num_threads()
+        for threads in sorted({1, usable_cores()}):
+            torch.set_num_threads(threads)
+            O.cook_torrance(a, n, r, m, None, view=view, light=light, intensity=inten, light_type="point", light_size=1.0)
+            t0 = time.perf_counter()
+            for _ in range(10):
+                O.cook_torrance(a, n, r, m, None, view=view, light=light, intensity=inten, light_type="point", light_size=1.0)
+            dt = (time.perf_counter() - t0) / 10
+            table.append({"size": S, "threads": threads, "ms": round(dt * 1e3, 2), "Mpixels_per_s": round(S * S / dt / 1e6, 3)})
+        torch.set_num_threads(saved)
+        best = max(table, key=lambda e: e["Mpixels_per_s"])
+        line["cpu_baseline"] = {"value": best["Mpixels_per_s"], "unit": "Mpixels/s", "cores": best["threads"], "usable_cores": usable_cores(),
+                                "host_cores": os.cpu_count() or 1, "kind": "port", "cpu_model": cpu_model(), "table": table,
+                                "sample": f"oracle/torch_oracle.py, the same {S}^2 call, 10 passes at 1 and {usable_cores()} threads (BASELINE.md 2: the reference itself 34.4 ms on the survey's 8 cores)"}
+    os.write(real_stdout, (json.dumps(line) + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="workload, SURVEY.md 8d numbering (BASELINE.json configs[config-1])")
+    ap.add_argument("--config", type=int, default=2, choices=[1] + sorted(CONFIGS), help="workload, SURVEY.md 8d numbering (BASELINE.json configs[config-1])")
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--size", type=int, default=None, help="override the configuration's map edge (tests)")
@@ -410,6 +524,12 @@ def main():
     # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer exchange between ranks fails with
     # `hipIpcGetMemHandle: invalid argument` (the image exports it; a launcher that builds its own environment may not)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.config == 1:
+        if args.gpus != 1:
+            raise SystemExit("--config 1 is the single-material latency case: one GPU")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm device; pypbr_amd has no CPU path")
+        return run_config1(args, real_stdout)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -254,6 +254,22 @@ def build_descriptor(albedo, normal, roughness, metallic, specular, out, *, view
     return d
 
 
+def refill_parameters(d, view_dir, light, light_intensity):
+    """Host values of view / light / intensity into an existing descriptor (same number of lights): what build_descriptor writes."""
+    v = _host_vec3(view_dir)
+    lights, intens = _host_vec3(light, rows=-1), _host_vec3(light_intensity, rows=-1)
+    if len(intens) == 1 and len(lights) > 1:
+        intens = intens * len(lights)
+    if len(lights) != len(intens) or len(lights) != d.n_lights:
+        raise ValueError("light [%d,3] and light_intensity [%d,3] disagree with the descriptor's %d lights" % (len(lights), len(intens), d.n_lights))
+    for c in range(3):
+        d.view_dir[c] = v[c]
+    for i, (l, it) in enumerate(zip(lights, intens)):
+        for c in range(3):
+            d.lights[i][c] = l[c]
+            d.intensities[i][c] = it[c]
+
+
 class RenderPlan:
     """A filled descriptor plus the tensors it points into: `launch()` is one C-ABI call
     (ctypes + hipLaunchKernel, a few microseconds), for callers that evaluate the same

@@ -542,6 +542,8 @@ class MaterialBase:
             self._bring_home_normal()
         new = copy.copy(self)
         new.__dict__.pop("_device_cache", None)
+        new.__dict__.pop("_plan_cache", None)
+        new.__dict__.pop("_plan_seen", None)
         new.__dict__["_lazy_blend"] = None
         object.__setattr__(new, "_maps", {k: (None if v is None else v.clone()) for k, v in self._raw.items()})
         return new

@@ -281,3 +281,67 @@ def test_repeat_inner_walk_serves_several_lights_bit_identically(workflow, light
     assert torch.equal(got, wrap.launch())
     full = F.cook_torrance(*[None if t is None else t.repeat(1, ny, nx) for t in maps], **kw)
     assert torch.equal(got.reshape(full.shape), full)
+
+
+# ---------------------------------------------------------------- plan reuse in CookTorranceBRDF.__call__
+def test_plan_reuse_is_invisible_except_for_its_speed():
+    """A device-resident material evaluated again reuses the filled descriptor of its last call (models.CookTorranceBRDF._reuse_plan).
+    Whatever changes between two calls must be seen: light / view values edited in place, maps edited in place, maps replaced, flags,
+    another light count; every result a fresh tensor; gradients never take the shortcut."""
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    from pypbr_amd.models import CookTorranceBRDF
+    maps = _maps(40, 64, seed=11)
+    mat = BasecolorMetallicMaterial(**maps)
+    brdf = CookTorranceBRDF("point")
+    view, light, inten = torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0])
+
+    def reference(**over):
+        CookTorranceBRDF.PLAN_REUSE = False
+        try:
+            return brdf(mat, over.get("view", view), over.get("light", light), over.get("inten", inten), over.get("size", 1.0), over.get("srgb", True)).clone()
+        finally:
+            CookTorranceBRDF.PLAN_REUSE = True
+    want = reference()
+    outs = [brdf(mat, view, light, inten, 1.0) for _ in range(4)]           # 1st: seen, 2nd: plan built, 3rd and 4th: reused
+    assert "_plan_cache" in mat.__dict__ and mat.__dict__["_plan_cache"][1].out is None
+    assert all(torch.equal(o, want) for o in outs) and len({o.data_ptr() for o in outs}) == 4
+    light[0] = -0.3                                                             # a CPU tensor edited in place
+    assert torch.equal(brdf(mat, view, light, inten, 1.0), reference())
+    lst = [0.2, 0.0, 1.0]
+    assert torch.equal(brdf(mat, lst, light, inten, 1.0), reference(view=lst))
+    lst[0] = -0.2                                                               # a Python list edited in place
+    assert torch.equal(brdf(mat, lst, light, inten, 1.0), reference(view=lst))
+    mat._raw["roughness"].mul_(0.5)                                             # a map edited in place: the kernel reads the memory as it is
+    assert torch.equal(brdf(mat, view, light, inten, 1.0), reference())
+    mat.roughness = torch.rand(1, 40, 64, generator=torch.Generator().manual_seed(1)).cuda() * 0.5 + 0.3        # a map replaced
+    assert torch.equal(brdf(mat, view, light, inten, 1.0), reference())
+    assert torch.equal(brdf(mat, view, light, inten, 1.0), reference())
+    assert torch.equal(brdf(mat, view, light, inten, 2.0), reference(size=2.0))                                   # another light size
+    assert torch.equal(brdf(mat, view, light, inten, 1.0, False), reference(srgb=False))
+    two = torch.tensor([[0.1, 0.1, 1.0], [-0.3, 0.2, 0.8]])
+    for _ in range(3):
+        assert torch.equal(brdf(mat, view, two, inten, 1.0), reference(light=two))
+    for _ in range(3):
+        assert torch.equal(brdf(mat, view, light, inten, 1.0), reference())
+    mat.to_linear()
+    for _ in range(3):
+        assert torch.equal(brdf(mat, view, light, inten, 1.0), reference())
+    tiled = BasecolorMetallicMaterial(**_maps(16, 32, seed=12)).tile(2)
+    ref_t = None
+    for _ in range(3):
+        got = brdf(tiled, view, light, inten, 1.0)
+        ref_t = got if ref_t is None else ref_t
+        assert got.shape == (3, 32, 64) and torch.equal(got, ref_t)
+    # gradients: the general path (autograd needs its graph)
+    leaf = mat._raw["albedo"].clone().requires_grad_(True)
+    mat.albedo = leaf
+    for _ in range(3):
+        out = brdf(mat, view, light, inten, 1.0)
+        assert out.requires_grad
+    out.sum().backward()
+    assert leaf.grad is not None and bool(torch.isfinite(leaf.grad).all())
+    # a clone does not share the plan
+    c = BasecolorMetallicMaterial(**maps)
+    for _ in range(3):
+        brdf(c, view, light, inten, 1.0)
+    assert "_plan_cache" not in c.clone().__dict__

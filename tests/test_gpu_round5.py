@@ -345,3 +345,42 @@ def test_plan_reuse_is_invisible_except_for_its_speed():
     for _ in range(3):
         brdf(c, view, light, inten, 1.0)
     assert "_plan_cache" not in c.clone().__dict__
+
+
+def test_host_overhead_of_the_eager_call_is_bounded_by_a_graph_replay():
+    """BASELINE configs[0] (one 256^2 material through CookTorranceBRDF.__call__): the eager call of a device-resident material costs at
+    most twice a HIP-graph replay of the same call (+ 5 us of slack for a noisy host); measured 13.3 against 9.8 us (bench.py --config 1)."""
+    import statistics
+    import time
+    from pypbr_amd.materials import BasecolorMetallicMaterial
+    from pypbr_amd.models import CookTorranceBRDF
+    mat = BasecolorMetallicMaterial(**_maps(256, 256, seed=1))
+    brdf = CookTorranceBRDF("point")
+    view, light, inten = torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]), torch.tensor([1.0, 1.0, 1.0])
+    call = lambda: brdf(mat, view, light, inten, 1.0)      # noqa: E731
+
+    def per_call(fn):
+        for _ in range(50):
+            fn()
+        torch.cuda.synchronize()
+        times = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            for _ in range(200):
+                fn()
+            torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / 200 * 1e6)
+        return statistics.median(times)
+    eager = per_call(call)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        call()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = call()
+    replay = per_call(graph.replay)
+    assert torch.equal(captured, call())
+    print(f"\n[256^2 call] eager {eager:.1f} us, graph replay {replay:.1f} us")
+    assert eager <= 2.0 * replay + 5.0, (eager, replay)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies files of a collection (gpurun_out/<tag>/, tools/collect_round4.sh) into profiles/ with the collection's stamp.json written
+"""Copies files of a collection (gpurun_out/<tag>/, tools/collect_round5.sh) into profiles/ with the collection's stamp.json written
 INTO each of them: JSON objects / lines get a "stamp" key (JSON arrays are wrapped: {"stamp": ..., "records": [...]} is avoided --
 consumers index them -- so a first element {"stamp": ...} is prepended), CSV and text files a leading `# stamp: {...}` line.
     python tools/stamp_profiles.py gpurun_out/r4x  bench.json=r04_bench_n1.json  trace/run_kernel_stats.csv=r04_kernel_stats.csv ..."""

@@ -578,6 +578,12 @@ __global__ __launch_bounds__(64) void resize_up2_kernel(const float *__restrict_
     const uint32_t band = wg / (uint32_t)groups_x, gx = wg - band * (uint32_t)groups_x;    // band = plane * groups_y + (y / kUpRows)
     const int plane = (int)(band / (uint32_t)groups_y), yb = (int)(band - (uint32_t)plane * (uint32_t)groups_y) * kUpRows;
     const int x0 = ((int)gx * 64 + (int)threadIdx.x) * 4;
+    // The rows' taps are wave-uniform (every lane of the workgroup works on rows yb .. yb + kUpRows - 1) but floating-point: the scalar unit
+    // cannot form them, and formed per lane they were ~30 vector instructions per row and lane (VALU busy 0.69 in a launch that should wait
+    // for its stores).  Lane r forms row r's taps ONCE; the others read them through v_readlane (same arithmetic, same bits) --
+    // formed before any lane leaves, so that the lanes read from are live.
+    int ty0; float tw0, tw1;
+    two_taps(fh, min(yb + (int)(threadIdx.x & (kUpRows - 1)), h_out - 1), ty0, tw0, tw1);
     if (x0 >= w_out) return;
     int first[4]; float wa[4], wb[4];
 #pragma unroll
@@ -593,8 +599,9 @@ __global__ __launch_bounds__(64) void resize_up2_kernel(const float *__restrict_
     for (int r = 0; r < kUpRows; ++r) {
         const int y = yb + r;
         if (y >= h_out) break;
-        int y0; float wy0, wy1;
-        two_taps(fh, y, y0, wy0, wy1);
+        const int y0 = __builtin_amdgcn_readlane(ty0, r);
+        const float wy0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tw0), r));
+        const float wy1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tw1), r));
         const int y1 = min(y0 + 1, h_in - 1);               // a one-tap window at the last row: weight 0 on a valid row
         const float *r0 = sp + (int64_t)y0 * w_in, *r1 = sp + (int64_t)y1 * w_in;
         const rf4 a4 = *reinterpret_cast<const rf4 *>(r0), b4 = *reinterpret_cast<const rf4 *>(r1);

@@ -183,9 +183,11 @@ Tensor cook_torrance(const Tensor &albedo, const OptTensor &normal, const Tensor
     return out;
 }
 
-// Gradients w.r.t. the maps (in the maps' storage type, OUTPUT-sized: folding over tile repeats / a batch-shared map is
-// pbr_hip::fold_gradient) and, when `want_params`, [3 + 6 L] floats: d/d view_dir | d/d lights | d/d intensities.
-// Unwanted gradients come back as empty (0-element) tensors.
+// Gradients w.r.t. the maps (in the maps' storage type) and, when `want_params`, [3 + 6 L] floats: d/d view_dir | d/d lights |
+// d/d intensities.  Unwanted gradients come back as empty (0-element) tensors.  Untiled maps: OUTPUT-sized (the sum over a batch that
+// shares a map is pbr_hip::fold_gradient).  TILED maps without light / view gradients and without batch-shared maps: MAP-sized, every
+// texel's sum over its repeats (pbr_cook_torrance_backward_folded: one kernel that walks the maps, or backward + fold through a workspace);
+// with light / view gradients or shared maps OUTPUT-sized as before (the autograd formula folds: pypbr_amd/torch_ops.py).
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> cook_torrance_backward(
     const Tensor &grad_out, const Tensor &albedo, const OptTensor &normal, const Tensor &roughness, const OptTensor &metallic,
     const OptTensor &specular, const Tensor &view_dir, const Tensor &lights, const Tensor &intensities, double light_size,
@@ -201,7 +203,12 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> cook_torrance_backwar
     p.d.out = const_cast<void *>(g.data_ptr());      // ignored by the backward entry points; must be non-NULL to validate
     p.d.out_dtype = PBR_F32;
     const auto opts = p.albedo.options();
-    auto buf = [&](bool want, int64_t c) { return want ? at::empty({p.B, c, p.H, p.W}, opts) : at::empty({0}, opts); };
+    const bool tiled = tile_y != 1 || tile_x != 1;
+    auto lone = [&](const OptTensor &t) { return t.has_value() && t->size(0) == 1 && p.B > 1; };
+    const bool shared = lone(OptTensor(p.albedo)) || lone(p.normal) || lone(OptTensor(p.roughness)) || lone(p.metallic) || lone(p.specular);
+    const bool folded = tiled && !want_params && !shared;
+    const int64_t gh = folded ? p.albedo.size(2) : p.H, gw = folded ? p.albedo.size(3) : p.W;
+    auto buf = [&](bool want, int64_t c) { return want ? at::empty({p.B, c, gh, gw}, opts) : at::empty({0}, opts); };
     Tensor ga = buf(want_albedo, 3), gn = buf(want_normal && p.normal.has_value(), 3), gr = buf(want_roughness, 1);
     Tensor gm = buf(want_metallic && p.d.workflow != PBR_WORKFLOW_SPECULAR, 1);
     Tensor gs = buf(want_specular && p.d.workflow == PBR_WORKFLOW_SPECULAR, 3);
@@ -214,6 +221,11 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> cook_torrance_backwar
         Tensor ws = at::empty({(int64_t)(pbr_param_grad_workspace_bytes(&p.d) / 4 + 1)}, opts.dtype(at::kFloat));
         check_status(pbr_cook_torrance_backward_params(&p.d, g.data_ptr(), ptr(ga), ptr(gn), ptr(gr), ptr(gm), ptr(gs), gp.data_ptr(),
                                                        ws.data_ptr(), stream), "pbr_hip::cook_torrance_backward");
+    } else if (folded) {
+        const size_t ws_bytes = pbr_backward_folded_workspace_bytes(&p.d);
+        Tensor ws = at::empty({(int64_t)ws_bytes}, opts.dtype(at::kByte));
+        check_status(pbr_cook_torrance_backward_folded(&p.d, g.data_ptr(), ptr(ga), ptr(gn), ptr(gr), ptr(gm), ptr(gs),
+                                                       ws_bytes ? ws.data_ptr() : nullptr, stream), "pbr_hip::cook_torrance_backward (folded)");
     } else {
         check_status(pbr_cook_torrance_backward(&p.d, g.data_ptr(), ptr(ga), ptr(gn), ptr(gr), ptr(gm), ptr(gs), stream),
                      "pbr_hip::cook_torrance_backward");

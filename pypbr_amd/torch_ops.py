@@ -67,6 +67,10 @@ def _register():
           albedo_is_srgb, specular_is_srgb, convert_to_diffuse_specular, return_srgb, y_offset, height_total, tile_y, tile_x, rows,
           want_albedo, want_normal, want_roughness, want_metallic, want_specular, want_params):
         B, H, W = _out_extent(albedo, tile_y, tile_x, y_offset, rows)
+        maps = [t for t in (albedo, normal, roughness, metallic, specular) if t is not None]
+        shared = B > 1 and any(t.shape[0] == 1 for t in maps)
+        if (tile_y, tile_x) != (1, 1) and not want_params and not shared:      # tiled maps: MAP-sized, folded over the repeats (torch_ops.cpp)
+            H, W = albedo.shape[-2:]
 
         def buf(want, c):
             return albedo.new_empty((B, c, H, W)) if want else albedo.new_empty((0,))
@@ -156,14 +160,17 @@ def _register():
             want_params)
         B, _, H, W = albedo.shape
         tiled = (tile_y, tile_x) != (1, 1)
-        if tiled and grad_out.shape[-2] != tile_y * H:
-            raise NotImplementedError("gradients of a tiled evaluation need the whole output, not a row band")
         grads = []
         for g, t, needed in zip((ga, gn, gr, gm, gs), tensors[:5], need[:5]):
             if not needed or t is None or g.numel() == 0:
                 grads.append(None)
                 continue
             shared = B > 1 and t.shape[0] == 1
+            if tiled and tuple(g.shape[-2:]) == (H, W) and not shared:         # already the map's: the operator folded over the repeats
+                grads.append(g)
+                continue
+            if tiled and grad_out.shape[-2] != tile_y * H:
+                raise NotImplementedError("gradients of a tiled evaluation with light / view gradients or batch-shared maps need the whole output, not a row band")
             if tiled or shared:        # a map repeated by the fused tile(), or shared by the batch, owns the SUM over its uses
                 g = torch.ops.pbr_hip.fold_gradient(g, H, W, shared)   # (fp16 gradients: summed in fp32, rounded once)
             grads.append(g)

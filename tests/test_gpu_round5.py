@@ -80,20 +80,24 @@ REPEAT_CASES = [
 ]
 
 
-def _tiled_grads(F, maps, kw, tile, gout, knob):
+def _tiled_grads(F, maps, kw, tile, gout, knob, binding="torch_op"):
     from pypbr_amd import _native as N
     leaves = [None if t is None else t.detach().clone().cuda().requires_grad_(True) for t in maps]
+    before = F.USE_TORCH_OPS
     try:
+        F.USE_TORCH_OPS = binding == "torch_op"          # the two bindings of the same C ABI: torch.ops.pbr_hip.* | ctypes
         N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, knob)
         out = F.cook_torrance(*leaves, tile=tile, **kw)
         (out * gout).sum().backward()
     finally:
         N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, -1)
+        F.USE_TORCH_OPS = before
     return out.detach(), [None if t is None else t.grad for t in leaves]
 
 
+@pytest.mark.parametrize("binding", ["torch_op", "ctypes"])
 @pytest.mark.parametrize("workflow,light_type,hw,tile,dtype,B", REPEAT_CASES)
-def test_repeat_inner_backward_equals_backward_plus_fold_and_float64_autograd(workflow, light_type, hw, tile, dtype, B):
+def test_repeat_inner_backward_equals_backward_plus_fold_and_float64_autograd(workflow, light_type, hw, tile, dtype, B, binding):
     """pbr_cook_torrance_backward_folded: ONE kernel walks the maps and accumulates every texel's gradient over its repeats in
     registers.  fp32 maps: bit-identical to pbr_cook_torrance_backward + pbr_fold_gradient (PBR_TUNE_TILE_REPEAT = 0 is that form);
     fp16 maps: the sum is rounded once instead of per repeat.  And against float64 autograd of the reference's ops through
@@ -110,9 +114,16 @@ def test_repeat_inner_backward_equals_backward_plus_fold_and_float64_autograd(wo
               convert_to_diffuse_specular=(workflow == "converted"))
     lead = () if B is None else (B,)
     gout = (torch.rand(*lead, 3, ny * h, nx * w, generator=g) - 0.3).cuda()
-    out1, one = _tiled_grads(F, maps, kw, tile, gout, -1)
-    out0, two = _tiled_grads(F, maps, kw, tile, gout, 0)
+    out1, one = _tiled_grads(F, maps, kw, tile, gout, -1, binding)
+    out0, two = _tiled_grads(F, maps, kw, tile, gout, 0, binding)
     assert torch.equal(out1, out0)
+    # the one-kernel form really is what ran: its launches need no workspace, the two-kernel form's do
+    import ctypes
+    from pypbr_amd import _native as N
+    plan = F.plan_cook_torrance(*[None if t is None else t.cuda() for t in maps], tile=tile, **kw)
+    assert N.lib().pbr_backward_folded_workspace_bytes(ctypes.byref(plan.desc)) == 0
+    wrap = F.plan_cook_torrance(*[None if t is None else t.cuda() for t in maps], tile=tile, tuning=dict(tile_repeat=0), **kw)      # (kept alive: the descriptor points into it)
+    assert N.lib().pbr_backward_folded_workspace_bytes(ctypes.byref(wrap.desc)) > 0
     for name, x, y in zip(("albedo", "normal", "roughness", "metallic", "specular"), one, two):
         if x is None:
             assert y is None

@@ -577,14 +577,16 @@ __global__ __launch_bounds__(64) void resize_up2_kernel(const float *__restrict_
     }
     const uint32_t band = wg / (uint32_t)groups_x, gx = wg - band * (uint32_t)groups_x;    // band = plane * groups_y + (y / kUpRows)
     const int plane = (int)(band / (uint32_t)groups_y), yb = (int)(band - (uint32_t)plane * (uint32_t)groups_y) * kUpRows;
-    const int x0 = ((int)gx * 64 + (int)threadIdx.x) * 4;
+    // Lanes past the row's end stay in the wave (they work on column 0 and store nothing): the rows' taps below are read ACROSS lanes,
+    // and a lane that has left has no defined values (the compiler is free to form them after the exit).
+    const int x_raw = ((int)gx * 64 + (int)threadIdx.x) * 4;
+    const bool live = x_raw < w_out;
+    const int x0 = live ? x_raw : 0;
     // The rows' taps are wave-uniform (every lane of the workgroup works on rows yb .. yb + kUpRows - 1) but floating-point: the scalar unit
     // cannot form them, and formed per lane they were ~30 vector instructions per row and lane (VALU busy 0.69 in a launch that should wait
-    // for its stores).  Lane r forms row r's taps ONCE; the others read them through v_readlane (same arithmetic, same bits) --
-    // formed before any lane leaves, so that the lanes read from are live.
+    // for its stores).  Lane r forms row r's taps ONCE; the others read them through v_readlane (same arithmetic, same bits).
     int ty0; float tw0, tw1;
     two_taps(fh, min(yb + (int)(threadIdx.x & (kUpRows - 1)), h_out - 1), ty0, tw0, tw1);
-    if (x0 >= w_out) return;
     int first[4]; float wa[4], wb[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) two_taps(fw, min(x0 + k, w_out - 1), first[k], wa[k], wb[k]);
@@ -618,6 +620,7 @@ __global__ __launch_bounds__(64) void resize_up2_kernel(const float *__restrict_
             out[k] = fmaf(wb[k], vb, wa[k] * va);
         }
         float *q = dp + (int64_t)y * w_out;
+        if (!live) continue;
         if (whole) {
             typedef float sf4 __attribute__((ext_vector_type(4), aligned(4)));
             const sf4 v = {out[0], out[1], out[2], out[3]};

@@ -111,8 +111,8 @@ def recorded_valu():
                 continue
             n = (r.get("sq") or {}).get("valu_wave_instructions")
             if n and str(r.get("case", "")).startswith("fwd_16_lights") and "batch_kernel" in r.get("kernel", ""):
-                return n * 64 / (4 * 4096 * 4096 * 16), "profiles/" + os.path.basename(path)
-    return None, None
+                return n * 64 / (4 * 4096 * 4096 * 16), "profiles/" + os.path.basename(path), (r.get("sq") or {}).get("shader_clock_GHz")
+    return None, None, None
 
 
 def synth_material(size, device, seed, dtype=torch.float32, rows=None):
@@ -770,12 +770,16 @@ def main():
                 line["roofline"]["kernel_over_box_pattern"] = round(per_rank_us[0] / (box_ms * 1e3), 4)
         if len(cfg["light"]) > 1:
             L = len(cfg["light"])
-            per_pl, valu_src = recorded_valu()
+            per_pl, valu_src, clock = recorded_valu()
             evals = per_rank_px[slow] * L / (kernel_all_ms * 1e-3) / 1e9
             ginstr = None if per_pl is None else per_pl * evals
             line["roofline_valu"] = {"bound": "valu", "achieved": None if ginstr is None else round(ginstr, 1), "peak": round(VALU_PEAK_GINSTR, 1),
                                      "unit": "G lane-instr/s", "frac": None if ginstr is None else round(ginstr / VALU_PEAK_GINSTR, 4),
                                      "light_evals_per_s_G": round(evals, 1),
+                                     # the chip does not hold 2.4 GHz under this launch (power-capped): against the clock the committed SQ
+                                     # pass measured DURING this kernel (GRBM_GUI_ACTIVE / time), the schedule is at this fraction of issue
+                                     "shader_clock_GHz_recorded": clock,
+                                     "frac_at_recorded_clock": None if (ginstr is None or not clock) else round(ginstr / (VALU_PEAK_GINSTR * clock / 2.4), 4),
                                      "basis": (f"{per_pl:.2f} vector instructions per (pixel, light) (rocprofv3 SQ_INSTS_VALU x 64 / (pixels x lights), {valu_src}) "
                                                if per_pl is not None else "no committed SQ pass for the 16-light kernel found under profiles/: ") +
                                               "against 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz; the launch is VALU-bound, its HBM "

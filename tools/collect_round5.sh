@@ -32,6 +32,8 @@ headline)
     ;;
 configs)
     cd /tmp
+    timeout 300 python3 "$R/bench.py" --config 1 > "$OUT/bench_c1.json" 2> "$OUT/bench_c1.err"
+    echo "config 1 done: $(head -c 300 "$OUT/bench_c1.json")"
     for c in 3 4 5; do
         timeout 300 python3 "$R/bench.py" --config $c > "$OUT/bench_c$c.json" 2> "$OUT/bench_c$c.err"
         timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_c$c" -o run -- \

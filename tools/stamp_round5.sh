@@ -11,7 +11,7 @@ python tools/pmc_to_json.py $G/$T r05_pmc_traffic.json > $G/$T/pmc_traffic.json
 python tools/stamp_profiles.py $G/$T bench.json=r05_bench_n1.json trace/run_kernel_stats.csv=r05_kernel_stats.csv pmc_traffic.json=r05_pmc_traffic.json configs.jsonl=r05_configs_1gpu.jsonl
 cp profiles/r05_pmc_traffic.json profiles/pmc_traffic.json
 python tools/configs_trace_summary.py $G/${T}_c > $G/${T}_c/configs_kernel_trace.json
-cat $G/${T}_c/bench_c3.json $G/${T}_c/bench_c4.json $G/${T}_c/bench_c5.json | grep '^{' > $G/${T}_c/bench_configs.jsonl
+cat $G/${T}_c/bench_c1.json $G/${T}_c/bench_c3.json $G/${T}_c/bench_c4.json $G/${T}_c/bench_c5.json | grep '^{' > $G/${T}_c/bench_configs.jsonl
 python tools/stamp_profiles.py $G/${T}_c bench_configs.jsonl=r05_bench_configs_1gpu.jsonl configs_kernel_trace.json=r05_configs_kernel_trace.json \
     trace_c3/run_kernel_stats.csv=r05_config3_kernel_stats.csv trace_c4/run_kernel_stats.csv=r05_config4_kernel_stats.csv trace_c5/run_kernel_stats.csv=r05_config5_kernel_stats.csv
 python tools/kernels_summary.py $G/${T}_k > $G/${T}_k/kernels.json

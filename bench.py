@@ -100,7 +100,8 @@ def recorded_valu():
     """(vector instructions per (pixel, light) of the 16-light batch-inner kernel, the committed file they come from): the newest
     profiles/rNN_kernels.json that holds the `fwd_16_lights` case (4 x 4096^2 fp16 maps, 16 point lights) with its SQ pass."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernels.json")), reverse=True):
+    found = glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernels.json")) + glob.glob(os.path.join(ROOT, "profiles", "history", "r[0-9][0-9]_kernels.json"))
+    for path in sorted(found, key=os.path.basename, reverse=True):
         try:
             with open(path) as f:
                 recs = json.load(f)
@@ -111,7 +112,7 @@ def recorded_valu():
                 continue
             n = (r.get("sq") or {}).get("valu_wave_instructions")
             if n and str(r.get("case", "")).startswith("fwd_16_lights") and "batch_kernel" in r.get("kernel", ""):
-                return n * 64 / (4 * 4096 * 4096 * 16), "profiles/" + os.path.basename(path), (r.get("sq") or {}).get("shader_clock_GHz")
+                return n * 64 / (4 * 4096 * 4096 * 16), os.path.relpath(path, ROOT), (r.get("sq") or {}).get("shader_clock_GHz")
     return None, None, None
 
 

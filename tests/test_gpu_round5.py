@@ -395,3 +395,39 @@ def test_host_overhead_of_the_eager_call_is_bounded_by_a_graph_replay():
     assert torch.equal(captured, call())
     print(f"\n[256^2 call] eager {eager:.1f} us, graph replay {replay:.1f} us")
     assert eager <= 2.0 * replay + 5.0, (eager, replay)
+
+
+@pytest.mark.parametrize("binding", ["torch_op", "ctypes"])
+@pytest.mark.parametrize("light_type,hw,tile,band", [("point", (16, 64), (3, 2), (5, 30)), ("point", (8, 32), (4, 1), (8, 16)),
+                                                     ("directional", (12, 48), (2, 2), (3, 20)), ("point", (16, 64), (3, 2), (20, 10))])
+def test_folded_gradients_of_a_row_band_of_a_tiled_image(binding, light_type, hw, tile, band):
+    """A row band of the tiled image (a multi-GPU shard, `y_offset` / `rows`): the folded gradient of a texel is the sum over its repeats
+    INSIDE the band (the ranks' partial sums add up to the whole).  Bands that hold a full period of the map's rows take the repeat-inner
+    kernel with its per-lane band test; thinner bands are refused by the one-kernel entry and go through backward + fold only as whole
+    outputs -- here: against autograd through the materialised repeat, cropped to the band."""
+    from pypbr_amd import functional as F
+    (h, w), (ny, nx), (y0, rows) = hw, tile, band
+    g = torch.Generator().manual_seed(7 * h + y0)
+    maps = [t.cuda() for t in _leaf_maps(g, h, w, "metallic")[:4]]
+    kw = dict(view_dir=[0.05, 0.1, 0.9], light=[0.1, 0.1, 1.0] if light_type == "point" else [0.3, -0.2, 1.0], light_intensity=[1.0, 0.9, 0.8],
+              light_type=light_type, light_size=1.5 if light_type == "point" else None)
+    gout = (torch.rand(3, rows, nx * w, generator=g) - 0.3).cuda()
+    ref_leaves = [t.clone().requires_grad_(True) for t in maps]
+    full = F.cook_torrance(*[t.repeat(1, ny, nx) for t in ref_leaves], **kw)
+    (full[:, y0:y0 + rows] * gout).sum().backward()
+    leaves = [t.clone().requires_grad_(True) for t in maps]
+    before = F.USE_TORCH_OPS
+    try:
+        F.USE_TORCH_OPS = binding == "torch_op"
+        if rows < h:
+            with pytest.raises(Exception):                       # thinner than one period of the map: not a folded-gradient launch
+                (F.cook_torrance(*leaves, tile=tile, y_offset=y0, rows=rows, **kw) * gout).sum().backward()
+            return
+        out = F.cook_torrance(*leaves, tile=tile, y_offset=y0, rows=rows, **kw)
+        assert torch.equal(out, full[:, y0:y0 + rows].detach())
+        (out * gout).sum().backward()
+    finally:
+        F.USE_TORCH_OPS = before
+    for name, x, y in zip(("albedo", "normal", "roughness", "metallic"), leaves, ref_leaves):
+        assert x.grad.shape == x.shape
+        assert (x.grad - y.grad).abs().max().item() <= 1e-5 * (float(y.grad.abs().max()) + 1e-12) + 1e-9, name

@@ -19,4 +19,3 @@ python tools/stamp_profiles.py $G/${T}_k kernels.json=r05_kernels.json cases.jso
 python tools/stamp_profiles.py $G/${T}_e examples.jsonl=r05_examples.jsonl copytrace_brdf/run_memory_copy_stats.csv=r05_example_brdf_memory_copy_stats.csv \
     copytrace_blend/run_memory_copy_stats.csv=r05_example_blend_memory_copy_stats.csv copytrace_brdf/run_kernel_stats.csv=r05_example_brdf_kernel_stats.csv \
     copytrace_blend/run_kernel_stats.csv=r05_example_blend_kernel_stats.csv
-python tools/stamp_profiles.py $G/${T}_ab ab_revisions.json=r05_ab_revisions_final.json

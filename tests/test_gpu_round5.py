@@ -431,3 +431,40 @@ def test_folded_gradients_of_a_row_band_of_a_tiled_image(binding, light_type, hw
     for name, x, y in zip(("albedo", "normal", "roughness", "metallic"), leaves, ref_leaves):
         assert x.grad.shape == x.shape
         assert (x.grad - y.grad).abs().max().item() <= 1e-5 * (float(y.grad.abs().max()) + 1e-12) + 1e-9, name
+
+
+def test_repeat_inner_backward_partial_requests_no_normal_and_strided_batches():
+    """Corners of the one-kernel folded backward: only some gradients wanted (the others are not written), a material without a normal
+    map (+Z, cooktorrance.py:147-152), a batch whose materials sit material-major in one arena (per-lane plane addresses), odd map
+    heights -- each against the two-kernel form bit for bit."""
+    from pypbr_amd import functional as F, _native as N
+    g = torch.Generator().manual_seed(21)
+    kw = dict(view_dir=[0.05, 0.1, 0.9], light=[0.1, 0.1, 1.0], light_intensity=[1.0, 0.9, 0.8], light_type="point", light_size=1.5)
+
+    def grads(maps, wanted, tile, knob, **extra):
+        leaves = [None if t is None else t.detach().clone().requires_grad_(w) for t, w in zip(maps, wanted)]
+        try:
+            N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, knob)
+            out = F.cook_torrance(*leaves, tile=tile, **dict(kw, **extra))
+            gout = torch.rand(out.shape, generator=torch.Generator().manual_seed(3)).cuda() - 0.3
+            (out * gout).sum().backward()
+        finally:
+            N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, -1)
+        return [None if t is None else t.grad for t in leaves]
+
+    def same(x, y):
+        return all((a is None and b is None) or (a is not None and b is not None and torch.equal(a, b)) for a, b in zip(x, y))
+    a, n, r, m, _ = [None if t is None else t.cuda() for t in _leaf_maps(g, 13, 40, "metallic")]
+    for wanted in ((True, False, False, False), (False, True, True, False), (False, False, False, True)):
+        one, two = grads((a, n, r, m), wanted, (2, 3), -1), grads((a, n, r, m), wanted, (2, 3), 0)
+        assert same(one, two) and [x is not None for x in one] == list(wanted), wanted
+    one, two = grads((a, None, r, m), (True, False, True, True), 2, -1), grads((a, None, r, m), (True, False, True, True), 2, 0)
+    assert same(one, two) and one[1] is None
+    B = 3
+    batched = [t.cuda() for t in _leaf_maps(g, 9, 24, "metallic", B=B)[:4]]
+    packed = F.pack_maps(*batched)                         # material-major: materials one pitch apart, no scalar plane addresses
+    assert packed[0].stride(0) != packed[0][0].numel()
+    one, two = grads(packed, (True,) * 4, (2, 2), -1), grads(packed, (True,) * 4, (2, 2), 0)
+    assert same(one, two) and one[0].shape == (B, 3, 9, 24)
+    lin = grads((a, n, r, m), (True,) * 4, 2, -1, albedo_is_srgb=False, return_srgb=False)
+    assert same(lin, grads((a, n, r, m), (True,) * 4, 2, 0, albedo_is_srgb=False, return_srgb=False))

@@ -11,9 +11,11 @@
 // accumulators in the order pbr_fold_gradient adds them (repeat rows outer, repeat columns inner).  Map-sized gradients are
 // written once: 12 B per output pixel + 64 B per texel instead of 76 + 32 (fold reads) + 32/n^2 per output pixel.
 //
-// Same functions, same statements per position as backward_body_to: for fp32 maps the result is BIT-IDENTICAL to
+// Same functions, same statements per position as backward_body_to: for fp32 maps under a POINT light the result is BIT-IDENTICAL to
 // pbr_cook_torrance_backward + pbr_fold_gradient (tests/test_gpu_round5.py); for fp16 maps the per-position gradients are summed
-// unrounded in fp32 and rounded once (the two-kernel form rounds every position's gradient to fp16 first).
+// unrounded in fp32 and rounded once (the two-kernel form rounds every position's gradient to fp16 first).  Under a DIRECTIONAL light
+// every repeat evaluates to the same colour and the chain rule is linear in the upstream gradient: the repeats' upstream values are
+// summed first and the texel is differentiated once (equal to the two-kernel form to fp32 rounding, not to the bit).
 //
 // With the MseLoss policy the upstream gradient is formed in the kernel from the target image (the rendering-loss step for tiled
 // maps: pbr_cook_torrance_mse_step lifts its "untiled" restriction through this kernel).
@@ -161,41 +163,43 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
     for (int c = 0; c < 3; ++c) { acc_a[c] = splat<R>(0.0f); acc_n[c] = splat<R>(0.0f); acc_s[c] = splat<R>(0.0f); }
     float sq = 0.0f;
 
-    for (int k = 0; k < n_pos; ++k) {
-        if (k + 1 < n_pos) load_upstream(k + 1, go_next);                       // the next position's 12 B per pixel travel under this one's arithmetic
-        const int ry = k / a.rep_x, rx = k - ry * a.rep_x;
-        if (!in_band(ry)) {                                                     // a repeat outside this rank's band: nothing to add
+    if constexpr (LIGHT == PBR_LIGHT_DIRECTIONAL) {
+        // A directional light does not know where the pixel is (:125-127): every repeat of a texel evaluates to the SAME colour, and the
+        // chain rule is linear in the upstream gradient -- so the repeats' upstream values are summed first (three adds per position) and
+        // the texel is differentiated ONCE: n^2 fewer evaluations, and the kernel is bound by its bytes (12 B per output pixel) instead of
+        // by instruction issue.  Exact in real arithmetic; in fp32 the sum of the per-position gradients (the two-kernel form) and the
+        // gradient of the summed upstream differ by rounding (~1e-7 relative), so THIS branch is not bit-identical to backward + fold.
+        const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, splat<R>(0.0f), 0.0f);
+        LightEvalT<R> e;
+        eval_light(x.pt, lg, lu.inten, e);
+        R out[3], gsum[3] = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c] = a.out_srgb ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180 (the loss compares this)
+        for (int k = 0; k < n_pos; ++k) {
+            if (k + 1 < n_pos) load_upstream(k + 1, go_next);
+            if (in_band(k / a.rep_x)) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if constexpr (LOSS) {
+                        const R d = out[c] - gather<R>(go[c], 0);
+                        if (p.valid) sq += hsum(d * d);
+                        gsum[c] = gsum[c] + d;
+                    } else {
+                        gsum[c] = gsum[c] + gather<R>(go[c], 0);
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
-            continue;
         }
-        float ys = 0.0f;
-        R xs[1] = {splat<R>(0.0f)};
-        if (LIGHT == PBR_LIGHT_POINT) {
-            ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, p.y + ry * a.H);
-            x_grid_w<R, 1, VEC>(a, a.out_W, p.x + rx * a.W, xs);
+        R g_col[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const R gc = LOSS ? gsum[c] * rb.scale : gsum[c];
+            g_col[c] = a.out_srgb ? gc * linear_to_srgb_grad_unit(e.uc[c]) : gc;
         }
-        const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[0], ys);
-        LightEvalT<R> e;
-        eval_light(x.pt, lg, lu.inten, e);
-        R gout_c[3], g_col[3];
-        if constexpr (LOSS) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const R out = a.out_srgb ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180
-                const R d = out - gather<R>(go[c], 0);
-                if (p.valid) sq += hsum(d * d);
-                gout_c[c] = d * rb.scale;
-            }
-        } else {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], 0);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-            g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
         PixelAdjointT<R> adj;
 #pragma unroll
         for (int c = 0; c < 3; ++c) { adj.g_kb[c] = splat<R>(0.0f); adj.g_f0[c] = splat<R>(0.0f); }
@@ -203,22 +207,67 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
         adj.g_n = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
         LightParamAdjT<R> pa;
         backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
-        R ga[3], gn[3], gs[3], gr, gm;
-        bwd_tail<WF, R>(x, adj, V, ga, gn, gr, gm, gs);
-        // one statement per sum: the position's gradient is a rounded value BEFORE it is added (no fused multiply-add across the
-        // two), which is what makes the sum equal pbr_fold_gradient's over the stored per-position gradients
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            acc_a[c] = acc_a[c] + ga[c];
-            acc_n[c] = acc_n[c] + gn[c];
-            acc_s[c] = acc_s[c] + gs[c];
+        bwd_tail<WF, R>(x, adj, V, acc_a, acc_n, acc_r, acc_m, acc_s);
+    } else {
+        for (int k = 0; k < n_pos; ++k) {
+            if (k + 1 < n_pos) load_upstream(k + 1, go_next);                       // the next position's 12 B per pixel travel under this one's arithmetic
+            const int ry = k / a.rep_x, rx = k - ry * a.rep_x;
+            if (!in_band(ry)) {                                                     // a repeat outside this rank's band: nothing to add
+    #pragma unroll
+                for (int c = 0; c < 3; ++c)
+    #pragma unroll
+                    for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
+                continue;
+            }
+            float ys = 0.0f;
+            R xs[1] = {splat<R>(0.0f)};
+            if (LIGHT == PBR_LIGHT_POINT) {
+                ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, p.y + ry * a.H);
+                x_grid_w<R, 1, VEC>(a, a.out_W, p.x + rx * a.W, xs);
+            }
+            const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[0], ys);
+            LightEvalT<R> e;
+            eval_light(x.pt, lg, lu.inten, e);
+            R gout_c[3], g_col[3];
+            if constexpr (LOSS) {
+    #pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const R out = a.out_srgb ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180
+                    const R d = out - gather<R>(go[c], 0);
+                    if (p.valid) sq += hsum(d * d);
+                    gout_c[c] = d * rb.scale;
+                }
+            } else {
+    #pragma unroll
+                for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], 0);
+            }
+    #pragma unroll
+            for (int c = 0; c < 3; ++c)
+                g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
+            PixelAdjointT<R> adj;
+    #pragma unroll
+            for (int c = 0; c < 3; ++c) { adj.g_kb[c] = splat<R>(0.0f); adj.g_f0[c] = splat<R>(0.0f); }
+            adj.g_a2 = adj.g_k = adj.g_ndv = splat<R>(0.0f);
+            adj.g_n = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
+            LightParamAdjT<R> pa;
+            backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
+            R ga[3], gn[3], gs[3], gr, gm;
+            bwd_tail<WF, R>(x, adj, V, ga, gn, gr, gm, gs);
+            // one statement per sum: the position's gradient is a rounded value BEFORE it is added (no fused multiply-add across the
+            // two), which is what makes the sum equal pbr_fold_gradient's over the stored per-position gradients
+    #pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                acc_a[c] = acc_a[c] + ga[c];
+                acc_n[c] = acc_n[c] + gn[c];
+                acc_s[c] = acc_s[c] + gs[c];
+            }
+            acc_r = acc_r + gr;
+            acc_m = acc_m + gm;
+    #pragma unroll
+            for (int c = 0; c < 3; ++c)
+    #pragma unroll
+                for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
         }
-        acc_r = acc_r + gr;
-        acc_m = acc_m + gm;
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
     }
     if constexpr (LOSS) {
         const float total = wave_sum(sq);

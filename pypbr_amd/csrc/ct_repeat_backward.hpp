@@ -147,7 +147,7 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
         }
     };
     float go[3][VEC] = {}, go_next[3][VEC] = {};
-    load_upstream(0, go);
+    if (LIGHT == PBR_LIGHT_POINT) load_upstream(0, go);
 
     if (!a.has_normal) {
 #pragma unroll
@@ -175,24 +175,28 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
         R out[3], gsum[3] = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
 #pragma unroll
         for (int c = 0; c < 3; ++c) out[c] = a.out_srgb ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180 (the loss compares this)
-        for (int k = 0; k < n_pos; ++k) {
-            if (k + 1 < n_pos) load_upstream(k + 1, go_next);
-            if (in_band(k / a.rep_x)) {
+        // the positions' loads do not depend on one another: four positions' worth (12 loads) in flight before the first add
+        constexpr int kChunk = 4;
+        for (int k0 = 0; k0 < n_pos; k0 += kChunk) {
+            float gq[kChunk][3][VEC] = {};
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if constexpr (LOSS) {
-                        const R d = out[c] - gather<R>(go[c], 0);
-                        if (p.valid) sq += hsum(d * d);
-                        gsum[c] = gsum[c] + d;
-                    } else {
-                        gsum[c] = gsum[c] + gather<R>(go[c], 0);
+            for (int q = 0; q < kChunk; ++q)
+                if (k0 + q < n_pos) load_upstream(k0 + q, gq[q]);
+#pragma unroll
+            for (int q = 0; q < kChunk; ++q) {
+                if (k0 + q < n_pos && in_band((k0 + q) / a.rep_x)) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        if constexpr (LOSS) {
+                            const R d = out[c] - gather<R>(gq[q][c], 0);
+                            if (p.valid) sq += hsum(d * d);
+                            gsum[c] = gsum[c] + d;
+                        } else {
+                            gsum[c] = gsum[c] + gather<R>(gq[q][c], 0);
+                        }
                     }
                 }
             }
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
         }
         R g_col[3];
 #pragma unroll

@@ -465,7 +465,7 @@ def test_repeat_inner_backward_partial_requests_no_normal_and_strided_batches():
     assert same(one, two) and one[1] is None
     B = 3
     batched = [t.cuda() for t in _leaf_maps(g, 9, 24, "metallic", B=B)[:4]]
-    packed = F.pack_maps(*batched)                         # material-major: materials one pitch apart, no scalar plane addresses
+    packed = F.pack_maps(*batched, material_major=True)    # material-major: materials one pitch apart, no scalar plane addresses
     assert packed[0].stride(0) != packed[0][0].numel()
     one, two = grads(packed, (True,) * 4, (2, 2), -1), grads(packed, (True,) * 4, (2, 2), 0)
     assert same(one, two) and one[0].shape == (B, 3, 9, 24)

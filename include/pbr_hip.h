@@ -234,11 +234,13 @@ int pbr_cook_torrance_backward(const pbr_render_desc *desc, const void *grad_out
  * but every non-NULL g_* is shaped like its MAP -- [B][3|1][map_height][map_width], contiguous, the maps' storage type -- and receives
  * the sum over the map's repeats inside the output the descriptor describes (the whole tiled image, or a row band of it that holds
  * at least one full period of the map's rows: a multi-GPU shard, whose partial sums the caller adds up across ranks).
- * One light, map rows a whole number of 4-texel groups: ONE kernel walks the maps, re-evaluates each texel's light-independent terms
- * once, visits its repeats and accumulates in registers (12 B per output pixel + 64 B per texel); `workspace` may be NULL.  Other
- * launches (several lights, ragged map widths) run pbr_cook_torrance_backward into `workspace`
+ * Map rows a whole number of 4-texel groups (one or several lights): ONE kernel walks the maps, re-evaluates each texel's
+ * light-independent terms once, visits its repeats and accumulates in registers (12 B per output pixel + 64 B per texel; under ONE
+ * directional light, whose repeats all evaluate alike, the upstream values are summed first and the texel is differentiated once);
+ * `workspace` may be NULL.  Other launches (ragged map widths) run pbr_cook_torrance_backward into `workspace`
  * (pbr_backward_folded_workspace_bytes(desc) bytes of device memory, 0 when the one-kernel form serves the descriptor) followed by
- * pbr_fold_gradient_typed per map: same values for fp32 maps bit for bit; fp16 gradients are rounded once instead of per repeat.
+ * pbr_fold_gradient_typed per map: same values for fp32 maps bit for bit (one directional light: to fp32 rounding); fp16 gradients are
+ * rounded once instead of per repeat.
  * Untiled descriptors are passed on to pbr_cook_torrance_backward.
  */
 size_t pbr_backward_folded_workspace_bytes(const pbr_render_desc *desc);

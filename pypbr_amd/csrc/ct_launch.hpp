@@ -252,6 +252,7 @@ KernelFn pick_repeat_kernel(const pbr_render_desc *d, int nt_knob);            /
 void fill_repeat_args(const pbr_render_desc *d, KArgs &k);
 // ct_repeat_backward.hip: gradients of TILED maps folded in registers (and, with `loss`, the rendering-loss step over tiled maps)
 bool repeat_backward_serves(const pbr_render_desc *d);
+bool repeat_loss_serves(const pbr_render_desc *d);
 int64_t repeat_backward_tiles(const pbr_render_desc *d);
 int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void *g_albedo, void *g_normal, void *g_roughness, void *g_metallic,
                            void *g_specular, bool loss, float scale, float *partials, hipStream_t st);

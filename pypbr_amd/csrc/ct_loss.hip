@@ -190,7 +190,7 @@ extern "C" {
 size_t pbr_mse_step_workspace_bytes(const pbr_render_desc *d) {
     const pbr::TuningScope tuning(d);
     if (pbr::validate(d) != PBR_OK) return 0;
-    if (pbr::is_tiled(d) && !pbr::repeat_backward_serves(d)) return 0;
+    if (pbr::is_tiled(d) && !pbr::repeat_loss_serves(d)) return 0;
     // tiled maps: one partial sum per workgroup of the repeat-inner kernel; else one pixel per lane: the most workgroups any launch of this descriptor has
     const int64_t tiles = pbr::is_tiled(d) ? pbr::repeat_backward_tiles(d) : pbr::mse_tiles(d, 1);
     return tiles < 0 ? 0 : pbr::mse_stage_offset((size_t)tiles) + (size_t)pbr::kMseStageGroups * sizeof(double);
@@ -212,7 +212,7 @@ int pbr_cook_torrance_mse_step(const pbr_render_desc *d, const void *target, voi
     if (is_tiled(d)) {
         // MaterialBase.tile fused (base.py:524-537): the repeat-inner kernel walks the maps, compares every repeat with the target and leaves
         // MAP-sized gradients (ct_repeat_backward.hpp); launches it does not serve are the caller's to split (render, loss, folded backward)
-        if (!repeat_backward_serves(d)) return PBR_ERR_UNSUPPORTED;
+        if (!repeat_loss_serves(d)) return PBR_ERR_UNSUPPORTED;
         const int64_t tiles = repeat_backward_tiles(d);
         if (tiles < 0) return PBR_ERR_SHAPE;
         const int e = launch_repeat_backward(d, target, g_albedo, g_normal, g_roughness, g_metallic, g_specular, true, (float)(2.0 / count),

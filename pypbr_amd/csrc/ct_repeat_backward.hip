@@ -9,29 +9,32 @@ namespace pbr {
 using RepBwdFn = void (*)(const KArgs, const BArgs, const RBArgs);
 
 template <int L, int W>
-static RepBwdFn repeat_bwd_types(bool half_maps, bool loss) {
+static RepBwdFn repeat_bwd_types(bool half_maps, bool loss, bool multi) {
+    if (multi) return half_maps ? cook_torrance_repeat_backward_kernel<L, W, __half, false, true> : cook_torrance_repeat_backward_kernel<L, W, float, false, true>;
     if (half_maps) return loss ? cook_torrance_repeat_backward_kernel<L, W, __half, true> : cook_torrance_repeat_backward_kernel<L, W, __half, false>;
     return loss ? cook_torrance_repeat_backward_kernel<L, W, float, true> : cook_torrance_repeat_backward_kernel<L, W, float, false>;
 }
 
 static RepBwdFn pick_repeat_bwd(const pbr_render_desc *d, bool loss) {
-    const bool point = d->light_type == PBR_LIGHT_POINT, half_maps = d->map_dtype == PBR_F16;
+    const bool point = d->light_type == PBR_LIGHT_POINT, half_maps = d->map_dtype == PBR_F16, multi = d->n_lights > 1;
     switch ((point ? 3 : 0) + d->workflow) {
-        case 0: return repeat_bwd_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(half_maps, loss);
-        case 1: return repeat_bwd_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(half_maps, loss);
-        case 2: return repeat_bwd_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(half_maps, loss);
-        case 3: return repeat_bwd_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(half_maps, loss);
-        case 4: return repeat_bwd_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(half_maps, loss);
-        default: return repeat_bwd_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(half_maps, loss);
+        case 0: return repeat_bwd_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(half_maps, loss, multi);
+        case 1: return repeat_bwd_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(half_maps, loss, multi);
+        case 2: return repeat_bwd_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(half_maps, loss, multi);
+        case 3: return repeat_bwd_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(half_maps, loss, multi);
+        case 4: return repeat_bwd_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(half_maps, loss, multi);
+        default: return repeat_bwd_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(half_maps, loss, multi);
     }
 }
 
-// The launches the repeat-inner backward serves: what the forward's repeat-inner kernel serves (one light, map rows a whole number of
+// The launches the repeat-inner backward serves: what the forward's repeat-inner kernel serves (map rows a whole number of
 // 4-texel lanes, an output band that holds a full period of the map's rows) with planes small enough for its 32-bit lane offsets
 // when it addresses them through a scalar base.  fp32 result / upstream gradient only (as every backward entry).
 bool repeat_backward_serves(const pbr_render_desc *d) {
-    return repeat_inner(d) && d->n_lights == 1 && d->out_dtype == PBR_F32 && g_max_vec >= 2;
+    return repeat_inner(d) && d->out_dtype == PBR_F32 && g_max_vec >= 2;
 }
+// ... and the rendering-loss step through it: one light (the two passes over several lights are built for the gradient only)
+bool repeat_loss_serves(const pbr_render_desc *d) { return repeat_backward_serves(d) && d->n_lights == 1; }
 
 // Workgroups of the launch for this descriptor (one partial sum each under the loss policy), -1 when it does not fit a 1-D grid.
 int64_t repeat_backward_tiles(const pbr_render_desc *d) {

@@ -114,9 +114,12 @@ struct RBArgs {
 //   LIGHT / WF: as everywhere.  TM: storage type of the maps and of their gradients.  LOSS: the rendering-loss step.
 // KArgs as fill_repeat_args leaves them (the grid of an untiled launch over the source maps; rep_y / rep_x / out_W / out_Ht /
 // y_offset / H_total describe the output) with o_cs = the MAP's plane (the gradient planes are dense [B][C][map_h * map_w]).
-template <int LIGHT, int WF, typename TM, bool LOSS>
+//   MULTI: several lights (H12: per-light clamp, sum, clamp, encode) -- per position the two passes over the lights of backward_body_to (the
+//   summed colour decides the outer clamp and the encode's slope; then every light's chain rule into one adjoint); no loss policy.
+template <int LIGHT, int WF, typename TM, bool LOSS, bool MULTI = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
 void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RBArgs rb) {
+    static_assert(!(MULTI && LOSS), "the loss step over tiled maps is built for one light");
     constexpr int VEC = 2;
     using R = f32x2;
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
@@ -163,7 +166,7 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
     for (int c = 0; c < 3; ++c) { acc_a[c] = splat<R>(0.0f); acc_n[c] = splat<R>(0.0f); acc_s[c] = splat<R>(0.0f); }
     float sq = 0.0f;
 
-    if constexpr (LIGHT == PBR_LIGHT_DIRECTIONAL) {
+    if constexpr (LIGHT == PBR_LIGHT_DIRECTIONAL && !MULTI) {
         // A directional light does not know where the pixel is (:125-127): every repeat of a texel evaluates to the SAME colour, and the
         // chain rule is linear in the upstream gradient -- so the repeats' upstream values are summed first (three adds per position) and
         // the texel is differentiated ONCE: n^2 fewer evaluations, and the kernel is bound by its bytes (12 B per output pixel) instead of
@@ -229,32 +232,56 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
                 ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, p.y + ry * a.H);
                 x_grid_w<R, 1, VEC>(a, a.out_W, p.x + rx * a.W, xs);
             }
-            const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[0], ys);
-            LightEvalT<R> e;
-            eval_light(x.pt, lg, lu.inten, e);
-            R gout_c[3], g_col[3];
-            if constexpr (LOSS) {
-    #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const R out = a.out_srgb ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180
-                    const R d = out - gather<R>(go[c], 0);
-                    if (p.valid) sq += hsum(d * d);
-                    gout_c[c] = d * rb.scale;
-                }
-            } else {
-    #pragma unroll
-                for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], 0);
-            }
-    #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
             PixelAdjointT<R> adj;
     #pragma unroll
             for (int c = 0; c < 3; ++c) { adj.g_kb[c] = splat<R>(0.0f); adj.g_f0[c] = splat<R>(0.0f); }
             adj.g_a2 = adj.g_k = adj.g_ndv = splat<R>(0.0f);
             adj.g_n = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
-            LightParamAdjT<R> pa;
-            backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
+            if constexpr (MULTI) {
+                R g_col[3], sum[3] = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
+                for (int l = 0; l < a.n_lights; ++l) {          // pass 1: the summed colour decides the outer clamp / the encode's slope
+                    const LightU ll = light_of(a, l);
+                    LightEvalT<R> e;
+                    eval_light(x.pt, light_geom<LIGHT, R>(ll, V, xs[0], ys), ll.inten, e);
+    #pragma unroll
+                    for (int c = 0; c < 3; ++c) sum[c] = sum[c] + e.uc[c];
+                }
+    #pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const R slope = a.out_srgb ? linear_to_srgb_grad_unit(clamp01(sum[c])) : splat<R>(1.0f);
+                    g_col[c] = masked(in_unit(sum[c]), gather<R>(go[c], 0) * slope);
+                }
+                for (int l = 0; l < a.n_lights; ++l) {          // pass 2: every light's chain rule into the one adjoint
+                    const LightU ll = light_of(a, l);
+                    const LightGeomT<R> lg = light_geom<LIGHT, R>(ll, V, xs[0], ys);
+                    LightEvalT<R> e;
+                    eval_light(x.pt, lg, ll.inten, e);
+                    LightParamAdjT<R> pa;
+                    backprop_light<LIGHT, false>(x.pt, lg, ll.inten, e, g_col, adj, V, pa);
+                }
+            } else {
+                const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[0], ys);
+                LightEvalT<R> e;
+                eval_light(x.pt, lg, lu.inten, e);
+                R gout_c[3], g_col[3];
+                if constexpr (LOSS) {
+        #pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const R out = a.out_srgb ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180
+                        const R d = out - gather<R>(go[c], 0);
+                        if (p.valid) sq += hsum(d * d);
+                        gout_c[c] = d * rb.scale;
+                    }
+                } else {
+        #pragma unroll
+                    for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], 0);
+                }
+        #pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
+                LightParamAdjT<R> pa;
+                backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
+            }
             R ga[3], gn[3], gs[3], gr, gm;
             bwd_tail<WF, R>(x, adj, V, ga, gn, gr, gm, gs);
             // one statement per sum: the position's gradient is a rounded value BEFORE it is added (no fused multiply-add across the

@@ -159,14 +159,14 @@ def test_repeat_inner_backward_equals_backward_plus_fold_and_float64_autograd(wo
 
 
 def test_repeat_inner_backward_dispatch_and_fallbacks():
-    """Which launches the one-kernel form serves is the library's decision (pbr_backward_folded_workspace_bytes == 0): one light and map
-    rows of whole 4-texel groups.  Several lights and ragged map widths go through the workspace -- same gradients as autograd of the
+    """Which launches the one-kernel form serves is the library's decision (pbr_backward_folded_workspace_bytes == 0): map rows of whole
+    4-texel groups, one or several lights.  Ragged map widths go through the workspace -- same gradients as autograd of the
     materialised repeat."""
     from pypbr_amd import functional as F, _native as N
     import ctypes
     g = torch.Generator().manual_seed(9)
     lib = N.lib()
-    for (h, w), lights, served in (((8, 32), 1, True), ((8, 30), 1, False), ((8, 32), 2, False)):
+    for (h, w), lights, served in (((8, 32), 1, True), ((8, 30), 1, False), ((8, 32), 2, True), ((8, 30), 2, False)):
         a, n, r, m, _ = [None if t is None else t.cuda() for t in _leaf_maps(g, h, w, "metallic")]
         L = [[0.1, 0.1, 1.0], [-0.3, 0.2, 0.8]][:lights]
         I = [[1.0, 0.9, 0.8], [0.5, 0.5, 0.5]][:lights]
@@ -471,3 +471,45 @@ def test_repeat_inner_backward_partial_requests_no_normal_and_strided_batches():
     assert same(one, two) and one[0].shape == (B, 3, 9, 24)
     lin = grads((a, n, r, m), (True,) * 4, 2, -1, albedo_is_srgb=False, return_srgb=False)
     assert same(lin, grads((a, n, r, m), (True,) * 4, 2, 0, albedo_is_srgb=False, return_srgb=False))
+
+
+@pytest.mark.parametrize("binding", ["torch_op", "ctypes"])
+@pytest.mark.parametrize("workflow,light_type,hw,tile,dtype", [("metallic", "point", (12, 48), (2, 2), torch.float32),
+                                                             ("specular", "directional", (9, 40), (3, 2), torch.float32),
+                                                             ("converted", "point", (8, 64), (2, 3), torch.float16)])
+def test_repeat_inner_backward_with_several_lights(binding, workflow, light_type, hw, tile, dtype):
+    """Several lights over tiled maps: the one-kernel folded backward runs backward_body_to's two passes over the lights per position
+    (the summed colour decides the outer clamp and the encode's slope, then every light's chain rule): fp32 bit-identical to the
+    wrap-around backward + fold, and against float64 autograd of the reference's ops through repeat()."""
+    from pypbr_amd import functional as F
+    (h, w), (ny, nx) = hw, tile
+    g = torch.Generator().manual_seed(17 * h + w)
+    maps = _leaf_maps(g, h, w, workflow, dtype)
+    view = torch.tensor([0.05, 0.1, 0.9])
+    L = torch.tensor([[0.1, 0.1, 1.0], [-0.4, 0.2, 0.7], [0.3, -0.3, 0.9]])
+    I = torch.tensor([[1.0, 0.9, 0.8], [0.4, 0.5, 0.6], [0.3, 0.3, 0.3]])
+    size = 1.5 if light_type == "point" else None
+    kw = dict(view_dir=view, light=L, light_intensity=I, light_type=light_type, light_size=size, convert_to_diffuse_specular=(workflow == "converted"))
+    gout = (torch.rand(3, ny * h, nx * w, generator=g) - 0.3).cuda()
+    out1, one = _tiled_grads(F, maps, kw, tile, gout, -1, binding)
+    out0, two = _tiled_grads(F, maps, kw, tile, gout, 0, binding)
+    assert torch.equal(out1, out0)
+    for name, x, y in zip(("albedo", "normal", "roughness", "metallic", "specular"), one, two):
+        if x is None:
+            continue
+        if dtype == torch.float32:
+            assert torch.equal(x, y), (name, float((x - y).abs().max()))
+        else:
+            assert (x.float() - y.float()).abs().max().item() <= 2e-3 * (float(y.float().abs().max()) + 1e-12) + 1e-6, name
+    leaves = [None if t is None else t.float().double().requires_grad_(True) for t in maps]
+    args = [None if t is None else t.repeat(1, ny, nx) for t in leaves]
+    okw = dict(view=view.double(), lights=L.double(), intensities=I.double(), light_type=light_type, light_size=size)
+    if workflow == "converted":
+        pytest.skip("the float64 oracle has no several-lights form of the converted workflow; the two-kernel comparison above stands")
+    ref = O.cook_torrance_multi(*args, **okw)
+    (ref * gout.cpu().double()).sum().backward()
+    for name, x, y in zip(("albedo", "normal", "roughness", "metallic", "specular"), one, leaves):
+        if x is None:
+            continue
+        err = (x.float().cpu().double() - y.grad).abs()
+        assert bool((err <= (2e-5 if dtype == torch.float32 else 2e-3) * (1 + y.grad.abs())).all()), (name, float(err.max()))

@@ -150,7 +150,7 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
         }
     };
     float go[3][VEC] = {}, go_next[3][VEC] = {};
-    if (LIGHT == PBR_LIGHT_POINT) load_upstream(0, go);
+    if (LIGHT == PBR_LIGHT_POINT || MULTI) load_upstream(0, go);        // (one directional light sums its positions in chunks, below)
 
     if (!a.has_normal) {
 #pragma unroll

@@ -145,7 +145,14 @@ if want("tiled_multi"):
     p = F.plan_cook_torrance(*maps, tile=2, tuning={"tile_repeat": 0}, **kw4)
     report("tiled_multi_wrap: the same launch in the wrap-around form (what it took until round 4)",
            "cook_torrance_kernel<1, 0, float, float, 4, true, false, false>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
-    del maps, p
+    leaves = maps
+    plan4 = F.plan_cook_torrance(*leaves, tile=2, **kw4)
+    gout = torch.rand(1, 3, S, S, device=DEV)
+    grads = [torch.empty_like(t) for t in leaves]
+    report("tiled_multi_bwd: folded gradient of the same tiled maps under 4 point lights: 8 map planes + 3 upstream planes of 4096^2 in, 8 gradient planes of 2048^2 out",
+           "cook_torrance_repeat_backward_kernel<1, 0, float, false, true>", 12 * PX + 64 * 2048 * 2048,
+           timed(lambda: N.check(lib.pbr_cook_torrance_backward_folded(ctypes.byref(plan4.desc), gout.data_ptr(), *[t.data_ptr() for t in grads], None, None, stream))))
+    del maps, p, plan4, gout, grads, leaves
 if want("tiled_bwd"):
     # round 5: gradients of tiled maps folded in registers (pbr_cook_torrance_backward_folded) and the loss step over tiled maps
     for dtype, tag in ((torch.float32, "f32"), (torch.float16, "f16")):

@@ -41,7 +41,7 @@ def run(cases=60, seed=0, verbose=True):
             out = F.cook_torrance(a, n, r, m, tile=(ny, nx), schedule=sched, **kw)
             if not torch.equal(out, ref):
                 raise AssertionError(desc + f": differs from the materialised repeat by {float((out.float() - ref.float()).abs().max()):.2e}")
-            if rng.random() < 0.35 and lights == 1:
+            if rng.random() < 0.35:
                 # gradients: a map repeated by the fused tile owns the SUM of the per-output-pixel gradients (pbr_fold_gradient[_typed]) -- what
                 # autograd gives through the materialised repeat
                 wt = (torch.rand(ref.shape, generator=g) - 0.5).cuda()

@@ -248,3 +248,65 @@ def test_loss_step_full_shape_4096(B, dtype):
         # fp16's subnormal range, where one rounding is 6e-8 absolute
         assert err <= (2e-5 * scale if dtype == torch.float32 else 2e-3 * scale + 1.3e-7), (name, err, scale)
         assert bool(torch.isfinite(x).all())
+
+
+@pytest.mark.parametrize("light_type", ["point", "directional"])
+def test_tiled_gradients_full_shape_2048_tile2(light_type):
+    """The example's material shape at full size -- 2048^2 maps under tile(2) -> a 4096^2 image (examples/example_brdf.py:11 scaled to
+    BASELINE's 4K): the folded gradients from ONE kernel that walks the maps (32 768 one-wave workgroups, 4 positions per texel pair)
+    against the two-kernel form (wrap-around backward over 16.8 M output pixels + pbr_fold_gradient): bit-identical under the point
+    light, to fp32 rounding under the directional one (its repeats are summed before the chain rule); finite; and a window of texels
+    against float64 autograd of the reference's ops through the materialised repeat of that window's rows (y_offset / H_total keep
+    the point-light grid the full image's)."""
+    from pypbr_amd import functional as F, _native as N
+    H = W = 2048
+    a, n, r, m = [t[0] for t in _maps(1, H, W, seed=77)]
+    r = r.clamp(min=0.2)
+    light = [0.1, 0.1, 1.0] if light_type == "point" else [0.3, -0.2, 1.0]
+    kw = dict(view_dir=[0.0, 0.1, 1.0], light=light, light_intensity=[1.0, 0.9, 0.8], light_type=light_type, light_size=1.0 if light_type == "point" else None)
+    gout = torch.rand(3, 2 * H, 2 * W, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5)) - 0.3
+
+    def grads(knob):
+        leaves = [t.clone().requires_grad_(True) for t in (a, n, r, m)]
+        try:
+            N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, knob)
+            (F.cook_torrance(*leaves, tile=2, **kw) * gout).sum().backward()
+        finally:
+            N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, -1)
+        return [t.grad for t in leaves]
+    one, two = grads(-1), grads(0)
+    for name, x, y in zip(("albedo", "normal", "roughness", "metallic"), one, two):
+        assert x.shape == y.shape == (x.shape[0], H, W) and bool(torch.isfinite(x).all()), name
+        if light_type == "point":
+            assert torch.equal(x, y), (name, float((x - y).abs().max()))
+        else:
+            assert (x - y).abs().max().item() <= 2e-6 * float(y.abs().max()) + 1e-9, name
+    del two
+    # the LAST texel rows, all columns of a 64-wide window at the right edge: float64 autograd through repeat() of those rows
+    y0, x0, h, w = H - 4, W - 64, 4, 64
+    crop = [t[:, y0:, x0:x0 + w].cpu().double().requires_grad_(True) for t in (a, n, r, m)]
+    total = None
+    for ry in range(2):
+        for rx in range(2):
+            # the window's repeat (ry, rx) sits at rows ry*H + y0 .., columns rx*W + x0 .. of the 4096^2 image: evaluate the full-width rows
+            # of that repeat for the window's columns only through the oracle's row band + a column crop of the upstream gradient
+            cols = slice(rx * W + x0, rx * W + x0 + w)
+            rows = slice(ry * H + y0, ry * H + y0 + h)
+            full_rows = [torch.zeros(c.shape[0], h, 2 * W, dtype=torch.float64) for c in crop]
+            args = []
+            for c, z in zip(crop, full_rows):
+                z = z.clone()
+                z[:, :, 2] = 1.0 if c.shape[0] == 3 and c is crop[1] else z[:, :, 2]
+                args.append(torch.cat([z[:, :, :cols.start], c, z[:, :, cols.stop:]], dim=2))
+            args[1] = torch.cat([torch.zeros(3, h, cols.start, dtype=torch.float64).index_fill_(0, torch.tensor([2]), 1.0), crop[1],
+                                 torch.zeros(3, h, 2 * W - cols.stop, dtype=torch.float64).index_fill_(0, torch.tensor([2]), 1.0)], dim=2)
+            args[2] = torch.cat([torch.full((1, h, cols.start), 0.5, dtype=torch.float64), crop[2], torch.full((1, h, 2 * W - cols.stop), 0.5, dtype=torch.float64)], dim=2)
+            out = O.cook_torrance(args[0], args[1], args[2], args[3], None, view=torch.tensor(kw["view_dir"], dtype=torch.float64),
+                                  light=torch.tensor(light, dtype=torch.float64), intensity=torch.tensor(kw["light_intensity"], dtype=torch.float64),
+                                  light_type=light_type, light_size=kw["light_size"], y_offset=rows.start, H_total=2 * H)
+            term = (out[:, :, cols] * gout[:, rows, cols].cpu().double()).sum()
+            total = term if total is None else total + term
+    total.backward()
+    for name, x, c in zip(("albedo", "normal", "roughness", "metallic"), one, crop):
+        got = x[:, y0:, x0:x0 + w].cpu().double()
+        assert bool(((got - c.grad).abs() <= 2e-5 * (1 + c.grad.abs())).all()), (name, float((got - c.grad).abs().max()))

@@ -288,19 +288,17 @@ def test_tiled_gradients_full_shape_2048_tile2(light_type):
     total = None
     for ry in range(2):
         for rx in range(2):
-            # the window's repeat (ry, rx) sits at rows ry*H + y0 .., columns rx*W + x0 .. of the 4096^2 image: evaluate the full-width rows
-            # of that repeat for the window's columns only through the oracle's row band + a column crop of the upstream gradient
+            # the window's repeat (ry, rx) sits at rows ry*H + y0 .., columns rx*W + x0 .. of the 4096^2 image: the oracle evaluates that row
+            # band at full width (its point-light grid needs the real columns) and only the window's columns meet the upstream gradient
             cols = slice(rx * W + x0, rx * W + x0 + w)
             rows = slice(ry * H + y0, ry * H + y0 + h)
-            full_rows = [torch.zeros(c.shape[0], h, 2 * W, dtype=torch.float64) for c in crop]
-            args = []
-            for c, z in zip(crop, full_rows):
-                z = z.clone()
-                z[:, :, 2] = 1.0 if c.shape[0] == 3 and c is crop[1] else z[:, :, 2]
-                args.append(torch.cat([z[:, :, :cols.start], c, z[:, :, cols.stop:]], dim=2))
-            args[1] = torch.cat([torch.zeros(3, h, cols.start, dtype=torch.float64).index_fill_(0, torch.tensor([2]), 1.0), crop[1],
-                                 torch.zeros(3, h, 2 * W - cols.stop, dtype=torch.float64).index_fill_(0, torch.tensor([2]), 1.0)], dim=2)
-            args[2] = torch.cat([torch.full((1, h, cols.start), 0.5, dtype=torch.float64), crop[2], torch.full((1, h, 2 * W - cols.stop), 0.5, dtype=torch.float64)], dim=2)
+
+            def across(c, fill):                    # the window's texels at their columns of a full-width row band; neutral texels elsewhere
+                left = torch.zeros(c.shape[0], h, cols.start, dtype=torch.float64) + fill.reshape(-1, 1, 1)
+                right = torch.zeros(c.shape[0], h, 2 * W - cols.stop, dtype=torch.float64) + fill.reshape(-1, 1, 1)
+                return torch.cat([left, c, right], dim=2)
+            args = [across(crop[0], torch.zeros(3, dtype=torch.float64)), across(crop[1], torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64)),
+                    across(crop[2], torch.tensor([0.5], dtype=torch.float64)), across(crop[3], torch.zeros(1, dtype=torch.float64))]
             out = O.cook_torrance(args[0], args[1], args[2], args[3], None, view=torch.tensor(kw["view_dir"], dtype=torch.float64),
                                   light=torch.tensor(light, dtype=torch.float64), intensity=torch.tensor(kw["light_intensity"], dtype=torch.float64),
                                   light_type=light_type, light_size=kw["light_size"], y_offset=rows.start, H_total=2 * H)

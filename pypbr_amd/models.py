@@ -147,7 +147,10 @@ class CookTorranceBRDF(BRDFModel):
         maps = (albedo, normal, rough, second)
         grad = torch.is_grad_enabled()
         for t in maps:
-            if t is not None and (t.device != albedo.device or t.dtype.itemsize > 4 or not t.is_floating_point() or (grad and t.requires_grad)):
+            # rows must be dense: a map with strided rows is evaluated through a contiguous COPY (functional._as_batched), and a kept plan
+            # would keep pointing at that copy while the caller edits the original
+            if t is not None and (t.device != albedo.device or t.dtype.itemsize > 4 or not t.is_floating_point() or (grad and t.requires_grad)
+                                  or t.stride(-1) != 1 or t.stride(-2) != t.shape[-1]):
                 return None
         key = (self.light_type, light_size, bool(return_srgb), bool(material.albedo_is_srgb), bool(getattr(material, "specular_is_srgb", True)),
                d.get("_lazy_tile", (1, 1)), "metallic" in store and store["metallic"] is not None,

@@ -354,6 +354,14 @@ def test_plan_reuse_is_invisible_except_for_its_speed():
         assert out.requires_grad
     out.sum().backward()
     assert leaf.grad is not None and bool(torch.isfinite(leaf.grad).all())
+    # a map whose rows are strided is evaluated through a copy: no plan is kept, edits of the original are seen
+    wide = torch.rand(1, 40, 128, generator=torch.Generator().manual_seed(2)).cuda() * 0.5 + 0.3
+    s_mat = BasecolorMetallicMaterial(**_maps(40, 64, seed=13))
+    s_mat._raw["roughness"] = wide[:, :, ::2]
+    first = [brdf(s_mat, view, light, inten, 1.0) for _ in range(3)][-1]
+    assert "_plan_cache" not in s_mat.__dict__
+    wide.mul_(0.5)
+    assert not torch.equal(brdf(s_mat, view, light, inten, 1.0), first)
     # a clone does not share the plan
     c = BasecolorMetallicMaterial(**maps)
     for _ in range(3):

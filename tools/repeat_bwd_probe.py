@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--tile", type=int, default=2)
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--schedule", type=int, default=0, help="pbr_render_desc.schedule: 0 = the rule, 1 = linear, 1 + c = runs of 1 << c tiles per XCD")
     args = ap.parse_args()
     S, T = args.size, args.tile
     lib = N.lib()
@@ -44,7 +45,7 @@ def main():
             m = torch.rand(1, S, S, device="cuda", generator=g)
             a, n, r, m = F.pack_maps(*[t.to(dtype) for t in (a, n, r, m)])
             kw = dict(view_dir=[0.0, 0.0, 1.0], light=light, light_intensity=[1.0, 1.0, 1.0], light_type=light_type, light_size=1.0)
-            plan = F.plan_cook_torrance(a, n, r, m, tile=T, **kw)
+            plan = F.plan_cook_torrance(a, n, r, m, tile=T, schedule=args.schedule, **kw)
             d = plan.desc
             gout = torch.rand(1, 3, S * T, S * T, device="cuda", generator=g)
             grads = [torch.empty_like(t) for t in (a, n, r, m)]

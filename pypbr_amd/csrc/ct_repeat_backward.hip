@@ -56,6 +56,14 @@ int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void 
     g.out_batch_stride = g.out_channel_stride = 0;
     fill_args(&g, 2, k, 6);                              // one-wave workgroups over the source maps, two texels per lane
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
+    // ONE directional light: the kernel sums the repeats' upstream values and differentiates once -- it is bound by its 8-byte streams (3 upstream
+    // planes x n^2 positions, 8 map planes, 8 gradient planes per wave), and those stream best when every XCD walks long runs of tiles: 2048^2
+    // tile(2) fp32, runs of 64 (the forward's rule) / 512 / 1024 / 4096 tiles: 86.4 / 79.7 / 76.3 / 76.1 us (tools/repeat_bwd_probe.py --schedule).
+    // The point-light form is VALU-bound and does not care (144-147 us whatever the order).
+    if (d->schedule == PBR_SCHEDULE_AUTO && d->light_type == PBR_LIGHT_DIRECTIONAL && d->n_lights == 1) {
+        k.xcd_log2 = 10;
+        k.xcd_tiles = (k.n_tiles >> (k.xcd_log2 + 3)) << (k.xcd_log2 + 3);
+    }
     k.x0 = full.x0; k.x1 = full.x1; k.xstep = full.xstep;
     k.y0 = full.y0; k.y1 = full.y1; k.ystep = full.ystep;
     k.rep_y = d->height_total / d->map_height; k.rep_x = d->width / d->map_width;

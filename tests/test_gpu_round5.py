@@ -521,3 +521,49 @@ def test_repeat_inner_backward_with_several_lights(binding, workflow, light_type
             continue
         err = (x.float().cpu().double() - y.grad).abs()
         assert bool((err <= (2e-5 if dtype == torch.float32 else 2e-3) * (1 + y.grad.abs())).all()), (name, float(err.max()))
+
+
+def test_loss_step_keeps_its_descriptor_across_training_steps_and_sees_every_change():
+    """A training loop hands the loss step the same leaf tensors every iteration: the filled descriptor of the last step is kept
+    (functional._MseStepFn._PLANS: pointers only, maps held weakly).  In-place updates of the maps (an optimiser step), edited light
+    values, another target, tiled and untiled calls: every step equals the step computed without the kept descriptor."""
+    import gc
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(8)
+    leaves = [t.cuda().requires_grad_(True) for t in _leaf_maps(g, 24, 48, "metallic")[:4]]
+    light = torch.tensor([0.1, 0.1, 1.0])
+    kw = dict(view_dir=[0.0, 0.1, 1.0], light=light, light_intensity=[1.0, 0.9, 0.8], light_type="point", light_size=1.5)
+
+    def step(keep, target, **extra):
+        for t in leaves:
+            t.grad = None
+        before = F._MseStepFn._PLANS_MAX
+        F._MseStepFn._PLANS_MAX = 8 if keep else 0
+        if not keep:
+            F._MseStepFn._PLANS.clear()
+        try:
+            loss = F.rendering_loss_mse(*leaves, target=target, **dict(kw, **extra))
+            loss.backward()
+        finally:
+            F._MseStepFn._PLANS_MAX = before
+        return loss.detach().clone(), [t.grad.clone() for t in leaves]
+    F._MseStepFn._PLANS.clear()
+    for it in range(6):
+        tiled = it % 2 == 1
+        target = torch.rand(3, 48 if tiled else 24, 96 if tiled else 48, generator=g).cuda()
+        extra = dict(tile=2) if tiled else {}
+        got = step(True, target, **extra)
+        want = step(False, target, **extra)
+        assert torch.equal(got[0], want[0]) and all(torch.equal(x, y) for x, y in zip(got[1], want[1])), it
+        with torch.no_grad():                               # an optimiser step, in place
+            for t, gr in zip(leaves, got[1]):
+                t.sub_(0.1 * gr)
+            leaves[2].clamp_(0.2, 1.0)
+        light[0] += 0.05                                    # a light edited in place between steps
+    step(True, torch.rand(3, 24, 48, generator=g).cuda())
+    assert 1 <= len(F._MseStepFn._PLANS) <= 2
+    # the kept descriptors do not keep the maps alive
+    probe = weakref_of = __import__("weakref").ref(leaves[0])
+    del leaves, got, want, t, gr
+    gc.collect()
+    assert probe() is None and weakref_of() is None

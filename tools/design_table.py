@@ -42,6 +42,7 @@ print(f'''| kernel (4096² probe shape unless noted) | algorithmic bytes per pix
 | `cook_torrance_backward_kernel<1,0,4,…,float,…>` | 44 in + 32 out | {us('bwd_f32')} | {fr('bwd_f32')} | {tr('bwd_f32')} | {vb('bwd_f32')} | HBM |
 | `cook_torrance_backward_stream_kernel<1,0,true>` — fp16 maps (directional: `<0,0,true>`) | 28 + 16 | {us('bwd_f16')} ({us('bwd_dir_f16')}) | {fr('bwd_f16')} ({fr('bwd_dir_f16')}) | 1.0001 | {vb('bwd_f16')} ({vb('bwd_dir_f16')}) | VALU issue |
 | **`cook_torrance_repeat_backward_kernel<1,0,float,false>`** — folded gradient of 2048² maps under `tile(2)` → 4096², point light (round 5) | 12 per output pixel + 64 per texel (= 26.7 per output pixel) | **{us('tiled_bwd_f32')}** | {fr('tiled_bwd_f32')} | **{tr('tiled_bwd_f32')}** | {vb('tiled_bwd_f32')} | **VALU issue** (46 M wave-instructions, two waves per SIMD); the two-kernel form it replaces: 319-327 µs, 1.95 GB |
+| same, ONE directional light (the repeats' upstream values summed before the chain rule; XCDs walk runs of 1 024 tiles) | as above | **{us('tiled_bwd_dir_f32')}** | **{fr('tiled_bwd_dir_f32')}** | {tr('tiled_bwd_dir_f32')} | {vb('tiled_bwd_dir_f32')} | HBM (8-byte streams) |
 | same, fp16 maps | 12 + 32 per texel | {us('tiled_bwd_f16')} | {fr('tiled_bwd_f16')} | {tr('tiled_bwd_f16')} | {vb('tiled_bwd_f16')} | VALU issue |
 | same with the loss policy — the rendering-loss step over tiled maps (fp32 / fp16 maps) | as above | {us('tiled_bwd_loss_f32')} / {us('tiled_bwd_loss_f16')} | {fr('tiled_bwd_loss_f32')} / {fr('tiled_bwd_loss_f16')} | {tr('tiled_bwd_loss_f32', 3)} / {tr('tiled_bwd_loss_f16', 3)} | {vb('tiled_bwd_loss_f32')} / {vb('tiled_bwd_loss_f16')} | VALU issue |
 | same, 4 point lights (`…, MULTI`) | as above | {us('tiled_multi_bwd')} | {fr('tiled_multi_bwd')} | {tr('tiled_multi_bwd')} | {vb('tiled_multi_bwd')} | VALU (two passes over the lights per position) |

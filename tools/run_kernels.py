@@ -172,6 +172,16 @@ if want("tiled_bwd"):
                timed(lambda: N.check(lib.pbr_cook_torrance_mse_step(ctypes.byref(plan.desc), gout.data_ptr(), *[t.data_ptr() for t in grads], None,
                                                                     loss.data_ptr(), ws.data_ptr(), stream))))
         del maps, plan, gout, grads, ws
+    # one directional light: the repeats' upstream values are summed before the chain rule (one evaluation per texel): memory-bound
+    maps = F.pack_maps(*synth_material(2048, DEV, 41))
+    sun = dict(view_dir=[0, 0, 1], light=[0.3, -0.2, 1.0], light_intensity=[1, 1, 1], light_type="directional")
+    plan = F.plan_cook_torrance(*maps, tile=2, **sun)
+    gout = torch.rand(1, 3, S, S, device=DEV)
+    grads = [torch.empty_like(t) for t in maps]
+    report("tiled_bwd_dir_f32: folded gradient of 2048^2 maps under tile(2) -> 4096^2, ONE directional light (fp32): 8 map planes + 3 upstream planes of 4096^2 in, 8 gradient planes of 2048^2 out",
+           "cook_torrance_repeat_backward_kernel<0, 0, float, false, false>", 12 * PX + 64 * 2048 * 2048,
+           timed(lambda: N.check(lib.pbr_cook_torrance_backward_folded(ctypes.byref(plan.desc), gout.data_ptr(), *[t.data_ptr() for t in grads], None, None, stream))))
+    del maps, plan, gout, grads
 if want("map_ops"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)

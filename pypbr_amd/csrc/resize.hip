@@ -55,7 +55,7 @@ __host__ __device__ __forceinline__ int first_tap(const AxisFilter &f, int i) {
     return xmin;
 }
 
-__device__ __forceinline__ float tap_weight(const AxisFilter &f, int j, int xmin, float center) {
+__host__ __device__ __forceinline__ float tap_weight(const AxisFilter &f, int j, int xmin, float center) {
     const float x = ((float)(j + xmin) - center + 0.5f) * f.invscale;
     return fmaxf(0.0f, 1.0f - fabsf(x));
 }
@@ -899,6 +899,10 @@ static int band_window(const AxisFilter &f, int n_out, int rows) {
     return worst;
 }
 
+}  // namespace pbr
+#include "resize_down.hpp"
+namespace pbr {
+
 static AxisFilter make_filter(int n_in, int n_out, bool antialias) {
     AxisFilter f;
     f.scale = (float)n_in / (float)n_out;            // area_pixel_compute_scale<float>, align_corners = False
@@ -907,6 +911,28 @@ static AxisFilter make_filter(int n_in, int n_out, bool antialias) {
     f.invscale = aa ? 1.0f / f.scale : 1.0f;
     f.n_in = n_in;
     return f;
+}
+
+// The three weight vectors of resize_down_kernel for the whole factor S (antialiased): an axis of 16 outputs has them all -- output 0 (window clipped
+// on the left), output 5 (whole window) and output 15 (clipped on the right) -- and they do not depend on the axis' length: with n_in = S n_out every
+// term of tap_window / tap_weight is a small dyadic number, exact in float.  Formed with the strip kernel's statements (phase 0 of resize_strip_kernel).
+static DownTaps down_taps(int S) {
+    DownTaps t;
+    const AxisFilter f = make_filter(16 * S, 16, true);
+    const int which[3] = {5, 0, 15};
+    float *const into[3] = {t.wi, t.wl, t.wr};
+    for (int s = 0; s < 3; ++s) {
+        const int i = which[s];
+        int xmin, n; float center, wsum = 0.0f;
+        tap_window(f, i, xmin, n, center);
+        for (int j = 0; j < n; ++j) wsum += tap_weight(f, j, xmin, center);
+        const float inv = wsum != 0.0f ? 1.0f / wsum : 0.0f;
+        for (int j = 0; j < 16; ++j) into[s][j] = 0.0f;
+        const int shift = xmin - (S * i - S / 2);            // the window's first tap among the K = 2 S of an unclipped one
+        for (int j = 0; j < n; ++j)
+            if (shift + j >= 0 && shift + j < 16) into[s][shift + j] = tap_weight(f, j, xmin, center) * inv;
+    }
+    return t;
 }
 
 static inline unsigned stream_grid(int64_t items) {
@@ -944,6 +970,33 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
             auto fn = rows == 8 ? resize_up2_kernel<8> : resize_up2_kernel<4>;
             hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(src), static_cast<float *>(dst),
                                (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)groups_x, (int)groups_y, xcd_groups, fw, fh);
+            const hipError_t e = hipGetLastError();
+            return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+        }
+    }
+    if (g_resize_up2 && antialias && w_out % 4 == 0 && w_out >= 8 && h_out >= 2 && h_in % h_out == 0 && w_in % w_out == 0 && h_in / h_out == w_in / w_out &&
+        ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+        // A whole factor 2 | 4 | 8 on both axes: the register form (resize_down.hpp).  A lane owns 32 bytes of every input row (8 / S output columns) and
+        // walks down a band of output rows, R rows per turn of its loop, the next input row in flight.  Bands are cut so that the launch has ~1 536
+        // waves -- six per CU, which then run side by side from the first to the last row: 3 x 4096^2 -> 2048^2 | 1024^2 | 512^2 (us) with
+        // 1 280 / 1 536 / 1 792 / 2 048 / 2 560 / 3 072 / 4 096 / 6 144 waves: 37.6 / 37.2 / 39.3 / 39.4 / 42.1 / 40.0 / 40.1 / 42.7 | 34.2 / 32.4 / 32.3 / 32.3 / 34.2 / 34.4 / 34.3 /
+        // 39.2 | 35.1 / 33.8 / 33.9 / 33.9 / 35.6 / 37.8 / 37.8 / 46.1 (tools/resize_down_probe.py; the strip kernel: 45.6 | 36.4, and 185 for the two passes the
+        // 19 taps of an 8 x down-scale fell to).  64 bytes per lane (16 lines per load instruction instead of 8), 3 or 7 rows in flight, 4 or 8 rows per
+        // turn: level or 2-8 % slower; non-temporal loads: 1.4-1.8 x slower (a lane's two 16-byte loads of a row are two instructions on the same lines).
+        const int S = h_in / h_out;
+        const int cols = 8 / S, R = S == 2 ? 4 : 2;                  // output columns per lane; output rows per turn of the kernel's loop (S == 2 | 4 | 8 below)
+        const int64_t groups_x = (w_out + 64 * cols - 1) / (64 * cols);
+        int64_t bands = 1536 / (planes * groups_x);
+        bands = bands < 1 ? 1 : bands;
+        int64_t band_rows = (h_out + bands - 1) / bands;
+        band_rows = (band_rows + R - 1) / R * R;
+        bands = (h_out + band_rows - 1) / band_rows;                 // every band holds at least one row
+        const int64_t pairs = planes * bands, n_groups = pairs * groups_x;
+        if ((S == 2 || S == 4 || S == 8) && n_groups <= INT32_MAX) {
+            const uint32_t mapped = (uint32_t)((pairs / 8) * 8 * groups_x);      // the (plane, band) pairs dealt to the XCDs by eights
+            auto fn = S == 2 ? resize_down_kernel<2, 4, 4, 1> : (S == 4 ? resize_down_kernel<4, 2, 2, 1> : resize_down_kernel<8, 2, 1, 1>);
+            hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(src), static_cast<float *>(dst),
+                               (int)h_out, (int)w_out, (int)groups_x, (int)bands, (int)band_rows, mapped, down_taps(S));
             const hipError_t e = hipGetLastError();
             return e == hipSuccess ? PBR_OK : 1000 + (int)e;
         }

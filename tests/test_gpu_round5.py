@@ -567,3 +567,47 @@ def test_loss_step_keeps_its_descriptor_across_training_steps_and_sees_every_cha
     del leaves, got, want, t, gr
     gc.collect()
     assert probe() is None and weakref_of() is None
+
+
+def test_whole_factor_downscale_register_kernel_equals_the_strip_kernel_and_aten():
+    """Round 5: an antialiased down-scale by 2 | 4 | 8 on both axes -- MaterialBase.resize of a 1024^2 ... 4096^2 texture to 512^2
+    (/root/reference/pypbr/materials/base.py:490-504) -- runs the register-only band-walking kernel (csrc/resize_down.hpp).  Factors 2 and 4: the strip
+    kernel's taps in the strip kernel's order, BIT-IDENTICAL (knob PBR_TUNE_RESIZE_UP2 = 0 selects the strip form); factor 8 had no strip form (19 taps:
+    two passes through a workspace, width first).  All: <= 2e-6 from ATen's antialiased interpolate.  Shapes: the smallest the kernel takes, widths that
+    leave lanes and whole workgroups idle, bands of ragged height, several planes, more than 1 536 / 8 column strips (one band)."""
+    from pypbr_amd import _native as N, functional as F
+    lib = N.lib()
+    g = torch.Generator().manual_seed(85)
+    try:
+        for S in (2, 4, 8):
+            for planes, ho, wo in ((1, 2, 8), (3, 8, 256), (2, 13, 260), (1, 64, 1028), (3, 37, 12), (1, 512, 512), (4, 301, 2048 // S), (1, 3, 8192 // S)):
+                x = (torch.rand(planes, S * ho, S * wo, generator=g) * 2 - 0.5)
+                xd = x.cuda()
+                lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
+                fast = F.resize(xd, (ho, wo))
+                lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 0)
+                other = F.resize(xd, (ho, wo))
+                if S < 8:
+                    assert torch.equal(fast, other), (S, planes, ho, wo, float((fast - other).abs().max()))
+                else:
+                    assert (fast - other).abs().max().item() <= 1e-6, (S, planes, ho, wo)
+                ref = torch.nn.functional.interpolate(x[None], size=(ho, wo), mode="bilinear", align_corners=False, antialias=True)[0]
+                assert (fast.cpu() - ref).abs().max().item() <= 2e-6, (S, planes, ho, wo)
+        # an input of infinities and NaNs stays where it is: taps outside a clipped window are never multiplied (0 x inf)
+        x = torch.rand(1, 64, 64, generator=g)
+        x[0, 0, 0] = float("inf"); x[0, 63, 63] = float("-inf"); x[0, 31, 0] = float("nan")
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
+        fast = F.resize(x.cuda(), (32, 32))
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 0)
+        other = F.resize(x.cuda(), (32, 32))
+        assert torch.equal(torch.isnan(fast), torch.isnan(other)) and torch.equal(torch.nan_to_num(fast), torch.nan_to_num(other))
+        ref = torch.nn.functional.interpolate(x[None], size=(32, 32), mode="bilinear", align_corners=False, antialias=True)[0]
+        assert torch.equal(torch.isfinite(fast).cpu(), torch.isfinite(ref))
+        # a view that starts off a 16-byte boundary, an aspect ratio that differs per axis: the strip form, whatever the knob says
+        flat = torch.rand(3 * 64 * 64 + 1, generator=g).cuda()
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
+        a, b = F.resize(flat[1:].view(3, 64, 64), (32, 32)), F.resize(flat[:-1].view(3, 64, 64), (32, 16))
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 0)
+        assert torch.equal(a, F.resize(flat[1:].view(3, 64, 64), (32, 32))) and torch.equal(b, F.resize(flat[:-1].view(3, 64, 64), (32, 16)))
+    finally:
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, -1)

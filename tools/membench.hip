@@ -2,8 +2,9 @@
 // 8 planar fp32 input planes -> 3 output planes, 16 B per lane per plane, optional synthetic
 // VALU work per pixel.  Tells how much of the fused kernel's time is the memory pattern
 // itself (no arithmetic) and how much VALU work that pattern hides.
-//   hipcc -O3 --offload-arch=gfx950 tools/membench.hip -o gpurun_out/membench && gpurun_out/membench
+//   hipcc -O3 --offload-arch=gfx950 tools/membench.hip -o tools/bin/membench && tools/bin/membench [S] [resize: the ceilings and the resize family's patterns only]
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -273,6 +274,25 @@ void oneshot_x2(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size
     st<NT>(out + i + 64, q0); st<NT>(out + plane + i + 64, q1); st<NT>(out + 2 * plane + i + 64, q2);
 }
 
+
+// the resize family's patterns (csrc/resize.hip, resize_down.hpp): RI 16-byte streams in, WO out per lane, nothing else -- a 2x down-scale or the
+// gradient of a 2x up-scale is 4 : 1, a 4x down-scale 16 : 1, a 1.5x up-scale 4 : 9, the gradient of a 2x down-scale 1 : 4.  NT: the loads'
+// hint (the stores are non-temporal always, as the kernels').  TWO: the lane's loads are pairs of neighbouring 16-byte pieces (a lane of
+// resize_down_kernel owns 32 contiguous bytes of a row: two instructions on the same lines) instead of RI streams a plane apart.
+template <int RI, int WO, bool NT, bool TWO>
+__global__ __launch_bounds__(64) void ratio_pattern(const f4 *__restrict__ in, f4 *__restrict__ out, size_t units) {
+    const size_t u = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (u >= units) return;
+    f4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < RI; ++r) {
+        const f4 *p = TWO ? in + (size_t)(r / 2) * 2 * units + 2 * u + (r & 1) : in + (size_t)r * units + u;
+        acc += NT ? __builtin_nontemporal_load(p) : *p;
+    }
+#pragma unroll
+    for (int w = 0; w < WO; ++w) __builtin_nontemporal_store(acc, out + (size_t)w * units + u);
+}
+
 // read-only and write-only ceilings
 template <bool NT> __global__ __launch_bounds__(256) void readonly(const f4 *__restrict__ in, f4 *__restrict__ out, size_t nv, size_t plane) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -319,12 +339,36 @@ int main(int argc, char **argv) {
     }
     const double bytes_rw = 44.0 * px, bytes_r = 32.0 * px, bytes_w = 12.0 * px;
     const int iters = 20;
+    const bool only_resize = argc > 2 && !strcmp(argv[2], "resize");
     auto report = [&](const char *name, double us, double bytes) { printf("%-44s %8.2f us  %7.1f GB/s\n", name, us, bytes / us / 1e3); fflush(stdout); };
 
     report("read-only 8 planes nt", time_us([&](int i) { hipLaunchKernelGGL(readonly<true>, dim3((nv + 255) / 256), dim3(256), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_r);
     report("read-only 8 planes", time_us([&](int i) { hipLaunchKernelGGL(readonly<false>, dim3((nv + 255) / 256), dim3(256), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane); }, iters), bytes_r);
     report("write-only 3 planes nt", time_us([&](int i) { hipLaunchKernelGGL(writeonly<true>, dim3((nv + 255) / 256), dim3(256), 0, 0, out[i % NSETS], nv, plane); }, iters), bytes_w);
     report("write-only 3 planes", time_us([&](int i) { hipLaunchKernelGGL(writeonly<false>, dim3((nv + 255) / 256), dim3(256), 0, 0, out[i % NSETS], nv, plane); }, iters), bytes_w);
+
+    {   // the resize family: 3 planes of S^2 on the large side
+        const size_t big = 3 * px / 4;                     // f4 units
+#define RATIO(RI, WO, NT, TWO, UNITS, WHAT) report(WHAT, time_us([&](int i) { hipLaunchKernelGGL((ratio_pattern<RI, WO, NT, TWO>), dim3((unsigned)(((UNITS) + 63) / 64)), dim3(64), 0, 0, in[i % NSETS], out[i % NSETS], (size_t)(UNITS)); }, iters), 16.0 * (UNITS) * (RI + WO))
+        RATIO(4, 1, false, false, big / 4, "resize pattern 4:1 (2x down, grad of 2x up), plain loads");
+        RATIO(4, 1, true, false, big / 4, "resize pattern 4:1, nt loads");
+        RATIO(4, 1, false, true, big / 4, "resize pattern 4:1, plain loads in 32-byte pairs");
+        RATIO(4, 1, true, true, big / 4, "resize pattern 4:1, nt loads in 32-byte pairs");
+        RATIO(16, 1, false, false, big / 16, "resize pattern 16:1 (4x down), plain loads");
+        RATIO(16, 1, true, false, big / 16, "resize pattern 16:1, nt loads");
+        RATIO(16, 1, false, true, big / 16, "resize pattern 16:1, plain loads in 32-byte pairs");
+        {   // 2.25 x the large side out: its own buffer
+            f4 *up = nullptr; CHECK(hipMalloc(&up, 9 * (big / 4) * 16));
+#define RATIO_UP(NT, WHAT) report(WHAT, time_us([&](int i) { hipLaunchKernelGGL((ratio_pattern<4, 9, NT, false>), dim3((unsigned)((big / 4 + 63) / 64)), dim3(64), 0, 0, in[i % NSETS], up, big / 4); }, iters), 16.0 * (big / 4) * 13)
+            RATIO_UP(false, "resize pattern 4:9 (1.5x up), plain loads");
+            RATIO_UP(true, "resize pattern 4:9, nt loads");
+            CHECK(hipFree(up));
+        }
+        RATIO(1, 4, false, false, big / 4, "resize pattern 1:4 (grad of 2x down), plain loads");
+        RATIO(1, 4, true, false, big / 4, "resize pattern 1:4, nt loads");
+        RATIO(4, 1, false, false, big / 4, "resize pattern 4:1 (2x down, grad of 2x up), plain loads");
+    }
+    if (only_resize) return 0;
 
 #define ONESHOT(NT, F, B) report("oneshot nt=" #NT " valu/px=" #F " block=" #B, time_us([&](int i) { hipLaunchKernelGGL((oneshot<NT, F, B>), dim3((nv + B - 1) / B), dim3(B), 0, 0, in[i % NSETS], out[i % NSETS], nv, plane, plane); }, iters), bytes_rw)
     ONESHOT(true, 0, 256); ONESHOT(false, 0, 256); ONESHOT(true, 0, 128); ONESHOT(true, 0, 512); ONESHOT(true, 0, 1024);

@@ -19,6 +19,10 @@ def run(cases=200, seed=0, verbose=True):
         h, w, ho, wo = pick(), pick(), pick(), pick()
         planes = rng.choice([1, 3, 4])
         aa = rng.random() < 0.6
+        if rng.random() < 0.25:                                          # a whole factor on both axes: the register-only down-scale (resize_down.hpp)
+            S = rng.choice([2, 4, 8])
+            ho, wo = rng.choice([2, 3, 8, 13, 64, 100]), rng.choice([8, 12, 64, 260, 512])
+            h, w, aa = S * ho, S * wo, True
         if aa and 1 in (ho, wo) and (h, w) != (ho, wo):
             # ATen's CPU antialias kernel returns its FIRST output row (column) in every row (column) when the other output extent is 1
             # (torch 2.10: interpolate(rand(1,1,200,1), (31,1), antialias=True) is constant) -- not a reference for these shapes

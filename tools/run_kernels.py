@@ -238,10 +238,14 @@ if want("map_ops"):
 if want("resize"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)
-    for (ho, wo), aa in (((S // 2, S // 2), True), ((S // 4, S // 4), True), ((S * 3 // 2, S * 3 // 2), False)):
+    # whole factors 2 | 4 | 8 down (what resize(512) of a 1024^2 ... 4096^2 texture is): the register-only band walk (round 5); any other down-scale: the
+    # strip kernel (4096 -> 1365: 3.0007x); up-scales: the two-tap register kernel
+    for (ho, wo), aa, kern in (((S // 2, S // 2), True, "resize_down_kernel<2, 4, 4, 1>"), ((S // 4, S // 4), True, "resize_down_kernel<4, 2, 2, 1>"),
+                               ((S // 8, S // 8), True, "resize_down_kernel<8, 2, 1, 1>"), ((1365, 1365), True, "resize_strip_kernel<false, false>"),
+                               ((S * 3 // 2, S * 3 // 2), False, "resize_up2_kernel<8>")):
         out = torch.empty(3, ho, wo, device=DEV)
         ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, S, wo) // 4), device=DEV)
-        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", "resize_strip_kernel<false, false>" if ho < S else "resize_up2_kernel<8>", 12 * (PX + ho * wo),
+        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", kern, 12 * (PX + ho * wo),
                timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), 3, S, S, ho, wo, int(aa), ws.data_ptr(), stream)))
         del out, ws
 if want("blend_bwd"):

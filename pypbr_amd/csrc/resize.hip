@@ -935,6 +935,60 @@ static DownTaps down_taps(int S) {
     return t;
 }
 
+// The TRANSPOSE of an up-scale by the whole factor S has the same shape: gradient element k gathers the 2 S upstream elements S k - S/2 ... S k + 3 S/2 - 1
+// (the outputs whose two-tap windows hold input k), with one weight vector for every interior k and clipped ones for the first and the last --
+// resize_down_kernel with other numbers in its three vectors.  Weights from the forward's own two-tap rule (resize_up2_kernel: two_taps).
+static DownTaps up_transpose_taps(int S) {
+    DownTaps t;
+    const AxisFilter f = make_filter(16, 16 * S, false);     // 16 gradient elements, 16 S upstream; up-scales: antialiasing changes nothing
+    const int which[3] = {5, 0, 15};
+    float *const into[3] = {t.wi, t.wl, t.wr};
+    for (int s = 0; s < 3; ++s) {
+        const int k = which[s];
+        for (int j = 0; j < 16; ++j) into[s][j] = 0.0f;
+        for (int j = 0; j < 2 * S; ++j) {
+            const int i = S * k - S / 2 + j;
+            if (i < 0 || i >= 16 * S) continue;
+            int first, n; float center;
+            tap_window(f, i, first, n, center);
+            const float a = tap_weight(f, 0, first, center), b = n > 1 ? tap_weight(f, 1, first, center) : 0.0f, inv = 1.0f / (a + b);
+            into[s][j] = (first == k ? a * inv : 0.0f) + (first + 1 == k ? b * inv : 0.0f);
+        }
+    }
+    return t;
+}
+
+// Launch of resize_down_kernel: `small` = the side with 1 / S^2 of the elements (the down-scale's result, the up-scale's gradient).  False when the
+// shape is not the kernel's (the caller goes on to its other forms).
+static bool launch_down(const float *large, float *small, int64_t planes, int h_small, int w_small, int S, const DownTaps &taps, hipStream_t s) {
+    // A lane owns 32 bytes of every row of the large side (8 / S columns of the small one) and walks down a band of rows, R rows of the small side per turn
+    // of its loop, the next large row in flight.  Bands are cut so that the launch has ~1 536 waves -- six per CU, which then run side by side from
+    // the first to the last row: 3 x 4096^2 -> 2048^2 | 1024^2 | 512^2 (us) with 1 280 / 1 536 / 1 792 / 2 048 / 2 560 / 3 072 / 4 096 / 6 144 waves:
+    // 37.6 / 37.2 / 39.3 / 39.4 / 42.1 / 40.0 / 40.1 / 42.7 | 34.2 / 32.4 / 32.3 / 32.3 / 34.2 / 34.4 / 34.3 / 39.2 | 35.1 / 33.8 / 33.9 / 33.9 / 35.6 / 37.8 / 37.8 / 46.1
+    // (tools/resize_down_probe.py; the strip kernel: 45.6 | 36.4, and 185 for the two passes the 19 taps of an 8 x down-scale fell to).  64 bytes per
+    // lane (16 lines per load instruction instead of 8), 3 or 7 rows in flight, 4 or 8 rows per turn: level or 2-8 % slower; non-temporal loads:
+    // 1.4-1.8 x slower (a lane's two 16-byte loads of a row are two instructions on the same lines).  These shapes -- one 3-plane 4096^2 map, 201 MB -- sit in
+    // the 256 MB memory-side cache between launches; with EIGHT planes (537 MB, nothing survives a launch) the same sweep reads 127.7 / 122.9 / 132.8 / 129.2 / 132.1
+    // at 1 536 / 2 048 / 3 072 / 4 096 / 6 144 waves for 2x (strip kernel 129.3), 103.6 / 101.5 / 106.7 / 104.3 / 106.1 for 4x (112.5), 99.2 / 95.9 / 101.2 / 101.8 / 104.8
+    // for 8x (two passes: 516): 0.68-0.71 of HBM, which is what plain (cached) loads stream at on this part (tools/membench.hip: read-only plain 5.6 TB/s,
+    // non-temporal 6.2); a map at a time is the caller's shape (MaterialBase.resize), so the rule is the 3-plane optimum.
+    if ((S != 2 && S != 4 && S != 8) || w_small % 4 != 0 || w_small < 8 || h_small < 2) return false;
+    if (((reinterpret_cast<uintptr_t>(large) | reinterpret_cast<uintptr_t>(small)) & 15u) != 0) return false;
+    const int cols = 8 / S, R = S == 2 ? 4 : 2;                  // columns of the small side per lane; its rows per turn of the kernel's loop
+    const int64_t groups_x = (w_small + 64 * cols - 1) / (64 * cols);
+    int64_t bands = 1536 / (planes * groups_x);
+    bands = bands < 1 ? 1 : bands;
+    int64_t band_rows = (h_small + bands - 1) / bands;
+    band_rows = (band_rows + R - 1) / R * R;
+    bands = (h_small + band_rows - 1) / band_rows;               // every band holds at least one row
+    const int64_t pairs = planes * bands, n_groups = pairs * groups_x;
+    if (n_groups > INT32_MAX) return false;
+    const uint32_t mapped = (uint32_t)((pairs / 8) * 8 * groups_x);      // the (plane, band) pairs dealt to the XCDs by eights
+    auto fn = S == 2 ? resize_down_kernel<2, 4, 4, 1> : (S == 4 ? resize_down_kernel<4, 2, 2, 1> : resize_down_kernel<8, 2, 1, 1>);
+    hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, large, small, h_small, w_small, (int)groups_x, (int)bands, (int)band_rows, mapped, taps);
+    return true;
+}
+
 static inline unsigned stream_grid(int64_t items) {
     const int64_t blocks = (items + 255) / 256, cap = 256 * 16;
     return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
@@ -974,32 +1028,11 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
             return e == hipSuccess ? PBR_OK : 1000 + (int)e;
         }
     }
-    if (g_resize_up2 && antialias && w_out % 4 == 0 && w_out >= 8 && h_out >= 2 && h_in % h_out == 0 && w_in % w_out == 0 && h_in / h_out == w_in / w_out &&
-        ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
-        // A whole factor 2 | 4 | 8 on both axes: the register form (resize_down.hpp).  A lane owns 32 bytes of every input row (8 / S output columns) and
-        // walks down a band of output rows, R rows per turn of its loop, the next input row in flight.  Bands are cut so that the launch has ~1 536
-        // waves -- six per CU, which then run side by side from the first to the last row: 3 x 4096^2 -> 2048^2 | 1024^2 | 512^2 (us) with
-        // 1 280 / 1 536 / 1 792 / 2 048 / 2 560 / 3 072 / 4 096 / 6 144 waves: 37.6 / 37.2 / 39.3 / 39.4 / 42.1 / 40.0 / 40.1 / 42.7 | 34.2 / 32.4 / 32.3 / 32.3 / 34.2 / 34.4 / 34.3 /
-        // 39.2 | 35.1 / 33.8 / 33.9 / 33.9 / 35.6 / 37.8 / 37.8 / 46.1 (tools/resize_down_probe.py; the strip kernel: 45.6 | 36.4, and 185 for the two passes the
-        // 19 taps of an 8 x down-scale fell to).  64 bytes per lane (16 lines per load instruction instead of 8), 3 or 7 rows in flight, 4 or 8 rows per
-        // turn: level or 2-8 % slower; non-temporal loads: 1.4-1.8 x slower (a lane's two 16-byte loads of a row are two instructions on the same lines).
-        const int S = h_in / h_out;
-        const int cols = 8 / S, R = S == 2 ? 4 : 2;                  // output columns per lane; output rows per turn of the kernel's loop (S == 2 | 4 | 8 below)
-        const int64_t groups_x = (w_out + 64 * cols - 1) / (64 * cols);
-        int64_t bands = 1536 / (planes * groups_x);
-        bands = bands < 1 ? 1 : bands;
-        int64_t band_rows = (h_out + bands - 1) / bands;
-        band_rows = (band_rows + R - 1) / R * R;
-        bands = (h_out + band_rows - 1) / band_rows;                 // every band holds at least one row
-        const int64_t pairs = planes * bands, n_groups = pairs * groups_x;
-        if ((S == 2 || S == 4 || S == 8) && n_groups <= INT32_MAX) {
-            const uint32_t mapped = (uint32_t)((pairs / 8) * 8 * groups_x);      // the (plane, band) pairs dealt to the XCDs by eights
-            auto fn = S == 2 ? resize_down_kernel<2, 4, 4, 1> : (S == 4 ? resize_down_kernel<4, 2, 2, 1> : resize_down_kernel<8, 2, 1, 1>);
-            hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(src), static_cast<float *>(dst),
-                               (int)h_out, (int)w_out, (int)groups_x, (int)bands, (int)band_rows, mapped, down_taps(S));
-            const hipError_t e = hipGetLastError();
-            return e == hipSuccess ? PBR_OK : 1000 + (int)e;
-        }
+    if (g_resize_up2 && antialias && h_in % h_out == 0 && w_in % w_out == 0 && h_in / h_out == w_in / w_out && h_in / h_out <= 8 &&
+        launch_down(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_out, w_out, h_in / h_out, down_taps(h_in / h_out), s)) {
+        // a whole factor 2 | 4 | 8 on both axes: the register form (resize_down.hpp)
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? PBR_OK : 1000 + (int)e;
     }
     {   // strip form: tap tables + the height-reduced strip [toh][pitch] of a toh x 64 output tile in LDS, up to 16 taps per axis
         const int kx = (int)(2.0f * fw.support) + 3, ky = (int)(2.0f * fh.support) + 3;      // taps per output: xsize <= 2 support + 2
@@ -1069,6 +1102,13 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
     int *lo_y = reinterpret_cast<int *>(wx + (size_t)kBwdMaxTaps * w_in), *cnt_y = lo_y + h_in, *lo_x = cnt_y + h_in, *cnt_x = lo_x + w_in;
     const auto g = static_cast<const float *>(grad_out);
     float *gi = static_cast<float *>(grad_in);
+    if (g_resize_up2 && h_out % h_in == 0 && w_out % w_in == 0 && h_out / h_in == w_out / w_in && h_out / h_in >= 2 && h_out / h_in <= 8 &&
+        launch_down(g, gi, planes, h_in, w_in, h_out / h_in, up_transpose_taps(h_out / h_in), s)) {
+        // gradient of an up-scale by a whole factor 2 | 4 | 8: the band walk of resize_down.hpp over the upstream gradient, with the transposed two-tap weights.
+        // 3 x 4096^2 upstream -> 2048^2: see DESIGN.md section 3 (the two-tap transpose below: 44.4 us, 1.17 x the bytes -- its lanes' windows overlap past L2)
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+    }
     if (g_resize_up2 && fw.scale <= 1.0f && fh.scale <= 1.0f && fw.scale >= 0.34f && fh.scale >= 0.25f && w_out >= 16) {
         // gradient of an up-scale (up to 3x across, 4x down the rows): the register-only transpose of the two-tap forward (round 4;
         // resize_bwd_probe.py (a probe of its round, removed with its knob: git 9ce0718:tools/)).  W from the exact window count of THIS shape; rows per lane 4.

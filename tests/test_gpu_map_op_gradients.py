@@ -188,11 +188,13 @@ def test_resize_gradient_forms_agree_with_float64_autograd(shape, size, antialia
 
 
 @pytest.mark.parametrize("shape,size", [((64, 96), (128, 192)), ((37, 53), (80, 97)), ((50, 70), (50, 70)), ((33, 130), (97, 131)), ((40, 44), (57, 128)),
-                                        ((9, 16), (10, 16)), ((128, 256), (300, 700)), ((5, 4), (11, 16)), ((24, 250), (31, 251))])
+                                        ((9, 16), (10, 16)), ((128, 256), (300, 700)), ((5, 4), (11, 16)), ((24, 250), (31, 251)),
+                                        ((2, 8), (4, 16)), ((13, 260), (52, 1040)), ((16, 8), (128, 64)), ((301, 512), (602, 1024)), ((64, 96), (256, 384))])
 def test_gradient_of_an_upscale_in_registers(shape, size):
     """pbr_resize_bilinear_backward for up-scales (round 4: resize_up2_backward_kernel, the register-only transpose of the two-tap forward):
     against float64 autograd of F.interpolate, and within rounding of the table-driven strip kernel it replaces on these shapes; exact 2x,
-    ragged and unaligned widths, 1:1, widths whose last lane is partial, a 3x up-scale across (16 upstream columns per lane)."""
+    ragged and unaligned widths, 1:1, widths whose last lane is partial, a 3x up-scale across (16 upstream columns per lane).  Whole factors 2 | 4 | 8
+    on both axes (round 5): the band walk of csrc/resize_down.hpp with the transposed two-tap weights -- the smallest shape, ragged bands, idle lanes."""
     from pypbr_amd import _native as N
     lib = N.lib()
     g = torch.Generator().manual_seed(15)

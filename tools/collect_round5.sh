@@ -44,6 +44,10 @@ configs)
 kernels)
     bash "$R/tools/collect_kernels.sh" "$TAG" > "$OUT/collect_kernels.log" 2>&1
     tail -3 "$OUT/collect_kernels.log"
+    # the bare access patterns of the resize family beside its kernels, on the same box (tools/membench.hip)
+    [ -x "$R/tools/bin/membench" ] || { mkdir -p "$R/tools/bin"; /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 "$R/tools/membench.hip" -o "$R/tools/bin/membench" 2> /dev/null; }
+    timeout 120 "$R/tools/bin/membench" 4096 resize > "$OUT/membench_resize.txt" 2>&1
+    cat "$OUT/membench_resize.txt"
     ;;
 examples)
     cd /tmp

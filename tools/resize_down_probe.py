@@ -57,21 +57,22 @@ for S in (2, 4, 8):
 print("failures:", bad, flush=True)
 
 Sz = 4096
-a = torch.rand(3, Sz, Sz, device=DEV, generator=g)
+P = int(os.environ.get("PLANES", "3"))
+a = torch.rand(P, Sz, Sz, device=DEV, generator=g)
 variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
 for rnd in range(2):
     for S in (2, 4, 8):
         ho = Sz // S
-        out = torch.empty(3, ho, ho, device=DEV)
-        ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, Sz, ho) // 4), device=DEV)
-        nbytes = 12 * (Sz * Sz + ho * ho)
+        out = torch.empty(P, ho, ho, device=DEV)
+        ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(P, Sz, ho) // 4), device=DEV)
+        nbytes = 4 * P * (Sz * Sz + ho * ho)
         line = []
         for v in variants:
             os.environ["PBR_DOWN_VARIANT"] = str(v)
-            us = timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), 3, Sz, Sz, ho, ho, 1, ws.data_ptr(), stream))
+            us = timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), P, Sz, Sz, ho, ho, 1, ws.data_ptr(), stream))
             line.append(f"v{v} {us:.1f} us ({nbytes / us / 8e6:.3f})")
         lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 0)
-        us = timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), 3, Sz, Sz, ho, ho, 1, ws.data_ptr(), stream), reps=10)
+        us = timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), P, Sz, Sz, ho, ho, 1, ws.data_ptr(), stream), reps=10)
         lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, -1)
-        print(f"3 x 4096^2 -> {ho}^2: " + " | ".join(line) + f" | strip / two-pass {us:.1f} us ({nbytes / us / 8e6:.3f})", flush=True)
+        print(f"{P} x 4096^2 -> {ho}^2: " + " | ".join(line) + f" | strip / two-pass {us:.1f} us ({nbytes / us / 8e6:.3f})", flush=True)
 sys.exit(1 if bad else 0)

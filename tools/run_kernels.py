@@ -239,15 +239,23 @@ if want("resize"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)
     # whole factors 2 | 4 | 8 down (what resize(512) of a 1024^2 ... 4096^2 texture is): the register-only band walk (round 5); any other down-scale: the
-    # strip kernel (4096 -> 1365: 3.0007x); up-scales: the two-tap register kernel
-    for (ho, wo), aa, kern in (((S // 2, S // 2), True, "resize_down_kernel<2, 4, 4, 1>"), ((S // 4, S // 4), True, "resize_down_kernel<4, 2, 2, 1>"),
-                               ((S // 8, S // 8), True, "resize_down_kernel<8, 2, 1, 1>"), ((1365, 1365), True, "resize_strip_kernel<false, false>"),
-                               ((S * 3 // 2, S * 3 // 2), False, "resize_up2_kernel<8>")):
-        out = torch.empty(3, ho, wo, device=DEV)
-        ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(3, S, wo) // 4), device=DEV)
-        report(f"resize 3 x 4096^2 -> {ho}x{wo} antialias={aa}", kern, 12 * (PX + ho * wo),
-               timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), 3, S, S, ho, wo, int(aa), ws.data_ptr(), stream)))
-        del out, ws
+    # strip kernel (4096 -> 1365: 3.0007x); up-scales: the two-tap register kernel.  THREE planes = one map, 201 MB: between launches it stays in the 256 MB
+    # memory-side cache; EIGHT planes (537 MB) is the same kernel with nothing left from the launch before -- the HBM figure.
+    for planes in (3, 8):
+        if planes == 8:
+            del a
+            a = torch.rand(8, S, S, device=DEV, generator=g)
+        for (ho, wo), aa, kern in (((S // 2, S // 2), True, "resize_down_kernel<2, 4, 4, 1>"), ((S // 4, S // 4), True, "resize_down_kernel<4, 2, 2, 1>"),
+                                   ((S // 8, S // 8), True, "resize_down_kernel<8, 2, 1, 1>"), ((1365, 1365), True, "resize_strip_kernel<false, false>"),
+                                   ((S * 3 // 2, S * 3 // 2), False, "resize_up2_kernel<8>")):
+            if planes == 8 and ho > S:
+                continue
+            out = torch.empty(planes, ho, wo, device=DEV)
+            ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(planes, S, wo) // 4), device=DEV)
+            report(f"resize {planes} x 4096^2 -> {ho}x{wo} antialias={aa}", kern, 4 * planes * (PX + ho * wo),
+                   timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), planes, S, S, ho, wo, int(aa), ws.data_ptr(), stream)))
+            del out, ws
+    del a
 if want("blend_bwd"):
     m1, m2 = synth_material(S, DEV, 21), synth_material(S, DEV, 22)
     mask = torch.rand(1, S, S, device=DEV)
@@ -289,9 +297,20 @@ if want("resize_bwd"):
     report("resize backward 3 x 2048^2 gradient -> 4096^2 (gradient of a 2x down-scale: 3 planes of 2048^2 in, 3 of 4096^2 out)", "resize_backward_gather_kernel<8, 8, true>", 12 * (ho * ho + PX), us,
            whole_call_us=round(us, 1))
     del gout, gin, ws
-    gout = torch.rand(3, S, S, device=DEV, generator=g)
-    gin = torch.empty(3, ho, ho, device=DEV)
-    ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(3, ho, ho, S, S) // 4), device=DEV)
-    us = timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, ho, ho, S, S, 1, ws.data_ptr(), stream))
-    report("resize backward 3 x 4096^2 gradient -> 2048^2 (gradient of a 2x up-scale: 3 planes of 4096^2 in, 3 of 2048^2 out): the two-tap transpose", "resize_up2_backward_kernel<12, 4>",
-           12 * (ho * ho + PX), us)
+    # gradient of a 2x up-scale: a whole factor -> the band walk of resize_down.hpp with the transposed two-tap weights (round 5).  SIX planes, so that the launch
+    # is told from the forward 2x down-scale of the `resize` case (same kernel, same shape otherwise) by its grid
+    gout = torch.rand(6, S, S, device=DEV, generator=g)
+    gin = torch.empty(6, ho, ho, device=DEV)
+    ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(6, ho, ho, S, S) // 4), device=DEV)
+    us = timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 6, ho, ho, S, S, 1, ws.data_ptr(), stream))
+    report("resize backward 6 x 4096^2 gradient -> 2048^2 (gradient of a 2x up-scale: 6 planes of 4096^2 in, 6 of 2048^2 out): the band walk with the transposed two-tap weights",
+           "resize_down_kernel<2, 4, 4, 1>", 24 * (ho * ho + PX), us)
+    del gout, gin, ws
+    # gradient of a 1.5x up-scale (no whole factor): the two-tap transpose
+    hu = S * 3 // 2
+    gout = torch.rand(3, hu, hu, device=DEV, generator=g)
+    gin = torch.empty(3, S, S, device=DEV)
+    ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(3, S, S, hu, hu) // 4), device=DEV)
+    us = timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 3, S, S, hu, hu, 1, ws.data_ptr(), stream))
+    report("resize backward 3 x 6144^2 gradient -> 4096^2 (gradient of a 1.5x up-scale: 3 planes of 6144^2 in, 3 of 4096^2 out): the two-tap transpose", "resize_up2_backward_kernel<8, 4>",
+           12 * (hu * hu + PX), us)

@@ -15,7 +15,7 @@ cat $G/${T}_c/bench_c1.json $G/${T}_c/bench_c3.json $G/${T}_c/bench_c4.json $G/$
 python tools/stamp_profiles.py $G/${T}_c bench_configs.jsonl=r05_bench_configs_1gpu.jsonl configs_kernel_trace.json=r05_configs_kernel_trace.json \
     trace_c3/run_kernel_stats.csv=r05_config3_kernel_stats.csv trace_c4/run_kernel_stats.csv=r05_config4_kernel_stats.csv trace_c5/run_kernel_stats.csv=r05_config5_kernel_stats.csv
 python tools/kernels_summary.py $G/${T}_k > $G/${T}_k/kernels.json
-python tools/stamp_profiles.py $G/${T}_k kernels.json=r05_kernels.json cases.jsonl=r05_kernels_cases.jsonl trace/run_kernel_stats.csv=r05_kernels_kernel_stats.csv
+python tools/stamp_profiles.py $G/${T}_k kernels.json=r05_kernels.json cases.jsonl=r05_kernels_cases.jsonl trace/run_kernel_stats.csv=r05_kernels_kernel_stats.csv membench_resize.txt=r05_membench_resize.txt
 python tools/stamp_profiles.py $G/${T}_e examples.jsonl=r05_examples.jsonl copytrace_brdf/run_memory_copy_stats.csv=r05_example_brdf_memory_copy_stats.csv \
     copytrace_blend/run_memory_copy_stats.csv=r05_example_blend_memory_copy_stats.csv copytrace_brdf/run_kernel_stats.csv=r05_example_brdf_kernel_stats.csv \
     copytrace_blend/run_kernel_stats.csv=r05_example_blend_kernel_stats.csv

@@ -967,16 +967,19 @@ static bool launch_down(const float *large, float *small, int64_t planes, int h_
     // 37.6 / 37.2 / 39.3 / 39.4 / 42.1 / 40.0 / 40.1 / 42.7 | 34.2 / 32.4 / 32.3 / 32.3 / 34.2 / 34.4 / 34.3 / 39.2 | 35.1 / 33.8 / 33.9 / 33.9 / 35.6 / 37.8 / 37.8 / 46.1
     // (tools/resize_down_probe.py; the strip kernel: 45.6 | 36.4, and 185 for the two passes the 19 taps of an 8 x down-scale fell to).  64 bytes per
     // lane (16 lines per load instruction instead of 8), 3 or 7 rows in flight, 4 or 8 rows per turn: level or 2-8 % slower; non-temporal loads:
-    // 1.4-1.8 x slower (a lane's two 16-byte loads of a row are two instructions on the same lines).  These shapes -- one 3-plane 4096^2 map, 201 MB -- sit in
-    // the 256 MB memory-side cache between launches; with EIGHT planes (537 MB, nothing survives a launch) the same sweep reads 127.7 / 122.9 / 132.8 / 129.2 / 132.1
-    // at 1 536 / 2 048 / 3 072 / 4 096 / 6 144 waves for 2x (strip kernel 129.3), 103.6 / 101.5 / 106.7 / 104.3 / 106.1 for 4x (112.5), 99.2 / 95.9 / 101.2 / 101.8 / 104.8
-    // for 8x (two passes: 516): 0.68-0.71 of HBM, which is what plain (cached) loads stream at on this part (tools/membench.hip: read-only plain 5.6 TB/s,
-    // non-temporal 6.2); a map at a time is the caller's shape (MaterialBase.resize), so the rule is the 3-plane optimum.
+    // 1.4-1.8 x slower (a lane's two 16-byte loads of a row are two instructions on the same lines).
+    // These shapes -- one 3-plane 4096^2 map, 201 MB -- sit in the 256 MB memory-side cache between launches, and only cached (plain) loads find them there.
+    // A large side that cannot (EIGHT planes, 537 MB: nothing survives a launch) reads 122.4 / 117.6 us at 1 536 / 2 048 waves for 2x (strip kernel 128), 123.0 / 112.3
+    // for 4x (118), 99 / 96 for 8x (two passes: 516) -- 0.64-0.71 of HBM, what cached loads stream at on this part (tools/membench.hip: read-only plain 5.6 TB/s,
+    // non-temporal 6.2).  There the lanes own 16 bytes of a row instead (4 / S columns: every line is touched by ONE instruction), loaded non-temporally,
+    // three rows in flight: 111.8 (0.75) | 108.4 (0.66); on the 3-plane shapes that form costs 36.8 -> 50 | 32.0 -> 46 (it streams past the memory-side cache).
     if ((S != 2 && S != 4 && S != 8) || w_small % 4 != 0 || w_small < 8 || h_small < 2) return false;
     if (((reinterpret_cast<uintptr_t>(large) | reinterpret_cast<uintptr_t>(small)) & 15u) != 0) return false;
-    const int cols = 8 / S, R = S == 2 ? 4 : 2;                  // columns of the small side per lane; its rows per turn of the kernel's loop
+    const bool streams = (int64_t)planes * h_small * w_small * S * S * 4 > (256ll << 20);      // the large side does not fit the memory-side cache
+    const bool narrow = streams && S < 8;                        // 16 bytes of a row per lane, non-temporal loads
+    const int cols = (narrow ? 4 : 8) / S, R = S == 2 ? 4 : 2;   // columns of the small side per lane; its rows per turn of the kernel's loop
     const int64_t groups_x = (w_small + 64 * cols - 1) / (64 * cols);
-    int64_t bands = 1536 / (planes * groups_x);
+    int64_t bands = (streams ? 2048 : 1536) / (planes * groups_x);
     bands = bands < 1 ? 1 : bands;
     int64_t band_rows = (h_small + bands - 1) / bands;
     band_rows = (band_rows + R - 1) / R * R;
@@ -985,6 +988,7 @@ static bool launch_down(const float *large, float *small, int64_t planes, int h_
     if (n_groups > INT32_MAX) return false;
     const uint32_t mapped = (uint32_t)((pairs / 8) * 8 * groups_x);      // the (plane, band) pairs dealt to the XCDs by eights
     auto fn = S == 2 ? resize_down_kernel<2, 4, 4, 1> : (S == 4 ? resize_down_kernel<4, 2, 2, 1> : resize_down_kernel<8, 2, 1, 1>);
+    if (narrow) fn = S == 2 ? resize_down_kernel<2, 4, 2, 3, true> : resize_down_kernel<4, 2, 1, 3, true>;
     hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, large, small, h_small, w_small, (int)groups_x, (int)bands, (int)band_rows, mapped, taps);
     return true;
 }

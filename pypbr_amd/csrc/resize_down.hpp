@@ -30,7 +30,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 
 struct DownTaps { float wi[16], wl[16], wr[16]; };       // K = 2 S normalised weights of an interior output, of output 0, of the last output; zero where the window is clipped
 
-template <int S, int R, int C, int D>
+template <int S, int R, int C, int D, bool NT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void resize_down_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_out, int w_out,
                                                                                              int groups_x, int bands, int band_rows, uint32_t mapped, const DownTaps t) {
     constexpr int K = 2 * S, H = S / 2, N = C * S;       // taps per axis, halo columns either side, input columns a lane owns (C output columns)
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
             const float *row = sp + (int64_t)yi * w_in;
 #pragma unroll
             for (int q = 0; q < N / 4; ++q) {
-                const lf4 a = *reinterpret_cast<const lf4 *>(row + 4 * q);      // cached: the two loads of a 32-byte run of a lane are two instructions
+                const lf4 a = NT ? __builtin_nontemporal_load(reinterpret_cast<const lf4 *>(row + 4 * q)) : *reinterpret_cast<const lf4 *>(row + 4 * q);      // cached: the two loads of a 32-byte run of a lane are two instructions
                 v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
             }
             if (extra) {

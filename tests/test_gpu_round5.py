@@ -593,6 +593,15 @@ def test_whole_factor_downscale_register_kernel_equals_the_strip_kernel_and_aten
                     assert (fast - other).abs().max().item() <= 1e-6, (S, planes, ho, wo)
                 ref = torch.nn.functional.interpolate(x[None], size=(ho, wo), mode="bilinear", align_corners=False, antialias=True)[0]
                 assert (fast.cpu() - ref).abs().max().item() <= 2e-6, (S, planes, ho, wo)
+        # a large side beyond the 256 MB memory-side cache: lanes of 16 bytes per row, non-temporal loads (S = 2, 4) -- the same sums
+        big = torch.rand(5, 4096, 4096, device="cuda")
+        for S in (2, 4, 8):
+            lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 1)
+            fast = F.resize(big, (4096 // S, 4096 // S))
+            lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 0)
+            other = F.resize(big, (4096 // S, 4096 // S))
+            assert torch.equal(fast, other) if S < 8 else (fast - other).abs().max().item() <= 1e-6, S
+        del big, fast, other
         # an input of infinities and NaNs stays where it is: taps outside a clipped window are never multiplied (0 x inf)
         x = torch.rand(1, 64, 64, generator=g)
         x[0, 0, 0] = float("inf"); x[0, 63, 63] = float("-inf"); x[0, 31, 0] = float("nan")

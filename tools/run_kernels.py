@@ -245,8 +245,11 @@ if want("resize"):
         if planes == 8:
             del a
             a = torch.rand(8, S, S, device=DEV, generator=g)
-        for (ho, wo), aa, kern in (((S // 2, S // 2), True, "resize_down_kernel<2, 4, 4, 1>"), ((S // 4, S // 4), True, "resize_down_kernel<4, 2, 2, 1>"),
-                                   ((S // 8, S // 8), True, "resize_down_kernel<8, 2, 1, 1>"), ((1365, 1365), True, "resize_strip_kernel<false, false>"),
+        # (8 planes: lanes of 16 bytes per row and non-temporal loads for 2x and 4x -- resize.hip: launch_down)
+        k2, k4 = ("resize_down_kernel<2, 4, 4, 1, false>", "resize_down_kernel<4, 2, 2, 1, false>") if planes == 3 else \
+                 ("resize_down_kernel<2, 4, 2, 3, true>", "resize_down_kernel<4, 2, 1, 3, true>")
+        for (ho, wo), aa, kern in (((S // 2, S // 2), True, k2), ((S // 4, S // 4), True, k4),
+                                   ((S // 8, S // 8), True, "resize_down_kernel<8, 2, 1, 1, false>"), ((1365, 1365), True, "resize_strip_kernel<false, false>"),
                                    ((S * 3 // 2, S * 3 // 2), False, "resize_up2_kernel<8>")):
             if planes == 8 and ho > S:
                 continue
@@ -297,14 +300,14 @@ if want("resize_bwd"):
     report("resize backward 3 x 2048^2 gradient -> 4096^2 (gradient of a 2x down-scale: 3 planes of 2048^2 in, 3 of 4096^2 out)", "resize_backward_gather_kernel<8, 8, true>", 12 * (ho * ho + PX), us,
            whole_call_us=round(us, 1))
     del gout, gin, ws
-    # gradient of a 2x up-scale: a whole factor -> the band walk of resize_down.hpp with the transposed two-tap weights (round 5).  SIX planes, so that the launch
-    # is told from the forward 2x down-scale of the `resize` case (same kernel, same shape otherwise) by its grid
+    # gradient of a 2x up-scale: a whole factor -> the band walk of resize_down.hpp with the transposed two-tap weights (round 5).  SIX planes (403 MB of upstream
+    # gradient: the streaming form), so that the launch is told from the forward down-scales of the `resize` case (same kernel) by its grid
     gout = torch.rand(6, S, S, device=DEV, generator=g)
     gin = torch.empty(6, ho, ho, device=DEV)
     ws = torch.empty(max(1, lib.pbr_resize_backward_workspace_bytes(6, ho, ho, S, S) // 4), device=DEV)
     us = timed(lambda: lib.pbr_resize_bilinear_backward(gout.data_ptr(), gin.data_ptr(), 6, ho, ho, S, S, 1, ws.data_ptr(), stream))
     report("resize backward 6 x 4096^2 gradient -> 2048^2 (gradient of a 2x up-scale: 6 planes of 4096^2 in, 6 of 2048^2 out): the band walk with the transposed two-tap weights",
-           "resize_down_kernel<2, 4, 4, 1>", 24 * (ho * ho + PX), us)
+           "resize_down_kernel<2, 4, 2, 3, true>", 24 * (ho * ho + PX), us)
     del gout, gin, ws
     # gradient of a 1.5x up-scale (no whole factor): the two-tap transpose
     hu = S * 3 // 2

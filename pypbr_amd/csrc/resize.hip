@@ -914,8 +914,8 @@ static AxisFilter make_filter(int n_in, int n_out, bool antialias) {
 }
 
 // The three weight vectors of resize_down_kernel for the whole factor S (antialiased): an axis of 16 outputs has them all -- output 0 (window clipped
-// on the left), output 5 (whole window) and output 15 (clipped on the right) -- and they do not depend on the axis' length: with n_in = S n_out every
-// term of tap_window / tap_weight is a small dyadic number, exact in float.  Formed with the strip kernel's statements (phase 0 of resize_strip_kernel).
+// on the left), output 5 (whole window) and output 15 (clipped on the right) -- and they do not depend on the axis' length: with n_in = S n_out the
+// tap positions relative to the window are small whole and half numbers, exact in float, whatever the output's index.  Formed with the strip kernel's statements (phase 0 of resize_strip_kernel).
 static DownTaps down_taps(int S) {
     DownTaps t;
     const AxisFilter f = make_filter(16 * S, 16, true);
@@ -973,11 +973,12 @@ static bool launch_down(const float *large, float *small, int64_t planes, int h_
     // for 4x (118), 99 / 96 for 8x (two passes: 516) -- 0.64-0.71 of HBM, what cached loads stream at on this part (tools/membench.hip: read-only plain 5.6 TB/s,
     // non-temporal 6.2).  There the lanes own 16 bytes of a row instead (4 / S columns: every line is touched by ONE instruction), loaded non-temporally,
     // three rows in flight: 111.8 (0.75) | 108.4 (0.66); on the 3-plane shapes that form costs 36.8 -> 50 | 32.0 -> 46 (it streams past the memory-side cache).
-    if ((S != 2 && S != 4 && S != 8) || w_small % 4 != 0 || w_small < 8 || h_small < 2) return false;
+    if (S < 2 || S > 8 || w_small % 4 != 0 || w_small < 8 || h_small < 2) return false;
     if (((reinterpret_cast<uintptr_t>(large) | reinterpret_cast<uintptr_t>(small)) & 15u) != 0) return false;
     const bool streams = (int64_t)planes * h_small * w_small * S * S * 4 > (256ll << 20);      // the large side does not fit the memory-side cache
-    const bool narrow = streams && S < 8;                        // 16 bytes of a row per lane, non-temporal loads
-    const int cols = (narrow ? 4 : 8) / S, R = S == 2 ? 4 : 2;   // columns of the small side per lane; its rows per turn of the kernel's loop
+    const bool narrow = streams && (S == 2 || S == 4);           // 16 bytes of a row per lane, non-temporal loads
+    // columns of the small side per lane: 32 bytes of the large side's row where S divides 8, else the fewest whose S-fold is a whole number of 16-byte pieces
+    const int cols = narrow ? 4 / S : (8 % S == 0 ? 8 / S : (S == 6 ? 2 : 4)), R = S == 2 ? 4 : 2;      // ... and its rows per turn of the kernel's loop
     const int64_t groups_x = (w_small + 64 * cols - 1) / (64 * cols);
     int64_t bands = (streams ? 2048 : 1536) / (planes * groups_x);
     bands = bands < 1 ? 1 : bands;
@@ -987,7 +988,16 @@ static bool launch_down(const float *large, float *small, int64_t planes, int h_
     const int64_t pairs = planes * bands, n_groups = pairs * groups_x;
     if (n_groups > INT32_MAX) return false;
     const uint32_t mapped = (uint32_t)((pairs / 8) * 8 * groups_x);      // the (plane, band) pairs dealt to the XCDs by eights
-    auto fn = S == 2 ? resize_down_kernel<2, 4, 4, 1> : (S == 4 ? resize_down_kernel<4, 2, 2, 1> : resize_down_kernel<8, 2, 1, 1>);
+    void (*fn)(const float *, float *, int, int, int, int, int, uint32_t, const DownTaps) = nullptr;
+    switch (S) {
+        case 2: fn = resize_down_kernel<2, 4, 4, 1>; break;
+        case 3: fn = resize_down_kernel<3, 2, 4, 1>; break;
+        case 4: fn = resize_down_kernel<4, 2, 2, 1>; break;
+        case 5: fn = resize_down_kernel<5, 2, 4, 1>; break;
+        case 6: fn = resize_down_kernel<6, 2, 2, 1>; break;
+        case 7: fn = resize_down_kernel<7, 2, 4, 1>; break;
+        default: fn = resize_down_kernel<8, 2, 1, 1>; break;
+    }
     if (narrow) fn = S == 2 ? resize_down_kernel<2, 4, 2, 3, true> : resize_down_kernel<4, 2, 1, 3, true>;
     hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, large, small, h_small, w_small, (int)groups_x, (int)bands, (int)band_rows, mapped, taps);
     return true;
@@ -1032,9 +1042,9 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
             return e == hipSuccess ? PBR_OK : 1000 + (int)e;
         }
     }
-    if (g_resize_up2 && antialias && h_in % h_out == 0 && w_in % w_out == 0 && h_in / h_out == w_in / w_out && h_in / h_out <= 8 &&
+    if (g_resize_up2 && antialias && h_in % h_out == 0 && w_in % w_out == 0 && h_in / h_out == w_in / w_out && h_in / h_out >= 2 && h_in / h_out <= 8 &&
         launch_down(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_out, w_out, h_in / h_out, down_taps(h_in / h_out), s)) {
-        // a whole factor 2 | 4 | 8 on both axes: the register form (resize_down.hpp)
+        // a whole factor 2 ... 8 on both axes: the register form (resize_down.hpp)
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? PBR_OK : 1000 + (int)e;
     }
@@ -1106,9 +1116,11 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
     int *lo_y = reinterpret_cast<int *>(wx + (size_t)kBwdMaxTaps * w_in), *cnt_y = lo_y + h_in, *lo_x = cnt_y + h_in, *cnt_x = lo_x + w_in;
     const auto g = static_cast<const float *>(grad_out);
     float *gi = static_cast<float *>(grad_in);
-    if (g_resize_up2 && h_out % h_in == 0 && w_out % w_in == 0 && h_out / h_in == w_out / w_in && h_out / h_in >= 2 && h_out / h_in <= 8 &&
-        launch_down(g, gi, planes, h_in, w_in, h_out / h_in, up_transpose_taps(h_out / h_in), s)) {
-        // gradient of an up-scale by a whole factor 2 | 4 | 8: the band walk of resize_down.hpp over the upstream gradient, with the transposed two-tap weights.
+    const int up = h_out % h_in == 0 && w_out % w_in == 0 && h_out / h_in == w_out / w_in ? h_out / h_in : 0;
+    if (g_resize_up2 && (up == 2 || up == 4 || up == 8) && launch_down(g, gi, planes, h_in, w_in, up, up_transpose_taps(up), s)) {
+        // gradient of an up-scale by 2 | 4 | 8: the band walk of resize_down.hpp over the upstream gradient, with the transposed two-tap weights.  (Powers of two only:
+        // the forward's scale 1 / S is then exact and its two weights are the same for every S-th output; with 1/3, 1/5 ... the forward's fp32 tap positions drift
+        // by ~6e-8 of the index, and the exact transpose of THAT is what the two-tap transpose below forms.)
         // 3 x 4096^2 upstream -> 2048^2: see DESIGN.md section 3 (the two-tap transpose below: 44.4 us, 1.17 x the bytes -- its lanes' windows overlap past L2)
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? PBR_OK : 1000 + (int)e;

@@ -1,17 +1,17 @@
-// resize_down.hpp -- antialiased down-scale by a whole factor S = 2 | 4 | 8 on both axes, registers only (round 5).
+// resize_down.hpp -- antialiased down-scale by a whole factor S = 2 ... 8 on both axes, registers only (round 5).
 //
 // What MaterialBase.resize (/root/reference/pypbr/materials/base.py:490-504) does to a 1024^2 / 2048^2 / 4096^2 texture on its way to
 // 512^2: torchvision's resize = F.interpolate(mode="bilinear", antialias=True), i.e. ATen's separable triangle filter of support S
 // (resize.hip's header has the rule).  With n_in = S n_out the tap pattern is the same for every output index: output i reads the
-// K = 2 S inputs S i - S/2 ... S i + 3 S/2 - 1 with the weights (j + 0.5) / S^2 mirrored around the middle; only the FIRST and the LAST
-// output of an axis have a clipped window (S/2 taps fall outside; the rest are normalised by their own sum).  So there is nothing to
+// K = 2 S inputs S i - floor(S/2) ... S i - floor(S/2) + 2 S - 1 with the triangle's weights (an odd S: the last one is 0); only the FIRST and the LAST
+// output of an axis have a clipped window (the taps that fall outside are dropped; the rest are normalised by their own sum).  So there is nothing to
 // look up: the three weight vectors (interior, first, last -- the same for both axes) are formed on the host with resize.hip's own
 // tap_window / tap_weight arithmetic and travel as kernel arguments, i.e. in scalar registers.
 //
-// A lane owns C (4; 2 for S = 8) consecutive output columns of a BAND of output rows and walks down the band.  It streams the input rows that feed
+// A lane owns C consecutive output columns of a BAND of output rows and walks down the band.  It streams the input rows that feed
 // them: C S / 4 16-byte loads per row (its own C S input columns, contiguous), the height pass as fma into the accumulators of the one or two output rows a input row
 // feeds (taps in ascending order, as resize_strip_kernel forms them: bit-identical results).  When an output row's height pass is
-// complete, the S/2 height-reduced columns either side of the lane's own come from the neighbouring lanes (one cross-lane move each;
+// complete, the floor(S/2) | ceil(S/2) height-reduced columns left | right of the lane's own come from the neighbouring lanes (one cross-lane move each;
 // the wave's first and last lane load the neighbouring 16-byte piece themselves and run the height pass on it too), and the width pass
 // is C K fma out of registers.  No tables, no LDS strip, no barriers: the strip kernel's three barrier-separated phases per tile kept
 // it at 0.70-0.74 of HBM on these shapes with every byte read once.
@@ -33,9 +33,9 @@ struct DownTaps { float wi[16], wl[16], wr[16]; };       // K = 2 S normalised w
 template <int S, int R, int C, int D, bool NT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void resize_down_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_out, int w_out,
                                                                                              int groups_x, int bands, int band_rows, uint32_t mapped, const DownTaps t) {
-    constexpr int K = 2 * S, H = S / 2, N = C * S;       // taps per axis, halo columns either side, input columns a lane owns (C output columns)
+    constexpr int K = 2 * S, HL = S / 2, HR = S - HL, N = C * S;      // taps per axis, halo columns left / right, input columns a lane owns (C output columns)
     constexpr int CH = S * R;                            // input rows per turn of the loop: R output rows
-    static_assert(N % 4 == 0 && H <= 4 && K <= 16, "whole 16-byte pieces; the halo comes out of one piece");
+    static_assert(N % 4 == 0 && HR <= 4 && K <= 16, "whole 16-byte pieces; the halo comes out of one piece");
     static_assert(R % 2 == 0 && CH % (D + 1) == 0, "the accumulator pair and the ring of rows come round with every turn of the loop");
     typedef float lf4 __attribute__((ext_vector_type(4)));
     // (plane, band) pairs are dealt to the XCDs round-robin, ALL column strips of a pair to the same XCD: neighbouring strips share the 128-byte
@@ -66,10 +66,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
 #pragma unroll
     for (int k = 0; k < N + 4; ++k) acc[0][k] = acc[1][k] = 0.0f;
     float *dp = dst + (int64_t)plane * h_out * w_out + x0;
-    // The band's input rows S yb - H ... S (yb + rows_here) + H - 1, `rel` counted from the first.  Row rel feeds output row rel / S (its taps
+    // The band's input rows S yb - HL ... S (yb + rows_here) + HR - 1, `rel` counted from the first.  Row rel feeds output row rel / S (its taps
     // 0 .. S - 1) and the one before (taps S .. 2 S - 1), which is complete with the last of them.  Rows are loaded D rows ahead of their use into a
     // ring of D + 1 rows; every array index is a compile-time constant (static_for over one turn of the loop), so the arrays are registers.
-    const int row0 = S * yb - H, n_rows = S * rows_here + S;
+    const int row0 = S * yb - HL, n_rows = S * rows_here + S;
     float ring[D + 1][N + 4];
     auto load_row = [&](auto ic, int base) {             // relative row base + i into slot i mod (D + 1)
         constexpr int i = decltype(ic)::value;
@@ -111,14 +111,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
             if constexpr (j == S - 1) {
                 // ---- output row y - 1 is reduced down the rows: halo columns, width pass, store
                 const float *a = a_old;
-                float e[N + 2 * H];                      // height-reduced columns S x0 - H ... S x0 + N + H - 1
+                float e[N + HL + HR];                    // height-reduced columns S x0 - HL ... S x0 + N + HR - 1
 #pragma unroll
-                for (int k = 0; k < N; ++k) e[H + k] = a[k];
+                for (int k = 0; k < N; ++k) e[HL + k] = a[k];
 #pragma unroll
-                for (int k = 0; k < H; ++k) {
-                    const float from_left = __shfl_up(a[N - H + k], 1, 64), from_right = __shfl_down(a[k], 1, 64);
-                    e[k] = lane == 0 ? a[N + 4 - H + k] : from_left;                          // the extra piece is zero where the row starts
-                    e[H + N + k] = lane == 63 ? a[N + k] : (at_right ? 0.0f : from_right);
+                for (int k = 0; k < HL; ++k) {
+                    const float from_left = __shfl_up(a[N - HL + k], 1, 64);
+                    e[k] = lane == 0 ? a[N + 4 - HL + k] : from_left;                         // the extra piece is zero where the row starts
+                }
+#pragma unroll
+                for (int k = 0; k < HR; ++k) {
+                    const float from_right = __shfl_down(a[k], 1, 64);
+                    e[HL + N + k] = lane == 63 ? a[N + k] : (at_right ? 0.0f : from_right);
                 }
                 float o[C];
 #pragma unroll

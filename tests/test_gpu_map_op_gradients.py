@@ -189,12 +189,14 @@ def test_resize_gradient_forms_agree_with_float64_autograd(shape, size, antialia
 
 @pytest.mark.parametrize("shape,size", [((64, 96), (128, 192)), ((37, 53), (80, 97)), ((50, 70), (50, 70)), ((33, 130), (97, 131)), ((40, 44), (57, 128)),
                                         ((9, 16), (10, 16)), ((128, 256), (300, 700)), ((5, 4), (11, 16)), ((24, 250), (31, 251)),
-                                        ((2, 8), (4, 16)), ((13, 260), (52, 1040)), ((16, 8), (128, 64)), ((301, 512), (602, 1024)), ((64, 96), (256, 384))])
+                                        ((2, 8), (4, 16)), ((13, 260), (52, 1040)), ((16, 8), (128, 64)), ((301, 512), (602, 1024)), ((64, 96), (256, 384)),
+                                        ((37, 12), (111, 36)), ((20, 64), (100, 320)), ((9, 40), (54, 240)), ((6, 8), (42, 56))])
 def test_gradient_of_an_upscale_in_registers(shape, size):
     """pbr_resize_bilinear_backward for up-scales (round 4: resize_up2_backward_kernel, the register-only transpose of the two-tap forward):
     against float64 autograd of F.interpolate, and within rounding of the table-driven strip kernel it replaces on these shapes; exact 2x,
     ragged and unaligned widths, 1:1, widths whose last lane is partial, a 3x up-scale across (16 upstream columns per lane).  Whole factors 2 | 4 | 8
-    on both axes (round 5): the band walk of csrc/resize_down.hpp with the transposed two-tap weights -- the smallest shape, ragged bands, idle lanes."""
+    on both axes (round 5): the band walk of csrc/resize_down.hpp with the transposed two-tap weights -- the smallest shape, ragged bands, idle lanes
+    (3 x, 5 x, 6 x, 7 x stay with the two-tap transpose: their fp32 tap positions are not periodic)."""
     from pypbr_amd import _native as N
     lib = N.lib()
     g = torch.Generator().manual_seed(15)
@@ -215,7 +217,7 @@ def test_gradient_of_an_upscale_in_registers(shape, size):
     (TF.interpolate(x, size=(ho, wo), mode="bilinear", align_corners=False, antialias=True)[0] * gout.cpu().double()).sum().backward()
     assert bool(torch.isfinite(got[1]).all())
     assert (got[1].cpu().double() - x.grad[0]).abs().max().item() <= 3e-5      # float64 tap positions against float32 ones: the bound of the strip kernel's test
-    assert (got[1] - got[0]).abs().max().item() <= 2e-6
+    assert (got[1] - got[0]).abs().max().item() <= 2e-6 * max(1.0, float(got[0].abs().max()))      # (a gradient element of an S x up-scale sums S^2 upstream values)
     # the whole of an upstream gradient of ones comes back: every output's weights sum to one
     ones = torch.ones(3, ho, wo, device="cuda")
     gin = torch.empty(3, h, w, device="cuda")

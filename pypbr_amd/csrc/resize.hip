@@ -292,7 +292,9 @@ __device__ __forceinline__ void width_to_global_quads(const float *mid, float *d
 // upstream gradient.  Phase 0 copies the tile's slices of the tables into the same LDS arrays; phases 1 and 2 do not change.
 struct StripTables { const int *lo_x, *cnt_x, *lo_y, *cnt_y; const float *w_x, *w_y; int nx, ny, h_src; const float *band; const int *col_base; const float *col_w; };
 
-template <bool TABLES, bool QUADS>
+// WIDE: the instantiation for 17 ... 36 taps per axis (down-scales of 6.5x ... 16.5x; round 5) -- its own kernel, so that its registers (36 pieces of a column in
+// flight: 190 VGPRs) are not the occupancy of the common one (89).
+template <bool TABLES, bool QUADS, bool WIDE = false>
 __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_out,
                                                            int w_out, int w_in, StripGeom tg, AxisFilter fw, AxisFilter fh, StripTables tb) {
     extern __shared__ float lds[];
@@ -387,7 +389,10 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
     const int cols_left = w_in - xbase;
 #define PBR_HEIGHT(KK) (tg.vec_ok ? height_from_global<KK, true>(sp, mid, wy, yo, yn, tg.toh, oh, in_cols, tg.pitch, w_in, cols_left, tid) \
                                   : height_from_global<KK, false>(sp, mid, wy, yo, yn, tg.toh, oh, in_cols, tg.pitch, w_in, cols_left, tid))
-    if (ky <= 4) PBR_HEIGHT(4);
+    if (WIDE) {
+        if (ky <= 24) PBR_HEIGHT(24);
+        else PBR_HEIGHT(36);
+    } else if (ky <= 4) PBR_HEIGHT(4);
     else if (ky <= 6) PBR_HEIGHT(6);
     else if (ky <= 8) PBR_HEIGHT(8);
     else if (ky <= 12) PBR_HEIGHT(12);
@@ -399,7 +404,10 @@ __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restri
     const bool quads = QUADS && (ow & 3) == 0;
 #define PBR_WIDTH(KK) (quads ? width_to_global_quads<KK>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid) \
                              : width_to_global<KK>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid))
-    if (kx <= 4) PBR_WIDTH(4);
+    if (WIDE) {
+        if (kx <= 24) width_to_global<24>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid);
+        else width_to_global<36>(mid, dp, wx, xo, xn, tg.pitch, oh, ow, oy0, ox0, w_out, tid);
+    } else if (kx <= 4) PBR_WIDTH(4);
     else if (kx <= 6) PBR_WIDTH(6);
     else if (kx <= 8) PBR_WIDTH(8);
     else if (kx <= 12) PBR_WIDTH(12);
@@ -1048,14 +1056,14 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? PBR_OK : 1000 + (int)e;
     }
-    {   // strip form: tap tables + the height-reduced strip [toh][pitch] of a toh x 64 output tile in LDS, up to 16 taps per axis
+    {   // strip form: tap tables + the height-reduced strip [toh][pitch] of a toh x 64 output tile in LDS, up to 36 taps per axis
         const int kx = (int)(2.0f * fw.support) + 3, ky = (int)(2.0f * fh.support) + 3;      // taps per output: xsize <= 2 support + 2
         const bool vec_ok = w_in % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
-        if (kx <= 16 && ky <= 16) {
+        if (kx <= 36 && ky <= 36) {                                                           // (round 5: 16 -> 36 taps, i.e. down-scales up to 16.5x keep the one-kernel form)
             const int cols_max = (int)(kTileW * fw.scale + 2.0f * fw.support) + 4 + 3;       // + 3: window start aligned down to 16 bytes
             const int pitch = ((cols_max + 3) & ~3) + 4;                                      // + 4 floats: rows land on different banks
             auto lds_for = [&](int rows) {
-                return sizeof(float) * ((size_t)kx * kTileW + (size_t)ky * rows + 2 * (kTileW + rows) + (size_t)rows * pitch + 16);
+                return sizeof(float) * ((size_t)kx * kTileW + (size_t)ky * rows + 2 * (kTileW + rows) + (size_t)rows * pitch + 40);      // slack: a window's taps are read up to the template's K
             };
             // Output rows per workgroup: as many as keep the workgroup's LDS within 24 KiB (6 workgroups per CU).  More rows
             // amortise the tables and re-read fewer input rows; more resident workgroups overlap the phases
@@ -1076,7 +1084,7 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
                 if (chunk > n_tiles / 8) chunk = n_tiles / 8;
                 const int quads = 0;      // 16-byte stores in the forward width pass: 62.7 against 54.0 us with them (4096^2 -> 2048^2): never
                 const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0), quads};
-                auto strip = resize_strip_kernel<false, false>;
+                auto strip = kx <= 16 && ky <= 16 ? resize_strip_kernel<false, false> : resize_strip_kernel<false, false, true>;
                 hipLaunchKernelGGL(strip, dim3((unsigned)(planes * tx * tyy)), dim3(256), lds, s,
                                    static_cast<const float *>(src), static_cast<float *>(dst), (int)h_out, (int)w_out, (int)w_in, tg, fw, fh, StripTables{});
                 const hipError_t e = hipGetLastError();
@@ -1084,7 +1092,7 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
             }
         }
     }
-    // more than 16 taps per axis (down-scales beyond ~6.5x): two passes through `workspace`
+    // more than 36 taps per axis (down-scales beyond ~16.5x): two passes through `workspace`
     hipLaunchKernelGGL(resize_width_kernel, dim3(stream_grid(planes * h_in * w_out)), dim3(256), 0, s,
                        static_cast<const float *>(src), tmp, planes * h_in, (int)w_out, fw);
     hipLaunchKernelGGL(resize_height_kernel, dim3(stream_grid(planes * h_out * w_out)), dim3(256), 0, s,

@@ -752,11 +752,12 @@ def test_fused_tile_gradients_and_material_api():
 
 
 @pytest.mark.parametrize("shape,size", [((3, 300, 500), (37, 41)), ((2, 257, 130), (100, 64)), ((1, 40, 60), (90, 100)),
-                                        ((2, 3, 96, 200), (48, 100)), ((1, 2000, 70), (9, 70)), ((1, 33, 1000), (33, 130))])
+                                        ((2, 3, 96, 200), (48, 100)), ((1, 2000, 70), (9, 70)), ((1, 33, 1000), (33, 130)),
+                                        ((1, 1024, 1024), (64, 64)), ((2, 700, 1100), (64, 100)), ((1, 640, 1024), (37, 64)), ((3, 512, 2048), (40, 128))])
 @pytest.mark.parametrize("antialias", [True, False])
 def test_resize_fused_and_two_pass_forms_against_aten(shape, size, antialias):
-    """Both schedules of pbr_resize_bilinear (LDS-fused tile kernel; two-pass for extreme down-scales) against the
-    op the reference ends up in: torch.nn.functional.interpolate(bilinear, align_corners=False, antialias) on CPU."""
+    """The schedules of pbr_resize_bilinear (LDS-fused tile kernel, its instantiation for 17 ... 36 taps -- down-scales of 6.5x ... 16.5x, round 5 --, two
+    passes beyond) against the op the reference ends up in: torch.nn.functional.interpolate(bilinear, align_corners=False, antialias) on CPU."""
     from pypbr_amd import functional as F
     g = torch.Generator().manual_seed(sum(shape) + size[0])
     x = torch.rand(*shape, generator=g)

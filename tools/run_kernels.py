@@ -239,7 +239,7 @@ if want("resize"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)
     # whole factors 2 ... 8 down (what resize(512) of a 1024^2 ... 4096^2 texture is): the register-only band walk (round 5); any other down-scale: the
-    # strip kernel (4096 -> 1365: 3.0007x); up-scales: the two-tap register kernel.  THREE planes = one map, 201 MB: between launches it stays in the 256 MB
+    # strip kernel (4096 -> 1365: 3.0007x; 4096 -> 400: 10.24x, its 17 ... 36-tap instantiation); up-scales: the two-tap register kernel.  THREE planes = one map, 201 MB: between launches it stays in the 256 MB
     # memory-side cache; EIGHT planes (537 MB) is the same kernel with nothing left from the launch before -- the HBM figure.
     for planes in (3, 8):
         if planes == 8:
@@ -249,7 +249,8 @@ if want("resize"):
         k2, k4 = ("resize_down_kernel<2, 4, 4, 1, false>", "resize_down_kernel<4, 2, 2, 1, false>") if planes == 3 else \
                  ("resize_down_kernel<2, 4, 2, 3, true>", "resize_down_kernel<4, 2, 1, 3, true>")
         for (ho, wo), aa, kern in (((S // 2, S // 2), True, k2), ((S // 4, S // 4), True, k4),
-                                   ((S // 8, S // 8), True, "resize_down_kernel<8, 2, 1, 1, false>"), ((1365, 1365), True, "resize_strip_kernel<false, false>"),
+                                   ((S // 8, S // 8), True, "resize_down_kernel<8, 2, 1, 1, false>"), ((1365, 1365), True, "resize_strip_kernel<false, false, false>"),
+                                   ((400, 400), True, "resize_strip_kernel<false, false, true>"),
                                    ((S * 3 // 2, S * 3 // 2), False, "resize_up2_kernel<8>")):
             if planes == 8 and ho > S:
                 continue

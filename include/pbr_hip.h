@@ -84,7 +84,7 @@ enum {
     PBR_TUNE_BWD_RUN = 8,               /* rounds of the streamed backward kernel for fp16 maps with one light (-1 = rule, 0 = the one-tile kernels) */
     PBR_TUNE_MSE_STREAM = 9,            /* rendering-loss step for fp16 maps with one light: the streamed kernel (1, default) or the one-tile kernels (0) */
     PBR_TUNE_TILE_REPEAT = 10,          /* tiled maps: every texel loaded and decoded once and evaluated / differentiated at all its repeats (-1 = rule: on, 0 = wrap-around addressing, gradients folded by a second kernel) */
-    PBR_TUNE_RESIZE_UP2 = 11,           /* the register-only resize kernels -- two taps for up-scales on both axes, the band walk for whole factors 2 ... 8 down (1, default) -- or the strip kernels (0) */
+    PBR_TUNE_RESIZE_UP2 = 11,           /* the register-only resize kernels -- two taps for up-scales on both axes, the band walk for whole factors 2 ... 8 | 16 down (1, default) -- or the strip kernels (0) */
     PBR_TUNE_COUNT = 12
 };
 /* (ABI 6 carried 23 knobs; the 11 whose experiments are closed -- workgroup interleave, 16-byte streamed backward, the resize

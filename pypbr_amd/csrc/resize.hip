@@ -935,10 +935,10 @@ static DownTaps down_taps(int S) {
         tap_window(f, i, xmin, n, center);
         for (int j = 0; j < n; ++j) wsum += tap_weight(f, j, xmin, center);
         const float inv = wsum != 0.0f ? 1.0f / wsum : 0.0f;
-        for (int j = 0; j < 16; ++j) into[s][j] = 0.0f;
+        for (int j = 0; j < 32; ++j) into[s][j] = 0.0f;
         const int shift = xmin - (S * i - S / 2);            // the window's first tap among the K = 2 S of an unclipped one
         for (int j = 0; j < n; ++j)
-            if (shift + j >= 0 && shift + j < 16) into[s][shift + j] = tap_weight(f, j, xmin, center) * inv;
+            if (shift + j >= 0 && shift + j < 32) into[s][shift + j] = tap_weight(f, j, xmin, center) * inv;
     }
     return t;
 }
@@ -953,7 +953,7 @@ static DownTaps up_transpose_taps(int S) {
     float *const into[3] = {t.wi, t.wl, t.wr};
     for (int s = 0; s < 3; ++s) {
         const int k = which[s];
-        for (int j = 0; j < 16; ++j) into[s][j] = 0.0f;
+        for (int j = 0; j < 32; ++j) into[s][j] = 0.0f;
         for (int j = 0; j < 2 * S; ++j) {
             const int i = S * k - S / 2 + j;
             if (i < 0 || i >= 16 * S) continue;
@@ -981,12 +981,12 @@ static bool launch_down(const float *large, float *small, int64_t planes, int h_
     // for 4x (118), 99 / 96 for 8x (two passes: 516) -- 0.64-0.71 of HBM, what cached loads stream at on this part (tools/membench.hip: read-only plain 5.6 TB/s,
     // non-temporal 6.2).  There the lanes own 16 bytes of a row instead (4 / S columns: every line is touched by ONE instruction), loaded non-temporally,
     // three rows in flight: 111.8 (0.75) | 108.4 (0.66); on the 3-plane shapes that form costs 36.8 -> 50 | 32.0 -> 46 (it streams past the memory-side cache).
-    if (S < 2 || S > 8 || w_small % 4 != 0 || w_small < 8 || h_small < 2) return false;
+    if (S < 2 || (S > 8 && S != 16) || w_small % 4 != 0 || w_small < 8 || h_small < 2) return false;
     if (((reinterpret_cast<uintptr_t>(large) | reinterpret_cast<uintptr_t>(small)) & 15u) != 0) return false;
     const bool streams = (int64_t)planes * h_small * w_small * S * S * 4 > (256ll << 20);      // the large side does not fit the memory-side cache
     const bool narrow = streams && (S == 2 || S == 4);           // 16 bytes of a row per lane, non-temporal loads
     // columns of the small side per lane: 32 bytes of the large side's row where S divides 8, else the fewest whose S-fold is a whole number of 16-byte pieces
-    const int cols = narrow ? 4 / S : (8 % S == 0 ? 8 / S : (S == 6 ? 2 : 4)), R = S == 2 ? 4 : 2;      // ... and its rows per turn of the kernel's loop
+    const int cols = narrow ? 4 / S : (S == 16 ? 1 : (8 % S == 0 ? 8 / S : (S == 6 ? 2 : 4))), R = S == 2 ? 4 : 2;      // ... and its rows per turn of the kernel's loop (16 x: 64 bytes per lane)
     const int64_t groups_x = (w_small + 64 * cols - 1) / (64 * cols);
     int64_t bands = (streams ? 2048 : 1536) / (planes * groups_x);
     bands = bands < 1 ? 1 : bands;
@@ -1004,7 +1004,8 @@ static bool launch_down(const float *large, float *small, int64_t planes, int h_
         case 5: fn = resize_down_kernel<5, 2, 4, 1>; break;
         case 6: fn = resize_down_kernel<6, 2, 2, 1>; break;
         case 7: fn = resize_down_kernel<7, 2, 4, 1>; break;
-        default: fn = resize_down_kernel<8, 2, 1, 1>; break;
+        case 8: fn = resize_down_kernel<8, 2, 1, 1>; break;
+        default: fn = resize_down_kernel<16, 2, 1, 1>; break;
     }
     if (narrow) fn = S == 2 ? resize_down_kernel<2, 4, 2, 3, true> : resize_down_kernel<4, 2, 1, 3, true>;
     hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, large, small, h_small, w_small, (int)groups_x, (int)bands, (int)band_rows, mapped, taps);
@@ -1050,9 +1051,9 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
             return e == hipSuccess ? PBR_OK : 1000 + (int)e;
         }
     }
-    if (g_resize_up2 && antialias && h_in % h_out == 0 && w_in % w_out == 0 && h_in / h_out == w_in / w_out && h_in / h_out >= 2 && h_in / h_out <= 8 &&
+    if (g_resize_up2 && antialias && h_in % h_out == 0 && w_in % w_out == 0 && h_in / h_out == w_in / w_out && h_in / h_out >= 2 && h_in / h_out <= 16 &&
         launch_down(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_out, w_out, h_in / h_out, down_taps(h_in / h_out), s)) {
-        // a whole factor 2 ... 8 on both axes: the register form (resize_down.hpp)
+        // a whole factor 2 ... 8 | 16 on both axes: the register form (resize_down.hpp)
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? PBR_OK : 1000 + (int)e;
     }
@@ -1125,7 +1126,7 @@ int pbr_resize_bilinear_backward(const void *grad_out, void *grad_in, int64_t pl
     const auto g = static_cast<const float *>(grad_out);
     float *gi = static_cast<float *>(grad_in);
     const int up = h_out % h_in == 0 && w_out % w_in == 0 && h_out / h_in == w_out / w_in ? h_out / h_in : 0;
-    if (g_resize_up2 && (up == 2 || up == 4 || up == 8) && launch_down(g, gi, planes, h_in, w_in, up, up_transpose_taps(up), s)) {
+    if (g_resize_up2 && (up == 2 || up == 4 || up == 8 || up == 16) && launch_down(g, gi, planes, h_in, w_in, up, up_transpose_taps(up), s)) {
         // gradient of an up-scale by 2 | 4 | 8: the band walk of resize_down.hpp over the upstream gradient, with the transposed two-tap weights.  (Powers of two only:
         // the forward's scale 1 / S is then exact and its two weights are the same for every S-th output; with 1/3, 1/5 ... the forward's fp32 tap positions drift
         // by ~6e-8 of the index, and the exact transpose of THAT is what the two-tap transpose below forms.)

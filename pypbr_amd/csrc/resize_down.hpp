@@ -1,4 +1,4 @@
-// resize_down.hpp -- antialiased down-scale by a whole factor S = 2 ... 8 on both axes, registers only (round 5).
+// resize_down.hpp -- antialiased down-scale by a whole factor S = 2 ... 8 | 16 on both axes, registers only (round 5).
 //
 // What MaterialBase.resize (/root/reference/pypbr/materials/base.py:490-504) does to a 1024^2 / 2048^2 / 4096^2 texture on its way to
 // 512^2: torchvision's resize = F.interpolate(mode="bilinear", antialias=True), i.e. ATen's separable triangle filter of support S
@@ -28,14 +28,15 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-struct DownTaps { float wi[16], wl[16], wr[16]; };       // K = 2 S normalised weights of an interior output, of output 0, of the last output; zero where the window is clipped
+struct DownTaps { float wi[32], wl[32], wr[32]; };       // K = 2 S normalised weights of an interior output, of output 0, of the last output; zero where the window is clipped
 
 template <int S, int R, int C, int D, bool NT = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void resize_down_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_out, int w_out,
                                                                                              int groups_x, int bands, int band_rows, uint32_t mapped, const DownTaps t) {
     constexpr int K = 2 * S, HL = S / 2, HR = S - HL, N = C * S;      // taps per axis, halo columns left / right, input columns a lane owns (C output columns)
+    constexpr int E = (HR + 3) / 4, X = 4 * E;           // 16-byte pieces (columns) the wave's first / last lane loads beside its own: the halo no neighbour lane holds
     constexpr int CH = S * R;                            // input rows per turn of the loop: R output rows
-    static_assert(N % 4 == 0 && HR <= 4 && K <= 16, "whole 16-byte pieces; the halo comes out of one piece");
+    static_assert(N % 4 == 0 && HR <= N && K <= 32, "whole 16-byte pieces; the halo comes out of the neighbouring lane's own columns");
     static_assert(R % 2 == 0 && CH % (D + 1) == 0, "the accumulator pair and the ring of rows come round with every turn of the loop");
     typedef float lf4 __attribute__((ext_vector_type(4)));
     // (plane, band) pairs are dealt to the XCDs round-robin, ALL column strips of a pair to the same XCD: neighbouring strips share the 128-byte
@@ -54,29 +55,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
     const int w_in = S * w_out, h_in = S * h_out;
     const bool at_left = x0 == 0, at_right = x0 + C >= w_out;
     const float *sp = src + (int64_t)plane * h_in * w_in + S * x0;
-    // the wave's first / last lane: the 16-byte piece left / right of its own columns (inside the row)
+    // the wave's first / last lane: the E 16-byte pieces left / right of its own columns (inside the row)
     const bool extra = (lane == 0 && !at_left) || (lane == 63 && !at_right);
-    const float *ep = sp + (lane == 0 ? -4 : N);
+    const float *ep = sp + (lane == 0 ? -X : N);
     // column weights: the inner columns of a lane are interior outputs always; column 0 is output 0 in the row's first lane, column C - 1 the last output in its last
     float wc0[K], wcl[K];
 #pragma unroll
     for (int j = 0; j < K; ++j) { wc0[j] = at_left ? t.wl[j] : (C == 1 && at_right ? t.wr[j] : t.wi[j]); wcl[j] = at_right ? t.wr[j] : t.wi[j]; }     // (C = 1: the lane's one column is both)
 
-    float acc[2][N + 4];                                 // the two output rows in flight: own columns, then the first / last lane's extra piece
+    float acc[2][N + X];                                 // the two output rows in flight: own columns, then the first / last lane's extra pieces
 #pragma unroll
-    for (int k = 0; k < N + 4; ++k) acc[0][k] = acc[1][k] = 0.0f;
+    for (int k = 0; k < N + X; ++k) acc[0][k] = acc[1][k] = 0.0f;
     float *dp = dst + (int64_t)plane * h_out * w_out + x0;
     // The band's input rows S yb - HL ... S (yb + rows_here) + HR - 1, `rel` counted from the first.  Row rel feeds output row rel / S (its taps
     // 0 .. S - 1) and the one before (taps S .. 2 S - 1), which is complete with the last of them.  Rows are loaded D rows ahead of their use into a
     // ring of D + 1 rows; every array index is a compile-time constant (static_for over one turn of the loop), so the arrays are registers.
     const int row0 = S * yb - HL, n_rows = S * rows_here + S;
-    float ring[D + 1][N + 4];
+    float ring[D + 1][N + X];
     auto load_row = [&](auto ic, int base) {             // relative row base + i into slot i mod (D + 1)
         constexpr int i = decltype(ic)::value;
         const int rel = base + i, yi = row0 + rel;
         float *v = ring[i % (D + 1)];
 #pragma unroll
-        for (int k = 0; k < N + 4; ++k) v[k] = 0.0f;
+        for (int k = 0; k < N + X; ++k) v[k] = 0.0f;
         if (rel < n_rows && yi >= 0 && yi < h_in) {      // wave-uniform; rows outside the image are taps outside a clipped window (weight 0, value 0)
             const float *row = sp + (int64_t)yi * w_in;
 #pragma unroll
@@ -85,8 +86,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
                 v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
             }
             if (extra) {
-                const lf4 a = *reinterpret_cast<const lf4 *>(ep + (int64_t)yi * w_in);
-                v[N] = a.x; v[N + 1] = a.y; v[N + 2] = a.z; v[N + 3] = a.w;
+#pragma unroll
+                for (int q = 0; q < E; ++q) {
+                    const lf4 a = *reinterpret_cast<const lf4 *>(ep + (int64_t)yi * w_in + 4 * q);
+                    v[N + 4 * q] = a.x; v[N + 4 * q + 1] = a.y; v[N + 4 * q + 2] = a.z; v[N + 4 * q + 3] = a.w;
+                }
             }
         }
     };
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
             const float w_new = y == 0 ? t.wl[j] : (y == h_out - 1 ? t.wr[j] : t.wi[j]);
             const float w_old = y == 1 ? t.wl[j + S] : (y == h_out ? t.wr[j + S] : t.wi[j + S]);
 #pragma unroll
-            for (int k = 0; k < N + 4; ++k) {
+            for (int k = 0; k < N + X; ++k) {
                 a_new[k] = fmaf(w_new, v[k], j == 0 ? 0.0f : a_new[k]);
                 a_old[k] = fmaf(w_old, v[k], a_old[k]);
                 asm volatile("" : "+v"(a_new[k]), "+v"(a_old[k]));      // formed HERE: otherwise the chains sink to the row's end and all K input rows stay live
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
 #pragma unroll
                 for (int k = 0; k < HL; ++k) {
                     const float from_left = __shfl_up(a[N - HL + k], 1, 64);
-                    e[k] = lane == 0 ? a[N + 4 - HL + k] : from_left;                         // the extra piece is zero where the row starts
+                    e[k] = lane == 0 ? a[N + X - HL + k] : from_left;                         // the extra pieces are zero where the row starts
                 }
 #pragma unroll
                 for (int k = 0; k < HR; ++k) {

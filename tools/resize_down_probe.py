@@ -40,7 +40,7 @@ def timed(fn, reps=50, warm=5):
 
 g = torch.Generator(device=DEV).manual_seed(5)
 bad = 0
-for S in (2, 3, 4, 5, 6, 7, 8):
+for S in (2, 3, 4, 5, 6, 7, 8, 16):
     for planes, ho, wo in ((1, 2, 8), (3, 8, 256), (2, 13, 260), (1, 64, 1028), (3, 37, 12), (1, 512, 512), (2, 100, 2048 // S // 4 * 4)):
         a = torch.rand(planes, S * ho, S * wo, device=DEV, generator=g) * 2 - 0.5
         new, strip = resize(a, ho, wo, 1), resize(a, ho, wo, 0)
@@ -61,7 +61,7 @@ P = int(os.environ.get("PLANES", "3"))
 a = torch.rand(P, Sz, Sz, device=DEV, generator=g)
 variants = [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]
 for rnd in range(2):
-    for S in (2, 4, 8):
+    for S in (2, 4, 8, 16):
         ho = Sz // S
         out = torch.empty(P, ho, ho, device=DEV)
         ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(P, Sz, ho) // 4), device=DEV)

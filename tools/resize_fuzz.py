@@ -20,7 +20,7 @@ def run(cases=200, seed=0, verbose=True):
         planes = rng.choice([1, 3, 4])
         aa = rng.random() < 0.6
         if rng.random() < 0.25:                                          # a whole factor on both axes: the register-only down-scale (resize_down.hpp)
-            S = rng.choice([2, 3, 4, 5, 6, 7, 8])
+            S = rng.choice([2, 3, 4, 5, 6, 7, 8, 16])
             ho, wo = rng.choice([2, 3, 8, 13, 64, 100]), rng.choice([8, 12, 64, 260, 512])
             h, w, aa = S * ho, S * wo, True
         if aa and 1 in (ho, wo) and (h, w) != (ho, wo):

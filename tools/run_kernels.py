@@ -238,7 +238,7 @@ if want("map_ops"):
 if want("resize"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)
-    # whole factors 2 ... 8 down (what resize(512) of a 1024^2 ... 4096^2 texture is): the register-only band walk (round 5); any other down-scale: the
+    # whole factors 2 ... 8 | 16 down (what resize(512) of a 1024^2 ... 4096^2 texture is): the register-only band walk (round 5); any other down-scale: the
     # strip kernel (4096 -> 1365: 3.0007x; 4096 -> 400: 10.24x, its 17 ... 36-tap instantiation); up-scales: the two-tap register kernel.  THREE planes = one map, 201 MB: between launches it stays in the 256 MB
     # memory-side cache; EIGHT planes (537 MB) is the same kernel with nothing left from the launch before -- the HBM figure.
     for planes in (3, 8):

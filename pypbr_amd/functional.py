@@ -820,7 +820,7 @@ class _MseStepFn(torch.autograd.Function):
     # step host-bound (150 us at 256^2 against 23 us captured into a graph); the descriptor is a third of that.
     _PLANS = collections.OrderedDict()
     _PLANS_MAX = 8
-    _LOCK = threading.Lock()                                # a kept descriptor is refilled and launched under it (ctypes calls release the GIL)
+    _LOCK = threading.Lock()                                # guards _PLANS itself; a kept descriptor is refilled and launched under ITS entry's lock
 
     @staticmethod
     def _kept_plan(maps, kwargs):
@@ -847,35 +847,58 @@ class _MseStepFn(torch.autograd.Function):
         hit = _MseStepFn._PLANS.get(key)
         if hit is not None:
             if all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(hit[1], maps)):
-                if hit[2] != vals:
-                    try:
-                        refill_parameters(hit[0].desc, *vals)
-                    except ValueError:                      # another number of lights: another kernel
-                        del _MseStepFn._PLANS[key]
-                        return None, key, vals
-                    hit[2] = vals
                 _MseStepFn._PLANS.move_to_end(key)
-                return hit[0], key, vals
+                return hit, key, vals                       # [plan, weak maps, parameter values, the entry's lock]: refilled by the caller under that lock
             del _MseStepFn._PLANS[key]
         return None, key, vals
 
     @staticmethod
     def forward(ctx, albedo, normal, roughness, metallic, specular, target, kwargs):
         maps = (albedo, normal, roughness, metallic, specular)
+        # The process-wide lock covers the cache lookup and refill only: plan construction, the target's upload, the workspace
+        # and the launch run outside it, under the ENTRY's own lock -- threads that drive different materials / GPUs do not serialise.
         with _MseStepFn._LOCK:
-            plan, key, vals = _MseStepFn._kept_plan(maps, kwargs)
+            hit, key, vals = _MseStepFn._kept_plan(maps, kwargs)
+        plan = entry_lock = None
+        if hit is not None:
+            if hit[3].acquire(False):
+                entry_lock, plan = hit[3], hit[0]
+            else:                                           # another thread is launching through this very plan: build a private one, keep nothing
+                key = None
+        kept = plan is not None
+        try:
+            if kept and hit[2] != vals:                     # light / view VALUES are re-read every call
+                try:
+                    refill_parameters(plan.desc, *vals)
+                    hit[2] = vals
+                except ValueError:                          # another number of lights: another kernel, another plan
+                    with _MseStepFn._LOCK:
+                        if _MseStepFn._PLANS.get(key) is hit:
+                            del _MseStepFn._PLANS[key]
+                    plan, kept = None, False
             if plan is None:
                 plan = plan_cook_torrance(*[None if t is None else t.detach() for t in maps], **kwargs)
                 plan.out = None                                 # the colour is never written
-                if key is not None and plan._param_block is None and all(p is None or p.data_ptr() == t.data_ptr() for p, t in zip(plan._keep, maps)):
-                    plan._keep = ()                             # the cache holds the maps weakly (their owner keeps them alive while it wants the plan)
-                    _MseStepFn._PLANS[key] = [plan, tuple(None if t is None else weakref.ref(t) for t in maps), vals]
-                    while len(_MseStepFn._PLANS) > _MseStepFn._PLANS_MAX:
-                        _MseStepFn._PLANS.popitem(last=False)
             d = plan.desc
             present = (True, bool(d.normal.data), True, bool(d.metallic.data), bool(d.specular.data))
             wanted = [bool(ctx.needs_input_grad[i] and present[i] and maps[i] is not None) for i in range(5)]
-            loss, bufs = _MseStepFn._launch(plan, target, maps, wanted)
+            try:
+                loss, bufs = _MseStepFn._launch(plan, target, maps, wanted)
+            except _StepNotServed:
+                if kept:                                        # never again through the cache: the fallback must not meet it on every call
+                    with _MseStepFn._LOCK:
+                        _MseStepFn._PLANS.pop(key, None)
+                raise
+            if (not kept and key is not None and plan._param_block is None
+                    and all(p is None or p.data_ptr() == t.data_ptr() for p, t in zip(plan._keep, maps))):
+                plan._keep = ()                                 # the cache holds the maps weakly (their owner keeps them alive while it wants the plan)
+                with _MseStepFn._LOCK:                          # cached only AFTER a launch that was served
+                    _MseStepFn._PLANS[key] = [plan, tuple(None if t is None else weakref.ref(t) for t in maps), vals, threading.Lock()]
+                    while len(_MseStepFn._PLANS) > _MseStepFn._PLANS_MAX:
+                        _MseStepFn._PLANS.popitem(last=False)
+        finally:
+            if entry_lock is not None:
+                entry_lock.release()
         # the plan (descriptor + strong references to every map) is NOT kept: a second backward rebuilds it from the saved tensors
         ctx.kwargs, ctx.wanted, ctx.grads = kwargs, wanted, bufs
         ctx.present = [t is not None for t in maps]

@@ -154,9 +154,14 @@ class CookTorranceBRDF(BRDFModel):
                 return None
         key = (self.light_type, light_size, bool(return_srgb), bool(material.albedo_is_srgb), bool(getattr(material, "specular_is_srgb", True)),
                d.get("_lazy_tile", (1, 1)), "metallic" in store and store["metallic"] is not None,
-               tuple((id(t), t.data_ptr(), t.shape) if t is not None else None for t in maps))
+               tuple((id(t), t.data_ptr(), t.shape, t.dtype, t.stride()) if t is not None else None for t in maps))
         hit = d.get("_plan_cache")
-        if hit is None or hit[0] != key:
+        if hit is not None and (hit[0] != key or not all((r is None and t is None) or (r is not None and r() is t) for r, t in zip(hit[5], maps))):
+            # the store moved on (resize, an assignment, to(), a conversion): the kept descriptor describes maps that are no longer the
+            # material's.  It holds them only weakly, so nothing was pinned; drop it now rather than at the next refill.
+            d.pop("_plan_cache", None)
+            hit = None
+        if hit is None:
             if d.get("_plan_seen") != key:                    # first sighting of this call: a material whose maps are new tensors every step
                 d["_plan_seen"] = key                         # (a training loop) never pays for a plan it would not use twice
                 return None
@@ -268,8 +273,16 @@ class CookTorranceBRDF(BRDFModel):
                                          specular_is_srgb=specular_is_srgb, return_srgb=return_srgb, tile=getattr(material, "lazy_tile", (1, 1)))
             with torch.cuda.device(plan.device):
                 color = plan.launch()
-            material.__dict__["_plan_cache"] = [reuse_key, plan, (self._host_values(view_dir), self._host_values(light_dir_or_position),
-                                                                 self._host_values(light_intensity)), threading.Lock(), tuple(plan.out.shape)]
+            four = (maps[0], maps[1], maps[2], maps[3] if maps[3] is not None else maps[4])       # _reuse_plan's order
+            held = tuple(t for t in four if t is not None)
+            if plan._param_block is None and all(p is None or any(p.data_ptr() == t.data_ptr() for t in held) for p in plan._keep):
+                # the plan points INTO the material's own tensors (no staging copy): the material keeps them alive for as long as it wants
+                # this plan, so the plan holds them weakly -- a resize() / to() / assignment that replaces the store frees the old maps at
+                # once instead of leaving e.g. 537 MB of 4K maps pinned behind a descriptor nobody will launch again
+                plan._keep = ()
+                material.__dict__["_plan_cache"] = [reuse_key, plan, (self._host_values(view_dir), self._host_values(light_dir_or_position),
+                                                                     self._host_values(light_intensity)), threading.Lock(), tuple(plan.out.shape),
+                                                    tuple(None if t is None else weakref.ref(t) for t in four)]
             plan.out = None                                   # the result belongs to the caller; later calls bring their own
             return color
         color = F_.cook_torrance(

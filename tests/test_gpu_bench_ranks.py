@@ -91,13 +91,25 @@ def test_named_configs_on_one_gpu_at_reduced_size(config, flags, kernel, bpp):
         assert line["per_gpu_share_of_8"]["batch"] == 2 and line["per_gpu_share_of_8"]["kernel_us"] > 0
 
 
+def _cpu_baseline_is_well_formed(cb):
+    """STRUCTURE only -- no assertion here depends on how fast the host is (VERDICT r5 #1b): a record either holds measured legs with
+    a value taken from them, or says which legs it skipped."""
+    assert cb["kind"] == "port" and cb["cpu_model"] and cb["unit"] == "Mpixels/s"
+    assert 1 <= cb["usable_cores"] <= cb["host_cores"]
+    assert {e["threads"] for e in cb["table"]} <= {1, cb["usable_cores"]}
+    if cb["table"]:
+        assert all(e["ms"] >= 0 and e["size"] > 0 for e in cb["table"])
+        assert cb["value"] in {e["Mpixels_per_s"] for e in cb["table"]} and cb["cores"] in (1, cb["usable_cores"])
+    else:
+        assert cb["value"] is None and "skipped" in cb["sample"]
+
+
 def test_named_config_parity_leg_at_reduced_size():
     """The checker's legs of configs 3 and 5 (converted / 16 lights on fp16 maps): bands of the timed output against both oracles."""
     for config, flags in ((3, ("--batch", 2, "--size", 256)), (5, ("--batch", 2, "--size", 256))):
         line, _ = _bench("--config", config, *flags, "--steps", 3, "--warmup", 1, "--settle", 1, "--cpu-budget", 2)
         assert line["parity"]["max_abs_err_vs_fp64_oracle"] <= 2e-6, (config, line["parity"])
-        cb = line["cpu_baseline"]
-        assert cb["kind"] == "port" and cb["cpu_model"] and {e["threads"] for e in cb["table"]} >= {1} and cb["value"] > 0
+        _cpu_baseline_is_well_formed(line["cpu_baseline"])
 
 
 def test_rccl_runs_under_the_suite_with_one_rank():
@@ -130,8 +142,7 @@ def test_plain_single_gpu_line_forms_an_rccl_group_of_one():
 def test_cpu_baseline_runs_on_the_cores_the_process_has():
     """VERDICT r3 next #5: no leg with more threads than the process may use; an exhausted budget gives a skipped record, not a lost line."""
     line, _ = _bench("--size", 256, "--steps", 3, "--warmup", 1, "--settle", 1, "--cpu-budget", 6)
-    cb = line["cpu_baseline"]
-    assert cb["usable_cores"] <= cb["host_cores"] and {e["threads"] for e in cb["table"]} <= {1, cb["usable_cores"]}
-    assert cb["value"] > 0 and cb["cores"] in (1, cb["usable_cores"])
+    _cpu_baseline_is_well_formed(line["cpu_baseline"])
+    assert line["cpu_baseline"]["table"], "a positive budget always measures the first leg, however slow the host"
     none, _ = _bench("--size", 256, "--steps", 3, "--warmup", 1, "--settle", 1, "--cpu-budget", 0)
     assert none["cpu_baseline"]["value"] is None and none["cpu_baseline"]["table"] == [] and "skipped" in none["cpu_baseline"]["sample"]

@@ -4,8 +4,6 @@
   * NaN texels: what the build returns where the reference returns NaN (stated, not hidden);
   * BASELINE.json configs[0] at the size it names: a CPU-resident 256x256 BasecolorMetallicMaterial loaded from the reference's
     PNG fixtures, resize((256, 256)), point light, through CookTorranceBRDF (SURVEY.md 8c anchors 0.492009 / 0.256256)."""
-import os
-import warnings
 
 import numpy as np
 import pytest
@@ -131,26 +129,3 @@ def test_nan_texels_what_the_build_returns_where_the_reference_returns_nan(golde
         print(f"\n[edge/nan texels/{lk}] reference NaN at {int(ref_nan.sum())} values; build there: "
               f"{int(np.isnan(there).sum())} NaN, {int(np.isfinite(there).sum())} finite in [{np.nanmin(there):.3f}, {np.nanmax(there):.3f}]")
         assert np.isfinite(there).all() and there.min() >= 0.0 and there.max() <= 1.0
-
-
-@pytest.mark.parametrize("folder,mean", [("tiles", 0.492009), ("rocks", 0.256256)])
-def test_config0_256x256_cpu_material_from_the_reference_png_fixtures(golden, folder, mean):
-    """BASELINE.json configs[0]: single 256x256 BasecolorMetallicMaterial, point light, the examples/example_brdf.py path with
-    the material left on the CPU (uploaded, evaluated on the device, returned on the CPU)."""
-    from pypbr_amd.io import load_material_from_folder
-    from pypbr_amd.models import CookTorranceBRDF
-    z = golden("edge")
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        material = load_material_from_folder(os.path.join(os.path.dirname(__file__), "golden", folder), preferred_workflow="metallic")
-    assert material.device.type == "cpu"
-    material.resize((256, 256))
-    assert material.size == (256, 256) and material.albedo.device.type == "cpu"
-    out = CookTorranceBRDF(light_type="point")(material, torch.tensor([0.0, 0.0, 1.0]), torch.tensor([0.1, 0.1, 1.0]),
-                                               torch.tensor([1.0, 1.0, 1.0]), 1.0)
-    assert out.shape == (3, 256, 256) and out.device.type == "cpu"
-    want = z[f"out_{folder}256"]
-    err = np.abs(out.numpy() - want)
-    print(f"\n[config0/{folder}256] max|hip-ref32| = {err.max():.2e}, mean {float(out.double().mean()):.6f} (reference {float(z[f'mean_{folder}256']):.6f})")
-    assert err.max() <= TOL
-    assert abs(float(out.double().mean()) - mean) <= 1e-6 and abs(float(out.double().mean()) - float(z[f"mean_{folder}256"])) <= 1e-6

@@ -1,10 +1,9 @@
-"""BASELINE.json configs 3, 4 (per-GPU share) and 5 (per-GPU share) at their FULL shapes: one launch over the whole
-batch -- the XCD-run workgroup order, 8-pixel lanes and rows = B * H arithmetic at sizes the small tests never reach --
-then sampled parity: crops / row bands (first and LAST material, first and LAST rows included) against the ATen
+"""Full shapes beyond the five BASELINE.json configurations (those: tests/test_gpu_00_baseline_configs.py): offsets past 2^31
+elements, the streamed backward, the loss step and tiled gradients at sizes the small tests never reach -- with
+sampled parity: crops / row bands (first and LAST material, first and LAST rows included) against the ATen
 restatement of the reference (fp32, pinned bit-equal to it) and against float64 (the plain-C oracle), under the
 criterion of tests/test_gpu_parity.py.  Plus the size-independent properties: finite, in [0,1], a second launch is
 bit-identical, a band evaluated on its own equals the rows of the full launch."""
-import math
 
 import numpy as np
 import pytest
@@ -42,95 +41,6 @@ def _check_properties(F, out, maps, kw):
     again = F.cook_torrance(*maps, **kw)
     assert torch.equal(out, again)
     del again
-
-
-@pytest.mark.parametrize("quirk", [True, False])
-def test_config3_full_shape_64x2048_converted_directional(quirk):
-    """B=64 2048^2, directional light, sRGB decode + metallic -> diffuse/specular conversion fused, both settings of
-    the upstream specular_is_srgb quirk."""
-    from pypbr_amd import functional as F
-    B, H, W = 64, 2048, 2048
-    maps = _maps(B, H, W, seed=3)
-    view, light, inten = [0.0, 0.0, 1.0], [0.3, -0.2, 1.0], [1.0, 1.0, 1.0]
-    kw = dict(view_dir=view, light=light, light_intensity=inten, light_type="directional",
-              convert_to_diffuse_specular=True, specular_is_srgb=quirk)
-    plan = F.plan_cook_torrance(*maps, **kw)
-    assert plan.kernel_name == "ct_directional_converted_f32_f32_v4"
-    out = plan.launch()
-    _check_properties(F, out, maps, kw)
-    worst32 = worst64 = 0.0
-    n_hip = n_ref = 0
-    for b, y0, x0 in _windows(B, H, W, 128, 128, 10, seed=33):
-        crop = [t[b, :, y0:y0 + 128, x0:x0 + 128].cpu() for t in maps]
-        got = out[b, :, y0:y0 + 128, x0:x0 + 128].cpu().numpy()
-        okw = dict(view=torch.tensor(view), light=torch.tensor(light), intensity=torch.tensor(inten), light_type="directional")
-        ref32 = O.cook_torrance_converted(*crop, quirk_specular_srgb=quirk, **okw).numpy()
-        ref64 = O.cook_torrance_converted(*[t.double() for t in crop], quirk_specular_srgb=quirk,
-                                          **{k: (v.double() if isinstance(v, torch.Tensor) else v) for k, v in okw.items()}).numpy()
-        rep = parity_report(got, ref32, ref64, crop[2].numpy(), what=("cfg3", quirk, b, y0, x0))
-        worst32, worst64 = max(worst32, rep["max32"]), max(worst64, rep["max64"])
-        n_hip, n_ref = n_hip + rep["n_hip"], n_ref + rep["n_ref"]
-    print(f"\n[cfg3 64x2048^2 converted directional quirk={quirk}] 10 crops of 128^2: max|hip-ref32| {worst32:.2e}, "
-          f"max|hip-ref64| {worst64:.2e}, values > 1e-5 vs ref32: {n_hip} (reference vs its own float64: {n_ref})")
-
-
-def test_config4_share_full_shape_64x1024_point():
-    """Per-GPU share of config 4: B=64 1024^2, point light.  Row bands span the full width (the point-light grid)."""
-    from pypbr_amd import functional as F
-    B, H, W = 64, 1024, 1024
-    maps = _maps(B, H, W, seed=4)
-    view, light, inten = [0.0, 0.0, 1.0], [0.1, 0.1, 1.0], [1.0, 1.0, 1.0]
-    kw = dict(view_dir=view, light=light, light_intensity=inten, light_type="point", light_size=1.0)
-    out = F.cook_torrance(*maps, **kw)
-    _check_properties(F, out, maps, kw)
-    band = F.cook_torrance(*[t[B - 1:, :, H - 24:] for t in maps], y_offset=H - 24, height_total=H, **kw)
-    assert torch.equal(band, out[B - 1:, :, H - 24:])
-    worst32 = worst64 = 0.0
-    n_hip = n_ref = 0
-    for b, y0, _ in _windows(B, H, W, 16, W, 10, seed=44):
-        crop = [t[b, :, y0:y0 + 16].cpu() for t in maps]
-        got = out[b, :, y0:y0 + 16].cpu().numpy()
-        ref32 = O.cook_torrance(*crop, None, view=torch.tensor(view), light=torch.tensor(light), intensity=torch.tensor(inten),
-                                light_type="point", light_size=1.0, y_offset=y0, H_total=H).numpy()
-        ref64 = C.render(*[t.numpy() for t in crop], None, view=view, lights=light, intensities=inten, light_type="point",
-                         light_size=1.0, y_offset=y0, H_total=H, dtype=np.float64)
-        rep = parity_report(got, ref32, ref64, crop[2].numpy(), what=("cfg4", b, y0))
-        worst32, worst64 = max(worst32, rep["max32"]), max(worst64, rep["max64"])
-        n_hip, n_ref = n_hip + rep["n_hip"], n_ref + rep["n_ref"]
-    print(f"\n[cfg4 share 64x1024^2 point] 10 bands of 16 rows: max|hip-ref32| {worst32:.2e}, max|hip-ref64| {worst64:.2e}, "
-          f"values > 1e-5 vs ref32: {n_hip} (reference vs its own float64: {n_ref})")
-
-
-@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16])
-def test_config5_share_full_shape_4x4096_16_lights_fp16(out_dtype):
-    """Per-GPU share of config 5: B=4 4096^2, 16 point lights on a ring, fp16 maps, fp32 accumulate.  The oracle is fed
-    the exact fp32 up-casts of the fp16 maps (SURVEY.md 8c iii); an fp16 result adds its own rounding (<= 4.9e-4)."""
-    from pypbr_amd import functional as F
-    B, H, W = 4, 4096, 4096
-    maps = _maps(B, H, W, seed=5, dtype=torch.float16)
-    lights = [[math.cos(2 * math.pi * i / 16), math.sin(2 * math.pi * i / 16), 1.0] for i in range(16)]
-    inten = [[1.0 / 16] * 3] * 16
-    view = [0.0, 0.0, 1.0]
-    kw = dict(view_dir=view, light=lights, light_intensity=inten, light_type="point", light_size=1.0, out_dtype=out_dtype)
-    out = F.cook_torrance(*maps, **kw)
-    assert out.dtype == out_dtype
-    _check_properties(F, out, maps, kw)
-    worst32 = worst64 = 0.0
-    for b, y0, _ in _windows(B, H, W, 4, W, 8, seed=55):
-        crop = [t[b, :, y0:y0 + 4].float().cpu() for t in maps]
-        got = out[b, :, y0:y0 + 4].float().cpu().numpy()
-        ref32 = O.cook_torrance_multi(*crop, None, lights=torch.tensor(lights), intensities=torch.tensor(inten), view=torch.tensor(view),
-                                      light_type="point", light_size=1.0, y_offset=y0, H_total=H).numpy()
-        ref64 = C.render(*[t.numpy() for t in crop], None, view=view, lights=lights, intensities=inten, light_type="point",
-                         light_size=1.0, y_offset=y0, H_total=H, dtype=np.float64)
-        if out_dtype == torch.float32:
-            rep = parity_report(got, ref32, ref64, crop[2].numpy(), what=("cfg5", b, y0))
-            worst32, worst64 = max(worst32, rep["max32"]), max(worst64, rep["max64"])
-        else:       # fp16 storage of the result: half an fp16 ulp below 1 on top of the fp32 criterion
-            e64 = np.abs(got.astype(np.float64) - ref64)
-            worst64 = max(worst64, float(e64.max()))
-            assert e64.max() <= 4.9e-4 + 2e-6, (b, y0, float(e64.max()))
-    print(f"\n[cfg5 share 4x4096^2 16 lights fp16 -> {out_dtype}] 8 bands of 4 rows: max|hip-ref32| {worst32:.2e}, max|hip-ref64| {worst64:.2e}")
 
 
 def test_offsets_beyond_2_to_31_elements():

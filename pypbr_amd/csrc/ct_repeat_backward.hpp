@@ -11,11 +11,16 @@
 // accumulators in the order pbr_fold_gradient adds them (repeat rows outer, repeat columns inner).  Map-sized gradients are
 // written once: 12 B per output pixel + 64 B per texel instead of 76 + 32 (fold reads) + 32/n^2 per output pixel.
 //
-// Same functions, same statements per position as backward_body_to: for fp32 maps under a POINT light the result is BIT-IDENTICAL to
-// pbr_cook_torrance_backward + pbr_fold_gradient (tests/test_gpu_round5.py); for fp16 maps the per-position gradients are summed
-// unrounded in fp32 and rounded once (the two-kernel form rounds every position's gradient to fp16 first).  Under a DIRECTIONAL light
+// Same functions per position as backward_body_to.  What differs from pbr_cook_torrance_backward + pbr_fold_gradient is the ORDER OF
+// SUMMATION, never a formula (round 6): the chain rule splits into a per-position part (light geometry, eval_light, backprop_light:
+// adjoints of kb / f0 / a2 / k / N.V / the unit normal) and a light-independent tail (bwd_tail) that is LINEAR in those adjoints with
+// coefficients that depend on the texel only.  The positions' adjoints are accumulated (backprop_light's fused multiply-adds, straight
+// into one PixelAdjoint) and the tail runs once per texel -- in round 5 the tail ran per position and the per-position gradients were
+// added (bit-identical to the two-kernel form, 45 packed instructions per position more; measured: DESIGN.md 3.2).  Equal to the
+// two-kernel form in real arithmetic and to fp32 rounding in practice (tests/test_gpu_round5.py: <= 4e-6 of the largest gradient;
+// both forms against float64 autograd through repeat()).  fp16 maps: the sum is rounded once.  Under a DIRECTIONAL light
 // every repeat evaluates to the same colour and the chain rule is linear in the upstream gradient: the repeats' upstream values are
-// summed first and the texel is differentiated once (equal to the two-kernel form to fp32 rounding, not to the bit).
+// summed first and the texel is differentiated once.
 //
 // With the MseLoss policy the upstream gradient is formed in the kernel from the target image (the rendering-loss step for tiled
 // maps: pbr_cook_torrance_mse_step lifts its "untiled" restriction through this kernel).
@@ -23,6 +28,7 @@
 // One packed pair (2 texels) per lane: the texel state that must stay live across the repeat loop (PixelTerms, colour slopes,
 // 8-10 accumulators) plus one position's working set is ~150 VGPRs per pair; two pairs would leave one wave per SIMD.
 #pragma once
+#include <type_traits>
 #include "ct_backward.hpp"
 
 namespace pbr {
@@ -150,7 +156,7 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
         }
     };
     float go[3][VEC] = {}, go_next[3][VEC] = {};
-    if (LIGHT == PBR_LIGHT_POINT || MULTI) load_upstream(0, go);        // (one directional light sums its positions in chunks, below)
+    // (a point light / several lights: the position loop below keeps its own running addresses; one directional light sums its positions in chunks)
 
     if (!a.has_normal) {
 #pragma unroll
@@ -216,89 +222,112 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
         backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
         bwd_tail<WF, R>(x, adj, V, acc_a, acc_n, acc_r, acc_m, acc_s);
     } else {
-        for (int k = 0; k < n_pos; ++k) {
-            if (k + 1 < n_pos) load_upstream(k + 1, go_next);                       // the next position's 12 B per pixel travel under this one's arithmetic
-            const int ry = k / a.rep_x, rx = k - ry * a.rep_x;
-            if (!in_band(ry)) {                                                     // a repeat outside this rank's band: nothing to add
-    #pragma unroll
-                for (int c = 0; c < 3; ++c)
-    #pragma unroll
-                    for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
-                continue;
-            }
-            float ys = 0.0f;
-            R xs[1] = {splat<R>(0.0f)};
-            if (LIGHT == PBR_LIGHT_POINT) {
-                ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, p.y + ry * a.H);
-                x_grid_w<R, 1, VEC>(a, a.out_W, p.x + rx * a.W, xs);
-            }
-            PixelAdjointT<R> adj;
-    #pragma unroll
+        // The position loop, written for the SCALAR unit as much as for the vector one (round 6).  With two waves per SIMD a wave's own
+        // scalar instructions are time its vector pipe idles unless the other wave happens to issue: the loop used to spend ~130 scalar
+        // instructions and ~15 branches per position on the upstream addresses (a division k / rep_x for this position and the next, a
+        // 64-bit product per channel, the scalar-base / 64-bit-lane choice tested per load) beside ~300 vector ones.  Now: ONE per-lane
+        // 64-bit address for the lane's place in the first repeat (channel 0), the channel planes and the repeat as a running SCALAR
+        // offset that is advanced by additions; (ry, rx) of this position and of the next as running counters; the point light's row
+        // coordinate once per repeat ROW.  (Measured: 151 -> 148 us alone; with the branches below and the tail hoisted 151 -> 138.)
+        const char *const lane_base = reinterpret_cast<const char *>(rb.gout) +
+            4 * (((int64_t)p.b * 3) * rb.gout_cs + ((int64_t)p.y - a.y_offset) * a.out_W + p.x);     // (b, channel 0, repeat (0,0)); below the band's first row for y < y_offset: never dereferenced there
+        const int64_t plane_bytes = 4 * rb.gout_cs;
+        const int64_t col_step = 4 * (int64_t)a.W, row_step = 4 * ((int64_t)a.H * a.out_W - (int64_t)(a.rep_x - 1) * a.W);
+        auto row_in_band = [&](int yrow) { const int yy = yrow - a.y_offset; return yy >= 0 && yy < a.H_total; };
+        auto fetch = [&](int64_t rep_bytes, float (&dst)[3][VEC]) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) Ld<float, VEC>::template load<true>(lane_base + (rep_bytes + c * plane_bytes), 0, dst[c]);
+        };
+        // the position in flight: loaded one iteration ahead
+        int n_ry = 0, n_rx = 0, n_yrow = p.y;
+        int64_t n_rep = 0;
+        if (row_in_band(n_yrow)) fetch(n_rep, go);
+        float ys = 0.0f;
+        PixelAdjointT<R> adj;                   // summed over the positions; the tail is applied once, behind the loop
+        auto clear_adjoint = [&]() {
+#pragma unroll
             for (int c = 0; c < 3; ++c) { adj.g_kb[c] = splat<R>(0.0f); adj.g_f0[c] = splat<R>(0.0f); }
             adj.g_a2 = adj.g_k = adj.g_ndv = splat<R>(0.0f);
             adj.g_n = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
-            if constexpr (MULTI) {
-                R g_col[3], sum[3] = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
-                for (int l = 0; l < a.n_lights; ++l) {          // pass 1: the summed colour decides the outer clamp / the encode's slope
-                    const LightU ll = light_of(a, l);
-                    LightEvalT<R> e;
-                    eval_light(x.pt, light_geom<LIGHT, R>(ll, V, xs[0], ys), ll.inten, e);
+        };
+        clear_adjoint();
+        // The output encode is a launch-wide flag: tested once, outside the loop (two copies of the loop) -- inside it was three scalar
+        // branches per position, and a branch costs a wave of a two-wave SIMD ~12 cycles (tools/valu_occupancy.hip).
+        auto positions = [&](auto srgb_tag) {
+        constexpr bool SRGB = decltype(srgb_tag)::value;
+        for (int k = 0; k < n_pos; ++k) {
+            const int ry = n_ry, rx = n_rx, yrow = n_yrow;
+            // advance to the next position and start its loads: they travel under this position's arithmetic
+            ++n_rx; n_rep += col_step;
+            if (n_rx == a.rep_x) { n_rx = 0; ++n_ry; n_yrow += a.H; n_rep += row_step - col_step; }
+            if (k + 1 < n_pos && row_in_band(n_yrow)) fetch(n_rep, go_next);
+            if (row_in_band(yrow)) {                                                  // a repeat outside this rank's band: nothing to add
+                R xs[1] = {splat<R>(0.0f)};
+                if (LIGHT == PBR_LIGHT_POINT) {
+                    if (rx == 0) ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, yrow);
+                    // x_grid_w's one-sided form without its wave vote: the output's width is a multiple of 4 (repeat_inner: map_w % 4 == 0),
+                    // so its midpoint is even and a lane's pair of columns never straddles it -- the same statements, no branch
+                    const int x0 = p.x + rx * a.W;
+                    const bool lo = x0 < (a.out_W >> 1);
+                    const float f0 = (float)(lo ? x0 : a.out_W - 1 - x0);
+                    xs[0] = fma_(splat<R>(lo ? a.xstep : -a.xstep), fma_(splat<R>(lo ? 1.0f : -1.0f), lane_offsets<R>(0), splat<R>(f0)), splat<R>(lo ? a.x0 : a.x1));
+                }
+                if constexpr (MULTI) {
+                    R g_col[3], sum[3] = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
+                    for (int l = 0; l < a.n_lights; ++l) {          // pass 1: the summed colour decides the outer clamp / the encode's slope
+                        const LightU ll = light_of(a, l);
+                        LightEvalT<R> e;
+                        eval_light(x.pt, light_geom<LIGHT, R>(ll, V, xs[0], ys), ll.inten, e);
     #pragma unroll
-                    for (int c = 0; c < 3; ++c) sum[c] = sum[c] + e.uc[c];
-                }
+                        for (int c = 0; c < 3; ++c) sum[c] = sum[c] + e.uc[c];
+                    }
     #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const R slope = a.out_srgb ? linear_to_srgb_grad_unit(clamp01(sum[c])) : splat<R>(1.0f);
-                    g_col[c] = masked(in_unit(sum[c]), gather<R>(go[c], 0) * slope);
-                }
-                for (int l = 0; l < a.n_lights; ++l) {          // pass 2: every light's chain rule into the one adjoint
-                    const LightU ll = light_of(a, l);
-                    const LightGeomT<R> lg = light_geom<LIGHT, R>(ll, V, xs[0], ys);
-                    LightEvalT<R> e;
-                    eval_light(x.pt, lg, ll.inten, e);
-                    LightParamAdjT<R> pa;
-                    backprop_light<LIGHT, false>(x.pt, lg, ll.inten, e, g_col, adj, V, pa);
-                }
-            } else {
-                const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[0], ys);
-                LightEvalT<R> e;
-                eval_light(x.pt, lg, lu.inten, e);
-                R gout_c[3], g_col[3];
-                if constexpr (LOSS) {
-        #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const R out = a.out_srgb ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180
-                        const R d = out - gather<R>(go[c], 0);
-                        if (p.valid) sq += hsum(d * d);
-                        gout_c[c] = d * rb.scale;
+                        const R slope = SRGB ? linear_to_srgb_grad_unit(clamp01(sum[c])) : splat<R>(1.0f);
+                        g_col[c] = masked(in_unit(sum[c]), gather<R>(go[c], 0) * slope);
+                    }
+                    for (int l = 0; l < a.n_lights; ++l) {          // pass 2: every light's chain rule into the one adjoint
+                        const LightU ll = light_of(a, l);
+                        const LightGeomT<R> lg = light_geom<LIGHT, R>(ll, V, xs[0], ys);
+                        LightEvalT<R> e;
+                        eval_light(x.pt, lg, ll.inten, e);
+                        LightParamAdjT<R> pa;
+                        backprop_light<LIGHT, false>(x.pt, lg, ll.inten, e, g_col, adj, V, pa);
                     }
                 } else {
-        #pragma unroll
-                    for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], 0);
+                    const LightGeomT<R> lg = light_geom<LIGHT, R>(lu, V, xs[0], ys);
+                    LightEvalT<R> e;
+                    eval_light(x.pt, lg, lu.inten, e);
+                    R gout_c[3], g_col[3];
+                    if constexpr (LOSS) {
+            #pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const R out = SRGB ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180
+                            const R d = out - gather<R>(go[c], 0);
+                            if (p.valid) sq += hsum(d * d);
+                            gout_c[c] = d * rb.scale;
+                        }
+                    } else {
+            #pragma unroll
+                        for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], 0);
+                    }
+            #pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        g_col[c] = SRGB ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
+                    LightParamAdjT<R> pa;
+                    backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
                 }
-        #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
-                LightParamAdjT<R> pa;
-                backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
             }
-            R ga[3], gn[3], gs[3], gr, gm;
-            bwd_tail<WF, R>(x, adj, V, ga, gn, gr, gm, gs);
-            // one statement per sum: the position's gradient is a rounded value BEFORE it is added (no fused multiply-add across the
-            // two), which is what makes the sum equal pbr_fold_gradient's over the stored per-position gradients
-    #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                acc_a[c] = acc_a[c] + ga[c];
-                acc_n[c] = acc_n[c] + gn[c];
-                acc_s[c] = acc_s[c] + gs[c];
-            }
-            acc_r = acc_r + gr;
-            acc_m = acc_m + gm;
     #pragma unroll
             for (int c = 0; c < 3; ++c)
     #pragma unroll
                 for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
         }
+        };
+        if (a.out_srgb) positions(std::true_type{}); else positions(std::false_type{});
+        // The light-independent tail of the chain rule is LINEAR in the adjoints it receives, with coefficients that do not depend on the
+        // position: the positions' adjoints were summed above (fused multiply-adds straight into `adj`), the tail runs ONCE per texel.
+        bwd_tail<WF, R>(x, adj, V, acc_a, acc_n, acc_r, acc_m, acc_s);
     }
     if constexpr (LOSS) {
         const float total = wave_sum(sq);

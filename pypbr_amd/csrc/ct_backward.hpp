@@ -95,6 +95,17 @@ template <class R> __device__ __forceinline__ R linear_to_srgb_grad_unit(R c) {
     return select_(le_(c, splat<R>(0.0031308f)), splat<R>(12.92f), hi);
 }
 
+// utils.linear_to_srgb (functions.py:50-66) and its derivative for c already in [0,1], from ONE log2 (the loss steps need both of the
+// same value): the two functions above / in brdf_math.hpp evaluate log2_hw(c) each -- the very same instruction on the very same operand,
+// which the compiler does not merge across their inline assembly.  Same statements otherwise: bit-identical to calling them separately.
+template <class R> __device__ __forceinline__ void linear_to_srgb_unit_and_grad(R c, R &value, R &slope) {
+    const R l = log2_hw(c);
+    const MaskT<R> low = le_(c, splat<R>(0.0031308f));
+    const R hi = fma_sat_after_trans(splat<R>(1.055f), exp2_hw(l * (1.0f / 2.4f)), splat<R>(-0.055f));
+    value = select_(low, c * 12.92f, hi);
+    slope = select_(low, splat<R>(12.92f), exp2_hw(l * (1.0f / 2.4f - 1.0f)) * 0.43958333f /* 1.055/2.4 */);
+}
+
 // Forward terms of one (pixel, light) pair that the chain rule needs again.
 template <class R> struct LightEvalT {
     R ndl_raw, ndl, c, s2, den, dl, dD, ds, q, dg, rad;
@@ -282,11 +293,13 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
 #pragma unroll
             for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], g);
         }
+        R enc_slope[3] = {splat<R>(1.0f), splat<R>(1.0f), splat<R>(1.0f)};       // the loss step: the encode's slope at `lin`, from the encode's own log2
         auto loss_gradient = [&](const R (&lin)[3]) {           // lin: the clamped linear colour of the pixel (:177), as the forward kernel holds it
             if constexpr (Loss::on) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const R out = a.out_srgb ? linear_to_srgb_unit(lin[c]) : lin[c];               // :179-180
+                    R out = lin[c];
+                    if (a.out_srgb) linear_to_srgb_unit_and_grad(lin[c], out, enc_slope[c]);        // :179-180
                     const R d = out - gather<R>(loss.tgt[c], g);
                     loss.sq += hsum(d * d);
                     gout_c[c] = d * loss.scale;
@@ -312,7 +325,7 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const R slope = a.out_srgb ? linear_to_srgb_grad_unit(clamp01(sum[c])) : splat<R>(1.0f);
+                const R slope = Loss::on ? enc_slope[c] : (a.out_srgb ? linear_to_srgb_grad_unit(clamp01(sum[c])) : splat<R>(1.0f));
                 g_col[c] = masked(in_unit(sum[c]), gout_c[c] * slope);
             }
         }
@@ -330,7 +343,7 @@ __device__ __forceinline__ void backward_body_to(const KArgs &a, const BArgs &b,
                 if constexpr (Loss::on) loss_gradient(e.uc);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    g_col[c] = a.out_srgb ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
+                    g_col[c] = a.out_srgb ? gout_c[c] * (Loss::on ? enc_slope[c] : linear_to_srgb_grad_unit(e.uc[c])) : gout_c[c];
             }
             LightParamAdjT<R> pa;
             backprop_light<LIGHT, PGRAD>(pt, lg, lu.inten, e, g_col, adj, V, pa);

@@ -109,6 +109,31 @@ __device__ __forceinline__ void bwd_tail(const BwdTexelT<R> &x, const PixelAdjoi
     gn[2] = (gnh.z - x.pt.n.z * radial) * rn;
 }
 
+// The texel state only the TAIL reads (decoded colours and their slopes, metallic, roughness, the stored normal) is parked in LDS across the
+// position loop -- written once, read once (round 6).  With the tail behind the loop the gradient kernels of ONE light then need 164
+// registers instead of 196: THREE waves per SIMD without a spill (2048^2 tile(2) fp32 point: 140 -> 128 us, fp16 maps 136 -> 120).  The
+// loss policy and the several-lights form stay at two waves: they need 184 / 180 with the state parked, and the spills that a forced
+// third wave costs them (28-52 bytes of scratch per lane) cost more than it brings (fp32 loss step 135 -> 152 us; fp16 134 -> 131).
+// Round 5 had parked the tail's inputs with the tail INSIDE the loop (read back at every position): +12...21 %, not adopted then.
+template <bool LOSS, bool MULTI> struct RepeatBwdShape { static constexpr bool park = !LOSS && !MULTI; static constexpr int waves = park ? 3 : 2; };
+template <int WF>
+__device__ __forceinline__ void park_texel(float2 *slot, BwdTexelT<f32x2> &x, bool restore) {
+    int i = 0;
+    auto io = [&](f32x2 &v) {
+        float2 *q = slot + 64 * i++;
+        if (restore) { const float2 t = *q; v = f32x2{t.x, t.y}; } else { *q = make_float2(v.x, v.y); }
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { io(x.base[c]); io(x.dbase[c]); }
+    io(x.m); io(x.rough); io(x.nraw.x); io(x.nraw.y); io(x.nraw.z);
+    if (WF != PBR_WORKFLOW_METALLIC) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { io(x.df0[c]); io(x.alin[c]); }
+        io(x.om);
+    }
+}
+constexpr int kParkSlots = 18;
+
 // Extra kernel arguments: where the upstream gradient (or the target image) of the OUTPUT lives.
 struct RBArgs {
     const float *gout;          // upstream gradient, or with the loss policy the target image: [B][3][band rows][out_W] fp32 contiguous
@@ -123,7 +148,7 @@ struct RBArgs {
 //   MULTI: several lights (H12: per-light clamp, sum, clamp, encode) -- per position the two passes over the lights of backward_body_to (the
 //   summed colour decides the outer clamp and the encode's slope; then every light's chain rule into one adjoint); no loss policy.
 template <int LIGHT, int WF, typename TM, bool LOSS, bool MULTI = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RepeatBwdShape<LOSS, MULTI>::waves, 4)))
 void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RBArgs rb) {
     static_assert(!(MULTI && LOSS), "the loss step over tiled maps is built for one light");
     constexpr int VEC = 2;
@@ -182,8 +207,12 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
         LightEvalT<R> e;
         eval_light(x.pt, lg, lu.inten, e);
         R out[3], gsum[3] = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
+        R enc_slope[3] = {splat<R>(1.0f), splat<R>(1.0f), splat<R>(1.0f)};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) out[c] = a.out_srgb ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180 (the loss compares this)
+        for (int c = 0; c < 3; ++c) {                                                                           // :179-180 (the loss compares this) and its slope
+            out[c] = e.uc[c];
+            if (a.out_srgb) { if (LOSS) linear_to_srgb_unit_and_grad(e.uc[c], out[c], enc_slope[c]); else enc_slope[c] = linear_to_srgb_grad_unit(e.uc[c]); }
+        }
         // the positions' loads do not depend on one another: four positions' worth (12 loads) in flight before the first add
         constexpr int kChunk = 4;
         for (int k0 = 0; k0 < n_pos; k0 += kChunk) {
@@ -211,7 +240,7 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const R gc = LOSS ? gsum[c] * rb.scale : gsum[c];
-            g_col[c] = a.out_srgb ? gc * linear_to_srgb_grad_unit(e.uc[c]) : gc;
+            g_col[c] = a.out_srgb ? gc * enc_slope[c] : gc;
         }
         PixelAdjointT<R> adj;
 #pragma unroll
@@ -251,6 +280,9 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
             adj.g_n = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
         };
         clear_adjoint();
+        constexpr bool kPark = RepeatBwdShape<LOSS, MULTI>::park;
+        __shared__ float2 s_park[kPark ? kParkSlots * 64 : 1];
+        if constexpr (kPark) park_texel<WF>(s_park + threadIdx.x, x, false);
         // The output encode is a launch-wide flag: tested once, outside the loop (two copies of the loop) -- inside it was three scalar
         // branches per position, and a branch costs a wave of a two-wave SIMD ~12 cycles (tools/valu_occupancy.hip).
         auto positions = [&](auto srgb_tag) {
@@ -302,18 +334,20 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
                     if constexpr (LOSS) {
             #pragma unroll
                         for (int c = 0; c < 3; ++c) {
-                            const R out = SRGB ? linear_to_srgb_unit(e.uc[c]) : e.uc[c];               // :179-180
+                            R out = e.uc[c], slope = splat<R>(1.0f);
+                            if (SRGB) linear_to_srgb_unit_and_grad(e.uc[c], out, slope);               // :179-180 and its slope, one log2
                             const R d = out - gather<R>(go[c], 0);
                             if (p.valid) sq += hsum(d * d);
                             gout_c[c] = d * rb.scale;
+                            g_col[c] = SRGB ? gout_c[c] * slope : gout_c[c];
                         }
                     } else {
             #pragma unroll
-                        for (int c = 0; c < 3; ++c) gout_c[c] = gather<R>(go[c], 0);
+                        for (int c = 0; c < 3; ++c) {
+                            gout_c[c] = gather<R>(go[c], 0);
+                            g_col[c] = SRGB ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
+                        }
                     }
-            #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        g_col[c] = SRGB ? gout_c[c] * linear_to_srgb_grad_unit(e.uc[c]) : gout_c[c];
                     LightParamAdjT<R> pa;
                     backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
                 }
@@ -327,6 +361,10 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
         if (a.out_srgb) positions(std::true_type{}); else positions(std::false_type{});
         // The light-independent tail of the chain rule is LINEAR in the adjoints it receives, with coefficients that do not depend on the
         // position: the positions' adjoints were summed above (fused multiply-adds straight into `adj`), the tail runs ONCE per texel.
+        if constexpr (kPark) {
+            park_texel<WF>(s_park + threadIdx.x, x, true);
+            if (WF == PBR_WORKFLOW_METALLIC) { x.om = splat<R>(1.0f) - x.m; x.kd_scale = x.om; }      // (1 - m: recomputed, the same subtraction)
+        }
         bwd_tail<WF, R>(x, adj, V, acc_a, acc_n, acc_r, acc_m, acc_s);
     }
     if constexpr (LOSS) {

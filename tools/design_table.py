@@ -23,7 +23,7 @@ def g(key):
 def us(k): return "%.1f" % g(k)["avg_us"]
 def fr(k, d=3): return ("%." + str(d) + "f") % g(k)["frac_of_8TBps_at_avg"]
 def tr(k, d=4): return ("%." + str(d) + "f") % g(k)["traffic_over_algorithmic"]
-def vb(k): return "%.2f" % g(k)["sq"]["valu_busy_fraction"]
+def vb(k): return "%.2f" % g(k)["sq"]["valu_active_wave_cycles_per_simd_cycle"]
 def clk(k): return "%.2f" % g(k)["sq"]["shader_clock_GHz"]
 
 

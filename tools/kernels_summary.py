@@ -103,10 +103,19 @@ for key in sorted(rec):
         m = {k: statistics.mean(v) for k, v in c.items()}
         sq = {"median_us_under_counters": round(statistics.median(c["_sq_us"]), 1)}
         cycles = m["GRBM_GUI_ACTIVE"] / 8
-        sq["shader_clock_GHz"] = round(cycles / (sq["median_us_under_counters"] * 1e-6) / 1e9, 3)
+        # GRBM_GUI_ACTIVE spans the whole dispatch slot, idle head and tail included: under ~20 us the ratio is not a clock (round 5 printed
+        # 15 GHz for a 2 us kernel) -- not derived there, and nothing that divides by `cycles` is either
+        short_kernel = sq["median_us_under_counters"] < 20.0
+        sq["shader_clock_GHz"] = None if short_kernel else round(cycles / (sq["median_us_under_counters"] * 1e-6) / 1e9, 3)
         sq["valu_wave_instructions"] = int(m["SQ_INSTS_VALU"])
-        sq["valu_busy_fraction"] = round(4 * m["SQ_ACTIVE_INST_VALU"] / (1024 * cycles), 3)
-        sq["mean_resident_waves_per_cu"] = round(4 * m["SQ_WAVE_CYCLES"] / (256 * cycles), 2)
+        # SQ_ACTIVE_INST_VALU counts, per WAVE, the quad-cycles it spends in vector instructions; a SIMD overlaps the vector instructions
+        # of two waves, so the sum per SIMD cycle is NOT a fraction of 1.  Calibrated with pure instruction streams (tools/valu_counters.sh,
+        # profiles/r06_valu_counter_calibration.txt): it saturates at 1.5-1.6 for plain fp32 (v_fma / v_mul at 8 waves per SIMD), 0.91 for
+        # packed fp32 (v_pk_*), 0.97 for transcendentals, 1.18 for compare + select pairs.  Round 5 called it `valu_busy_fraction` and printed
+        # 1.054 for a plain-fp32 kernel: the number was right, the name was not.
+        sq["valu_active_wave_cycles_per_simd_cycle"] = None if short_kernel else round(4 * m["SQ_ACTIVE_INST_VALU"] / (1024 * cycles), 3)
+        sq["valu_active_ceiling_by_instruction_class"] = {"plain_fp32": 1.55, "packed_fp32": 0.91, "transcendental": 0.97, "compare_select": 1.18}
+        sq["mean_resident_waves_per_cu"] = None if short_kernel else round(4 * m["SQ_WAVE_CYCLES"] / (256 * cycles), 2)
         sq["wait_any_fraction_of_wave_cycles"] = round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3)
         sq["wait_inst_any_fraction_of_wave_cycles"] = round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 3)
         ent["sq"] = sq

@@ -78,7 +78,7 @@ def sq_summary(sq, sq_us):
             cycles = m["GRBM_GUI_ACTIVE"] / 8          # the per-dispatch value is the sum over the 8 XCDs
             third["shader_clock_GHz"] = round(cycles / (us * 1e-6) / 1e9, 3)
             if "SQ_ACTIVE_INST_VALU" in m:             # SQ_* tick in quad-cycles, summed over the 1024 SIMDs (256 CUs x 4)
-                third["valu_busy_fraction"] = round(4 * m["SQ_ACTIVE_INST_VALU"] / (1024 * cycles), 3)
+                third["valu_active_wave_cycles_per_simd_cycle"] = round(4 * m["SQ_ACTIVE_INST_VALU"] / (1024 * cycles), 3)
             if "SQ_WAVE_CYCLES" in m:
                 third["mean_resident_waves_per_cu"] = round(4 * m["SQ_WAVE_CYCLES"] / (256 * cycles), 2)
         return third

@@ -27,7 +27,7 @@ for k, c in acc.items():
     cycles = m["GRBM_GUI_ACTIVE"] / 8
     us = statistics.median(c["_us"])
     print(k)
-    print("   us %.1f  clock %.3f GHz  VALU insts %d  VALU busy %.3f  waves/CU %.2f  wait_any %.3f  wait_inst %.3f  inst_any_active %.3f" % (
+    print("   us %.1f  clock %.3f GHz  VALU insts %d  VALU active wave-cycles per SIMD cycle %.3f (ceilings: plain fp32 1.55, packed 0.91, trans 0.97)  waves/CU %.2f  wait_any %.3f  wait_inst %.3f  inst_any_active %.3f" % (
         us, cycles / (us * 1e-6) / 1e9, m["SQ_INSTS_VALU"], 4 * m["SQ_ACTIVE_INST_VALU"] / (1024 * cycles), 4 * m["SQ_WAVE_CYCLES"] / (256 * cycles),
         m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"]))
 PY

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PBR_HIP_ABI_VERSION 7      /* 7: folded gradients of tiled maps (pbr_cook_torrance_backward_folded), the loss step over tiled maps, 12 schedule knobs (was 23); 6: pbr_render_desc.tuning (per-call schedule knobs; pbr_set_tuning demoted to a process-global test hook); 5: pbr_render_desc.device_params (view / light / intensity read from device memory); 4: light_size follows Python truthiness, gradients of the map ops */
+#define PBR_HIP_ABI_VERSION 8      /* 8: pbr_cook_torrance_blend_backward over tiled maps (map-sized gradients), pbr_blend_backward_serves; 7: folded gradients of tiled maps (pbr_cook_torrance_backward_folded), the loss step over tiled maps, 12 schedule knobs (was 23); 6: pbr_render_desc.tuning (per-call schedule knobs; pbr_set_tuning demoted to a process-global test hook); 5: pbr_render_desc.device_params (view / light / intensity read from device memory); 4: light_size follows Python truthiness, gradients of the map ops */
 #define PBR_MAX_LIGHTS 16
 
 /* ---- status codes (negative = caller error, positive = HIP runtime error code + 1000) */
@@ -204,8 +204,15 @@ int pbr_cook_torrance_blend(const pbr_render_desc *desc, const pbr_blend_desc *b
  * call (PBR_BLEND_SIGN_COMPUTE recomputes the flags; row bands need PBR_BLEND_SIGN_GIVEN); `grad_out` [B][3][H][W] fp32
  * contiguous.  Every non-NULL member of g_material1 / g_material2 and g_mask receives a contiguous fp32 gradient with one value
  * per OUTPUT pixel and material ([B][3|1][H][W]; g_mask [B][1][H][W]); a map or mask that the batch shares (batch_stride 0) owns
- * the sum over the batch, which is left to the caller (pbr_fold_gradient).  Untiled maps only (PBR_ERR_UNSUPPORTED otherwise).
+ * the sum over the batch, which is left to the caller (pbr_fold_gradient).
+ * TILED maps (ABI 8; desc.map_height / map_width: MaterialBase.tile of the blended material, base.py:524-537 -- the blend itself is
+ * map-sized, examples/example_blend.py:14-16): every gradient is MAP-sized ([B][3|1][map_height][map_width]; g_mask likewise), each texel
+ * owning the sum over its repeats: one kernel blends once per texel, visits the repeats (the walk of pbr_cook_torrance_backward_folded) and
+ * runs the folded gradients through the blend's chain rule.  One light, fp32, map widths of whole 4-texel groups, whole outputs or row bands
+ * that hold a period of the map's rows: pbr_blend_backward_serves(desc) says whether a descriptor is served (1) or the call would return
+ * PBR_ERR_UNSUPPORTED (0: evaluate the differentiable pieces -- pbr_blend_maps_backward, pbr_decode_normal_backward, the folded backward).
  */
+int pbr_blend_backward_serves(const pbr_render_desc *desc);
 typedef struct pbr_map_grads { void *albedo, *normal, *roughness, *metallic, *specular; } pbr_map_grads;
 int pbr_cook_torrance_blend_backward(const pbr_render_desc *desc, const pbr_blend_desc *blend, void *workspace, const void *grad_out,
                                      const pbr_map_grads *g_material1, const pbr_map_grads *g_material2, void *g_mask, void *stream);

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBR_HIP_LIB") or os.path.join(_HERE, "libpbr_hip.so")   # env override: A/B of two builds
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_LIGHTS = 16
 
 F32, F16 = 0, 1
@@ -35,7 +35,7 @@ EXPORTS = (
     "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
     "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask", "pbr_cook_torrance_autotune",
     "pbr_cook_torrance_blend", "pbr_fold_gradient", "pbr_decode_normal_backward",
-    "pbr_blend_normal_sign", "pbr_blend_maps_backward", "pbr_param_grad_workspace_bytes", "pbr_cook_torrance_backward_params",
+    "pbr_blend_normal_sign", "pbr_blend_backward_serves", "pbr_blend_maps_backward", "pbr_param_grad_workspace_bytes", "pbr_cook_torrance_backward_params",
     "pbr_srgb_to_linear_backward", "pbr_linear_to_srgb_backward", "pbr_metallic_to_specular_backward",
     "pbr_specular_to_metallic_backward", "pbr_resize_backward_workspace_bytes", "pbr_resize_bilinear_backward",
     "pbr_blend_sigmoid_mask_backward", "pbr_cook_torrance_blend_backward", "pbr_fold_gradient_typed",
@@ -138,6 +138,8 @@ def lib():
     L.pbr_cook_torrance_blend_backward.restype = ctypes.c_int
     L.pbr_blend_normal_sign.argtypes = [ctypes.POINTER(RenderDesc), ctypes.POINTER(BlendDesc), vp, vp]
     L.pbr_blend_normal_sign.restype = ctypes.c_int
+    L.pbr_blend_backward_serves.argtypes = [ctypes.POINTER(RenderDesc)]
+    L.pbr_blend_backward_serves.restype = ctypes.c_int
     L.pbr_param_grad_workspace_bytes.argtypes = [ctypes.POINTER(RenderDesc)]
     L.pbr_param_grad_workspace_bytes.restype = ctypes.c_size_t
     L.pbr_cook_torrance_backward_params.argtypes = [ctypes.POINTER(RenderDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp]

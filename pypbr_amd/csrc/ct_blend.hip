@@ -5,6 +5,27 @@
 
 namespace pbr {
 
+// One flag per material: does the blended normal map have a negative component anywhere (base.py:212)?
+// Grid-stride over the B * P source pixels; a workgroup that finds its material's flag already set skips the pixel
+// block, so for real normal maps (negative components everywhere) the pass costs a launch, not a read of 7 planes.
+__global__ __launch_bounds__(256) void blend_normal_sign_kernel(const float *__restrict__ n1, const float *__restrict__ n2,
+                                                                const float *__restrict__ mask, int64_t n1_bs, int64_t n1_cs,
+                                                                int64_t n2_bs, int64_t n2_cs, int64_t k_bs, int64_t P,
+                                                                int64_t total, int *__restrict__ flag) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t bi = i / P, px = i - bi * P;
+        if (__hip_atomic_load(flag + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) continue;   // bypasses the CU's L1
+        const float wj = mask[bi * k_bs + px], iw = 1.0f - wj;
+        const float *pa = n1 + bi * n1_bs + px, *pb = n2 + bi * n2_bs + px;
+        const Vec3 a = {pa[0], pa[n1_cs], pa[2 * n1_cs]}, b = {pb[0], pb[n2_cs], pb[2 * n2_cs]};
+        const float ra = rsq(fmaxf(dot(a, a), 1e-24f)), rb = rsq(fmaxf(dot(b, b), 1e-24f));
+        const Vec3 c = {fmaf(wj, a.x * ra, iw * (b.x * rb)), fmaf(wj, a.y * ra, iw * (b.y * rb)), fmaf(wj, a.z * ra, iw * (b.z * rb))};
+        const float rc = rsq(fmaxf(dot(c, c), 1e-24f));
+        if (c.x * rc < 0.0f || c.y * rc < 0.0f || c.z * rc < 0.0f) flag[bi] = 1;
+    }
+}
+
 static int check_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, const void *workspace) {
     const int rc = validate(d);
     if (rc != PBR_OK) return rc;
@@ -55,9 +76,28 @@ int pbr_cook_torrance_blend_backward(const pbr_render_desc *d, const pbr_blend_d
     const int rc = check_blend(d, bl, workspace);
     if (rc != PBR_OK) return rc;
     if (!grad_out || !g_material1 || !g_material2) return PBR_ERR_NULL_MAP;
-    if (is_tiled(d)) return PBR_ERR_UNSUPPORTED;              // a repeated texel owns a sum over its repeats: evaluate unfused
-    if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE && d->height != d->height_total) return PBR_ERR_UNSUPPORTED;
     if (nan_light_size(d)) return PBR_ERR_UNSUPPORTED;
+    if (is_tiled(d)) {
+        // A repeated texel owns the SUM over its repeats: the repeat-inner walk (ct_repeat_backward.hpp) blends once per texel, visits the
+        // repeats, and runs the folded gradients through the blend's chain rule -- MAP-sized gradients (round 6).  Whole outputs and row
+        // bands that hold a period of the map's rows, one light; the sign flags of tiled maps are always the whole map's.
+        if (!repeat_blend_backward_serves(d)) return PBR_ERR_UNSUPPORTED;
+        KBlend kb;
+        fill_blend(bl, workspace, kb);
+        hipStream_t tst = static_cast<hipStream_t>(stream);
+        if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE) {
+            if (hipMemsetAsync(workspace, 0, sizeof(int) * (size_t)d->batch, tst) != hipSuccess) return 1000 + (int)hipGetLastError();
+            const int src = launch_normal_sign(d, bl, workspace, tst);
+            if (src != PBR_OK) return src;
+        }
+        const bool tspec = d->workflow == PBR_WORKFLOW_SPECULAR;
+        const BArgs t1 = {nullptr, g_material1->albedo, g_material1->normal, g_material1->roughness, tspec ? nullptr : g_material1->metallic,
+                          tspec ? g_material1->specular : nullptr, nullptr};
+        const BBlend t2 = {g_material2->albedo, g_material2->normal, g_material2->roughness, tspec ? nullptr : g_material2->metallic,
+                           tspec ? g_material2->specular : nullptr, static_cast<float *>(g_mask)};
+        return launch_repeat_blend_backward(d, &kb, grad_out, &t1, &t2, tst);
+    }
+    if (bl->sign_mode == PBR_BLEND_SIGN_COMPUTE && d->height != d->height_total) return PBR_ERR_UNSUPPORTED;
     const int vec = d->width >= 2 && g_max_vec >= 2 ? 2 : 1;  // two pixels per lane: both materials' raw texels stay live through the chain rule
     KArgs k;
     fill_args(d, vec, k, 6);
@@ -94,6 +134,12 @@ int pbr_cook_torrance_blend_backward(const pbr_render_desc *d, const pbr_blend_d
     hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(64, 1, 1), 0, st, k, b, g1, g2);
     const hipError_t err = hipGetLastError();
     return err == hipSuccess ? PBR_OK : 1000 + (int)err;
+}
+
+int pbr_blend_backward_serves(const pbr_render_desc *d) {
+    const pbr::TuningScope tuning(d);
+    if (pbr::validate(d) != PBR_OK || d->map_dtype != PBR_F32 || d->out_dtype != PBR_F32) return 0;
+    return pbr::is_tiled(d) ? (pbr::repeat_blend_backward_serves(d) ? 1 : 0) : 1;
 }
 
 int pbr_blend_normal_sign(const pbr_render_desc *d, const pbr_blend_desc *bl, void *workspace, void *stream) {

@@ -82,25 +82,4 @@ void cook_torrance_blend_kernel(const KArgs a, const KBlend b) {
     shade_and_store<LIGHT, WF, float, VEC, MULTI, true, MULTI>(a, p, t);
 }
 
-// One flag per material: does the blended normal map have a negative component anywhere (base.py:212)?
-// Grid-stride over the B * P source pixels; a workgroup that finds its material's flag already set skips the pixel
-// block, so for real normal maps (negative components everywhere) the pass costs a launch, not a read of 7 planes.
-__global__ __launch_bounds__(256) void blend_normal_sign_kernel(const float *__restrict__ n1, const float *__restrict__ n2,
-                                                                const float *__restrict__ mask, int64_t n1_bs, int64_t n1_cs,
-                                                                int64_t n2_bs, int64_t n2_cs, int64_t k_bs, int64_t P,
-                                                                int64_t total, int *__restrict__ flag) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t bi = i / P, px = i - bi * P;
-        if (__hip_atomic_load(flag + bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) continue;   // bypasses the CU's L1
-        const float wj = mask[bi * k_bs + px], iw = 1.0f - wj;
-        const float *pa = n1 + bi * n1_bs + px, *pb = n2 + bi * n2_bs + px;
-        const Vec3 a = {pa[0], pa[n1_cs], pa[2 * n1_cs]}, b = {pb[0], pb[n2_cs], pb[2 * n2_cs]};
-        const float ra = rsq(fmaxf(dot(a, a), 1e-24f)), rb = rsq(fmaxf(dot(b, b), 1e-24f));
-        const Vec3 c = {fmaf(wj, a.x * ra, iw * (b.x * rb)), fmaf(wj, a.y * ra, iw * (b.y * rb)), fmaf(wj, a.z * ra, iw * (b.z * rb))};
-        const float rc = rsq(fmaxf(dot(c, c), 1e-24f));
-        if (c.x * rc < 0.0f || c.y * rc < 0.0f || c.z * rc < 0.0f) flag[bi] = 1;
-    }
-}
-
 }  // namespace pbr

@@ -21,6 +21,77 @@ struct BBlend {
     float *g_mask;                                               // [B][1][H][W] (one value per output pixel), NULL = not wanted
 };
 
+// The blend's own chain rule: the gradients w.r.t. the BLENDED texels (what the shading read) -> both materials' maps and the mask, stored.
+// `t` / `u`: the two materials' raw texels, `w` the mask, `at`-style indexing through a.o_cs (elements per gradient plane) and p.pix
+// (the lane's first pixel inside a plane): one gradient value per pixel the LANE OWNS -- output pixels for cook_torrance_blend_backward_kernel,
+// source texels for the repeat-inner walk over tiled maps (ct_repeat_backward.hpp, where ga ... gs are already the sums over the repeats).
+template <int WF, int VEC>
+__device__ __forceinline__ void blend_backward_sink(const KArgs &a, const LanePos &p, int mat, const Texels<VEC> &t, const Texels<VEC> &u, const float (&w)[VEC],
+                                                    bool keep_signed, const BArgs &g1, const BBlend &g2, float (&ga)[3][VEC], float (&gn)[3][VEC],
+                                                    float (&gr)[VEC], float (&gm)[VEC], float (&gs)[3][VEC]) {
+    float gw[VEC], o1[VEC], o2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) gw[j] = 0.0f;
+    // every plain map: x = w a + (1 - w) b  ->  g_a = w g, g_b = (1 - w) g, g_w += g (a - b)      (functional.py:103-110)
+    auto lerp_back = [&](const float (&g)[VEC], const float (&av)[VEC], const float (&bv)[VEC], void *p1, void *p2, int channels, int c) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            o1[j] = w[j] * g[j];
+            o2[j] = (1.0f - w[j]) * g[j];
+            gw[j] = fmaf(g[j], av[j] - bv[j], gw[j]);
+        }
+        const int64_t at = ((int64_t)mat * channels + c) * a.o_cs + p.pix;
+        if (p1) Ld<float, VEC>::template store<true>(p1, at, o1);
+        if (p2) Ld<float, VEC>::template store<true>(p2, at, o2);
+    };
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lerp_back(ga[c], t.al[c], u.al[c], g1.g_albedo, g2.g_albedo, 3, c);
+    lerp_back(gr, t.ro, u.ro, g1.g_rough, g2.g_rough, 1, 0);
+    if (WF != PBR_WORKFLOW_SPECULAR) {
+        lerp_back(gm, t.me, u.me, g1.g_metal, g2.g_metal, 1, 0);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) lerp_back(gs[c], t.sp[c], u.sp[c], g1.g_spec, g2.g_spec, 3, c);
+    }
+    // the normal: o = normalize(w a^ + (1 - w) b^) (functional.py:119-145), then on re-assignment -- unless the blended map
+    // counts as signed -- normalize(2 o - 1) (base.py:214-216).  gn is the adjoint of what the shading read.
+    float n1[3][VEC], n2[3][VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float wj = w[j], iw = 1.0f - wj;
+        const Vec3 av = {t.nm[0][j], t.nm[1][j], t.nm[2][j]}, bv = {u.nm[0][j], u.nm[1][j], u.nm[2][j]};
+        const float ra = rsq(fmaxf(dot(av, av), 1e-24f)), rb = rsq(fmaxf(dot(bv, bv), 1e-24f));
+        const Vec3 ah = {av.x * ra, av.y * ra, av.z * ra}, bh = {bv.x * rb, bv.y * rb, bv.z * rb};
+        const Vec3 c = {fmaf(wj, ah.x, iw * bh.x), fmaf(wj, ah.y, iw * bh.y), fmaf(wj, ah.z, iw * bh.z)};
+        const float rc = rsq(fmaxf(dot(c, c), 1e-24f));
+        const Vec3 o = {c.x * rc, c.y * rc, c.z * rc};
+        Vec3 g = {gn[0][j], gn[1][j], gn[2][j]};
+        if (!keep_signed) {
+            const Vec3 d = {fmaf(o.x, 2.0f, -1.0f), fmaf(o.y, 2.0f, -1.0f), fmaf(o.z, 2.0f, -1.0f)};
+            const float rd = rsq(fmaxf(dot(d, d), 1e-24f));
+            const Vec3 e = {d.x * rd, d.y * rd, d.z * rd};
+            const float eg = dot(e, g);
+            g = {2.0f * (g.x - e.x * eg) * rd, 2.0f * (g.y - e.y * eg) * rd, 2.0f * (g.z - e.z * eg) * rd};
+        }
+        const float og = dot(o, g);                                  // F.normalize: (g - o (o.g)) / |c|
+        const Vec3 gc = {(g.x - o.x * og) * rc, (g.y - o.y * og) * rc, (g.z - o.z * og) * rc};
+        gw[j] += gc.x * (ah.x - bh.x) + gc.y * (ah.y - bh.y) + gc.z * (ah.z - bh.z);
+        const Vec3 gA = {wj * gc.x, wj * gc.y, wj * gc.z};
+        const float da = dot(ah, gA);
+        n1[0][j] = (gA.x - ah.x * da) * ra; n1[1][j] = (gA.y - ah.y * da) * ra; n1[2][j] = (gA.z - ah.z * da) * ra;
+        const Vec3 gB = {iw * gc.x, iw * gc.y, iw * gc.z};
+        const float db = dot(bh, gB);
+        n2[0][j] = (gB.x - bh.x * db) * rb; n2[1][j] = (gB.y - bh.y * db) * rb; n2[2][j] = (gB.z - bh.z * db) * rb;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int64_t at = ((int64_t)mat * 3 + c) * a.o_cs + p.pix;
+        if (g1.g_normal) Ld<float, VEC>::template store<true>(g1.g_normal, at, n1[c]);
+        if (g2.g_normal) Ld<float, VEC>::template store<true>(g2.g_normal, at, n2[c]);
+    }
+    if (g2.g_mask) Ld<float, VEC>::template store<true>(g2.g_mask, (int64_t)mat * a.o_cs + p.pix, gw);
+}
+
 template <int LIGHT, int WF, int VEC, bool MULTI>
 __global__ __launch_bounds__(64) void cook_torrance_blend_backward_kernel(const KArgs a, const KBlend b, const BArgs g1, const BBlend g2) {
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
@@ -40,68 +111,9 @@ __global__ __launch_bounds__(64) void cook_torrance_blend_backward_kernel(const 
     blend_texels<WF, VEC>(x, u, w, keep_signed);
     backward_body_to<LIGHT, WF, VEC, MULTI, float, false>(a, g1, p, x, go, nullptr, 0,
         [&](float (&ga)[3][VEC], float (&gn)[3][VEC], float (&gr)[VEC], float (&gm)[VEC], float (&gs)[3][VEC]) {
-            float gw[VEC], o1[VEC], o2[VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) gw[j] = 0.0f;
-            // every plain map: x = w a + (1 - w) b  ->  g_a = w g, g_b = (1 - w) g, g_w += g (a - b)      (functional.py:103-110)
-            auto lerp_back = [&](const float (&g)[VEC], const float (&av)[VEC], const float (&bv)[VEC], void *p1, void *p2, int channels, int c) {
-#pragma unroll
-                for (int j = 0; j < VEC; ++j) {
-                    o1[j] = w[j] * g[j];
-                    o2[j] = (1.0f - w[j]) * g[j];
-                    gw[j] = fmaf(g[j], av[j] - bv[j], gw[j]);
-                }
-                const int64_t at = ((int64_t)mat * channels + c) * a.o_cs + p.pix;
-                if (p1) Ld<float, VEC>::template store<true>(p1, at, o1);
-                if (p2) Ld<float, VEC>::template store<true>(p2, at, o2);
-            };
-#pragma unroll
-            for (int c = 0; c < 3; ++c) lerp_back(ga[c], t.al[c], u.al[c], g1.g_albedo, g2.g_albedo, 3, c);
-            lerp_back(gr, t.ro, u.ro, g1.g_rough, g2.g_rough, 1, 0);
-            if (WF != PBR_WORKFLOW_SPECULAR) {
-                lerp_back(gm, t.me, u.me, g1.g_metal, g2.g_metal, 1, 0);
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) lerp_back(gs[c], t.sp[c], u.sp[c], g1.g_spec, g2.g_spec, 3, c);
-            }
-            // the normal: o = normalize(w a^ + (1 - w) b^) (functional.py:119-145), then on re-assignment -- unless the blended map
-            // counts as signed -- normalize(2 o - 1) (base.py:214-216).  gn is the adjoint of what the shading read.
-            float n1[3][VEC], n2[3][VEC];
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) {
-                const float wj = w[j], iw = 1.0f - wj;
-                const Vec3 av = {t.nm[0][j], t.nm[1][j], t.nm[2][j]}, bv = {u.nm[0][j], u.nm[1][j], u.nm[2][j]};
-                const float ra = rsq(fmaxf(dot(av, av), 1e-24f)), rb = rsq(fmaxf(dot(bv, bv), 1e-24f));
-                const Vec3 ah = {av.x * ra, av.y * ra, av.z * ra}, bh = {bv.x * rb, bv.y * rb, bv.z * rb};
-                const Vec3 c = {fmaf(wj, ah.x, iw * bh.x), fmaf(wj, ah.y, iw * bh.y), fmaf(wj, ah.z, iw * bh.z)};
-                const float rc = rsq(fmaxf(dot(c, c), 1e-24f));
-                const Vec3 o = {c.x * rc, c.y * rc, c.z * rc};
-                Vec3 g = {gn[0][j], gn[1][j], gn[2][j]};
-                if (!keep_signed) {
-                    const Vec3 d = {fmaf(o.x, 2.0f, -1.0f), fmaf(o.y, 2.0f, -1.0f), fmaf(o.z, 2.0f, -1.0f)};
-                    const float rd = rsq(fmaxf(dot(d, d), 1e-24f));
-                    const Vec3 e = {d.x * rd, d.y * rd, d.z * rd};
-                    const float eg = dot(e, g);
-                    g = {2.0f * (g.x - e.x * eg) * rd, 2.0f * (g.y - e.y * eg) * rd, 2.0f * (g.z - e.z * eg) * rd};
-                }
-                const float og = dot(o, g);                                  // F.normalize: (g - o (o.g)) / |c|
-                const Vec3 gc = {(g.x - o.x * og) * rc, (g.y - o.y * og) * rc, (g.z - o.z * og) * rc};
-                gw[j] += gc.x * (ah.x - bh.x) + gc.y * (ah.y - bh.y) + gc.z * (ah.z - bh.z);
-                const Vec3 gA = {wj * gc.x, wj * gc.y, wj * gc.z};
-                const float da = dot(ah, gA);
-                n1[0][j] = (gA.x - ah.x * da) * ra; n1[1][j] = (gA.y - ah.y * da) * ra; n1[2][j] = (gA.z - ah.z * da) * ra;
-                const Vec3 gB = {iw * gc.x, iw * gc.y, iw * gc.z};
-                const float db = dot(bh, gB);
-                n2[0][j] = (gB.x - bh.x * db) * rb; n2[1][j] = (gB.y - bh.y * db) * rb; n2[2][j] = (gB.z - bh.z * db) * rb;
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int64_t at = ((int64_t)mat * 3 + c) * a.o_cs + p.pix;
-                if (g1.g_normal) Ld<float, VEC>::template store<true>(g1.g_normal, at, n1[c]);
-                if (g2.g_normal) Ld<float, VEC>::template store<true>(g2.g_normal, at, n2[c]);
-            }
-            if (g2.g_mask) Ld<float, VEC>::template store<true>(g2.g_mask, (int64_t)mat * a.o_cs + p.pix, gw);
+            blend_backward_sink<WF, VEC>(a, p, mat, t, u, w, keep_signed, g1, g2, ga, gn, gr, gm, gs);
         });
 }
+
 
 }  // namespace pbr

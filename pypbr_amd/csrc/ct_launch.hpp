@@ -256,6 +256,9 @@ bool repeat_loss_serves(const pbr_render_desc *d);
 int64_t repeat_backward_tiles(const pbr_render_desc *d);
 int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void *g_albedo, void *g_normal, void *g_roughness, void *g_metallic,
                            void *g_specular, bool loss, float scale, float *partials, hipStream_t st);
+// pbr_cook_torrance_blend_backward over tiled maps through the same walk (ct_repeat_backward.hip); kblend / g1 / g2: KBlend / BArgs / BBlend by address
+bool repeat_blend_backward_serves(const pbr_render_desc *d);
+int launch_repeat_blend_backward(const pbr_render_desc *d, const void *kblend, const void *grad_out, const void *g1, const void *g2, hipStream_t st);
 
 // Tiled maps evaluated by the repeat-inner kernel (ct_kernel.hpp: cook_torrance_repeat_kernel): map rows a whole number of
 // 4-texel lanes, and an output -- the whole tiled image, or a row band of it (a multi-GPU shard) -- that holds at least one full period

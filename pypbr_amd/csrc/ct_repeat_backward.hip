@@ -45,11 +45,9 @@ int64_t repeat_backward_tiles(const pbr_render_desc *d) {
     return k.n_tiles;
 }
 
-// `upstream`: the gradient w.r.t. the output, or (loss != nullptr) the target image; [B][3][d->height][d->width] fp32 contiguous.
-// g_*: MAP-sized ([B][C][map_height][map_width], dense), in the maps' storage type.
-int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void *g_albedo, void *g_normal, void *g_roughness, void *g_metallic,
-                           void *g_specular, bool loss, float scale, float *partials, hipStream_t st) {
-    KArgs full, k;
+// KArgs of the walk over the SOURCE maps for this descriptor (the output described through rep / out_* / y_offset / H_total).
+static int fill_repeat_backward(const pbr_render_desc *d, KArgs &k) {
+    KArgs full;
     fill_args(d, 4, full);                               // the output's point-light grid, view, light, flags
     pbr_render_desc g = *d;
     g.height = g.height_total = d->map_height; g.width = d->map_width; g.map_height = g.map_width = 0; g.y_offset = 0;
@@ -70,11 +68,48 @@ int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void 
     k.out_W = d->width; k.out_Ht = d->height_total;
     k.y_offset = d->y_offset; k.H_total = d->height;     // `upstream` holds the rows [y_offset, y_offset + height) of the tiled image
     k.o_cs = (int64_t)d->map_height * d->map_width; k.o_bs = 3 * k.o_cs;      // the gradient planes: dense, map-sized
-    const int64_t out_plane = (int64_t)d->height * d->width;
-    if (out_plane >= (1ll << 30)) k.sbase = 0;           // the lane's offset inside the output's first repeat must fit 32 bits of bytes
+    if ((int64_t)d->height * d->width >= (1ll << 30)) k.sbase = 0;           // the lane's offset inside the output's first repeat must fit 32 bits of bytes
+    return PBR_OK;
+}
+
+// `upstream`: the gradient w.r.t. the output, or (loss != nullptr) the target image; [B][3][d->height][d->width] fp32 contiguous.
+// g_*: MAP-sized ([B][C][map_height][map_width], dense), in the maps' storage type.
+int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void *g_albedo, void *g_normal, void *g_roughness, void *g_metallic,
+                           void *g_specular, bool loss, float scale, float *partials, hipStream_t st) {
+    KArgs k;
+    const int rc = fill_repeat_backward(d, k);
+    if (rc != PBR_OK) return rc;
     const BArgs b = {nullptr, g_albedo, g_normal, g_roughness, g_metallic, g_specular, nullptr};
-    const RBArgs rb = {static_cast<const float *>(upstream), out_plane, scale, partials};
+    const RBArgs rb = {static_cast<const float *>(upstream), (int64_t)d->height * d->width, scale, partials};
     hipLaunchKernelGGL(pick_repeat_bwd(d, loss), dim3((unsigned)k.n_tiles, 1, 1), dim3(64, 1, 1), 0, st, k, b, rb);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+}
+
+// pbr_cook_torrance_blend_backward over TILED maps (round 6): what the one-kernel folded backward serves, with one light, fp32 maps.
+bool repeat_blend_backward_serves(const pbr_render_desc *d) {
+    return repeat_backward_serves(d) && d->n_lights == 1 && d->map_dtype == PBR_F32 && d->normal.data != nullptr;
+}
+// kblend: ct_blend.hpp's KBlend (the second material, the mask, the normal-sign flags); g1: BArgs with material 1's MAP-sized gradient planes
+// (gout unused); g2: BBlend with material 2's and the mask's.  `grad_out`: [B][3][d->height][d->width] fp32 contiguous.
+int launch_repeat_blend_backward(const pbr_render_desc *d, const void *kblend, const void *grad_out, const void *g1, const void *g2, hipStream_t st) {
+    KArgs k;
+    const int rc = fill_repeat_backward(d, k);
+    if (rc != PBR_OK) return rc;
+    k.sbase = 0;                                          // (the second material and the mask are addressed per lane, as in the untiled blend backward)
+    const RBArgs rb = {static_cast<const float *>(grad_out), (int64_t)d->height * d->width, 0.0f, nullptr};
+    void (*fn)(const KArgs, const KBlend, const BArgs, const BBlend, const RBArgs) = nullptr;
+    const bool point = d->light_type == PBR_LIGHT_POINT;
+    switch ((point ? 3 : 0) + d->workflow) {
+        case 0: fn = cook_torrance_repeat_blend_backward_kernel<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>; break;
+        case 1: fn = cook_torrance_repeat_blend_backward_kernel<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>; break;
+        case 2: fn = cook_torrance_repeat_blend_backward_kernel<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>; break;
+        case 3: fn = cook_torrance_repeat_blend_backward_kernel<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>; break;
+        case 4: fn = cook_torrance_repeat_blend_backward_kernel<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>; break;
+        default: fn = cook_torrance_repeat_blend_backward_kernel<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>; break;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(64, 1, 1), 0, st, k, *static_cast<const KBlend *>(kblend), *static_cast<const BArgs *>(g1),
+                       *static_cast<const BBlend *>(g2), rb);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? PBR_OK : 1000 + (int)e;
 }

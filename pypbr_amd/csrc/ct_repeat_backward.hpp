@@ -30,6 +30,7 @@
 #pragma once
 #include <type_traits>
 #include "ct_backward.hpp"
+#include "ct_blend_backward.hpp"
 
 namespace pbr {
 
@@ -147,10 +148,13 @@ struct RBArgs {
 // y_offset / H_total describe the output) with o_cs = the MAP's plane (the gradient planes are dense [B][C][map_h * map_w]).
 //   MULTI: several lights (H12: per-light clamp, sum, clamp, encode) -- per position the two passes over the lights of backward_body_to (the
 //   summed colour decides the outer clamp and the encode's slope; then every light's chain rule into one adjoint); no loss policy.
-template <int LIGHT, int WF, typename TM, bool LOSS, bool MULTI = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RepeatBwdShape<LOSS, MULTI>::waves, 4)))
-void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RBArgs rb) {
+//   BLEND (round 6): the texels are the blend of TWO materials under a mask (ct_blend.hpp: blend_texels, the blended normal re-decoded), formed
+//   once per texel in front of the walk; behind it the folded gradients run on through the blend's own chain rule (blend_backward_sink) into
+//   map-sized gradients of both materials and of the mask -- pbr_cook_torrance_blend_backward over tiled maps.  fp32 maps, no loss policy.
+template <int LIGHT, int WF, typename TM, bool LOSS, bool MULTI, bool BLEND>
+__device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs &b, const RBArgs &rb, const KBlend *kb, const BBlend *g2) {
     static_assert(!(MULTI && LOSS), "the loss step over tiled maps is built for one light");
+    static_assert(!BLEND || (sizeof(TM) == 4 && !LOSS), "the fused blend's tiled backward: fp32 maps, gradients only");
     constexpr int VEC = 2;
     using R = f32x2;
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
@@ -164,6 +168,17 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
         if (a.has_normal) load_texels_fixed<WF, TM, VEC, true, true, true>(a, p, t); else load_texels_fixed<WF, TM, VEC, true, true, false>(a, p, t);
     } else {
         if (a.has_normal) load_texels_fixed<WF, TM, VEC, true, false, true>(a, p, t); else load_texels_fixed<WF, TM, VEC, true, false, false>(a, p, t);
+    }
+    Texels<VEC> t1, u;                        // BLEND: the two materials' own texels (the sink needs them again), `t` becomes the blended texel
+    float w[VEC] = {};
+    bool keep_signed = false;
+    const int mat = p.sb ? p.b0 : p.b;
+    if constexpr (BLEND) {
+        t1 = t;
+        load_texels<WF, float, VEC, true>(*kb, true, p, u);
+        Ld<float, VEC>::template load<true>(kb->mask, mat * kb->k_bs + p.src, w);
+        keep_signed = kb->normal_signed[mat] != 0;
+        blend_texels<WF, VEC>(t, u, w, keep_signed);
     }
     // Positions k = ry * rep_x + rx in pbr_fold_gradient's order; (ry, rx) are wave-uniform (scalar plane addresses need that), whether
     // a repeat's row lies inside the band `gout` holds -- rows [y_offset, y_offset + H_total) of the tiled image -- is the lane's own test.
@@ -280,7 +295,7 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
             adj.g_n = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};
         };
         clear_adjoint();
-        constexpr bool kPark = RepeatBwdShape<LOSS, MULTI>::park;
+        constexpr bool kPark = RepeatBwdShape<LOSS, MULTI>::park && !BLEND;       // (the blend form carries two materials' texels anyway: two waves)
         __shared__ float2 s_park[kPark ? kParkSlots * 64 : 1];
         if constexpr (kPark) park_texel<WF>(s_park + threadIdx.x, x, false);
         // The output encode is a launch-wide flag: tested once, outside the loop (two copies of the loop) -- inside it was three scalar
@@ -376,7 +391,20 @@ void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RB
 #pragma unroll
     for (int c = 0; c < 3; ++c) { scatter(oa[c], 0, acc_a[c]); scatter(on[c], 0, acc_n[c]); scatter(os[c], 0, acc_s[c]); }
     scatter(orr, 0, acc_r); scatter(om, 0, acc_m);
-    store_gradients<WF, VEC, TM>(a, b, p, oa, on, orr, om, os);
+    if constexpr (BLEND) blend_backward_sink<WF, VEC>(a, p, mat, t1, u, w, keep_signed, b, *g2, oa, on, orr, om, os);
+    else store_gradients<WF, VEC, TM>(a, b, p, oa, on, orr, om, os);
+}
+
+template <int LIGHT, int WF, typename TM, bool LOSS, bool MULTI = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RepeatBwdShape<LOSS, MULTI>::waves, 4)))
+void cook_torrance_repeat_backward_kernel(const KArgs a, const BArgs b, const RBArgs rb) {
+    repeat_backward_body<LIGHT, WF, TM, LOSS, MULTI, false>(a, b, rb, nullptr, nullptr);
+}
+
+template <int LIGHT, int WF>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void cook_torrance_repeat_blend_backward_kernel(const KArgs a, const KBlend kb, const BArgs b, const BBlend g2, const RBArgs rb) {
+    repeat_backward_body<LIGHT, WF, float, false, false, true>(a, b, rb, &kb, &g2);
 }
 
 }  // namespace pbr

@@ -495,7 +495,10 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
             for t in (albedo, normal, roughness, metallic, specular) + tuple(kwargs["blend"]) + tuple(kwargs.get(k) for k in _PARAM_KEYS)):
         if _fused_blend_backward_can_take(albedo, kwargs):
             kw = {k: v for k, v in kwargs.items() if k != "blend"}
-            return _FusedBlendFn.apply(kw, albedo, normal, roughness, metallic, specular, *kwargs["blend"])
+            try:
+                return _FusedBlendFn.apply(kw, albedo, normal, roughness, metallic, specular, *kwargs["blend"])
+            except _StepNotServed:
+                pass
         return _blend_then_render_with_grad(albedo, normal, roughness, metallic, specular, **kwargs)
     if USE_TORCH_OPS and _torch_op_can_take(albedo, kwargs):
         return _cook_torrance_via_torch_op(albedo, normal, roughness, metallic, specular, **kwargs)
@@ -512,12 +515,21 @@ def cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], roughnes
 def _fused_blend_backward_can_take(albedo, kw) -> bool:
     """pbr_cook_torrance_blend_backward covers gradients of the maps of both materials and of the mask: fp32, untiled, a fresh
     result.  Gradients of view / light parameters through a blend take the unfused differentiable pieces."""
-    if kw.get("out") is not None or kw.get("tile", 1) not in (1, (1, 1)) or kw.get("out_dtype") not in (None, torch.float32):
+    if kw.get("out") is not None or kw.get("out_dtype") not in (None, torch.float32):
         return False
     if any(isinstance(kw.get(k), torch.Tensor) and kw[k].requires_grad for k in _PARAM_KEYS):
         return False
     tensors = [albedo] + [t for t in kw["blend"] if t is not None]
-    return all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in tensors)
+    if not all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 for t in tensors):
+        return False
+    if kw.get("tile", 1) not in (1, (1, 1)):
+        # tiled maps (round 6, ABI 8): every map with its own planes here (a shared map would own a sum over the batch of MAP-sized planes);
+        # the library answers the rest when the plan exists (pbr_blend_backward_serves: one light, map rows of whole 4-texel groups, a whole
+        # output or a band that holds a period of the map's rows) -- _FusedBlendFn.forward raises _StepNotServed and the unfused pieces run
+        B = albedo.shape[0] if albedo.dim() == 4 else 1
+        if B > 1 and any(t.dim() < 4 or t.shape[0] == 1 for t in tensors):
+            return False
+    return True
 
 
 class _FusedBlendFn(torch.autograd.Function):
@@ -530,6 +542,8 @@ class _FusedBlendFn(torch.autograd.Function):
         maps, blend = tensors[:5], tensors[5:11]
         det = lambda t: None if t is None else t.detach()
         plan = plan_cook_torrance(*[det(t) for t in maps], blend=tuple(det(t) for t in blend), **kwargs)
+        if plan.desc.map_height and not N.lib().pbr_blend_backward_serves(ctypes.byref(plan.desc)):
+            raise _StepNotServed()                                # tiled, and not a launch of the fused tiled backward: the caller's unfused pieces
         ctx.plan = plan
         ctx.shapes = [None if t is None else tuple(t.shape) for t in tensors]
         ctx.save_for_backward(*[t for t in tensors if t is not None])   # for autograd's in-place-modification check
@@ -545,6 +559,8 @@ class _FusedBlendFn(torch.autograd.Function):
         d = plan.desc
         B, H, W = d.batch, d.height, d.width
         g = grad_out.reshape(B, 3, H, W).to(torch.float32).contiguous()
+        if d.map_height and (d.map_height != d.height_total or d.map_width != d.width):
+            H, W = d.map_height, d.map_width                      # tiled maps: MAP-sized gradients, every texel's sum over its repeats
         dev = g.device
         channels = (3, 3, 1, 1, 3)
         need = ctx.needs_input_grad[1:]                       # [0] is the kwargs dict
@@ -580,14 +596,17 @@ class _FusedBlendFn(torch.autograd.Function):
 
 
 def _blend_then_render_with_grad(albedo, normal, roughness, metallic, specular, *, blend, **kwargs):
-    """Gradients that the fused backward kernel does not cover (view / light parameters through a blend, tiled maps, fp16):
+    """Gradients that the fused backward kernel does not cover (view / light parameters through a blend, fp16; tiled maps where the fused
+    tiled backward does not serve them):
     the same computation runs unfused through the differentiable pieces -- blend_maps (pbr_blend_maps + pbr_blend_maps_backward) for every map, the
     re-decode of the blended normal (decode_normal and its backward: base.py:191-242 runs again on assignment), then the
     evaluation with its backward kernel -- so a rendering loss on a blended material (example_blend.py:14-32 inside a
     training loop) reaches both materials, the mask and the light / view parameters."""
     from .blending import blend_maps
-    if kwargs.get("out") is not None or kwargs.get("tile", 1) not in (1, (1, 1)):
-        raise NotImplementedError("gradients through the fused blend need out=None and untiled maps")
+    if kwargs.get("out") is not None:
+        raise NotImplementedError("gradients through the fused blend need out=None (the result must be a fresh tensor)")
+    # tile=n (round 6): the blend and the re-decode are MAP-sized operations -- the reference blends, assigns, then repeats (base.py:524-537)
+    # -- and the evaluation of the blended maps under tile=n is differentiable with map-sized (folded) gradients, so nothing here changes
     kwargs.pop("blend_flags", None)        # whole maps decide "already signed?" from their own values, as the reference does
     if kwargs.get("height_total") not in (None, albedo.shape[-2]):   # (the fused backward kernel takes row bands with given flags)
         # a ROW BAND cannot take that decision from its own rows (base.py:212 looks at the whole map), and the unfused

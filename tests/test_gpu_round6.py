@@ -1,0 +1,123 @@
+"""Round 6: the fused blend's backward over TILED maps (pbr_cook_torrance_blend_backward, ABI 8) -- `blend_with_mask(m1, m2, mask)` -> `tile(n)` ->
+CookTorranceBRDF inside a rendering loss (/root/reference/examples/example_blend.py:14-31, pypbr/materials/base.py:524-537,
+docs/source/tutorials/06_advanced.rst:73-107): MAP-sized gradients of both materials and of the mask from ONE kernel that blends once per
+texel, walks the repeats and runs the folded gradients through the blend's chain rule; where the library does not serve a launch, the
+differentiable pieces (which round 5 refused for tiled maps)."""
+import pytest
+import torch
+
+import blend_oracle as BO
+import torch_oracle as O
+from test_gpu_blend_backward import _check, _material
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_tiled(m1, m2, mask, wt, view, lights, intens, light_type, light_size, tile, converted=False):
+    """float64 autograd through the reference's ops: blend, re-assignment of the blended normal, repeat(1, ny, nx), the BRDF."""
+    ny, nx = tile
+    r1 = {k: v.double().requires_grad_(True) for k, v in m1.items()}
+    r2 = {k: v.double().requires_grad_(True) for k, v in m2.items()}
+    rm = mask.double().requires_grad_(True)
+    bl = {k: v.repeat(1, ny, nx) for k, v in BO.blend_materials(r1, r2, rm).items()}
+    kw = dict(view=view.double(), light_type=light_type, light_size=light_size)
+    L, I = lights.double().reshape(-1, 3), intens.double().reshape(-1, 3)
+    if converted:
+        ref = O.cook_torrance_converted(bl["albedo"], bl["normal"], bl["roughness"], bl["metallic"], light=L[0], intensity=I[0], **kw)
+    elif L.shape[0] > 1:
+        ref = O.cook_torrance_multi(bl["albedo"], bl["normal"], bl["roughness"], bl.get("metallic"), bl.get("specular"), lights=L, intensities=I, **kw)
+    else:
+        ref = O.cook_torrance(bl["albedo"], bl["normal"], bl["roughness"], bl.get("metallic"), bl.get("specular"), light=L[0], intensity=I[0], **kw)
+    (ref * wt.double()).sum().backward()
+    return ref.detach(), r1, r2, rm
+
+
+@pytest.mark.parametrize("workflow", ["metallic", "specular", "converted"])
+@pytest.mark.parametrize("light_type", ["point", "directional"])
+@pytest.mark.parametrize("flat", [False, True])
+def test_fused_blend_backward_over_tiled_maps_against_float64_autograd(workflow, light_type, flat):
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(300 + 7 * ["metallic", "specular", "converted"].index(workflow) + (3 if flat else 0))
+    H, W, tile = 18, 44, (2, 3)                                    # 44 = 11 groups of 4 texels: the repeat-inner walk
+    m1, m2 = _material(g, H, W, workflow, flat), _material(g, H, W, workflow, flat)
+    mask, wt = torch.rand(1, H, W, generator=g), torch.rand(3, tile[0] * H, tile[1] * W, generator=g) - 0.4
+    view = torch.tensor([0.0, 0.1, 1.0])
+    light = torch.tensor([0.1, 0.1, 1.0]) if light_type == "point" else torch.tensor([0.3, -0.2, 1.0])
+    inten = torch.tensor([1.0, 0.9, 0.8])
+    size = 1.5 if light_type == "point" else None
+    ref, r1, r2, rm = _reference_tiled(m1, m2, mask, wt, view, light, inten, light_type, size, tile, converted=(workflow == "converted"))
+    d1 = {k: v.clone().cuda().requires_grad_(True) for k, v in m1.items()}
+    d2 = {k: v.clone().cuda().requires_grad_(True) for k, v in m2.items()}
+    dm = mask.clone().cuda().requires_grad_(True)
+    kw = dict(view_dir=view, light=light, light_intensity=inten, light_type=light_type, light_size=size,
+              convert_to_diffuse_specular=(workflow == "converted"), specular_is_srgb=True, tile=tile)
+    second = (d2["albedo"], d2["normal"], d2["roughness"], d2.get("metallic"), d2.get("specular"), dm)
+    out = F.cook_torrance(d1["albedo"], d1["normal"], d1["roughness"], d1.get("metallic"), d1.get("specular"), blend=second, **kw)
+    assert out.shape == (3, tile[0] * H, tile[1] * W) and out.requires_grad
+    assert type(out.grad_fn).__name__ == "_FusedBlendFnBackward"                              # ONE kernel forward, ONE kernel backward
+    assert (out.detach().cpu().double() - ref).abs().max().item() <= 1e-5
+    (out * wt.cuda()).sum().backward()
+    for name in m1:
+        assert d1[name].grad.shape == m1[name].shape                                           # MAP-sized: the sums over the repeats
+        _check(d1[name].grad, r1[name].grad, (workflow, light_type, flat, "material 1", name))
+        _check(d2[name].grad, r2[name].grad, (workflow, light_type, flat, "material 2", name))
+    _check(dm.grad, rm.grad, "mask")
+
+
+def test_tiled_blend_gradients_the_library_does_not_fuse_take_the_differentiable_pieces():
+    """Several lights, and map widths that are not whole 4-texel groups: round 5 raised NotImplementedError for `tile` under a gradient through a
+    blend; now the blend (map-sized), the re-decode and the tiled evaluation with its folded backward run as pieces."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(11)
+    view, inten = torch.tensor([0.0, 0.1, 1.0]), torch.tensor([[0.6, 0.5, 0.4], [0.3, 0.3, 0.5]])
+    lights = torch.tensor([[0.1, 0.1, 1.0], [-0.3, 0.2, 0.8]])
+    for (H, W), L, I in (((12, 40), lights, inten), ((10, 38), lights[0], inten[0])):
+        tile = (2, 2)
+        m1, m2 = _material(g, H, W, "metallic"), _material(g, H, W, "metallic")
+        mask, wt = torch.rand(1, H, W, generator=g), torch.rand(3, 2 * H, 2 * W, generator=g) - 0.4
+        ref, r1, r2, rm = _reference_tiled(m1, m2, mask, wt, view, L, I, "point", 1.0, tile)
+        d1 = {k: v.clone().cuda().requires_grad_(True) for k, v in m1.items()}
+        d2 = {k: v.clone().cuda().requires_grad_(True) for k, v in m2.items()}
+        dm = mask.clone().cuda().requires_grad_(True)
+        second = (d2["albedo"], d2["normal"], d2["roughness"], d2["metallic"], None, dm)
+        out = F.cook_torrance(d1["albedo"], d1["normal"], d1["roughness"], d1["metallic"], blend=second, view_dir=view, light=L, light_intensity=I,
+                              light_type="point", light_size=1.0, tile=tile)
+        assert type(out.grad_fn).__name__ != "_FusedBlendFnBackward"
+        assert (out.detach().cpu().double() - ref).abs().max().item() <= 1e-5
+        (out * wt.cuda()).sum().backward()
+        for name in m1:
+            _check(d1[name].grad, r1[name].grad, ((H, W), "material 1", name))
+            _check(d2[name].grad, r2[name].grad, ((H, W), "material 2", name))
+        _check(dm.grad, rm.grad, "mask")
+
+
+def test_rendering_loss_on_a_blended_resized_tiled_material_reaches_both_materials():
+    """The blend example's material inside the tutorial's loss: blender(m1, m2) -> tile(2) -> RenderingLoss; both source materials and the mask
+    receive MAP-sized gradients, equal to the gradients through the materialised blend + repeat."""
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    H, W = 32, 64
+    m1, m2 = _material(g, H, W, "metallic"), _material(g, H, W, "metallic")
+    mask = torch.rand(1, H, W, generator=g).cuda()
+    target = torch.rand(3, 2 * H, 2 * W, generator=g).cuda()
+    kw = dict(view_dir=[0.0, 0.0, 1.0], light=[0.1, 0.1, 1.0], light_intensity=[1.0, 1.0, 1.0], light_type="point", light_size=1.0)
+
+    def step(fused):
+        d1 = {k: v.clone().cuda().requires_grad_(True) for k, v in m1.items()}
+        d2 = {k: v.clone().cuda().requires_grad_(True) for k, v in m2.items()}
+        dm = mask.clone().requires_grad_(True)
+        second = (d2["albedo"], d2["normal"], d2["roughness"], d2["metallic"], None, dm)
+        if fused:
+            out = F.cook_torrance(d1["albedo"], d1["normal"], d1["roughness"], d1["metallic"], blend=second, tile=2, **kw)
+        else:
+            out = F._blend_then_render_with_grad(d1["albedo"], d1["normal"], d1["roughness"], d1["metallic"], None, blend=second, tile=2, **kw)
+        loss = torch.nn.functional.mse_loss(out, target)
+        loss.backward()
+        return loss.detach(), d1, d2, dm
+    lf, f1, f2, fm = step(True)
+    lu, u1, u2, um = step(False)
+    assert abs(float(lf) - float(lu)) <= 2e-6 * float(lu)
+    for name in m1:
+        for a, b in ((f1[name].grad, u1[name].grad), (f2[name].grad, u2[name].grad)):
+            assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-5 * (1 + float(b.abs().max())), name
+    assert (fm.grad - um.grad).abs().max().item() <= 2e-5 * (1 + float(um.grad.abs().max()))

@@ -276,6 +276,25 @@ if want("blend_bwd"):
            timed(lambda: N.check(lib.pbr_cook_torrance_blend_backward(ctypes.byref(p.desc), ctypes.byref(bd), p._workspace.data_ptr(), gout.data_ptr(),
                                                                       ctypes.byref(G1), ctypes.byref(G2), gm.data_ptr(), stream))))
     del m1, m2, mask, p, gout, g1, g2, gm
+if want("blend_bwd_tiled"):
+    # round 6: the fused blend's backward over TILED maps -- the blend example's material under tile(2) inside a rendering loss: one kernel blends
+    # once per texel, walks the repeats and runs the folded gradients through the blend's chain rule (MAP-sized gradients of both materials + the mask)
+    m1, m2 = synth_material(2048, DEV, 21), synth_material(2048, DEV, 22)
+    mask = torch.rand(1, 2048, 2048, device=DEV)
+    p = F.plan_cook_torrance(*m1, blend=(m2[0], m2[1], m2[2], m2[3], None, mask), tile=2, **PT)
+    p.launch(stream)
+    gout = torch.rand(1, 3, S, S, device=DEV)
+    g1, g2, gm = [torch.empty_like(t) for t in m1], [torch.empty_like(t) for t in m2], torch.empty_like(mask)
+    G1 = N.MapGrads(g1[0].data_ptr(), g1[1].data_ptr(), g1[2].data_ptr(), g1[3].data_ptr(), None)
+    G2 = N.MapGrads(g2[0].data_ptr(), g2[1].data_ptr(), g2[2].data_ptr(), g2[3].data_ptr(), None)
+    bd = N.BlendDesc.from_buffer_copy(p._blend)
+    bd.sign_mode = N.BLEND_SIGN_GIVEN
+    assert lib.pbr_blend_backward_serves(ctypes.byref(p.desc)) == 1
+    report("blend_bwd_tiled: backward of the fused blend + render over 2048^2 maps under tile(2) -> 4096^2 (17 map planes of 2048^2 + 3 upstream planes of 4096^2 in, 17 gradient planes of 2048^2 out)",
+           "cook_torrance_repeat_blend_backward_kernel<1, 0>", 12 * PX + 136 * 2048 * 2048,
+           timed(lambda: N.check(lib.pbr_cook_torrance_blend_backward(ctypes.byref(p.desc), ctypes.byref(bd), p._workspace.data_ptr(), gout.data_ptr(),
+                                                                      ctypes.byref(G1), ctypes.byref(G2), gm.data_ptr(), stream))))
+    del m1, m2, mask, p, gout, g1, g2, gm
 if want("loss_step"):
     for dtype, tag, kern, bpp in ((torch.float32, "loss_step_f32", "cook_torrance_mse_step_kernel<1, 0, 2, false, float>", 76),
                                   (torch.float16, "loss_step_f16", "cook_torrance_mse_stream_kernel<1, 0, true>", 44)):

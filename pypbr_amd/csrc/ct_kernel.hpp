@@ -89,6 +89,8 @@ struct KArgs {
     int32_t grey_lights;     // every light's three intensities are equal: radiance * intensity once per light, not per channel
     LightU lights[PBR_MAX_LIGHTS];
     int32_t rep_y, rep_x;    // cook_torrance_repeat_kernel: the grid walks the SOURCE maps (H x W texels), every lane evaluates its texels at all rep_y * rep_x positions of the output
+    int32_t win_y0;          // repeat kernels, a row band THINNER than a period of the map's rows (round 6): the walk covers only the H source rows the band
+                             // touches, row i of it is source row (win_y0 + i) mod map_h; map_h is the period there (H == map_h: the whole map, win_y0 = 0)
     int32_t out_W, out_Ht;   // ... whose rows are out_W pixels wide and whose point-light grid spans out_Ht x out_W; `out` holds the rows
                              // [y_offset, y_offset + H_total) of it (the repeat kernel's H_total: the band's rows; it has no other use there)
     uint64_t dev;            // pbr_render_desc.device_params (address of a DevParams block, 0 = none): when set, V and the light blocks are read from it (view_of / light_of)
@@ -785,13 +787,24 @@ void cook_torrance_batch_kernel(const KArgs a) {
 // terms cost 1 / (rep_y rep_x) per output pixel; a directional light (position-independent) is evaluated ONCE and stored
 // rep_y x rep_x times.  Same functions in the same order per pixel as cook_torrance_kernel: bit-identical to evaluating the
 // materialised repeat.  One light, 4 texels per lane (fp16 maps: 8-byte loads -- loads are the minor stream here), packed
-// arithmetic; row bands of the tiled output (multi-GPU shards) are served when they hold at least one full period of the map's rows; thinner
-// bands, several lights and ragged map widths keep the wrap-around form.
+// arithmetic; row bands of the tiled output (multi-GPU shards) of any height: a band thinner than a period walks the window of source rows
+// it touches (repeat_window); ragged map widths keep their 4-texel lanes (the last lane of a row moves back: lane_pos).
 // NTL / NTS: the streaming hint on the loads / on the stores.
 // MULTI (round 5): several lights -- the light loop sits INSIDE the position loop (a position's lights are summed, clamped and encoded as
 // cook_torrance_kernel<.., MULTI = true> does: per-light clamp, sum, clamp, encode), so texels are still loaded, decoded and turned into
 // pixel terms once for all repeats and all lights.  The launch is VALU-bound; what the walk saves is the second read of every texel
 // (the wrap-around form: 1.40 x the maps from HBM) and 1 - 1/(rep_y rep_x) of the decode.
+// A row band thinner than one period of the map's rows (a multi-GPU shard of ONE tiled material): the band's rows touch a cyclic
+// window of the source rows -- row i of the walk is source row (win_y0 + i) mod map_h -- and each of them exactly once vertically (the band
+// test of the position loop picks that repeat), while the horizontal repeats still share the texel: every texel the band needs is loaded
+// and decoded once, none that it does not need is touched (until round 6 such bands took the wrap-around form: 1.40 x the maps from HBM).
+__device__ __forceinline__ void repeat_window(const KArgs &a, LanePos &p) {
+    int sy = a.win_y0 + p.y;
+    sy -= sy >= a.map_h ? a.map_h : 0;
+    p.y = sy;
+    p.src = p.pix = (int64_t)sy * a.W + p.x;
+}
+
 template <int LIGHT, int WF, typename TI, typename TO, bool NTL, bool NTS, bool MULTI = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void cook_torrance_repeat_kernel(const KArgs a) {
@@ -799,8 +812,10 @@ void cook_torrance_repeat_kernel(const KArgs a) {
     using R = f32x2;
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
     const int ty = (int)a.div_tx.div(tile);
-    const LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);      // over the SOURCE maps: a.H x a.W texels per material
+    LanePos p = lane_pos<VEC>(a, (int)tile - ty * a.tiles_x, ty);            // over the SOURCE maps: a.H x a.W texels per material
     if (!p.valid) return;
+    const int PH = a.map_h;                                                  // the period of the map's rows
+    if (a.H != PH) repeat_window(a, p);                                      // a thin band: the walk's rows are a cyclic window of the map's
     Texels<VEC> t;
     load_texels<WF, TI, VEC, NTL>(a, a.has_normal != 0, p, t);
     decode_texels<WF, VEC, true>(a, t);
@@ -813,9 +828,9 @@ void cook_torrance_repeat_kernel(const KArgs a) {
     const uint32_t lane_out = (uint32_t)(p.y * a.out_W + p.x);              // inside the first repeat; < 2^30 when p.sb (fill_args)
     // `out` holds the rows [y_offset, y_offset + H_total) of the tiled image (all of it, or a multi-GPU shard's band): a repeat whose
     // row falls outside is skipped; the others land y_offset rows higher.  (rep may be negative; rep + the lane's part never is.)
-    auto in_band = [&](int ry) { const int yy = p.y + ry * a.H - a.y_offset; return yy >= 0 && yy < a.H_total; };
+    auto in_band = [&](int ry) { const int yy = p.y + ry * PH - a.y_offset; return yy >= 0 && yy < a.H_total; };
     auto store_at = [&](int ry, int rx, const R (&res)[3][NG]) {
-        const int64_t rep = ((int64_t)ry * a.H - a.y_offset) * a.out_W + (int64_t)rx * a.W;
+        const int64_t rep = ((int64_t)ry * PH - a.y_offset) * a.out_W + (int64_t)rx * a.W;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float o[VEC];
@@ -873,7 +888,7 @@ void cook_torrance_repeat_kernel(const KArgs a) {
     }
     for (int ry = 0; ry < a.rep_y; ++ry) {
         if (!in_band(ry)) continue;
-        const float ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, p.y + ry * a.H);
+        const float ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, p.y + ry * PH);
         for (int rx = 0; rx < a.rep_x; ++rx) {
             R xs[NG], res[3][NG];
             x_grid_w<R, NG, VEC>(a, a.out_W, p.x + rx * a.W, xs);

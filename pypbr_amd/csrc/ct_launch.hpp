@@ -260,14 +260,16 @@ int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void 
 bool repeat_blend_backward_serves(const pbr_render_desc *d);
 int launch_repeat_blend_backward(const pbr_render_desc *d, const void *kblend, const void *grad_out, const void *g1, const void *g2, hipStream_t st);
 
-// Tiled maps evaluated by the repeat-inner kernel (ct_kernel.hpp: cook_torrance_repeat_kernel): map rows a whole number of
-// 4-texel lanes, and an output -- the whole tiled image, or a row band of it (a multi-GPU shard) -- that holds at least one full period
-// of the map's rows: in a thinner band no texel row is used twice vertically, there is nothing for the kernel to share, and every source
-// row outside the band would be loaded for nothing.  Thin bands and ragged map widths take the wrap-around form.
+// The repeat-inner kernels (cook_torrance_repeat_kernel, cook_torrance_repeat_backward_kernel) serve every tiled launch whose map rows hold a
+// 4-texel lane: the whole tiled image or a row band of it (a multi-GPU shard) of ANY height -- a band thinner than a period walks the window
+// of source rows it touches -- and ragged map widths (the last lane of a row moves back and overlaps its neighbour, as everywhere).  Until
+// round 6 thin bands and ragged widths took the wrap-around form of cook_torrance_kernel (a second read of every texel: 1.40 x the maps from
+// HBM); it remains for map rows shorter than 4 texels and behind PBR_TUNE_TILE_REPEAT = 0 (the A/B of the tests).
 inline bool repeat_inner(const pbr_render_desc *d) {
-    return g_tile_repeat != 0 && is_tiled(d) && d->height >= d->map_height &&
-           d->map_width % 4 == 0 && g_max_vec >= 4;
+    return g_tile_repeat != 0 && is_tiled(d) && d->map_width >= 4 && g_max_vec >= 4;
 }
+// A band thinner than one period of the map's rows: the walk covers the cyclic window of source rows the band touches (KArgs::win_y0).
+inline bool repeat_thin_band(const pbr_render_desc *d) { return d->height < d->map_height; }
 
 // Materials per lane for this launch, or 0 for the one-material kernels.  Several lights make the launch VALU-bound, and
 // the light geometry is shared by every material at a pixel position: groups of 4 (or 2) consecutive materials per lane.

@@ -34,7 +34,10 @@ bool repeat_backward_serves(const pbr_render_desc *d) {
     return repeat_inner(d) && d->out_dtype == PBR_F32 && g_max_vec >= 2;
 }
 // ... and the rendering-loss step through it: one light (the two passes over several lights are built for the gradient only)
-bool repeat_loss_serves(const pbr_render_desc *d) { return repeat_backward_serves(d) && d->n_lights == 1; }
+//     (its squared-difference sum counts every pixel once: no overlapping last lanes, i.e. map rows of whole pairs; bands of at least a period)
+bool repeat_loss_serves(const pbr_render_desc *d) {
+    return repeat_backward_serves(d) && d->n_lights == 1 && d->map_width % 4 == 0 && !repeat_thin_band(d);
+}
 
 // Workgroups of the launch for this descriptor (one partial sum each under the loss policy), -1 when it does not fit a 1-D grid.
 int64_t repeat_backward_tiles(const pbr_render_desc *d) {
@@ -50,7 +53,8 @@ static int fill_repeat_backward(const pbr_render_desc *d, KArgs &k) {
     KArgs full;
     fill_args(d, 4, full);                               // the output's point-light grid, view, light, flags
     pbr_render_desc g = *d;
-    g.height = g.height_total = d->map_height; g.width = d->map_width; g.map_height = g.map_width = 0; g.y_offset = 0;
+    const bool thin = repeat_thin_band(d);               // a band thinner than a period: the cyclic window of source rows it touches (KArgs::win_y0)
+    g.height = g.height_total = thin ? d->height : d->map_height; g.width = d->map_width; g.map_height = g.map_width = 0; g.y_offset = 0;
     g.out_batch_stride = g.out_channel_stride = 0;
     fill_args(&g, 2, k, 6);                              // one-wave workgroups over the source maps, two texels per lane
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
@@ -67,6 +71,7 @@ static int fill_repeat_backward(const pbr_render_desc *d, KArgs &k) {
     k.rep_y = d->height_total / d->map_height; k.rep_x = d->width / d->map_width;
     k.out_W = d->width; k.out_Ht = d->height_total;
     k.y_offset = d->y_offset; k.H_total = d->height;     // `upstream` holds the rows [y_offset, y_offset + height) of the tiled image
+    k.map_h = d->map_height; k.win_y0 = thin ? d->y_offset % d->map_height : 0;
     k.o_cs = (int64_t)d->map_height * d->map_width; k.o_bs = 3 * k.o_cs;      // the gradient planes: dense, map-sized
     if ((int64_t)d->height * d->width >= (1ll << 30)) k.sbase = 0;           // the lane's offset inside the output's first repeat must fit 32 bits of bytes
     return PBR_OK;
@@ -88,7 +93,7 @@ int launch_repeat_backward(const pbr_render_desc *d, const void *upstream, void 
 
 // pbr_cook_torrance_blend_backward over TILED maps (round 6): what the one-kernel folded backward serves, with one light, fp32 maps.
 bool repeat_blend_backward_serves(const pbr_render_desc *d) {
-    return repeat_backward_serves(d) && d->n_lights == 1 && d->map_dtype == PBR_F32 && d->normal.data != nullptr;
+    return repeat_backward_serves(d) && d->n_lights == 1 && d->map_dtype == PBR_F32 && d->normal.data != nullptr && !repeat_thin_band(d);
 }
 // kblend: ct_blend.hpp's KBlend (the second material, the mask, the normal-sign flags); g1: BArgs with material 1's MAP-sized gradient planes
 // (gout unused); g2: BBlend with material 2's and the mask's.  `grad_out`: [B][3][d->height][d->width] fp32 contiguous.
@@ -141,11 +146,21 @@ int pbr_cook_torrance_backward_folded(const pbr_render_desc *d, const void *grad
     if (d->out_dtype != PBR_F32) return PBR_ERR_DTYPE;
     if (!is_tiled(d))                                         // nothing to fold: the gradients are map-sized as they come
         return pbr_cook_torrance_backward(d, grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, stream);
-    if (d->height != d->height_total && d->height < d->map_height) return PBR_ERR_UNSUPPORTED;   // a band thinner than one period of the map
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (repeat_backward_serves(d))
+    if (repeat_backward_serves(d)) {
+        if (repeat_thin_band(d)) {
+            // the band touches only a window of the map's rows: the texels outside it have no repeat inside the band -- their partial sum is 0
+            const size_t esz = d->map_dtype == PBR_F32 ? 4 : 2, plane = (size_t)d->batch * d->map_height * d->map_width * esz;
+            void *const bufs[5] = {g_albedo, d->normal.data ? g_normal : nullptr, g_roughness, d->workflow == PBR_WORKFLOW_SPECULAR ? nullptr : g_metallic,
+                                   d->workflow == PBR_WORKFLOW_SPECULAR ? g_specular : nullptr};
+            const int chans[5] = {3, 3, 1, 1, 3};
+            for (int i = 0; i < 5; ++i)
+                if (bufs[i] && hipMemsetAsync(bufs[i], 0, chans[i] * plane, st) != hipSuccess) return 1000 + (int)hipGetLastError();
+        }
         return launch_repeat_backward(d, grad_out, g_albedo, g_normal, g_roughness, g_metallic, g_specular, false, 0.0f, nullptr, st);
-    // the two-kernel form: per-output-pixel gradients into the workspace, then the sums (whole outputs only: a band's repeats are not whole)
+    }
+    // the two-kernel form (map rows shorter than 4 texels; PBR_TUNE_TILE_REPEAT = 0): per-output-pixel gradients into the workspace, then the
+    // sums (whole outputs only: a band's repeats are not whole)
     if (!workspace) return PBR_ERR_NULL_MAP;
     if (d->height != d->height_total) return PBR_ERR_UNSUPPORTED;
     const size_t esz = d->map_dtype == PBR_F32 ? 4 : 2;

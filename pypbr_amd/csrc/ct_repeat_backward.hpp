@@ -159,8 +159,10 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
     using R = f32x2;
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
     const int ty = (int)a.div_tx.div(tile);
-    const LanePos p = lane_pos<VEC, LOSS>(a, (int)tile - ty * a.tiles_x, ty);      // over the SOURCE maps; LOSS: every lane reaches the wave sum
+    LanePos p = lane_pos<VEC, LOSS>(a, (int)tile - ty * a.tiles_x, ty);            // over the SOURCE maps; LOSS: every lane reaches the wave sum
     if (!LOSS && !p.valid) return;
+    const int PH = a.map_h;                                                        // the period of the map's rows
+    if (!LOSS && a.H != PH) repeat_window(a, p);                                   // a thin band: the walk's rows are a cyclic window of the map's (ct_kernel.hpp)
     Texels<VEC> t;
     if constexpr (sizeof(TM) == 4) {
         load_texels<WF, TM, VEC, true>(a, a.has_normal != 0, p, t);
@@ -184,11 +186,11 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
     // a repeat's row lies inside the band `gout` holds -- rows [y_offset, y_offset + H_total) of the tiled image -- is the lane's own test.
     const int n_pos = a.rep_y * a.rep_x;
     const uint32_t lane_out = (uint32_t)(p.y * a.out_W + p.x);                  // inside the first repeat; < 2^30 when p.sb (launch_repeat_backward)
-    auto in_band = [&](int ry) { const int yy = p.y + ry * a.H - a.y_offset; return yy >= 0 && yy < a.H_total; };
+    auto in_band = [&](int ry) { const int yy = p.y + ry * PH - a.y_offset; return yy >= 0 && yy < a.H_total; };
     auto load_upstream = [&](int k, float (&go)[3][VEC]) {
         const int ry = k / a.rep_x, rx = k - ry * a.rep_x;
         if (!in_band(ry)) return;
-        const int64_t rep = ((int64_t)ry * a.H - a.y_offset) * a.out_W + (int64_t)rx * a.W;      // may be negative; rep + the lane's part never is
+        const int64_t rep = ((int64_t)ry * PH - a.y_offset) * a.out_W + (int64_t)rx * a.W;      // may be negative; rep + the lane's part never is
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             if (p.sb) Ld<float, VEC>::template load<true>(plane_at<float>(rb.gout, (p.b0 * 3 + c) * rb.gout_cs + rep, lane_out), 0, go[c]);
@@ -276,7 +278,7 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
         const char *const lane_base = reinterpret_cast<const char *>(rb.gout) +
             4 * (((int64_t)p.b * 3) * rb.gout_cs + ((int64_t)p.y - a.y_offset) * a.out_W + p.x);     // (b, channel 0, repeat (0,0)); below the band's first row for y < y_offset: never dereferenced there
         const int64_t plane_bytes = 4 * rb.gout_cs;
-        const int64_t col_step = 4 * (int64_t)a.W, row_step = 4 * ((int64_t)a.H * a.out_W - (int64_t)(a.rep_x - 1) * a.W);
+        const int64_t col_step = 4 * (int64_t)a.W, row_step = 4 * ((int64_t)PH * a.out_W - (int64_t)(a.rep_x - 1) * a.W);
         auto row_in_band = [&](int yrow) { const int yy = yrow - a.y_offset; return yy >= 0 && yy < a.H_total; };
         auto fetch = [&](int64_t rep_bytes, float (&dst)[3][VEC]) {
 #pragma unroll
@@ -306,7 +308,7 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
             const int ry = n_ry, rx = n_rx, yrow = n_yrow;
             // advance to the next position and start its loads: they travel under this position's arithmetic
             ++n_rx; n_rep += col_step;
-            if (n_rx == a.rep_x) { n_rx = 0; ++n_ry; n_yrow += a.H; n_rep += row_step - col_step; }
+            if (n_rx == a.rep_x) { n_rx = 0; ++n_ry; n_yrow += PH; n_rep += row_step - col_step; }
             if (k + 1 < n_pos && row_in_band(n_yrow)) fetch(n_rep, go_next);
             if (row_in_band(yrow)) {                                                  // a repeat outside this rank's band: nothing to add
                 R xs[1] = {splat<R>(0.0f)};
@@ -315,9 +317,13 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
                     // x_grid_w's one-sided form without its wave vote: the output's width is a multiple of 4 (repeat_inner: map_w % 4 == 0),
                     // so its midpoint is even and a lane's pair of columns never straddles it -- the same statements, no branch
                     const int x0 = p.x + rx * a.W;
-                    const bool lo = x0 < (a.out_W >> 1);
-                    const float f0 = (float)(lo ? x0 : a.out_W - 1 - x0);
-                    xs[0] = fma_(splat<R>(lo ? a.xstep : -a.xstep), fma_(splat<R>(lo ? 1.0f : -1.0f), lane_offsets<R>(0), splat<R>(f0)), splat<R>(lo ? a.x0 : a.x1));
+                    if (a.out_W & 3) {                    // ragged map widths (round 6): a pair may straddle the midpoint -- the general form
+                        x_grid_w<R, 1, VEC>(a, a.out_W, x0, xs);
+                    } else {
+                        const bool lo = x0 < (a.out_W >> 1);
+                        const float f0 = (float)(lo ? x0 : a.out_W - 1 - x0);
+                        xs[0] = fma_(splat<R>(lo ? a.xstep : -a.xstep), fma_(splat<R>(lo ? 1.0f : -1.0f), lane_offsets<R>(0), splat<R>(f0)), splat<R>(lo ? a.x0 : a.x1));
+                    }
                 }
                 if constexpr (MULTI) {
                     R g_col[3], sum[3] = {splat<R>(0.0f), splat<R>(0.0f), splat<R>(0.0f)};

@@ -44,7 +44,8 @@ void fill_repeat_args(const pbr_render_desc *d, KArgs &k) {
     KArgs full;
     fill_args(d, 4, full);                               // the output's point-light grid (x0 .. ystep), view, light, flags
     pbr_render_desc g = *d;
-    g.height = g.height_total = d->map_height;
+    const bool thin = repeat_thin_band(d);               // the walk covers the source rows the band touches: all of them, or a cyclic window
+    g.height = g.height_total = thin ? d->height : d->map_height;
     g.width = d->map_width;
     g.map_height = g.map_width = 0;
     g.y_offset = 0;
@@ -57,6 +58,7 @@ void fill_repeat_args(const pbr_render_desc *d, KArgs &k) {
     k.rep_y = d->height_total / d->map_height; k.rep_x = d->width / d->map_width;
     k.out_W = d->width; k.out_Ht = d->height_total;
     k.y_offset = d->y_offset; k.H_total = d->height;     // the rows [y_offset, y_offset + H_total) of the tiled image are what `out` holds (KArgs: out_Ht)
+    k.map_h = d->map_height; k.win_y0 = thin ? d->y_offset % d->map_height : 0;
     if (plane >= (1ll << 30)) k.sbase = 0;               // the lane's offset inside the result's first repeat must fit 32 bits of bytes
 }
 

@@ -121,3 +121,124 @@ def test_rendering_loss_on_a_blended_resized_tiled_material_reaches_both_materia
         for a, b in ((f1[name].grad, u1[name].grad), (f2[name].grad, u2[name].grad)):
             assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-5 * (1 + float(b.abs().max())), name
     assert (fm.grad - um.grad).abs().max().item() <= 2e-5 * (1 + float(um.grad.abs().max()))
+
+
+# ---------------------------------------------------------------- thin row bands and ragged map widths on the repeat-inner walk
+def _tiled_maps(g, h, w, dtype=torch.float32):
+    a = torch.rand(3, h, w, generator=g)
+    n = torch.cat([torch.rand(2, h, w, generator=g) - 0.5, torch.ones(1, h, w)], 0) * (0.7 + torch.rand(1, h, w, generator=g))
+    r = torch.rand(1, h, w, generator=g) * 0.7 + 0.25
+    m = torch.rand(1, h, w, generator=g)
+    return [t.to(dtype).cuda() for t in (a, n, r, m)]
+
+
+def _knob(value):
+    from pypbr_amd import _native as N
+    N.lib().pbr_set_tuning(N.TUNE_TILE_REPEAT, value)
+
+
+@pytest.mark.parametrize("light_type", ["point", "directional"])
+@pytest.mark.parametrize("lights", [1, 3])
+@pytest.mark.parametrize("hw,tile,dtype", [((16, 64), (3, 2), torch.float32), ((13, 40), (4, 1), torch.float32), ((16, 64), (2, 2), torch.float16),
+                                           ((9, 38), (3, 2), torch.float32), ((8, 6), (3, 5), torch.float32), ((7, 13), (2, 3), torch.float16)])
+def test_thin_bands_and_ragged_widths_take_the_repeat_inner_walk_and_equal_the_full_image(light_type, lights, hw, tile, dtype):
+    """A multi-GPU shard of ONE tiled material is a row band of the tiled image, usually thinner than a period of the map's rows (tile(2) over 8
+    ranks: a quarter period).  Every band -- any offset, any height, across a period boundary or not -- equals the rows of the whole image bit
+    for bit, and so do maps whose width is not a whole number of 4-texel lanes; both forms name the repeat-inner kernel now, not the wrap-around one."""
+    from pypbr_amd import functional as F
+    (h, w), (ny, nx) = hw, tile
+    g = torch.Generator().manual_seed(5 * h + w + lights)
+    maps = _tiled_maps(g, h, w, dtype)
+    L = [[0.1, 0.1, 1.0], [-0.4, 0.2, 0.7], [0.3, -0.3, 0.9]][:lights] if light_type == "point" else [[0.3, -0.2, 1.0], [0.1, 0.4, 0.8], [-0.2, 0.1, 1.0]][:lights]
+    I = [[1.0, 0.9, 0.8], [0.4, 0.5, 0.6], [0.3, 0.3, 0.3]][:lights]
+    kw = dict(view_dir=[0.05, 0.1, 0.9], light=L if lights > 1 else L[0], light_intensity=I if lights > 1 else I[0], light_type=light_type,
+              light_size=1.5 if light_type == "point" else None)
+    plan = F.plan_cook_torrance(*maps, tile=tile, **kw)
+    assert plan.kernel_name.startswith("ctr_"), plan.kernel_name              # the repeat-inner walk serves ragged widths too
+    full = plan.launch().clone()
+    try:
+        _knob(0)
+        wrap = F.cook_torrance(*maps, tile=tile, **kw)                        # the wrap-around form: the same functions per pixel
+    finally:
+        _knob(-1)
+    assert torch.equal(full, wrap)
+    H = ny * h
+    bands = [(0, 1), (h - 1, 2), (1, h - 1), (h // 2, h // 2 + 1), (H - 3, 3), (h + 2, max(1, h - 3)), (2, h), (0, H)]
+    for y0, rows in bands:
+        rows = min(rows, H - y0)
+        p = F.plan_cook_torrance(*maps, tile=tile, y_offset=y0, rows=rows, **kw)
+        assert p.kernel_name.startswith("ctr_"), (y0, rows, p.kernel_name)
+        got = p.launch()
+        assert got.shape == (3, rows, nx * w) and torch.equal(got, full[:, y0:y0 + rows]), (y0, rows)
+
+
+@pytest.mark.parametrize("binding", ["torch_op", "ctypes"])
+@pytest.mark.parametrize("light_type", ["point", "directional"])
+@pytest.mark.parametrize("hw,tile", [((16, 64), (3, 2)), ((9, 38), (2, 3)), ((7, 13), (4, 2))])
+def test_folded_gradients_of_thin_bands_add_up_to_the_whole_images_gradient(binding, light_type, hw, tile):
+    """The ranks' partial sums: bands that partition the tiled image -- thinner than a period, one crossing a period boundary -- each give
+    MAP-sized gradients with zeros where the band touches no repeat of a texel; their sum is the gradient of the whole image (to rounding), and
+    each band equals float64 autograd through the materialised repeat cropped to it.  Ragged map widths included (9 x 38, 7 x 13)."""
+    from pypbr_amd import functional as F
+    (h, w), (ny, nx) = hw, tile
+    g = torch.Generator().manual_seed(3 * h + w)
+    maps = _tiled_maps(g, h, w)
+    kw = dict(view_dir=[0.05, 0.1, 0.9], light=[0.1, 0.1, 1.0] if light_type == "point" else [0.3, -0.2, 1.0], light_intensity=[1.0, 0.9, 0.8],
+              light_type=light_type, light_size=1.5 if light_type == "point" else None)
+    H = ny * h
+    gout = (torch.rand(3, H, nx * w, generator=g) - 0.3).cuda()
+    before = F.USE_TORCH_OPS
+    try:
+        F.USE_TORCH_OPS = binding == "torch_op"
+        whole = [t.clone().requires_grad_(True) for t in maps]
+        (F.cook_torrance(*whole, tile=tile, **kw) * gout).sum().backward()
+        cuts = sorted({0, h // 3, h - 1, h + 2, H - 2, H} | {min(H, k * (H // 5 + 1)) for k in range(6)})
+        total = [torch.zeros_like(t) for t in maps]
+        for y0, y1 in zip(cuts[:-1], cuts[1:]):
+            leaves = [t.clone().requires_grad_(True) for t in maps]
+            out = F.cook_torrance(*leaves, tile=tile, y_offset=y0, rows=y1 - y0, **kw)
+            (out * gout[:, y0:y1]).sum().backward()
+            # float64 autograd through the materialised repeat, cropped to the band
+            ref = [t.detach().cpu().double().requires_grad_(True) for t in maps]
+            okw = dict(view=torch.tensor(kw["view_dir"]).double(), light=torch.tensor(kw["light"]).double(), intensity=torch.tensor(kw["light_intensity"]).double(),
+                       light_type=light_type, light_size=kw["light_size"])
+            img = O.cook_torrance(*[t.repeat(1, ny, nx) for t in ref], None, **okw)
+            (img[:, y0:y1] * gout[:, y0:y1].cpu().double()).sum().backward()
+            for name, x, r, acc in zip(("albedo", "normal", "roughness", "metallic"), leaves, ref, total):
+                err = (x.grad.cpu().double() - r.grad).abs()
+                assert bool((err <= 2e-5 * (1 + r.grad.abs())).all()), (name, y0, y1, float(err.max()))
+                acc += x.grad
+        for name, acc, wl in zip(("albedo", "normal", "roughness", "metallic"), total, whole):
+            assert (acc - wl.grad).abs().max().item() <= 1e-5 * (float(wl.grad.abs().max()) + 1e-12) + 1e-9, name
+    finally:
+        F.USE_TORCH_OPS = before
+
+
+def test_ragged_widths_backward_equals_the_two_kernel_form_and_the_loss_step_falls_back():
+    from pypbr_amd import functional as F
+    g = torch.Generator().manual_seed(9)
+    maps = _tiled_maps(g, 11, 30)
+    kw = dict(view_dir=[0.05, 0.1, 0.9], light=[0.1, 0.1, 1.0], light_intensity=[1.0, 0.9, 0.8], light_type="point", light_size=1.5)
+    gout = (torch.rand(3, 22, 90, generator=g) - 0.3).cuda()
+
+    def grads(knob):
+        leaves = [t.clone().requires_grad_(True) for t in maps]
+        try:
+            _knob(knob)
+            (F.cook_torrance(*leaves, tile=(2, 3), **kw) * gout).sum().backward()
+        finally:
+            _knob(-1)
+        return [t.grad for t in leaves]
+    for x, y in zip(grads(-1), grads(0)):
+        assert (x - y).abs().max().item() <= 4e-6 * float(y.abs().max()) + 1e-9
+    # the rendering-loss step over ragged tiled maps: not one pass (its sum must count every pixel once) -- the three steps, same values
+    leaves = [t.clone().requires_grad_(True) for t in maps]
+    target = torch.rand(3, 22, 90, generator=g).cuda()
+    loss = F.rendering_loss_mse(*leaves, target=target, tile=(2, 3), **kw)
+    loss.backward()
+    ref = [t.clone().requires_grad_(True) for t in maps]
+    want = torch.nn.functional.mse_loss(F.cook_torrance(*[t.repeat(1, 2, 3) for t in ref], **kw), target)
+    want.backward()
+    assert abs(float(loss) - float(want)) <= 2e-6 * float(want)
+    for x, y in zip(leaves, ref):
+        assert (x.grad - y.grad).abs().max().item() <= 1e-5 * (float(y.grad.abs().max()) + 1e-12) + 1e-9

@@ -73,11 +73,12 @@ typedef struct pbr_map {
  * (measured on MI355X); a caller that knows better passes a pbr_tuning with the descriptor -- per call, caller-owned,
  * nothing outlives the call.  Entries left at PBR_TUNE_UNSET follow the rule (or the process-wide test hook pbr_set_tuning). */
 enum {
-    PBR_TUNE_NONTEMPORAL = 0,           /* streaming hint on loads and stores: 1 = rule, 0 off, 2 also on launches over tiled maps (repeat-inner kernel: 2 loads + stores, 3 stores only, 4 loads only) */
+    PBR_TUNE_RESERVED_0 = 0,            /* (ABI <= 7: PBR_TUNE_NONTEMPORAL.  The streaming hints are rules since ABI 8 -- on for vector lanes, stores only in the repeat-inner kernels --
+                                           and the instantiations only this knob reached are not built; the slot is ignored) */
     PBR_TUNE_BLOCK_LOG2 = 1,            /* workgroup = 1 << value lanes (6..8); 0 = rule */
     PBR_TUNE_F16_VEC = 2,               /* pixels per lane for fp16 maps (4 | 8) */
     PBR_TUNE_LDS_BYTES = 3,             /* unused dynamic LDS per workgroup of the render kernel: an occupancy governor (-1 = rule) */
-    PBR_TUNE_BWD_VEC = 4,               /* pixels per lane of the backward kernels (2 | 4 force; 0 = rule) */
+    PBR_TUNE_RESERVED_4 = 4,            /* (ABI <= 7: PBR_TUNE_BWD_VEC.  Pixels per lane of the backward kernels are a rule since ABI 8; ignored) */
     PBR_TUNE_BATCH_INNER = 5,           /* several lights: materials per lane of the batch-inner kernel (-1 = rule, 0 = one-material kernel) */
     PBR_TUNE_SCALAR_BASE = 6,           /* scalar plane addresses: 0 never, 1 rule (single materials), 2 whenever the launch allows them */
     PBR_TUNE_MAX_VEC = 7,               /* at most this many pixels per lane (8 default; 1 = the one-pixel kernels everywhere) */
@@ -87,7 +88,7 @@ enum {
     PBR_TUNE_RESIZE_UP2 = 11,           /* the register-only resize kernels -- two taps for up-scales on both axes, the band walk for whole factors 2 ... 8 | 16 down (1, default) -- or the strip kernels (0) */
     PBR_TUNE_COUNT = 12
 };
-/* (ABI 6 carried 23 knobs; the 11 whose experiments are closed -- workgroup interleave, 16-byte streamed backward, the resize
+/* (10 knobs in use since ABI 8.  ABI 6 carried 23 knobs; the 11 whose experiments are closed -- workgroup interleave, 16-byte streamed backward, the resize
  * kernels' row / tile-order / quad-store / gradient-form switches, the map kernels' launch shape, the wrap-around fold order, packed
  * one-light arithmetic, the XCD run length that pbr_render_desc.schedule already carries -- are rules now: profiles/EXPERIMENTS.md.) */
 #define PBR_TUNE_UNSET INT32_MIN

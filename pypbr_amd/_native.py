@@ -15,12 +15,12 @@ MAX_LIGHTS = 16
 F32, F16 = 0, 1
 LIGHT_DIRECTIONAL, LIGHT_POINT = 0, 1
 WORKFLOW_METALLIC, WORKFLOW_SPECULAR, WORKFLOW_CONVERTED = 0, 1, 2
-(TUNE_NONTEMPORAL, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, TUNE_BWD_VEC, TUNE_BATCH_INNER, TUNE_SCALAR_BASE, TUNE_MAX_VEC, TUNE_BWD_RUN,
+# (slots 0 and 4 are retired since ABI 8 -- PBR_TUNE_NONTEMPORAL, PBR_TUNE_BWD_VEC: their experiments are closed, the library ignores them)
+(_TUNE_RESERVED_0, TUNE_BLOCK_LOG2, TUNE_F16_VEC, TUNE_LDS_BYTES, _TUNE_RESERVED_4, TUNE_BATCH_INNER, TUNE_SCALAR_BASE, TUNE_MAX_VEC, TUNE_BWD_RUN,
  TUNE_MSE_STREAM, TUNE_TILE_REPEAT, TUNE_RESIZE_UP2) = range(12)
 
 TUNE_COUNT, TUNE_SLOTS, TUNE_UNSET = 12, 32, -2 ** 31
-TUNE_NAMES = {"nontemporal": TUNE_NONTEMPORAL, "block_log2": TUNE_BLOCK_LOG2, "f16_vec": TUNE_F16_VEC, "lds_bytes": TUNE_LDS_BYTES,
-              "bwd_vec": TUNE_BWD_VEC, "batch_inner": TUNE_BATCH_INNER, "scalar_base": TUNE_SCALAR_BASE, "max_vec": TUNE_MAX_VEC,
+TUNE_NAMES = {"block_log2": TUNE_BLOCK_LOG2, "f16_vec": TUNE_F16_VEC, "lds_bytes": TUNE_LDS_BYTES, "batch_inner": TUNE_BATCH_INNER, "scalar_base": TUNE_SCALAR_BASE, "max_vec": TUNE_MAX_VEC,
               "bwd_run": TUNE_BWD_RUN, "mse_stream": TUNE_MSE_STREAM, "tile_repeat": TUNE_TILE_REPEAT, "resize_up2": TUNE_RESIZE_UP2}
 
 OK = 0
@@ -49,7 +49,7 @@ class PbrMap(ctypes.Structure):
 
 
 class Tuning(ctypes.Structure):
-    """pbr_tuning: per-call schedule knobs (PBR_TUNE_* index; TUNE_UNSET = the rule).  `Tuning.of(nontemporal=0, ...)` builds one."""
+    """pbr_tuning: per-call schedule knobs (PBR_TUNE_* index; TUNE_UNSET = the rule).  `Tuning.of(lds_bytes=0, ...)` builds one."""
     _fields_ = [("knob", ctypes.c_int32 * TUNE_SLOTS)]
 
     @classmethod

@@ -30,7 +30,7 @@ namespace pbr {
 
 // The process-wide values of the schedule knobs (tuning.hpp), initialised to the rules.  Indexed by PBR_TUNE_*.
 static constexpr int kKnobRules[PBR_TUNE_COUNT] = {
-    /* NONTEMPORAL */ 1, /* BLOCK_LOG2 */ 0, /* F16_VEC */ 8, /* LDS_BYTES */ -1, /* BWD_VEC */ 0, /* BATCH_INNER */ -1,
+    /* (retired: NONTEMPORAL) */ 1, /* BLOCK_LOG2 */ 0, /* F16_VEC */ 8, /* LDS_BYTES */ -1, /* BWD_VEC */ 0, /* BATCH_INNER */ -1,
     /* SCALAR_BASE */ 1, /* MAX_VEC */ 8, /* BWD_RUN */ -1, /* MSE_STREAM */ 1, /* TILE_REPEAT */ -1, /* RESIZE_UP2 */ 1};
 std::atomic<int> g_knobs[PBR_TUNE_COUNT] = {
     {kKnobRules[0]}, {kKnobRules[1]}, {kKnobRules[2]}, {kKnobRules[3]}, {kKnobRules[4]}, {kKnobRules[5]}, {kKnobRules[6]}, {kKnobRules[7]},
@@ -40,38 +40,31 @@ thread_local const pbr_tuning *t_tuning = nullptr;
 struct KernelEntry { KernelFn fn; const char *name; };
 
 // Storage-type pairs built: (f32 -> f32), (f32 -> f16), (f16 -> f32), (f16 -> f16).
+// The streaming hint is a RULE since ABI 8 (on for the 4- and 8-pixel lanes, off for the one-pixel kernels), and one light over fp32 maps
+// always takes the plain-fp32 body: the instantiations that only the closed experiments' knobs reached (no hint on vector lanes; the
+// packed one-light body PACK1 for the wrap-around form of tiled launches, which the repeat-inner kernels have replaced) are not built.
 template <int LIGHT, int WF, typename TI, typename TO>
-static KernelFn pick_variant(int vec, bool multi, bool nt, bool pack1) {
-    if constexpr (sizeof(TI) == 4) {
-        // fp32 maps, one light, packed body (PACK1): tiled launches (VALU-bound; their loads never carry the streaming hint
-        // unless PBR_TUNE_NONTEMPORAL = 2 asks for it)
-        if (pack1 && vec == 4 && !multi) return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 4, false, true, true>
-                                                   : cook_torrance_kernel<LIGHT, WF, TI, TO, 4, false, false, true>;
-    }
+static KernelFn pick_variant(int vec, bool multi) {
     if constexpr (sizeof(TI) == 2) {
         if (vec == 8 && !multi) {        // pick_vec hands out 8-pixel lanes for ONE light only (several lights are VALU-bound: 4-pixel lanes);
                                          // the 8-pixel multi-light body would not fit 128 VGPRs (it spilled 220-304 bytes when it was instantiated)
-            return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 8, false, true>
-                      : cook_torrance_kernel<LIGHT, WF, TI, TO, 8, false, false>;
+            return cook_torrance_kernel<LIGHT, WF, TI, TO, 8, false, true>;
         }
     }
     if (vec == 1) return multi ? cook_torrance_kernel<LIGHT, WF, TI, TO, 1, true, false>
                                : cook_torrance_kernel<LIGHT, WF, TI, TO, 1, false, false>;
-    if (multi) return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 4, true, true>
-                         : cook_torrance_kernel<LIGHT, WF, TI, TO, 4, true, false>;
-    return nt ? cook_torrance_kernel<LIGHT, WF, TI, TO, 4, false, true>
-              : cook_torrance_kernel<LIGHT, WF, TI, TO, 4, false, false>;
+    return multi ? cook_torrance_kernel<LIGHT, WF, TI, TO, 4, true, true> : cook_torrance_kernel<LIGHT, WF, TI, TO, 4, false, true>;
 }
 
 template <int LIGHT, int WF>
-static KernelFn pick_types(int in_dt, int out_dt, int vec, bool multi, bool nt, bool pack1) {
-    if (in_dt == PBR_F32) return out_dt == PBR_F32 ? pick_variant<LIGHT, WF, float, float>(vec, multi, nt, pack1)
-                                                   : pick_variant<LIGHT, WF, float, __half>(vec, multi, nt, pack1);
-    if (out_dt == PBR_F32) return pick_variant<LIGHT, WF, __half, float>(vec, multi, nt, pack1);
-    return pick_variant<LIGHT, WF, __half, __half>(vec, multi, nt, pack1);
+static KernelFn pick_types(int in_dt, int out_dt, int vec, bool multi) {
+    if (in_dt == PBR_F32) return out_dt == PBR_F32 ? pick_variant<LIGHT, WF, float, float>(vec, multi)
+                                                   : pick_variant<LIGHT, WF, float, __half>(vec, multi);
+    if (out_dt == PBR_F32) return pick_variant<LIGHT, WF, __half, float>(vec, multi);
+    return pick_variant<LIGHT, WF, __half, __half>(vec, multi);
 }
 
-static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
+static KernelEntry pick_kernel(const pbr_render_desc *d, int vec) {
     static thread_local char name[96];
     static const char *const wf_names[3] = {"metallic", "specular", "converted"};
     const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
@@ -80,25 +73,23 @@ static KernelEntry pick_kernel(const pbr_render_desc *d, int vec, bool nt) {
     if (repeat_inner(d)) {
         std::snprintf(name, sizeof(name), "ctr_%s_%s_%s_%s_v4%s", point ? "point" : "directional", wf_names[d->workflow],
                       idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", multi ? "_multi" : "");
-        return KernelEntry{pick_repeat_kernel(d, g_nontemporal), name};
+        return KernelEntry{pick_repeat_kernel(d), name};
     }
-    // packed arithmetic for ONE light over fp32 maps: the rule is tiled launches only (ct_kernel.hpp: PACK1)
-    const bool pack1 = idt == PBR_F32 && !multi && vec == 4 && is_tiled(d);
     if (nb) {
         std::snprintf(name, sizeof(name), "ctb_%s_%s_%s_%s_v2_b%d", point ? "point" : "directional", wf_names[d->workflow],
                       idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", nb);
-        return KernelEntry{pick_batch_kernel(d, nb, nt), name};
+        return KernelEntry{pick_batch_kernel(d, nb), name};
     }
     std::snprintf(name, sizeof(name), "ct_%s_%s_%s_%s_v%d%s", point ? "point" : "directional", wf_names[d->workflow],
-                  idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", vec, multi ? "_multi" : (pack1 ? "_pk" : ""));
+                  idt == PBR_F32 ? "f32" : "f16", odt == PBR_F32 ? "f32" : "f16", vec, multi ? "_multi" : "");
     KernelFn fn = nullptr;
     switch ((point ? 3 : 0) + d->workflow) {
-        case 0: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi, nt, pack1); break;
-        case 1: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi, nt, pack1); break;
-        case 2: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi, nt, pack1); break;
-        case 3: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi, nt, pack1); break;
-        case 4: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi, nt, pack1); break;
-        default: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi, nt, pack1); break;
+        case 0: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi); break;
+        case 1: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi); break;
+        case 2: fn = pick_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi); break;
+        case 3: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(idt, odt, vec, multi); break;
+        case 4: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(idt, odt, vec, multi); break;
+        default: fn = pick_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(idt, odt, vec, multi); break;
     }
     return KernelEntry{fn, name};
 }
@@ -149,7 +140,7 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
     if (repeat_inner(d)) {           // tile(n), whole output: texels loaded and decoded once, evaluated at every repeat (ct_tiled.hip)
         fill_repeat_args(d, k);
         if (k.n_tiles < 0) return PBR_ERR_SHAPE;
-        const KernelEntry e = pick_kernel(d, 4, g_nontemporal != 0);
+        const KernelEntry e = pick_kernel(d, 4);
         hipLaunchKernelGGL(e.fn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), g_lds_bytes >= 0 ? (size_t)g_lds_bytes : 0,
                            static_cast<hipStream_t>(stream), k);
         const hipError_t err = hipGetLastError();
@@ -165,11 +156,10 @@ int pbr_cook_torrance(const pbr_render_desc *d, void *stream) {
         fill_args(d, vec, k);
     }
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
-    // Tiled maps are re-read from L2 / Infinity Cache, so their loads must not carry the streaming hint, and the
-    // launch is then VALU-bound and wants every wave it can get (2048^2 tile(2): 81 us vs 122 us with the streaming
-    // settings, 120 us for the materialised 4096^2 maps; tile_probe.py (a probe of its round, removed with its knob: git 9ce0718:tools/)).
+    // (tiled maps in the wrap-around form -- map rows shorter than 4 texels, or the tests' PBR_TUNE_TILE_REPEAT = 0 -- are re-read from L2 /
+    // Infinity Cache; the one-pixel kernels carry no streaming hint, the tests' 4-pixel form does: speed only, never values)
     const bool tiled = k.tiled != 0;
-    const KernelEntry e = pick_kernel(d, vec, g_nontemporal != 0 && (!tiled || g_nontemporal == 2));
+    const KernelEntry e = pick_kernel(d, vec);
     // 1-D grid, one tile per workgroup, x fastest: consecutive workgroups touch consecutive runs of every plane
     const bool fp32_one_light = d->map_dtype == PBR_F32 && d->n_lights == 1 && k.bt_log2 == 6 && !tiled;
     size_t lds = g_lds_bytes >= 0 ? (size_t)g_lds_bytes : (fp32_one_light ? kLdsFor11WavesPerCu : 0);
@@ -216,7 +206,7 @@ int pbr_cook_torrance_autotune(const pbr_render_desc *d, void *stream, int32_t *
 const char *pbr_kernel_name(const pbr_render_desc *d) {
     const pbr::TuningScope tuning(d);
     if (pbr::validate(d) != PBR_OK) return nullptr;
-    return pbr::pick_kernel(d, pbr::pick_vec(d), true).name;
+    return pbr::pick_kernel(d, pbr::pick_vec(d)).name;
 }
 
 int pbr_bytes_per_pixel(const pbr_render_desc *d) {

@@ -8,11 +8,20 @@ namespace pbr {
 
 using BwdFn = void (*)(const KArgs, const BArgs);
 
+// Pixels per lane are a RULE since ABI 8 (launch_backward): four for the map gradients alone -- two for fp16 maps under one light --, two with the
+// light / view adjoints (PG), one for rows shorter than four pixels.  The bodies only the closed A/B knob reached (two pixels for fp32 maps
+// without PG, four for fp16 maps under one light) and the one nothing reached (four pixels with PG: 256 VGPRs + 40 AGPRs) are not built.
 template <int L, int W, typename T, bool PG>
 static BwdFn pick_bwd_variant(int vec, bool multi) {
-    if (vec == 2) return multi ? cook_torrance_backward_kernel<L, W, 2, true, T, PG> : cook_torrance_backward_kernel<L, W, 2, false, T, PG>;
-    if (vec == 4) return multi ? cook_torrance_backward_kernel<L, W, 4, true, T, PG> : cook_torrance_backward_kernel<L, W, 4, false, T, PG>;
-    return multi ? cook_torrance_backward_kernel<L, W, 1, true, T, PG> : cook_torrance_backward_kernel<L, W, 1, false, T, PG>;
+    if (vec == 1) return multi ? cook_torrance_backward_kernel<L, W, 1, true, T, PG> : cook_torrance_backward_kernel<L, W, 1, false, T, PG>;
+    if constexpr (PG) {
+        return multi ? cook_torrance_backward_kernel<L, W, 2, true, T, PG> : cook_torrance_backward_kernel<L, W, 2, false, T, PG>;
+    } else if constexpr (sizeof(T) == 2) {
+        if (multi) return cook_torrance_backward_kernel<L, W, 4, true, T, PG>;
+        return cook_torrance_backward_kernel<L, W, 2, false, T, PG>;
+    } else {
+        return multi ? cook_torrance_backward_kernel<L, W, 4, true, T, PG> : cook_torrance_backward_kernel<L, W, 4, false, T, PG>;
+    }
 }
 
 template <bool PG>
@@ -90,9 +99,9 @@ static int launch_backward(const pbr_render_desc *d, const void *grad_out, void 
     // Two pixels per lane (one packed pair): (a) with the light / view adjoints (PGRAD) the four-pixel body needs 256 VGPRs +
     // 40 AGPRs = one wave per SIMD, the two-pixel body 155 = three; (b) with fp16 maps and one light the launch is VALU-bound
     // and the two-pixel body (125 VGPRs, 4 waves per SIMD) runs 155.6 us against 162.6 us on a 4096^2 material (steady state,
-    // tools/bwd_ab.sh); with fp32 maps the four-pixel body wins (209 vs 218 us).  g_bwd_vec: A/B knob (2 | 4 force).
+    // tools/bwd_ab.sh of its round); with fp32 maps the four-pixel body wins (209 vs 218 us).  A rule since ABI 8 (pick_bwd_variant).
     const bool f16_one_light = d->map_dtype == PBR_F16 && d->n_lights == 1;
-    if (vec == 4 && (g_bwd_vec == 2 || g_params || (f16_one_light && g_bwd_vec != 4))) vec = 2;
+    if (vec == 4 && (g_params || f16_one_light)) vec = 2;
     // The light / view adjoints are sums over pixels: the overlapping last lane of a ragged row (lane_pos: dup) would
     // count its shared pixels twice, so odd widths take the one-pixel body there.
     if (g_params && (d->width & 1)) vec = 1;

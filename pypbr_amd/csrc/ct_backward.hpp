@@ -464,11 +464,16 @@ __device__ __forceinline__ void backward_body(const KArgs &a, const BArgs &b, co
 #define PBR_BWD_F16_WAVES 4
 #endif
 // Two-pixel lanes, one light, fp16 maps: the allocator lands on 129 VGPRs = 3 waves per SIMD, one register past 4 waves.
-template <int VEC, bool MULTI, typename TM, bool PGRAD>
-constexpr int bwd_min_waves() { return VEC == 2 && !MULTI && !PGRAD && sizeof(TM) == 2 ? PBR_BWD_F16_WAVES : 1; }
+// (The point-light / converted-workflow body needs four registers more: held to 128 it spilled 20 bytes per lane -- found by the resource scan
+// of tools/check_isa.py in round 6, present since round 4 -- so that one instantiation runs three waves per SIMD, without scratch.)
+template <int LIGHT, int WF, int VEC, bool MULTI, typename TM, bool PGRAD>
+constexpr int bwd_min_waves() {
+    if (!(VEC == 2 && !MULTI && !PGRAD && sizeof(TM) == 2)) return 1;
+    return LIGHT == PBR_LIGHT_POINT && WF == PBR_WORKFLOW_CONVERTED ? 3 : PBR_BWD_F16_WAVES;
+}
 
 template <int LIGHT, int WF, int VEC, bool MULTI, typename TM = float, bool PGRAD = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bwd_min_waves<VEC, MULTI, TM, PGRAD>())))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(bwd_min_waves<LIGHT, WF, VEC, MULTI, TM, PGRAD>())))
 void cook_torrance_backward_kernel(const KArgs a, const BArgs b) {
     // Packed two-pixel arithmetic for fp16 maps and for several lights, as in the forward kernels: A/B on 4096^2 maps --
     // fp16 maps 182 us packed vs 194 us scalar; 4 lights fp32 423 us vs 491 us; one light fp32 221 us packed vs 206 us

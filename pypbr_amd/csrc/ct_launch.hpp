@@ -16,7 +16,7 @@
 
 namespace pbr {
 
-// The schedule knobs (g_nontemporal, g_block_log2, ...) are read through tuning.hpp: per call (pbr_render_desc.tuning), else the
+// The schedule knobs (g_block_log2, g_lds_bytes, ...) are read through tuning.hpp: per call (pbr_render_desc.tuning), else the
 // process-wide test hook (pbr_set_tuning), else the rule.  What the rules are and why:
 //   * nt hint on: -5 % time; one-wave workgroups: -2 % vs 256 lanes (no LDS / barrier, so nothing is lost) -- 4096x4096 point /
 //     metallic, tools/tune.py, DESIGN.md "Schedule experiments";
@@ -247,8 +247,8 @@ inline int fill_result_nan(const pbr_render_desc *d, hipStream_t st) {
 }
 
 using KernelFn = void (*)(const KArgs);
-KernelFn pick_batch_kernel(const pbr_render_desc *d, int nb, bool nt);      // ct_batch.hip
-KernelFn pick_repeat_kernel(const pbr_render_desc *d, int nt_knob);            // ct_tiled.hip
+KernelFn pick_batch_kernel(const pbr_render_desc *d, int nb);               // ct_batch.hip
+KernelFn pick_repeat_kernel(const pbr_render_desc *d);                      // ct_tiled.hip
 void fill_repeat_args(const pbr_render_desc *d, KArgs &k);
 // ct_repeat_backward.hip: gradients of TILED maps folded in registers (and, with `loss`, the rendering-loss step over tiled maps)
 bool repeat_backward_serves(const pbr_render_desc *d);

@@ -5,36 +5,32 @@
 
 namespace pbr {
 
+// The streaming hint sits on the STORES only -- a rule since ABI 8 (tile_pack_probe.py of round 4, git 9ce0718:tools/, 2048^2 tile(2) -> 4096^2: fp32 maps 53.3 us
+// against 59.6 with the hint on loads and stores, 65.9 with none; fp16 maps 52.3 / 53.6-56.1 / 51.8): the stores are the major stream (every byte
+// written once, never read here); a lane's texel loads are few and short, and without the hint they stay clear of the write stream's path.
+// The three other hint combinations were instantiations that only the closed experiment's knob reached: not built any more.
 template <int LIGHT, int WF, typename TI, typename TO>
-static KernelFn repeat_hints(bool ntl, bool nts, bool multi) {
-    if (multi) return cook_torrance_repeat_kernel<LIGHT, WF, TI, TO, false, true, true>;      // several lights: VALU-bound, the rule's hints only
-    if (ntl) return nts ? cook_torrance_repeat_kernel<LIGHT, WF, TI, TO, true, true> : cook_torrance_repeat_kernel<LIGHT, WF, TI, TO, true, false>;
-    return nts ? cook_torrance_repeat_kernel<LIGHT, WF, TI, TO, false, true> : cook_torrance_repeat_kernel<LIGHT, WF, TI, TO, false, false>;
+static KernelFn repeat_hints(bool multi) {
+    return multi ? cook_torrance_repeat_kernel<LIGHT, WF, TI, TO, false, true, true> : cook_torrance_repeat_kernel<LIGHT, WF, TI, TO, false, true>;
 }
 
 template <int LIGHT, int WF>
-static KernelFn repeat_types(int in_dt, int out_dt, bool ntl, bool nts, bool multi) {
-    if (in_dt == PBR_F32) return out_dt == PBR_F32 ? repeat_hints<LIGHT, WF, float, float>(ntl, nts, multi) : repeat_hints<LIGHT, WF, float, __half>(ntl, nts, multi);
-    return out_dt == PBR_F32 ? repeat_hints<LIGHT, WF, __half, float>(ntl, nts, multi) : repeat_hints<LIGHT, WF, __half, __half>(ntl, nts, multi);
+static KernelFn repeat_types(int in_dt, int out_dt, bool multi) {
+    if (in_dt == PBR_F32) return out_dt == PBR_F32 ? repeat_hints<LIGHT, WF, float, float>(multi) : repeat_hints<LIGHT, WF, float, __half>(multi);
+    return out_dt == PBR_F32 ? repeat_hints<LIGHT, WF, __half, float>(multi) : repeat_hints<LIGHT, WF, __half, __half>(multi);
 }
 
-// PBR_TUNE_NONTEMPORAL for this kernel: 0 = no hints, 1 = rule, 2 = loads and stores, 3 = stores only, 4 = loads only.
-KernelFn pick_repeat_kernel(const pbr_render_desc *d, int nt_knob) {
+KernelFn pick_repeat_kernel(const pbr_render_desc *d) {
     const bool point = d->light_type == PBR_LIGHT_POINT;
     const int idt = d->map_dtype, odt = d->out_dtype;
     const bool multi = d->n_lights > 1;
-    bool ntl = nt_knob == 2 || nt_knob == 4, nts = nt_knob == 2 || nt_knob == 3;
-    // Rule (tile_pack_probe.py (a probe of its round, removed with its knob: git 9ce0718:tools/), 2048^2 tile(2) -> 4096^2): the hint on the STORES only.  fp32 maps 53.3 us against 59.6 with the hint
-    // on both, 65.9 with none; fp16 maps 52.3 / 53.6-56.1 / 51.8 (level).  The stores are the major stream (every byte written once, never
-    // read here); a lane's texel loads are few and short, and without the hint they stay clear of the write stream's path.
-    if (nt_knob == 1) { ntl = false; nts = true; }
     switch ((point ? 3 : 0) + d->workflow) {
-        case 0: return repeat_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(idt, odt, ntl, nts, multi);
-        case 1: return repeat_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(idt, odt, ntl, nts, multi);
-        case 2: return repeat_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(idt, odt, ntl, nts, multi);
-        case 3: return repeat_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(idt, odt, ntl, nts, multi);
-        case 4: return repeat_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(idt, odt, ntl, nts, multi);
-        default: return repeat_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(idt, odt, ntl, nts, multi);
+        case 0: return repeat_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC>(idt, odt, multi);
+        case 1: return repeat_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR>(idt, odt, multi);
+        case 2: return repeat_types<PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED>(idt, odt, multi);
+        case 3: return repeat_types<PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC>(idt, odt, multi);
+        case 4: return repeat_types<PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR>(idt, odt, multi);
+        default: return repeat_types<PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED>(idt, odt, multi);
     }
 }
 

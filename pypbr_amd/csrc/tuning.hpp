@@ -6,7 +6,7 @@
 //   2. the PROCESS: pbr_set_tuning(knob, value) -- a test / bench / profiling hook, documented as process-global in the header.  Atomic
 //      words, so a concurrent launch reads the old or the new value of a knob, never a torn one;
 //   3. the library's rule (the initial value of 2).
-// The launchers keep the names the knobs had as plain globals: `g_nontemporal` is now an expression that resolves 1 -> 2 -> 3.
+// The launchers keep the names the knobs had as plain globals: `g_block_log2` is now an expression that resolves 1 -> 2 -> 3.
 // The call's pbr_tuning reaches the helper functions of a launch (fill_args, pick_vec, ...) through a thread-local pointer that every
 // extern "C" entry point taking a descriptor sets for its own duration (TuningScope): per call and per thread, no shared state.
 #pragma once
@@ -36,11 +36,9 @@ struct TuningScope {
 
 }  // namespace pbr
 
-#define g_nontemporal      (::pbr::knob(PBR_TUNE_NONTEMPORAL))      // streaming hint: 1 = rule, 0 off, 2 also on tiled launches (repeat-inner kernel: 2 both, 3 stores, 4 loads)
 #define g_block_log2       (::pbr::knob(PBR_TUNE_BLOCK_LOG2))       // workgroup size: 64 (6), 128 (7) or 256 (8) lanes; 0 = rule (64; 256 for the one-pixel kernels)
 #define g_f16_vec          (::pbr::knob(PBR_TUNE_F16_VEC))          // pixels per lane for fp16 maps with one light: 8 (16-byte loads) or 4
 #define g_lds_bytes        (::pbr::knob(PBR_TUNE_LDS_BYTES))        // unused dynamic LDS per one-wave workgroup: an occupancy governor (-1 = rule, ct_launch.hpp)
-#define g_bwd_vec          (::pbr::knob(PBR_TUNE_BWD_VEC))          // pixels per lane of the backward kernels: 0 = rule, 2 | 4 = forced
 #define g_batch_inner      (::pbr::knob(PBR_TUNE_BATCH_INNER))      // materials per lane of the several-lights kernels: -1 = rule (4 | 2 | off), 0 = off, 2 | 4 = forced
 #define g_scalar_base      (::pbr::knob(PBR_TUNE_SCALAR_BASE))      // scalar plane addresses: 0 never, 1 = rule (single materials), 2 = whenever the launch allows them
 #define g_max_vec          (::pbr::knob(PBR_TUNE_MAX_VEC))          // at most this many pixels per lane (1 = the one-pixel kernels everywhere)

@@ -298,7 +298,7 @@ class RenderPlan:
         return N.lib().pbr_bytes_per_pixel(self._ref)
 
     def set_tuning(self, **knobs):
-        """Per-call schedule knobs of THIS plan (pbr_render_desc.tuning; names of _native.TUNE_NAMES, e.g. nontemporal=0, xcd_log2=6):
+        """Per-call schedule knobs of THIS plan (pbr_render_desc.tuning; names of _native.TUNE_NAMES, e.g. lds_bytes=0, block_log2=8):
         they travel with the descriptor, touch no process-wide state and change speed only, never results.  No arguments: back to the rules."""
         if knobs:
             self._tuning = N.Tuning.of(**knobs)
@@ -403,7 +403,7 @@ def plan_cook_torrance(albedo: torch.Tensor, normal: Optional[torch.Tensor], rou
     signed is decided over the WHOLE map (base.py:212); the launch works that out itself unless the maps are a row band
     of a taller untiled map -- then pass `blend_flags` (int32 [B] on the device: `RenderPlan.blend_normal_sign()` of
     every band, combined with max; distributed.cook_torrance_sharded does this).
-    `tuning={"nontemporal": 0, ...}`: per-call schedule knobs of this plan (RenderPlan.set_tuning); speed only, never results."""
+    `tuning={"lds_bytes": 0, ...}`: per-call schedule knobs of this plan (RenderPlan.set_tuning); speed only, never results."""
     if not isinstance(albedo, torch.Tensor) or not albedo.is_cuda:
         raise RuntimeError("pypbr_amd.functional.cook_torrance needs maps on a ROCm device "
                            "(use material.to('cuda')); there is no CPU path")

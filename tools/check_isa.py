@@ -278,25 +278,40 @@ def check(verbose=False):
         fns, meta = _functions(co), _metadata(co)
         # TI = __half ("6__half"), TO = float ("f"), VEC = 8, one light (the launcher never picks 8-pixel lanes for several)
         xp = sorted(s for s in fns if re.search(r"cook_torrance_kernelILi\dELi\dE6__halffLi8ELb0E", s))
-        if len(xp) != 12:
-            failures.append("expected 12 instantiations of cook_torrance_kernel<.., __half, float, 8, false, ..>, found %d" % len(xp))
+        if len(xp) != 6:      # (12 until ABI 7: with and without the streaming hint; the hint is a rule since ABI 8)
+            failures.append("expected 6 instantiations of cook_torrance_kernel<.., __half, float, 8, false, ..>, found %d" % len(xp))
         if any(re.search(r"cook_torrance_kernelILi\dELi\dE\S+Li8ELb1E", s) for s in fns):
             failures.append("an 8-pixel multi-light instantiation exists again (it does not fit 128 VGPRs and is never launched)")
         for s in xp:
             line, bad = check_xpose_kernel(s, fns[s], meta.get(s, {}))
             report.append(line)
             failures += bad
-        # every kernel of every object: the trans-forwarding hazard (inline-assembly consumers are not covered by the compiler)
-        n_kernels = 0
+        # every kernel of every object: the trans-forwarding hazard (inline-assembly consumers are not covered by the compiler), and --
+        # round 6, VERDICT r5 next #9 -- its RESOURCES: no kernel of the library may spill (scratch = 0: a spill is a silent 10-20 % and, in the
+        # hand-counted kernels, a broken wait count) or need more registers than two waves per SIMD leave it (VGPRs + AGPRs <= 256)
+        n_kernels, per_object, worst = 0, {}, ("", 0)
         for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".o") and f != "build_id.o"):      # build_id.o: host code only
             sub = tempfile.mkdtemp(prefix="pbr_isa_", dir=tmp)
-            fns = _functions(_code_object(path, sub))
+            co_path = _code_object(path, sub)
+            fns = _functions(co_path)
             n_kernels += len(fns)
+            kernels = _metadata(co_path)
+            per_object[os.path.basename(path)] = len(kernels)
+            for sym, f in kernels.items():
+                regs = f.get("vgpr_count", 0)          # (gfx950: the unified count, AGPRs included)
+                if f.get("private_segment_fixed_size", 0) != 0:
+                    failures.append("%s: %d bytes of scratch per lane (no kernel of the library may spill)" % (sym[:90], f["private_segment_fixed_size"]))
+                if regs > 256:
+                    failures.append("%s: %d registers (more than two waves per SIMD leave a wave)" % (sym[:90], regs))
+                if regs > worst[1]:
+                    worst = (sym, regs)
             for sym, producer, consumer in trans_forwarding_violations(fns):
                 failures.append("%s: %s directly followed by %s (needs a wait state: use the *_after_trans forms of brdf_math.hpp)" % (sym[:80], producer, consumer))
             for sym, store, writer in store_data_violations(fns):
                 failures.append("%s: %s directly followed by %s, which overwrites its data (needs a wait state)" % (sym[:80], store, writer))
         report.append("trans-forwarding hazard, store-data hazard: %d kernels scanned" % n_kernels)
+        report.append("resources: %d kernels, none with scratch, the most registers %d (%s); per object: %s" % (
+            sum(per_object.values()), worst[1], worst[0][:60], ", ".join("%s %d" % kv for kv in sorted(per_object.items()))))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     if verbose:

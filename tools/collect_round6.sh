@@ -1,13 +1,13 @@
 #!/bin/bash
-# Round-5 evidence (run ON the MI355X box).  From the dev container:
-#     HEAD=$(git rev-parse HEAD); gpurun --timeout 1150 -- "PBR_GIT_HEAD=$HEAD bash tools/collect_round5.sh r5x headline"
-#     ... "PBR_GIT_HEAD=$HEAD bash tools/collect_round5.sh r5y configs"      ... r5z kernels      ... r5w examples
+# Round-6 evidence (run ON the MI355X box).  From the dev container:
+#     HEAD=$(git rev-parse HEAD); gpurun --timeout 1150 -- "PBR_GIT_HEAD=$HEAD bash tools/collect_round6.sh r6x headline"
+#     ... "PBR_GIT_HEAD=$HEAD bash tools/collect_round6.sh r6y configs"      ... r6z kernels      ... r6w examples
 # Every collection starts by writing <out>/stamp.json (the commit, sha256 of libpbr_hip.so, the digest of the sources the library
 # was built from, the digest of the sources on the box) and REFUSES to measure a library that is not what these sources build
 # (round 3's committed rocprof summary predated the last kernel change).  tools/stamp_profiles.py copies a
 # collection into profiles/ with the stamp written into every file.
 set -u
-TAG=${1:-r5x}
+TAG=${1:-r6x}
 WHAT=${2:-headline}
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/$TAG

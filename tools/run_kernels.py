@@ -125,9 +125,11 @@ if want("tiled"):
     p = F.plan_cook_torrance(*maps, tile=2, **PT)
     report("tiled: 2048^2 maps, fused tile(2) -> 4096^2 image (8 planes of 2048^2 in once, 3 planes of 4096^2 out): repeat-inner kernel",
            "cook_torrance_repeat_kernel<1, 0, float, float, false, true>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
-    p = F.plan_cook_torrance(*maps, tile=2, tuning={"tile_repeat": 0}, **PT)
-    report("tiled_wrap: the same launch in the wrap-around form (what row bands of a tiled output and several lights take), packed arithmetic",
-           "cook_torrance_kernel<1, 0, float, float, 4, false, false, true>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
+    # a THIN row band of the same tiled image -- rows [1536, 2560) of 4096: a quarter of the image across the period boundary, what one of four
+    # ranks holds of ONE tiled material -- on the same kernel through its window of source rows (round 6; until then the wrap-around form)
+    p = F.plan_cook_torrance(*maps, tile=2, y_offset=1536, rows=1024, **PT)
+    report("tiled_band: rows [1536, 2560) of the same tiled image (a band thinner than a period: 1024 source rows x 2048 in once, 3 planes of 1024 x 4096 out)",
+           "cook_torrance_repeat_kernel<1, 0, float, float, false, true>", 32 * 1024 * 2048 + 12 * 1024 * S, timed(lambda: p.launch(stream)))
     del maps, p
     maps = [t.half() for t in synth_material(2048, DEV, 32)]
     p = F.plan_cook_torrance(*maps, tile=2, **PT)
@@ -142,9 +144,6 @@ if want("tiled_multi"):
     p = F.plan_cook_torrance(*maps, tile=2, **kw4)
     report("tiled_multi: 2048^2 maps, tile(2) -> 4096^2, 4 point lights: repeat-inner kernel (8 planes of 2048^2 in once, 3 planes of 4096^2 out)",
            "cook_torrance_repeat_kernel<1, 0, float, float, false, true, true>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
-    p = F.plan_cook_torrance(*maps, tile=2, tuning={"tile_repeat": 0}, **kw4)
-    report("tiled_multi_wrap: the same launch in the wrap-around form (what it took until round 4)",
-           "cook_torrance_kernel<1, 0, float, float, 4, true, false, false>", 32 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
     leaves = maps
     plan4 = F.plan_cook_torrance(*leaves, tile=2, **kw4)
     gout = torch.rand(1, 3, S, S, device=DEV)

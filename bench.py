@@ -38,7 +38,7 @@ Timing protocol.  Two timed regions, both K steps bracketed by barrier + synchro
 Rank 0 prints ONE JSON line (contract in the task statement).  Extra objects:
   roofline     -- achieved algorithmic HBM GB/s of the kernel (bytes per pixel x this rank's pixels per launch / average
                   launch duration from HIP events on the launch stream over the STEADY region -- the K steps `value` is quoted on;
-                  rounds 2-4 averaged the cold region in, which alone moved `frac` by 4 %: profiles/r05_driver_line_ab.md) vs 8 TB/s;
+                  rounds 2-4 averaged the cold region in, which alone moved `frac` by 4 %: profiles/history/r05_driver_line_ab.md) vs 8 TB/s;
                   for N > 1 the slowest rank's.  Config 2 also runs the BARE access pattern of the kernel (tools/boxcal.hip: the same
                   planes, the same bytes per lane, no arithmetic) on the same buffers right behind the steady region:
                   `box_pattern_us`, `kernel_over_box_pattern` -- a slow line with a ratio near 1 is a slow box, not a slow binary
@@ -92,7 +92,9 @@ CONFIGS = {
 }
 # config 5 is VALU-bound.  Vector instructions per (pixel, light) of the batch-inner kernel are COUNTED, not assumed: rocprofv3
 # SQ_INSTS_VALU x 64 / (pixels x lights) of the newest committed per-kernel evidence set (recorded_valu below) -- the algorithmic
-# figure its VALU roofline uses; the chip issues at most one vector instruction per SIMD per 4 cycles for a wave of 64:
+# figure its VALU roofline uses.  Peak = one vector instruction per SIMD per 4 cycles for a wave of 64 -- the right order for THIS kernel, whose
+# stream is packed fp32 (measured issue rates, tools/valu_occupancy.hip / profiles/r06_valu_issue_rates.txt: packed 4.3-4.8 cycles per wave
+# instruction, transcendentals 8.2; plain fp32 issues every 2.5 cycles once two waves feed a SIMD, which a packed kernel does not use):
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 4 * 64          # lane-instructions per ns: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles x 64 lanes
 
 

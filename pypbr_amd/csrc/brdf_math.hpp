@@ -151,9 +151,9 @@ template <class R> struct LightGeomT {
     Vec3T<R> d;    // point: light position - surface point, un-normalised; directional: L
     R rinv;        // point: 1/(dist + 1e-7); directional: 1.   N.L = (N.d) rinv costs 4 ops, never forming L
     R rdist;       // point: 1/dist (the v_rsq itself); only the light-parameter gradient reads it
-    Vec3T<R> L;    // light direction as the reference uses it (d * rinv); only the backward kernel reads it
-    Vec3T<R> h;    // V + L, un-normalised
+    Vec3T<R> h;    // V + L, un-normalised (L = d * rinv, the light direction as the reference uses it, is never kept: N.L = (N.d) rinv)
     R rhh;         // 1/|h|^2  (|h|^2 clamped at 1e-24: F.normalize's 1e-12 on the norm)
+    R rh;          // 1/|h|: the v_rsq that rhh is the square of; only the backward kernels read it (round 6: they took sqrt(rhh) twice per light)
     R att;         // 1/(dist^2+1e-7), 1 for directional
     R p5;          // (1 - clamp(Hv.V))^5
     R om5;         // 1 - p5:  F = f0 + (1 - f0) p5 = f0 om5 + p5, one fma per channel
@@ -177,11 +177,10 @@ __device__ __forceinline__ LightGeomT<R> point_light_geom(const Vec3 &V, const V
     const R r = rsq(dd);
     const R rinv = r * fma_(splat<R>(-1e-7f), r, splat<R>(1.0f));   // 1/(dist + 1e-7)  :139
     g.d = d; g.rinv = rinv; g.rdist = r;
-    g.L = {d.x * rinv, d.y * rinv, d.z * rinv};
     g.att = rcp(dd + 1e-7f);                                        // :140
     g.h = {fma_(d.x, rinv, splat<R>(V.x)), fma_(d.y, rinv, splat<R>(V.y)), fma_(d.z, rinv, splat<R>(V.z))};   // :155
     const R rh = rsq(dot_plus(g.h, g.h, 1e-24f));
-    g.rhh = rh * rh;
+    g.rhh = rh * rh; g.rh = rh;
     g.p5 = pow5(splat<R>(1.0f) - mul_sat_after_trans(dotu(g.h, V), rh));         // :156-158, :196  (rh: the v_rsq's own result)
     g.om5 = splat<R>(1.0f) - g.p5;
     return g;

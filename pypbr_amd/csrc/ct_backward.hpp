@@ -115,11 +115,11 @@ template <class R> struct LightEvalT {
 
 template <class R>
 __device__ __forceinline__ void eval_light(const PixelTermsT<R> &t, const LightGeomT<R> &g, const float inten[3], LightEvalT<R> &e) {
-    e.ndl_raw = dot(t.n, g.L);
+    e.ndl_raw = dot(t.n, g.d) * g.rinv;                             // N.L = (N.d) rinv: the forward kernels' form (shade_light), L never formed
     e.ndl = clamp01(e.ndl_raw);
     const R nh = e.ndl_raw + t.ndv_raw;                              // N.h = N.L + N.V
     e.den = ggx_den(t, g, nh, e.s2, e.nh_pos);
-    e.c = masked(e.nh_pos, nh * sqrt_hw(g.rhh));                     // clamp(N.H), :215
+    e.c = masked(e.nh_pos, nh * g.rh);                               // clamp(N.H), :215
     e.dl = fma_(e.ndl, t.omk, t.kk);
     e.dD = fma_(e.den * e.den, splat<R>(kPi), splat<R>(1e-7f));
     e.ds = fma_(t.ndv * 4.0f, e.ndl, splat<R>(1e-7f));
@@ -189,14 +189,14 @@ __device__ __forceinline__ void backprop_light(const PixelTermsT<R> &t, const Li
     adj.g_ndv = adj.g_ndv + g_ndv;                                           // N.V does not depend on the light
     // dots -> unit normal (clamps pass on the closed interval); c = N . h / |h|
     const R gl = masked(in_unit(e.ndl_raw, e.ndl), g_ndl);
-    const R gch = g_c * sqrt_hw(g.rhh);
-    adj.g_n.x = fma_(gl, g.L.x, fma_(gch, g.h.x, adj.g_n.x));
-    adj.g_n.y = fma_(gl, g.L.y, fma_(gch, g.h.y, adj.g_n.y));
-    adj.g_n.z = fma_(gl, g.L.z, fma_(gch, g.h.z, adj.g_n.z));
+    const R gch = g_c * g.rh, glr = gl * g.rinv;                             // d N.L / d n = L = d rinv
+    adj.g_n.x = fma_(glr, g.d.x, fma_(gch, g.h.x, adj.g_n.x));
+    adj.g_n.y = fma_(glr, g.d.y, fma_(gch, g.h.y, adj.g_n.y));
+    adj.g_n.z = fma_(glr, g.d.z, fma_(gch, g.h.z, adj.g_n.z));
     if constexpr (PG) {
         // ---- light / view parameters.  h = V + L (un-normalised); c = (n.h)/|h| (:215), cos = clamp((h.V)/|h|) (:156-158),
         // p5 = (1 - cos)^5 (:196).  d(x.h / |h|)/dh = (x - (x.h / |h|^2) h) / |h|.
-        const R rh = sqrt_hw(g.rhh);
+        const R rh = g.rh;
         const R hv = dotu(g.h, V);
         const R cos_raw = hv * rh;
         const R om = splat<R>(1.0f) - clamp01(cos_raw), om2 = om * om;

@@ -489,10 +489,10 @@ template <int LIGHT, class R>
 __device__ __forceinline__ LightGeomT<R> light_geom(const LightU &lu, const Vec3 &V, R xs, float ys) {
     if (LIGHT == PBR_LIGHT_POINT) return point_light_geom<R>(V, Vec3{lu.l[0], lu.l[1], lu.l[2]}, xs, ys);
     LightGeomT<R> g;                       // directional: everything folded on the host, wave-uniform
-    g.L = {splat<R>(lu.l[0]), splat<R>(lu.l[1]), splat<R>(lu.l[2])};
-    g.d = g.L; g.rinv = splat<R>(1.0f); g.rdist = splat<R>(1.0f);
+    g.d = {splat<R>(lu.l[0]), splat<R>(lu.l[1]), splat<R>(lu.l[2])};
+    g.rinv = splat<R>(1.0f); g.rdist = splat<R>(1.0f);
     g.h = {splat<R>(lu.h[0]), splat<R>(lu.h[1]), splat<R>(lu.h[2])};
-    g.rhh = splat<R>(lu.rhh); g.p5 = splat<R>(lu.p5); g.om5 = splat<R>(1.0f - lu.p5); g.att = splat<R>(1.0f);
+    g.rhh = splat<R>(lu.rhh); g.rh = sqrt_hw(g.rhh); g.p5 = splat<R>(lu.p5); g.om5 = splat<R>(1.0f - lu.p5); g.att = splat<R>(1.0f);
     return g;
 }
 

@@ -116,7 +116,7 @@ __device__ __forceinline__ void bwd_tail(const BwdTexelT<R> &x, const PixelAdjoi
 // loss policy and the several-lights form stay at two waves: they need 184 / 180 with the state parked, and the spills that a forced
 // third wave costs them (28-52 bytes of scratch per lane) cost more than it brings (fp32 loss step 135 -> 152 us; fp16 134 -> 131).
 // Round 5 had parked the tail's inputs with the tail INSIDE the loop (read back at every position): +12...21 %, not adopted then.
-template <bool LOSS, bool MULTI> struct RepeatBwdShape { static constexpr bool park = !LOSS && !MULTI; static constexpr int waves = park ? 3 : 2; };
+template <bool LOSS, bool MULTI> struct RepeatBwdShape { static constexpr bool park = true; static constexpr int waves = 3; };
 template <int WF>
 __device__ __forceinline__ void park_texel(float2 *slot, BwdTexelT<f32x2> &x, bool restore) {
     int i = 0;
@@ -287,7 +287,12 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
         // the position in flight: loaded one iteration ahead
         int n_ry = 0, n_rx = 0, n_yrow = p.y;
         int64_t n_rep = 0;
-        if (row_in_band(n_yrow)) fetch(n_rep, go);
+        // The upstream values (the loss step: the target's) of a position: the plain gradient kernels keep the NEXT position's in flight under this
+        // one's arithmetic (a second set of 6 registers: they fit three waves per SIMD with it); the loss step and the several-lights form request
+        // a position's values at its own start -- their registers peak in backprop_light, where a set in flight was what kept them at two waves
+        // (and several lights first read the values behind a whole pass over the lights).
+        constexpr bool kAhead = !LOSS && !MULTI;
+        if (kAhead && row_in_band(n_yrow)) fetch(n_rep, go);
         float ys = 0.0f;
         PixelAdjointT<R> adj;                   // summed over the positions; the tail is applied once, behind the loop
         auto clear_adjoint = [&]() {
@@ -306,11 +311,15 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
         constexpr bool SRGB = decltype(srgb_tag)::value;
         for (int k = 0; k < n_pos; ++k) {
             const int ry = n_ry, rx = n_rx, yrow = n_yrow;
+            const int64_t rep = n_rep;
             // advance to the next position and start its loads: they travel under this position's arithmetic
             ++n_rx; n_rep += col_step;
             if (n_rx == a.rep_x) { n_rx = 0; ++n_ry; n_yrow += PH; n_rep += row_step - col_step; }
-            if (k + 1 < n_pos && row_in_band(n_yrow)) fetch(n_rep, go_next);
-            if (row_in_band(yrow)) {                                                  // a repeat outside this rank's band: nothing to add
+            if constexpr (kAhead) {
+                if (k + 1 < n_pos && row_in_band(n_yrow)) fetch(n_rep, go_next);
+            }
+            if (row_in_band(yrow)) {                                                  // (a repeat outside this rank's band: nothing to add)
+                if constexpr (!kAhead) fetch(rep, go);
                 R xs[1] = {splat<R>(0.0f)};
                 if (LIGHT == PBR_LIGHT_POINT) {
                     if (rx == 0) ys = linspace_at(a.y0, a.y1, a.ystep, a.out_Ht, yrow);
@@ -373,10 +382,12 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
                     backprop_light<LIGHT, false>(x.pt, lg, lu.inten, e, g_col, adj, V, pa);
                 }
             }
+            if constexpr (kAhead) {
     #pragma unroll
-            for (int c = 0; c < 3; ++c)
+                for (int c = 0; c < 3; ++c)
     #pragma unroll
-                for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
+                    for (int j = 0; j < VEC; ++j) go[c][j] = go_next[c][j];
+            }
         }
         };
         if (a.out_srgb) positions(std::true_type{}); else positions(std::false_type{});
@@ -397,8 +408,17 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
 #pragma unroll
     for (int c = 0; c < 3; ++c) { scatter(oa[c], 0, acc_a[c]); scatter(on[c], 0, acc_n[c]); scatter(os[c], 0, acc_s[c]); }
     scatter(orr, 0, acc_r); scatter(om, 0, acc_m);
-    if constexpr (BLEND) blend_backward_sink<WF, VEC>(a, p, mat, t1, u, w, keep_signed, b, *g2, oa, on, orr, om, os);
-    else store_gradients<WF, VEC, TM>(a, b, p, oa, on, orr, om, os);
+    if constexpr (BLEND) {
+        blend_backward_sink<WF, VEC>(a, p, mat, t1, u, w, keep_signed, b, *g2, oa, on, orr, om, os);
+    } else {
+        // the lane's place in the gradient planes is formed AGAIN here (a few scalar and vector instructions) instead of being carried across
+        // the position loop: its 64-bit offsets are registers the loop does not have to hold (the loss form: the last one short of three waves)
+        LanePos q = lane_pos<VEC, LOSS>(a, (int)tile - ty * a.tiles_x, ty);
+        if (!LOSS && a.H != PH) repeat_window(a, q);
+        asm volatile("" : "+v"(q.x), "+v"(q.y));                   // (kept opaque: otherwise the compiler merges q with p and carries p)
+        q.pix = q.src = (int64_t)q.y * a.W + q.x;
+        store_gradients<WF, VEC, TM>(a, b, q, oa, on, orr, om, os);
+    }
 }
 
 template <int LIGHT, int WF, typename TM, bool LOSS, bool MULTI = false>

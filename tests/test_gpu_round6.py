@@ -301,3 +301,60 @@ def test_fused_blend_backward_over_a_batch_of_tiled_materials():
         (one * wt[b]).sum().backward()
         for x, y in zip(a1 + a2 + [dm], s1 + s2 + [sm]):
             assert torch.equal(x.grad[b], y.grad), b
+
+
+def test_folded_backward_guard_bands_thin_bands_and_ragged_widths():
+    """pbr_cook_torrance_backward_folded through the C ABI with every buffer inside a larger one: NaN around the maps and the upstream gradient (a read
+    outside would poison a gradient), a sentinel around the map-sized gradients (a write outside would damage it) -- random map shapes (ragged widths
+    included), tiles, and bands of the tiled image of any height and offset (thin bands: the window walk and its zero-fill)."""
+    import ctypes
+    from pypbr_amd import functional as F, _native as N
+    lib = N.lib()
+    g = torch.Generator().manual_seed(606)
+    G = 256
+
+    def guarded(t, fill):
+        flat = torch.full((t.numel() + 2 * G,), fill, dtype=t.dtype, device="cuda")
+        flat[G:G + t.numel()] = t.reshape(-1).cuda()
+        return flat, flat[G:G + t.numel()].view(t.shape)
+    for trial in range(24):
+        B = int(torch.randint(1, 3, (1,), generator=g))
+        h = int(torch.randint(2, 24, (1,), generator=g))
+        w = [4, 8, 12, 24, 40, 6, 14, 30, 38][int(torch.randint(0, 9, (1,), generator=g))]
+        ny, nx = int(torch.randint(1, 4, (1,), generator=g)), int(torch.randint(1, 4, (1,), generator=g))
+        if (ny, nx) == (1, 1):
+            ny = 2
+        H, W = ny * h, nx * w
+        y0 = int(torch.randint(0, H, (1,), generator=g))
+        rows = int(torch.randint(1, H - y0 + 1, (1,), generator=g))
+        lights = 1 if trial % 3 else 2
+        dtype = torch.float16 if trial % 4 == 3 else torch.float32
+        a = torch.rand(B, 3, h, w, generator=g).to(dtype)
+        n = torch.cat([torch.rand(B, 2, h, w, generator=g) - 0.5, torch.ones(B, 1, h, w)], 1).to(dtype)
+        r = (torch.rand(B, 1, h, w, generator=g) * 0.7 + 0.25).to(dtype)
+        m = torch.rand(B, 1, h, w, generator=g).to(dtype)
+        kw = dict(view_dir=[0.1, 0, 1], light=[[0.2, -0.1, 0.9], [-0.3, 0.3, 0.7]][:lights], light_intensity=[[1, 0.9, 0.8]] * lights,
+                  light_type="point" if trial % 5 else "directional", light_size=2.0, tile=(ny, nx), y_offset=y0, rows=rows)
+        bufs, views = zip(*[guarded(t, float("nan")) for t in (a, n, r, m)])
+        gbuf, gout = guarded(torch.rand(B, 3, rows, W, generator=g) - 0.3, float("nan"))
+        plan = F.plan_cook_torrance(*views, **kw)
+        assert lib.pbr_backward_folded_workspace_bytes(ctypes.byref(plan.desc)) == 0
+        outs, grads = zip(*[guarded(torch.zeros_like(t), 1.0) for t in (a, n, r, m)])
+        for o in outs:
+            o[G:-G] = -5.0                                      # (the kernel must write every gradient value)
+        st = torch.cuda.current_stream().cuda_stream
+        N.check(lib.pbr_cook_torrance_backward_folded(ctypes.byref(plan.desc), gout.data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(), grads[2].data_ptr(),
+                                                      grads[3].data_ptr(), None, None, st))
+        torch.cuda.synchronize()
+        tag = (trial, B, h, w, ny, nx, y0, rows, lights, str(dtype))
+        for o, gr in zip(outs, grads):
+            assert bool((o[:G] == 1.0).all()) and bool((o[-G:] == 1.0).all()), tag
+            assert bool(torch.isfinite(gr.float()).all()), tag
+        # values: autograd through the materialised repeat, cropped to the band
+        ref = [t.detach().clone().float().requires_grad_(True) for t in views]
+        kw_ref = {k: v for k, v in kw.items() if k not in ("tile", "y_offset", "rows")}
+        img = F.cook_torrance(*[t.repeat(1, 1, ny, nx) for t in ref], **kw_ref)
+        (img[:, :, y0:y0 + rows] * gout).sum().backward()
+        for gr, rf in zip(grads, ref):
+            tol = (1e-5 if dtype == torch.float32 else 4e-3) * (float(rf.grad.abs().max()) + 1e-12) + 1e-9
+            assert (gr.float() - rf.grad).abs().max().item() <= tol, tag

@@ -161,8 +161,9 @@ int pbr_cook_torrance_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, 
     if (nan_light_size(d)) return fill_result_nan(d, static_cast<hipStream_t>(stream));
     int vec = pick_vec(d);                                    // the second material and the mask only need element alignment
     if (vec == 8) vec = 4;
+    const bool walk = repeat_inner(d);                        // tiled maps: blended once per texel, evaluated at every repeat (cook_torrance_repeat_blend_kernel)
     KArgs k;
-    fill_args(d, vec, k);
+    if (walk) fill_repeat_args(d, k); else fill_args(d, vec, k);
     if (k.n_tiles < 0) return PBR_ERR_SHAPE;
     KBlend b;
     fill_blend(bl, workspace, b);
@@ -175,6 +176,22 @@ int pbr_cook_torrance_blend(const pbr_render_desc *d, const pbr_blend_desc *bl, 
     }
     // pass 2: blend + evaluate
     const bool multi = d->n_lights > 1, point = d->light_type == PBR_LIGHT_POINT;
+    if (walk) {
+        void (*wfn)(const KArgs, const KBlend) = nullptr;
+#define PBR_BLEND_WALK(L, W) wfn = multi ? cook_torrance_repeat_blend_kernel<L, W, true> : cook_torrance_repeat_blend_kernel<L, W, false>
+        switch ((point ? 3 : 0) + d->workflow) {
+            case 0: PBR_BLEND_WALK(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_METALLIC); break;
+            case 1: PBR_BLEND_WALK(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_SPECULAR); break;
+            case 2: PBR_BLEND_WALK(PBR_LIGHT_DIRECTIONAL, PBR_WORKFLOW_CONVERTED); break;
+            case 3: PBR_BLEND_WALK(PBR_LIGHT_POINT, PBR_WORKFLOW_METALLIC); break;
+            case 4: PBR_BLEND_WALK(PBR_LIGHT_POINT, PBR_WORKFLOW_SPECULAR); break;
+            default: PBR_BLEND_WALK(PBR_LIGHT_POINT, PBR_WORKFLOW_CONVERTED); break;
+        }
+#undef PBR_BLEND_WALK
+        hipLaunchKernelGGL(wfn, dim3((unsigned)k.n_tiles, 1, 1), dim3(1u << k.bt_log2, 1, 1), 0, st, k, b);
+        const hipError_t werr = hipGetLastError();
+        return werr == hipSuccess ? PBR_OK : 1000 + (int)werr;
+    }
     void (*fn)(const KArgs, const KBlend) = nullptr;
 #define PBR_BLEND(L, W)                                                                                              \
     fn = vec == 4 ? (multi ? cook_torrance_blend_kernel<L, W, 4, true> : cook_torrance_blend_kernel<L, W, 4, false>) \

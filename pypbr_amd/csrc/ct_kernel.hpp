@@ -805,9 +805,10 @@ __device__ __forceinline__ void repeat_window(const KArgs &a, LanePos &p) {
     p.src = p.pix = (int64_t)sy * a.W + p.x;
 }
 
-template <int LIGHT, int WF, typename TI, typename TO, bool NTL, bool NTS, bool MULTI = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void cook_torrance_repeat_kernel(const KArgs a) {
+//   `prepare(p, t)`: what happens to the lane's texels between the loads and the decode -- nothing, or (ct_blend.hpp, round 6) the blend with a second
+//   material under a mask: blended ONCE per texel, evaluated at every repeat.
+template <int LIGHT, int WF, typename TI, typename TO, bool NTL, bool NTS, bool MULTI, class Prepare>
+__device__ __forceinline__ void repeat_forward_body(const KArgs &a, Prepare &&prepare) {
     constexpr int VEC = 4, NG = 2;
     using R = f32x2;
     const uint32_t tile = tile_of_workgroup(a, blockIdx.x);
@@ -818,6 +819,7 @@ void cook_torrance_repeat_kernel(const KArgs a) {
     if (a.H != PH) repeat_window(a, p);                                      // a thin band: the walk's rows are a cyclic window of the map's
     Texels<VEC> t;
     load_texels<WF, TI, VEC, NTL>(a, a.has_normal != 0, p, t);
+    prepare(p, t);
     decode_texels<WF, VEC, true>(a, t);
     const Vec3 V = view_of(a);
     const LightU lu = light_of(a, 0);
@@ -896,6 +898,12 @@ void cook_torrance_repeat_kernel(const KArgs a) {
             store_at(ry, rx, res);
         }
     }
+}
+
+template <int LIGHT, int WF, typename TI, typename TO, bool NTL, bool NTS, bool MULTI = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void cook_torrance_repeat_kernel(const KArgs a) {
+    repeat_forward_body<LIGHT, WF, TI, TO, NTL, NTS, MULTI>(a, [](const LanePos &, Texels<4> &) {});
 }
 
 }  // namespace pbr

@@ -358,3 +358,47 @@ def test_folded_backward_guard_bands_thin_bands_and_ragged_widths():
         for gr, rf in zip(grads, ref):
             tol = (1e-5 if dtype == torch.float32 else 4e-3) * (float(rf.grad.abs().max()) + 1e-12) + 1e-9
             assert (gr.float() - rf.grad).abs().max().item() <= tol, tag
+
+
+@pytest.mark.parametrize("light_type", ["point", "directional"])
+@pytest.mark.parametrize("lights", [1, 3])
+@pytest.mark.parametrize("workflow,hw,tile,B", [("metallic", (16, 64), (2, 2), None), ("specular", (9, 38), (3, 2), None), ("converted", (12, 40), (2, 3), 2),
+                                                ("metallic", (7, 13), (3, 2), None)])
+def test_fused_blend_over_tiled_maps_walks_the_source_and_equals_the_wrap_around_form(light_type, lights, workflow, hw, tile, B):
+    """Round 6: `cook_torrance(blend=..., tile=n)` -- the blend example's material, lazily blended and tiled -- blends ONCE per texel and evaluates it at
+    every repeat (cook_torrance_repeat_blend_kernel) instead of blending at every output pixel (2 x 2048^2 under tile(2): 154 -> 90 us).  Same functions per
+    pixel: bit-identical to the wrap-around form (PBR_TUNE_TILE_REPEAT = 0) and to blend -> repeat -> render, whole images and row bands of any height."""
+    from pypbr_amd import functional as F
+    from pypbr_amd.blending import blend_maps
+    (h, w), (ny, nx) = hw, tile
+    g = torch.Generator().manual_seed(13 * h + w + lights)
+    lead = () if B is None else (B,)
+
+    def material():
+        m = [_material(g, h, w, workflow) for _ in range(B or 1)]
+        keys = ("albedo", "normal", "roughness", "metallic" if workflow != "specular" else "specular")
+        cols = [torch.stack([x[k] for x in m]) if B else m[0][k] for k in keys]
+        return [t.cuda() for t in cols]
+    a1, n1, r1, x1 = material()
+    a2, n2, r2, x2 = material()
+    mask = torch.rand(*lead, 1, h, w, generator=g).cuda()
+    spec = workflow == "specular"
+    first = (a1, n1, r1, None if spec else x1, x1 if spec else None)
+    second = (a2, n2, r2, None if spec else x2, x2 if spec else None, mask)
+    L = [[0.1, 0.1, 1.0], [-0.4, 0.2, 0.7], [0.3, -0.3, 0.9]][:lights] if light_type == "point" else [[0.3, -0.2, 1.0], [0.1, 0.4, 0.8], [-0.2, 0.1, 1.0]][:lights]
+    I = [[1.0, 0.9, 0.8], [0.4, 0.5, 0.6], [0.3, 0.3, 0.3]][:lights]
+    kw = dict(view_dir=[0.05, 0.1, 0.9], light=L if lights > 1 else L[0], light_intensity=I if lights > 1 else I[0], light_type=light_type,
+              light_size=1.5 if light_type == "point" else None, convert_to_diffuse_specular=(workflow == "converted"))
+    full = F.cook_torrance(*first, blend=second, tile=tile, **kw)
+    try:
+        _knob(0)
+        wrap = F.cook_torrance(*first, blend=second, tile=tile, **kw)
+    finally:
+        _knob(-1)
+    assert torch.equal(full, wrap)
+    H = ny * h
+    for y0, rows in ((0, 1), (h - 1, 2), (1, h - 1), (H - 3, 3), (2, h), (h // 2 + 1, h + 1)):
+        rows = min(rows, H - y0)
+        band_kw = dict(kw, tile=tile, y_offset=y0, rows=rows)
+        got = F.cook_torrance(*first, blend=second, **band_kw)
+        assert got.shape[-2:] == (rows, nx * w) and torch.equal(got, full[..., y0:y0 + rows, :]), (y0, rows)

@@ -49,6 +49,7 @@ print(f'''| kernel (4096² probe shape unless noted) | algorithmic bytes per pix
 | `cook_torrance_mse_step_kernel` — rendering-loss step, fp32 | 44 + 32 | {us('loss_step_f32')} | {fr('loss_step_f32')} | {tr('loss_step_f32')} | {vb('loss_step_f32')} | HBM / VALU |
 | `cook_torrance_mse_stream_kernel` — the same, fp16 maps | 28 + 16 | {us('loss_step_f16')} | {fr('loss_step_f16')} | {tr('loss_step_f16')} | {vb('loss_step_f16')} | VALU issue |
 | `cook_torrance_blend_kernel` — blend + re-decode + render | 68 + 12 | {us('blend_fused')} | {fr('blend_fused')} | {tr('blend_fused')} | {vb('blend_fused')} | HBM (20 streams) |
+| **`cook_torrance_repeat_blend_kernel`** — the fused blend over TILED maps (round 6): 2 × 2048² materials + mask under `tile(2)` → 4096², blended once per texel, evaluated at every repeat | 68 per texel + 12 per output pixel | **{us('blend_tiled_fwd')}** | {fr('blend_tiled_fwd')} | **{tr('blend_tiled_fwd')}** | {vb('blend_tiled_fwd')} | HBM / VALU (until round 6 the wrap-around form, the blend at every output pixel: 154 µs) |
 | `cook_torrance_blend_backward_kernel` | 80 + 68 | {us('blend_bwd')} | {fr('blend_bwd')} | {tr('blend_bwd')} | {vb('blend_bwd')} | HBM (37 streams) |
 | **`cook_torrance_repeat_blend_backward_kernel`** — the fused blend's backward over TILED maps (round 6): 2 × 2048² materials + mask under `tile(2)` → 4096² | 12 per output pixel + 136 per texel | **{us('blend_bwd_tiled')}** | {fr('blend_bwd_tiled')} | **{tr('blend_bwd_tiled')}** | {vb('blend_bwd_tiled')} | VALU issue (two waves per SIMD: 254 registers); unfused: blend backward + decode backward + folded render backward |
 | `colour_kernel` / `colour_backward_kernel` | 12 + 12 / 24 + 12 | {us('map_ops srgb_to_linear 3 x 4096^2 fp32')} / {us('map_ops srgb_to_linear backward')} | {fr('map_ops srgb_to_linear 3 x 4096^2 fp32', 2)} / {fr('map_ops srgb_to_linear backward', 2)} | 1.0001 | 0.25 | HBM |

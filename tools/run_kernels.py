@@ -120,6 +120,15 @@ if want("blend_fused"):
     report("blend_fused: blend_with_mask + re-decode + render, 4096^2 (17 planes in, 3 out)", "cook_torrance_blend_kernel<1, 0, 4, false>",
            80 * PX, timed(lambda: p.launch(stream)))
     del m1, m2, mask, p
+if want("blend_tiled_fwd"):
+    # round 6: the fused blend over TILED maps walks the source -- both materials' texels and the mask loaded once, blended once per texel, evaluated at
+    # every repeat (until then: wrap-around addressing, the blend at every output pixel: 154 us)
+    m1, m2 = synth_material(2048, DEV, 21), synth_material(2048, DEV, 22)
+    mask = torch.rand(1, 2048, 2048, device=DEV)
+    p = F.plan_cook_torrance(*m1, blend=(m2[0], m2[1], m2[2], m2[3], None, mask), tile=2, **PT)
+    report("blend_tiled_fwd: blend_with_mask + re-decode + render over 2048^2 maps under tile(2) -> 4096^2 (17 planes of 2048^2 in once, 3 planes of 4096^2 out)",
+           "cook_torrance_repeat_blend_kernel<1, 0, false>", 68 * 2048 * 2048 + 12 * PX, timed(lambda: p.launch(stream)))
+    del m1, m2, mask, p
 if want("tiled"):
     maps = synth_material(2048, DEV, 31)
     p = F.plan_cook_torrance(*maps, tile=2, **PT)

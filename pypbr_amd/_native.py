@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PBR_HIP_LIB") or os.path.join(_HERE, "libpbr_hip.so")   # env override: A/B of two builds
 
 ABI_VERSION = 8
+RESIZE_TWO_PASS, RESIZE_STRIP, RESIZE_TWO_TAP, RESIZE_BAND_WALK, RESIZE_ROW_WALK = range(5)      # pbr_resize_form
 MAX_LIGHTS = 16
 
 F32, F16 = 0, 1
@@ -32,7 +33,7 @@ EXPORTS = (
     "pbr_cook_torrance", "pbr_srgb_to_linear", "pbr_linear_to_srgb", "pbr_metallic_to_specular",
     "pbr_specular_to_metallic", "pbr_decode_normal", "pbr_abi_version", "pbr_error_string",
     "pbr_kernel_name", "pbr_bytes_per_pixel", "pbr_set_tuning", "pbr_render_desc_size",
-    "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_cook_torrance_backward",
+    "pbr_resize_workspace_bytes", "pbr_resize_bilinear", "pbr_resize_form", "pbr_cook_torrance_backward",
     "pbr_blend_maps", "pbr_blend_sigmoid_mask", "pbr_blend_gradient_mask", "pbr_cook_torrance_autotune",
     "pbr_cook_torrance_blend", "pbr_fold_gradient", "pbr_decode_normal_backward",
     "pbr_blend_normal_sign", "pbr_blend_backward_serves", "pbr_blend_maps_backward", "pbr_param_grad_workspace_bytes", "pbr_cook_torrance_backward_params",
@@ -199,6 +200,8 @@ def lib():
     L.pbr_resize_workspace_bytes.restype = ctypes.c_size_t
     L.pbr_resize_bilinear.argtypes = [vp, vp, i64, i32, i32, i32, i32, ctypes.c_int, vp, vp]
     L.pbr_resize_bilinear.restype = ctypes.c_int
+    L.pbr_resize_form.argtypes = [vp, vp, i64, i32, i32, i32, i32, ctypes.c_int, vp]
+    L.pbr_resize_form.restype = ctypes.c_int
     L.pbr_blend_maps.argtypes = [vp, vp, vp, vp, i32, i64, ctypes.c_int, vp]
     L.pbr_blend_maps_backward.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i64, ctypes.c_int, ctypes.c_int, vp]
     L.pbr_blend_maps_backward.restype = ctypes.c_int

@@ -909,6 +909,7 @@ static int band_window(const AxisFilter &f, int n_out, int rows) {
 
 }  // namespace pbr
 #include "resize_down.hpp"
+#include "resize_stream.hpp"
 namespace pbr {
 
 static AxisFilter make_filter(int n_in, int n_out, bool antialias) {
@@ -968,7 +969,7 @@ static DownTaps up_transpose_taps(int S) {
 
 // Launch of resize_down_kernel: `small` = the side with 1 / S^2 of the elements (the down-scale's result, the up-scale's gradient).  False when the
 // shape is not the kernel's (the caller goes on to its other forms).
-static bool launch_down(const float *large, float *small, int64_t planes, int h_small, int w_small, int S, const DownTaps &taps, hipStream_t s) {
+static bool launch_down(const float *large, float *small, int64_t planes, int h_small, int w_small, int S, const DownTaps &taps, hipStream_t s, bool dry = false) {
     // A lane owns 32 bytes of every row of the large side (8 / S columns of the small one) and walks down a band of rows, R rows of the small side per turn
     // of its loop, the next large row in flight.  Bands are cut so that the launch has ~1 536 waves -- six per CU, which then run side by side from
     // the first to the last row: 3 x 4096^2 -> 2048^2 | 1024^2 | 512^2 (us) with 1 280 / 1 536 / 1 792 / 2 048 / 2 560 / 3 072 / 4 096 / 6 144 waves:
@@ -1008,7 +1009,61 @@ static bool launch_down(const float *large, float *small, int64_t planes, int h_
         default: fn = resize_down_kernel<16, 2, 1, 1>; break;
     }
     if (narrow) fn = S == 2 ? resize_down_kernel<2, 4, 2, 3, true> : resize_down_kernel<4, 2, 1, 3, true>;
+    if (dry) return true;                                   // (pbr_resize_form: the shape is this kernel's)
     hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, large, small, h_small, w_small, (int)groups_x, (int)bands, (int)band_rows, mapped, taps);
+    return true;
+}
+
+// Launch of resize_stream_kernel (resize_stream.hpp): antialiased down-scales by any factor 1.01 <= s <= 16.5 on both axes.  False when the shape is
+// not the kernel's (the caller goes on to the strip form).  `workspace` holds the tables: pbr_resize_workspace_bytes is planes x h_in x w_out floats,
+// the tables need 5 h_in + 2 h_out + (kt + 2) w_out.
+static bool launch_stream(const float *src, float *dst, int64_t planes, int h_in, int w_in, int h_out, int w_out, const AxisFilter &fw, const AxisFilter &fh,
+                          float *workspace, hipStream_t s, bool dry = false) {
+    if (fw.scale < 1.01f || fh.scale < 1.01f || fw.support != fw.scale || fh.support != fh.scale) return false;      // (support = scale: antialiased)
+    if ((int)(2.0f * fw.support) + 3 > 36 || (int)(2.0f * fh.support) + 3 > 36 || w_in % 4 != 0 || w_out < 16 || h_out < 4) return false;      // (the strip form's range of taps)
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(workspace)) & 15u) != 0) return false;
+    const int kt = (int)(2.0f * fw.support) + 2, kw = (kt + 3) & ~3;    // rows of the column table (a window holds at most ceil(2 s) taps: hi - lo < 2 s + 1); taps the width pass walks: whole groups of four
+    const size_t words = 4 * (size_t)h_in + (size_t)h_in + 2 * (size_t)h_out + (size_t)(kt + 2) * (size_t)w_out;
+    if (words > (size_t)planes * (size_t)h_in * (size_t)w_out) return false;
+    // One 16-byte piece of a row per lane (a strip spans 256 input columns), four rows in flight, ~2 048 workgroups, whatever the factor and the number of
+    // planes (tools/resize_stream_probe.py on 3 | 8 x 4096^2 -> 3000^2 ... 300^2, every repetition on freshly allocated buffers: two pieces per lane 5-20 %
+    // slower at every factor; 1 024 | 1 536 | 3 072 | 4 096 workgroups 20 | 3 | 2-10 | 5-20 % slower; eight rows in flight level below 1.6 x, 3-6 % slower above).
+    constexpr int P = 1, D = 4;
+    const bool nt = (int64_t)planes * h_in * w_in * 4 > (256ll << 20);      // the input does not fit the memory-side cache: it streams (8 x 4096^2: 110 -> 101 us at 10 x)
+    // output columns per strip: as many as keep every strip's window (its start aligned down to 16 bytes) within 256 P input columns
+    auto window_fits = [&](int oc) {
+        for (int xb = 0; xb < w_out; xb += oc) {
+            const int last = (xb + oc < w_out ? xb + oc : w_out) - 1;
+            int lo, n, lo2, n2; float c;
+            tap_window(fw, xb, lo, n, c);
+            tap_window(fw, last, lo2, n2, c);
+            if (lo2 + n2 - (lo & ~3) > 256 * P) return false;
+        }
+        return true;
+    };
+    int oc = (int)(((float)(256 * P - 5) - 2.0f * fw.support) / fw.scale);
+    if (oc > w_out) oc = w_out;
+    while (oc >= 8 && !window_fits(oc)) --oc;
+    if (oc < 8) return false;
+    const int64_t strips = (w_out + oc - 1) / oc;
+    int64_t bands = 2048 / (planes * strips);
+    bands = bands < 1 ? 1 : bands;
+    int64_t band_rows = (h_out + bands - 1) / bands;
+    band_rows = band_rows < 4 ? 4 : band_rows;
+    bands = (h_out + band_rows - 1) / band_rows;
+    const int64_t pairs = planes * bands, n_groups = pairs * strips;
+    if (n_groups > INT32_MAX) return false;
+    const size_t lds = sizeof(float) * ((size_t)2 * (4 / P) * (256 * P + 40) + (size_t)(kw + 2) * oc + 8);      // two buffers of finished rows | the strip's column table | two notes
+    if (lds > 32 * 1024) return false;
+    if (dry) return true;
+    float4 *rec = reinterpret_cast<float4 *>(workspace);
+    int *orow = reinterpret_cast<int *>(rec + h_in), *ylo = orow + h_in, *yhi = ylo + h_out, *xlo = yhi + h_out, *xn = xlo + w_out;
+    float *wx = reinterpret_cast<float *>(xn + w_out);
+    const int groups_y = (h_in + 255) / 256, groups_x = (w_out + 255) / 256;
+    hipLaunchKernelGGL(resize_stream_tables_kernel, dim3(groups_y + groups_x), dim3(256), 0, s, rec, orow, ylo, yhi, xlo, xn, wx, kt, h_out, w_out, fh, fw, groups_y);
+    const StreamGeom g = {h_out, w_out, h_in, w_in, kw, kt, oc, (int)strips, (int)bands, (int)band_rows, (uint32_t)((pairs / 8) * 8 * strips)};
+    auto fn = nt ? resize_stream_kernel<P, D, true> : resize_stream_kernel<P, D, false>;
+    hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(128), lds, s, src, dst, g, rec, orow, ylo, yhi, xlo, xn, wx);
     return true;
 }
 
@@ -1025,8 +1080,9 @@ size_t pbr_resize_workspace_bytes(int64_t planes, int32_t h_in, int32_t w_out) {
     return planes < 1 || h_in < 1 || w_out < 1 ? 0 : (size_t)planes * (size_t)h_in * (size_t)w_out * sizeof(float);
 }
 
-int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
-                        int32_t w_out, int antialias, void *workspace, void *stream) {
+// pbr_resize_bilinear and pbr_resize_form: `form` receives the kernel family; `dry` = decide, launch nothing
+static int resize_forward(const void *src, void *dst, int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
+                          int32_t w_out, int antialias, void *workspace, void *stream, bool dry, int *form) {
     using namespace pbr;
     if (!src || !dst || !workspace) return PBR_ERR_NULL_MAP;
     if (planes < 1 || h_in < 1 || w_in < 1 || h_out < 1 || w_out < 1) return PBR_ERR_SHAPE;
@@ -1045,6 +1101,8 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
             const uint32_t span = 8u << kUpRunLog2;
             const uint32_t xcd_groups = (uint32_t)(n_groups / span) * span;
             auto fn = rows == 8 ? resize_up2_kernel<8> : resize_up2_kernel<4>;
+            *form = PBR_RESIZE_TWO_TAP;
+            if (dry) return PBR_OK;
             hipLaunchKernelGGL(fn, dim3((unsigned)n_groups), dim3(64), 0, s, static_cast<const float *>(src), static_cast<float *>(dst),
                                (int)h_in, (int)w_in, (int)h_out, (int)w_out, (int)groups_x, (int)groups_y, xcd_groups, fw, fh);
             const hipError_t e = hipGetLastError();
@@ -1052,8 +1110,24 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
         }
     }
     if (g_resize_up2 && antialias && h_in % h_out == 0 && w_in % w_out == 0 && h_in / h_out == w_in / w_out && h_in / h_out >= 2 && h_in / h_out <= 16 &&
-        launch_down(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_out, w_out, h_in / h_out, down_taps(h_in / h_out), s)) {
+        launch_down(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_out, w_out, h_in / h_out, down_taps(h_in / h_out), s, dry)) {
         // a whole factor 2 ... 8 | 16 on both axes: the register form (resize_down.hpp)
+        *form = PBR_RESIZE_BAND_WALK;
+        if (dry) return PBR_OK;
+        const hipError_t e = hipGetLastError();
+        return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+    }
+    // Antialiased down-scales from 6.5 x up (17 ... 36 taps per axis: the strip form's WIDE instantiation): every input row once (resize_stream.hpp).
+    // tools/resize_stream_probe.py, us, stream | strip, every repetition on freshly allocated buffers, six boxes:  8 x 4096^2 -> 400^2  99-110 | 126-130,
+    // -> 300^2  96-111 | 127-131;  3 x 4096^2 -> 400^2  40-43 | 44, -> 300^2  42-45 | 59-61.  Below 6.5 x the walk is built and bit-identical too (knob value 2
+    // takes it wherever the shape allows) but not the rule: 8 planes 1.4 ... 6 x: level with the strip form on most boxes (-> 1365^2 111-125 | 118-123,
+    // -> 2000^2 120-143 | 140-143), up to 30 % behind on others (-> 3000^2 165-252 | 178-182: these launches write half of what they read, and the walk's
+    // narrow row pieces take their box's memory placement harder than tiles do); 3 planes 3 ... 6 x: 2-6 % behind (its tables kernel: 3 of 40 us).
+    const bool many_taps = (int)(2.0f * fw.support) + 3 > 16 || (int)(2.0f * fh.support) + 3 > 16;
+    if (g_resize_up2 && antialias && (many_taps || g_resize_up2 == 2) &&
+        launch_stream(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_in, w_in, h_out, w_out, fw, fh, tmp, s, dry)) {
+        *form = PBR_RESIZE_ROW_WALK;
+        if (dry) return PBR_OK;
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? PBR_OK : 1000 + (int)e;
     }
@@ -1086,6 +1160,8 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
                 const int quads = 0;      // 16-byte stores in the forward width pass: 62.7 against 54.0 us with them (4096^2 -> 2048^2): never
                 const StripGeom tg = {toh, (int)tx, (int)tyy, kx, ky, pitch, vec_ok ? 1 : 0, (int)chunk, (int)(chunk ? (n_tiles / (8 * chunk)) * 8 * chunk : 0), quads};
                 auto strip = kx <= 16 && ky <= 16 ? resize_strip_kernel<false, false> : resize_strip_kernel<false, false, true>;
+                *form = PBR_RESIZE_STRIP;
+                if (dry) return PBR_OK;
                 hipLaunchKernelGGL(strip, dim3((unsigned)(planes * tx * tyy)), dim3(256), lds, s,
                                    static_cast<const float *>(src), static_cast<float *>(dst), (int)h_out, (int)w_out, (int)w_in, tg, fw, fh, StripTables{});
                 const hipError_t e = hipGetLastError();
@@ -1094,12 +1170,27 @@ int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in
         }
     }
     // more than 36 taps per axis (down-scales beyond ~16.5x): two passes through `workspace`
+    *form = PBR_RESIZE_TWO_PASS;
+    if (dry) return PBR_OK;
     hipLaunchKernelGGL(resize_width_kernel, dim3(stream_grid(planes * h_in * w_out)), dim3(256), 0, s,
                        static_cast<const float *>(src), tmp, planes * h_in, (int)w_out, fw);
     hipLaunchKernelGGL(resize_height_kernel, dim3(stream_grid(planes * h_out * w_out)), dim3(256), 0, s,
                        tmp, static_cast<float *>(dst), planes, (int)h_out, (int)w_out, fh);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? PBR_OK : 1000 + (int)e;
+}
+
+int pbr_resize_bilinear(const void *src, void *dst, int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
+                        int32_t w_out, int antialias, void *workspace, void *stream) {
+    int form = 0;
+    return resize_forward(src, dst, planes, h_in, w_in, h_out, w_out, antialias, workspace, stream, false, &form);
+}
+
+int pbr_resize_form(const void *src, const void *dst, int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
+                    int32_t w_out, int antialias, const void *workspace) {
+    int form = -1;
+    const int rc = resize_forward(src, const_cast<void *>(dst), planes, h_in, w_in, h_out, w_out, antialias, const_cast<void *>(workspace), nullptr, true, &form);
+    return rc == PBR_OK ? form : -1;
 }
 
 // workspace layout (floats): tmp [planes][h_in][w_out] | inv_y [h_out] | inv_x [w_out] | wy [kBwdMaxTaps][h_in] | wx [kBwdMaxTaps][w_in] |

@@ -402,3 +402,75 @@ def test_fused_blend_over_tiled_maps_walks_the_source_and_equals_the_wrap_around
         band_kw = dict(kw, tile=tile, y_offset=y0, rows=rows)
         got = F.cook_torrance(*first, blend=second, **band_kw)
         assert got.shape[-2:] == (rows, nx * w) and torch.equal(got, full[..., y0:y0 + rows, :]), (y0, rows)
+
+
+def test_row_walk_downscale_equals_the_strip_kernel_and_aten():
+    """Round 6: antialiased down-scales that are NOT a whole factor -- MaterialBase.resize of a 4096^2 texture to 400^2 or 1365^2
+    (/root/reference/pypbr/materials/base.py:490-504) -- as a walk down the INPUT rows (csrc/resize_stream.hpp): every row read once, added to the (at most three)
+    output rows whose windows hold it, finished rows through LDS to a second wave for the width pass.  The strip kernel's taps in the strip kernel's order:
+    BIT-IDENTICAL to it at every factor (knob PBR_TUNE_RESIZE_UP2 = 2 takes the walk wherever the shape allows, 0 the strip form), <= 2e-6 from ATen's
+    antialiased interpolate.  The rule (knob 1) takes it from 6.5 x up; pbr_resize_form says which family serves a call, so the comparison cannot pass on
+    one kernel compared with itself.  Shapes: factors 1.02 ... 16.4 that differ per axis, one and several strips / bands, widths that leave the last strip a few
+    columns, several planes, windows clipped at all four edges."""
+    from pypbr_amd import _native as N
+    lib = N.lib()
+    stream = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator().manual_seed(86)
+
+    def run(x, ho, wo, knob):
+        planes, hi, wi = x.shape
+        out = torch.full((planes, ho, wo), float("nan"), device="cuda")
+        ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(planes, hi, wo) // 4), device="cuda")
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, knob)
+        form = lib.pbr_resize_form(x.data_ptr(), out.data_ptr(), planes, hi, wi, ho, wo, 1, ws.data_ptr())
+        N.check(lib.pbr_resize_bilinear(x.data_ptr(), out.data_ptr(), planes, hi, wi, ho, wo, 1, ws.data_ptr(), stream))
+        torch.cuda.synchronize()
+        return out, form
+
+    shapes = [(1, 64, 64, 40, 40), (3, 512, 512, 341, 341), (2, 1024, 1024, 100, 100), (1, 1000, 1024, 333, 700), (3, 256, 2048, 77, 1365),
+              (1, 2048, 2048, 1365, 1365), (2, 2048, 2048, 200, 200), (1, 4096, 4096, 400, 400), (1, 2048, 2048, 1500, 1500), (1, 1024, 1024, 1000, 1000),
+              (2, 777, 1024, 123, 321), (1, 96, 128, 17, 16), (3, 600, 800, 37, 49), (1, 4096, 4096, 249, 249), (4, 300, 512, 20, 500),
+              (1, 2048, 4096, 1990, 1366), (2, 128, 5000, 50, 1234)]
+    try:
+        for planes, hi, wi, ho, wo in shapes:
+            x = torch.rand(planes, hi, wi, generator=g) * 2 - 0.5
+            xd = x.cuda()
+            walk, f2 = run(xd, ho, wo, 2)
+            strip, f0 = run(xd, ho, wo, 0)
+            rule, f1 = run(xd, ho, wo, 1)
+            many_taps = max(hi / ho, wi / wo) >= 7.0
+            assert f2 == N.RESIZE_ROW_WALK and f0 == N.RESIZE_STRIP, (planes, hi, wi, ho, wo, f2, f0)
+            assert f1 == (N.RESIZE_ROW_WALK if many_taps else N.RESIZE_STRIP), (planes, hi, wi, ho, wo, f1)
+            assert torch.equal(walk, strip) and torch.equal(rule, strip), (planes, hi, wi, ho, wo, float((walk - strip).abs().max()))
+            ref = torch.nn.functional.interpolate(x[None], size=(ho, wo), mode="bilinear", align_corners=False, antialias=True)[0]
+            assert (walk.cpu() - ref).abs().max().item() <= 2e-6, (planes, hi, wi, ho, wo)
+        # an input beyond the 256 MB memory-side cache streams (non-temporal loads): the same sums
+        big = torch.rand(5, 4096, 4096, device="cuda")
+        for ho in (1365, 400):
+            walk, f2 = run(big, ho, ho, 2)
+            strip, f0 = run(big, ho, ho, 0)
+            assert f2 == N.RESIZE_ROW_WALK and f0 == N.RESIZE_STRIP and torch.equal(walk, strip), ho
+        del big, walk, strip
+        # infinities and NaNs poison exactly the outputs whose windows hold them: rows at weight 0 in front of a window's first tap, a slot's last row, do not leak
+        x = torch.rand(1, 512, 512, generator=g)
+        x[0, 100, 200] = float("inf"); x[0, 300, 17] = float("nan"); x[0, 511, 511] = float("-inf"); x[0, 0, 0] = float("inf")
+        for ho in (150, 40):
+            walk, f2 = run(x.cuda(), ho, ho, 2)
+            strip, _ = run(x.cuda(), ho, ho, 0)
+            ref = torch.nn.functional.interpolate(x[None], size=(ho, ho), mode="bilinear", align_corners=False, antialias=True)[0]
+            assert f2 == N.RESIZE_ROW_WALK
+            assert torch.equal(torch.isfinite(walk), torch.isfinite(strip)) and torch.equal(torch.isfinite(walk).cpu(), torch.isfinite(ref)), ho
+            assert torch.equal(walk[torch.isfinite(walk)], strip[torch.isfinite(strip)]), ho
+        # what the walk does not take stays with the other families whatever the knob says: rows that are not whole 16-byte pieces, a view off a 16-byte
+        # boundary, no antialiasing, an up-scale on one axis, a whole factor (the band walk), a factor within 1 % of 1, more than 36 taps
+        flat = torch.rand(3 * 64 * 64 + 1, generator=g).cuda()
+        for x, ho, wo, aa, want in ((torch.rand(2, 100, 1022, generator=g).cuda(), 30, 300, 1, N.RESIZE_STRIP), (flat[1:].view(3, 64, 64), 20, 20, 1, N.RESIZE_STRIP),
+                                    (torch.rand(1, 512, 512, generator=g).cuda(), 100, 100, 0, N.RESIZE_STRIP), (torch.rand(1, 512, 512, generator=g).cuda(), 100, 600, 1, N.RESIZE_STRIP),
+                                    (torch.rand(1, 512, 512, generator=g).cuda(), 128, 128, 1, N.RESIZE_BAND_WALK), (torch.rand(1, 2048, 512, generator=g).cuda(), 2047, 100, 1, N.RESIZE_STRIP), (torch.rand(1, 2048, 2048, generator=g).cuda(), 64, 64, 1, N.RESIZE_TWO_PASS)):
+            planes, hi, wi = x.shape
+            out = torch.empty(planes, ho, wo, device="cuda")
+            ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(planes, hi, wo) // 4), device="cuda")
+            lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 2)
+            assert lib.pbr_resize_form(x.data_ptr(), out.data_ptr(), planes, hi, wi, ho, wo, aa, ws.data_ptr()) == want, (hi, wi, ho, wo, aa)
+    finally:
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, -1)

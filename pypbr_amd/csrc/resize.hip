@@ -1117,14 +1117,20 @@ static int resize_forward(const void *src, void *dst, int64_t planes, int32_t h_
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? PBR_OK : 1000 + (int)e;
     }
-    // Antialiased down-scales from 6.5 x up (17 ... 36 taps per axis: the strip form's WIDE instantiation): every input row once (resize_stream.hpp).
-    // tools/resize_stream_probe.py, us, stream | strip, every repetition on freshly allocated buffers, six boxes:  8 x 4096^2 -> 400^2  99-110 | 126-130,
-    // -> 300^2  96-111 | 127-131;  3 x 4096^2 -> 400^2  40-43 | 44, -> 300^2  42-45 | 59-61.  Below 6.5 x the walk is built and bit-identical too (knob value 2
-    // takes it wherever the shape allows) but not the rule: 8 planes 1.4 ... 6 x: level with the strip form on most boxes (-> 1365^2 111-125 | 118-123,
-    // -> 2000^2 120-143 | 140-143), up to 30 % behind on others (-> 3000^2 165-252 | 178-182: these launches write half of what they read, and the walk's
-    // narrow row pieces take their box's memory placement harder than tiles do); 3 planes 3 ... 6 x: 2-6 % behind (its tables kernel: 3 of 40 us).
+    // Antialiased down-scales that are not a whole factor: every input row once (resize_stream.hpp) -- from 6.5 x up (17 ... 36 taps per axis: the strip form's
+    // WIDE instantiation) always, from a quarter of the pixels down when the input is larger than the 256 MB memory-side cache (a material's eight planes of 4096^2
+    // in one call: the strip form reads every input row about twice, which costs nothing out of that cache and 10-15 % out of HBM).
+    // tools/resize_stream_probe.py, median us, walk | strip, every repetition on freshly allocated buffers, eight boxes:
+    //   8 x 4096^2 -> 400^2   99-110 | 126-130     -> 300^2   96-111 | 127-131     3 x 4096^2 -> 400^2  40-43 | 44     -> 300^2  42-45 | 59-61
+    //   8 x 4096^2 -> 2000^2 119-143 | 140-143     -> 1365^2 106-125 | 118-123     -> 1000^2 101-120 | 108-116     -> 700^2 101-110 | 105-115
+    // The walk is built and bit-identical for every factor from 1.01 x (knob value 2 takes it wherever the shape allows) but not the rule elsewhere:
+    // 8 planes below 2 x: level on most boxes (-> 2731^2 151-160 | 157-160, -> 3000^2 175-182 | 174-182), 30 % behind on one in eight (209 | 158, 238 | 180:
+    // these launches write half of what they read, and the walk's narrow row pieces take a box's memory placement harder than tiles do);
+    // 3 planes between 2.2 x and 6.5 x: 2-6 % behind (-> 1365^2 41-43 | 40, -> 1000^2 38-39 | 37.5: the input sits in the memory-side cache).
     const bool many_taps = (int)(2.0f * fw.support) + 3 > 16 || (int)(2.0f * fh.support) + 3 > 16;
-    if (g_resize_up2 && antialias && (many_taps || g_resize_up2 == 2) &&
+    const bool streams = (int64_t)planes * h_in * w_in * 4 > (256ll << 20);
+    const bool walk = many_taps || (streams && fw.scale * fh.scale >= 4.0f);
+    if (g_resize_up2 && antialias && (walk || g_resize_up2 == 2) &&
         launch_stream(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_in, w_in, h_out, w_out, fw, fh, tmp, s, dry)) {
         *form = PBR_RESIZE_ROW_WALK;
         if (dry) return PBR_OK;

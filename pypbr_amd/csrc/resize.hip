@@ -1027,7 +1027,7 @@ static bool launch_stream(const float *src, float *dst, int64_t planes, int h_in
     if (words > (size_t)planes * (size_t)h_in * (size_t)w_out) return false;
     // One 16-byte piece of a row per lane (a strip spans 256 input columns), four rows in flight, ~2 048 workgroups, whatever the factor and the number of
     // planes (tools/resize_stream_probe.py on 3 | 8 x 4096^2 -> 3000^2 ... 300^2, every repetition on freshly allocated buffers: two pieces per lane 5-20 %
-    // slower at every factor; 1 024 | 1 536 | 3 072 | 4 096 workgroups 20 | 3 | 2-10 | 5-20 % slower; eight rows in flight level below 1.6 x, 3-6 % slower above).
+    // slower at every factor; 1 024 | 1 536 | 3 072 | 4 096 workgroups 20 | 3 | 2-10 | 5-20 % slower; eight rows in flight level below 1.6 x, 3-6 % slower above; 6 144 ... 24 576 short bands dispatched in memory order: 5-25 % slower from 2 x up, 10-15 % faster below 1.6 x on a box where the walk ran slow).
     constexpr int P = 1, D = 4;
     const bool nt = (int64_t)planes * h_in * w_in * 4 > (256ll << 20);      // the input does not fit the memory-side cache: it streams (8 x 4096^2: 110 -> 101 us at 10 x)
     // output columns per strip: as many as keep every strip's window (its start aligned down to 16 bytes) within 256 P input columns

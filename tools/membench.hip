@@ -364,6 +364,10 @@ int main(int argc, char **argv) {
             RATIO_UP(true, "resize pattern 4:9, nt loads");
             CHECK(hipFree(up));
         }
+        // EIGHT planes on the large side (537 MB: nothing survives a launch): what the row walk (resize_stream.hpp) is measured against
+        RATIO(9, 1, true, false, 2 * px / 9, "resize pattern 9:1 over 8 planes (3x down), nt loads");
+        RATIO(9, 1, false, false, 2 * px / 9, "resize pattern 9:1 over 8 planes, plain loads");
+        RATIO(105, 1, true, false, 2 * px / 105, "resize pattern 105:1 over 8 planes (10.24x down), nt loads");
         RATIO(1, 4, false, false, big / 4, "resize pattern 1:4 (grad of 2x down), plain loads");
         RATIO(1, 4, true, false, big / 4, "resize pattern 1:4, nt loads");
         RATIO(4, 1, false, false, big / 4, "resize pattern 4:1 (2x down, grad of 2x up), plain loads");

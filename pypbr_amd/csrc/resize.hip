@@ -1026,8 +1026,9 @@ static bool launch_stream(const float *src, float *dst, int64_t planes, int h_in
     const size_t words = 4 * (size_t)h_in + (size_t)h_in + 2 * (size_t)h_out + (size_t)(kt + 2) * (size_t)w_out;
     if (words > (size_t)planes * (size_t)h_in * (size_t)w_out) return false;
     // One 16-byte piece of a row per lane (a strip spans 256 input columns), four rows in flight, ~2 048 workgroups, whatever the factor and the number of
-    // planes (tools/resize_stream_probe.py on 3 | 8 x 4096^2 -> 3000^2 ... 300^2, every repetition on freshly allocated buffers: two pieces per lane 5-20 %
-    // slower at every factor; 1 024 | 1 536 | 3 072 | 4 096 workgroups 20 | 3 | 2-10 | 5-20 % slower; eight rows in flight level below 1.6 x, 3-6 % slower above; 6 144 ... 24 576 short bands dispatched in memory order: 5-25 % slower from 2 x up, 10-15 % faster below 1.6 x on a box where the walk ran slow).
+    // planes (tools/resize_stream_probe.py on 3 | 8 x 4096^2 -> 3000^2 ... 300^2, every repetition on freshly allocated buffers, with boost clocks AND after 150 ms
+    // of launches: two pieces per lane level to 20 % slower; 1 024 | 1 536 | 3 072 | 4 096 workgroups 20 | 3 | 2-20 | 5-20 % slower; eight rows in flight 3-6 % slower;
+    // 6 144 ... 24 576 short bands dispatched in memory order: 5-25 % slower from 2 x up).
     constexpr int P = 1, D = 4;
     const bool nt = (int64_t)planes * h_in * w_in * 4 > (256ll << 20);      // the input does not fit the memory-side cache: it streams (8 x 4096^2: 110 -> 101 us at 10 x)
     // output columns per strip: as many as keep every strip's window (its start aligned down to 16 bytes) within 256 P input columns
@@ -1117,19 +1118,14 @@ static int resize_forward(const void *src, void *dst, int64_t planes, int32_t h_
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? PBR_OK : 1000 + (int)e;
     }
-    // Antialiased down-scales that are not a whole factor: every input row once (resize_stream.hpp) -- from 6.5 x up (17 ... 36 taps per axis: the strip form's
-    // WIDE instantiation) always, from a quarter of the pixels down when the input is larger than the 256 MB memory-side cache (a material's eight planes of 4096^2
-    // in one call: the strip form reads every input row about twice, which costs nothing out of that cache and 10-15 % out of HBM).
-    // tools/resize_stream_probe.py, median us, walk | strip, every repetition on freshly allocated buffers, eight boxes:
-    //   8 x 4096^2 -> 400^2   99-110 | 126-130     -> 300^2   96-111 | 127-131     3 x 4096^2 -> 400^2  40-43 | 44     -> 300^2  42-45 | 59-61
-    //   8 x 4096^2 -> 2000^2 119-143 | 140-143     -> 1365^2 106-125 | 118-123     -> 1000^2 101-120 | 108-116     -> 700^2 101-110 | 105-115
-    // The walk is built and bit-identical for every factor from 1.01 x (knob value 2 takes it wherever the shape allows) but not the rule elsewhere:
-    // 8 planes below 2 x: level on most boxes (-> 2731^2 151-160 | 157-160, -> 3000^2 175-182 | 174-182), 30 % behind on one in eight (209 | 158, 238 | 180:
-    // these launches write half of what they read, and the walk's narrow row pieces take a box's memory placement harder than tiles do);
-    // 3 planes between 2.2 x and 6.5 x: 2-6 % behind (-> 1365^2 41-43 | 40, -> 1000^2 38-39 | 37.5: the input sits in the memory-side cache).
-    const bool many_taps = (int)(2.0f * fw.support) + 3 > 16 || (int)(2.0f * fh.support) + 3 > 16;
-    const bool streams = (int64_t)planes * h_in * w_in * 4 > (256ll << 20);
-    const bool walk = many_taps || (streams && fw.scale * fh.scale >= 4.0f);
+    // Antialiased down-scales from 6.5 x up that are not a whole factor (17 ... 36 taps per axis: the strip form's WIDE instantiation): every input row once
+    // (resize_stream.hpp).  tools/resize_stream_probe.py, us, walk | strip, after 150 ms of launches (settled clocks), every repetition on freshly allocated buffers:
+    //   8 x 4096^2 -> 400^2  100 | 126     -> 300^2  97 | 128     3 x 4096^2 -> 400^2  35-40 | 44     -> 300^2  42 | 60
+    // The walk is built and bit-identical for every factor from 1.01 x (knob value 2 takes it wherever the shape allows) but NOT the rule below 6.5 x: it has more
+    // instructions per byte there (a width pass per 1.4 ... 6 input rows) and loses with the clocks -- at boost clocks (the first ~20 launches after an idle moment)
+    // 8 x 4096^2 -> 2000^2 | 1365^2 | 1000^2 read 120 | 107 | 102 against the strip form's 140 | 119 | 108, after 150 ms of launches 139 | 125-132 | 107 against
+    // 140 | 117-122 | 108, and below 2 x 187-228 against 154-174; a cache-resident input (3 planes) between 2.2 x and 6.5 x is 2-6 % faster through the strip form.
+    const bool walk = (int)(2.0f * fw.support) + 3 > 16 || (int)(2.0f * fh.support) + 3 > 16;
     if (g_resize_up2 && antialias && (walk || g_resize_up2 == 2) &&
         launch_stream(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_in, w_in, h_out, w_out, fw, fh, tmp, s, dry)) {
         *form = PBR_RESIZE_ROW_WALK;

@@ -27,9 +27,21 @@ def resize(a, ho, wo, knob):
     return out
 
 
+WARM_MS = float(os.environ.get("WARM_MS", "150"))
+
+
 def timed(fn, reps=50, warm=5):
+    """After an idle moment the GPU runs ~20 launches at boost clocks and the next ones up to 25 % slower (tools/transient_probe.py): launch for WARM_MS first, as
+    tools/run_kernels.py does -- the walk loses more to the settled clocks than the strip kernel does (8 x 4096^2 -> 1365^2: 107 -> 132 us against 119 -> 122)."""
+    import time
     for _ in range(warm):
         fn()
+    torch.cuda.synchronize()
+    t_end = time.perf_counter() + WARM_MS * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):

@@ -247,8 +247,8 @@ if want("resize"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)
     # whole factors 2 ... 8 | 16 down (what resize(512) of a 1024^2 ... 4096^2 texture is): the register-only band walk (round 5); any other down-scale: the
-    # walk down the input rows (round 6: resize_stream.hpp; its time here is the call's: tables kernel + walk) from 6.5 x up (4096 -> 400: 10.24x) and, for inputs beyond
-    # the 256 MB memory-side cache, from 2 x up (8 planes 4096 -> 1365: 3.0007x), the strip kernel otherwise (3 planes 4096 -> 1365); up-scales: the two-tap register kernel.  THREE planes = one map, 201 MB: between launches it stays in the 256 MB
+    # strip kernel (4096 -> 1365: 3.0007x) below 6.5 x, the walk down the input rows (round 6: resize_stream.hpp; its time here is the call's: tables kernel + walk) from there up
+    # (4096 -> 400: 10.24x); up-scales: the two-tap register kernel.  THREE planes = one map, 201 MB: between launches it stays in the 256 MB
     # memory-side cache; EIGHT planes (537 MB) is the same kernel with nothing left from the launch before -- the HBM figure.
     for planes in (3, 8):
         if planes == 8:
@@ -258,7 +258,7 @@ if want("resize"):
         k2, k4 = ("resize_down_kernel<2, 4, 4, 1, false>", "resize_down_kernel<4, 2, 2, 1, false>") if planes == 3 else \
                  ("resize_down_kernel<2, 4, 2, 3, true>", "resize_down_kernel<4, 2, 1, 3, true>")
         for (ho, wo), aa, kern in (((S // 2, S // 2), True, k2), ((S // 4, S // 4), True, k4),
-                                   ((S // 8, S // 8), True, "resize_down_kernel<8, 2, 1, 1, false>"), ((1365, 1365), True, "resize_strip_kernel<false, false, false>" if planes == 3 else "resize_stream_kernel<1, 4, true>"),
+                                   ((S // 8, S // 8), True, "resize_down_kernel<8, 2, 1, 1, false>"), ((1365, 1365), True, "resize_strip_kernel<false, false, false>"),
                                    ((400, 400), True, "resize_stream_kernel<1, 4, %s>" % ("false" if planes == 3 else "true")),
                                    ((S * 3 // 2, S * 3 // 2), False, "resize_up2_kernel<8>")):
             if planes == 8 and ho > S:
@@ -268,14 +268,12 @@ if want("resize"):
             report(f"resize {planes} x 4096^2 -> {ho}x{wo} antialias={aa}", kern, 4 * planes * (PX + ho * wo),
                    timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), planes, S, S, ho, wo, int(aa), ws.data_ptr(), stream)))
             del out, ws
-        # 4096^2 -> 1365^2 by the family that is NOT the rule for this input: 3 planes (201 MB, cache-resident: the rule is the strip kernel) by the row walk (knob value 2),
-        # 8 planes (537 MB: the rule is the walk) by the strip kernel (knob value 0)
+        # 4096^2 -> 1365^2 by the row walk, which is NOT the rule below 6.5 x (knob value 2): the figure behind that rule (resize.hip)
         out = torch.empty(planes, 1365, 1365, device=DEV)
         ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(planes, S, 1365) // 4), device=DEV)
-        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 2 if planes == 3 else 0)
-        report(f"resize_other{planes}: {planes} x 4096^2 -> 1365x1365 antialias=True by " + ("the row walk (knob value 2; the rule for a cache-resident input is the strip kernel)" if planes == 3 else
-               "the strip kernel (knob value 0; the rule for an input that streams is the row walk)"),
-               "resize_stream_kernel<1, 4, false>" if planes == 3 else "resize_strip_kernel<false, false, false>", 4 * planes * (PX + 1365 * 1365),
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 2)
+        report(f"resize_walk{planes}: {planes} x 4096^2 -> 1365x1365 antialias=True by the row walk (knob value 2; the rule keeps the strip kernel below 6.5 x)",
+               "resize_stream_kernel<1, 4, %s>" % ("false" if planes == 3 else "true"), 4 * planes * (PX + 1365 * 1365),
                timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), planes, S, S, 1365, 1365, 1, ws.data_ptr(), stream)))
         lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, -1)
         del out, ws

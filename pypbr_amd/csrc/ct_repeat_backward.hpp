@@ -310,7 +310,7 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
         auto positions = [&](auto srgb_tag) {
         constexpr bool SRGB = decltype(srgb_tag)::value;
         for (int k = 0; k < n_pos; ++k) {
-            const int ry = n_ry, rx = n_rx, yrow = n_yrow;
+            const int rx = n_rx, yrow = n_yrow;
             const int64_t rep = n_rep;
             // advance to the next position and start its loads: they travel under this position's arithmetic
             ++n_rx; n_rep += col_step;

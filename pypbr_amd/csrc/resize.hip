@@ -13,7 +13,8 @@
 // With antialias off (or when up-scaling) this reduces to the ordinary 2-tap bilinear rule with
 // edge clamping, so one kernel covers both settings.
 //
-// Schedule: ONE kernel (resize_strip_kernel below), HEIGHT pass first.  The tap pattern down the rows is the same for
+// (The kernel families and which shapes each takes: pbr_resize_form in include/pbr_hip.h; the register-only ones live in resize_down.hpp and below, the row walk in
+// resize_stream.hpp.)  Schedule of the general one: ONE kernel (resize_strip_kernel below), HEIGHT pass first.  The tap pattern down the rows is the same for
 // every column, so the height pass needs no exchange between lanes: it runs on registers straight from global memory,
 // and only the height-reduced strip of a tile goes through LDS for the width pass.  Tap weights are normalised once per
 // tile (as ATen does) instead of per output.  4096^2 -> 2048^2, 3 planes, antialiased: 450 MB of HBM traffic for two

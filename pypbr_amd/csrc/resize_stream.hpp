@@ -1,4 +1,4 @@
-// resize_stream.hpp -- antialiased down-scale by ANY factor 1 < s <= 16.5 on both axes: every input row read ONCE (round 6).
+// resize_stream.hpp -- antialiased down-scale by ANY factor 1.01 <= s <= 16.5 on both axes: every input row read ONCE (round 6; the rule from 6.5 x up: resize.hip).
 //
 // What MaterialBase.resize (/root/reference/pypbr/materials/base.py:490-504) does when the target is not a whole fraction of the
 // texture (4096^2 -> 1365^2, -> 400^2, 2048^2 -> 1000^2 ...): torchvision's resize = F.interpolate(mode="bilinear", antialias=True), ATen's
@@ -6,12 +6,13 @@
 // of a tile it loads the row's K input rows, so every input row crosses L2 -> CU about twice, a tile's halo rows (102 read for the 82
 // owned at 10.24 x) leave HBM a second time (PMC: 1.15 x), and three barrier-separated phases share a workgroup's time.
 //
-// Here a one-wave workgroup owns a STRIP of output columns (the 256 P input columns their windows span, a 16-byte piece per lane and
-// P) and a BAND of output rows, and walks down the band's INPUT rows: row r is loaded once and added to the (at most three) output
-// rows whose windows hold it -- ceil(2 + 1/s) = 3 windows overlap for a triangle of support s whose centres are s apart -- each output
-// row's taps in ascending order, exactly the chain resize_strip_kernel forms (bit-identical results).  The three accumulators are a
-// shift register: slot 0 is the oldest output row still open; when its last tap is in, the row goes through the wave's own LDS strip
-// for the width pass (per-lane columns, weights from an LDS copy of the strip's slice of the column table) and the slots move up.
+// Here a workgroup owns a STRIP of output columns (the 256 P input columns their windows span, a 16-byte piece per lane and P) and a BAND
+// of output rows.  Its first wave walks down the band's INPUT rows: row r is loaded once and added to the (at most three) output rows
+// whose windows hold it -- ceil(2 + 1/s) = 3 windows overlap for a triangle of support s whose centres are s apart -- each output row's
+// taps in ascending order, exactly the chain resize_strip_kernel forms (bit-identical results).  The three accumulators are a shift
+// register: slot 0 is the oldest output row still open; when its last tap is in, the row goes to LDS and the slots move up.  The
+// workgroup's second wave runs the width pass over the finished rows (per-lane columns, weights from an LDS copy of the strip's slice
+// of the column table) and stores (why two waves: at the kernel).
 // What a row contributes to which slot is WAVE-UNIFORM and the same for every strip and plane: resize_stream_tables_kernel writes one
 // 16-byte record per input row (three normalised weights, the slots that START with this row, the number of output rows that END
 // with it) into the workspace, and the walk reads it with one scalar load per row: the weights are scalar operands of the fma.

@@ -285,7 +285,7 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
             for (int c = 0; c < 3; ++c) Ld<float, VEC>::template load<true>(lane_base + (rep_bytes + c * plane_bytes), 0, dst[c]);
         };
         // the position in flight: loaded one iteration ahead
-        int n_ry = 0, n_rx = 0, n_yrow = p.y;
+        int n_rx = 0, n_yrow = p.y;
         int64_t n_rep = 0;
         // The upstream values (the loss step: the target's) of a position: the plain gradient kernels keep the NEXT position's in flight under this
         // one's arithmetic (a second set of 6 registers: they fit three waves per SIMD with it); the loss step and the several-lights form request
@@ -314,7 +314,7 @@ __device__ __forceinline__ void repeat_backward_body(const KArgs &a, const BArgs
             const int64_t rep = n_rep;
             // advance to the next position and start its loads: they travel under this position's arithmetic
             ++n_rx; n_rep += col_step;
-            if (n_rx == a.rep_x) { n_rx = 0; ++n_ry; n_yrow += PH; n_rep += row_step - col_step; }
+            if (n_rx == a.rep_x) { n_rx = 0; n_yrow += PH; n_rep += row_step - col_step; }
             if constexpr (kAhead) {
                 if (k + 1 < n_pos && row_in_band(n_yrow)) fetch(n_rep, go_next);
             }

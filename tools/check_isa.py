@@ -202,6 +202,34 @@ TRANS_OPS = ("v_exp_f32", "v_log_f32", "v_rcp_f32", "v_rsq_f32", "v_sqrt_f32", "
              "v_exp_f16", "v_log_f16", "v_rcp_f16", "v_rsq_f16", "v_sqrt_f16", "v_sin_f16", "v_cos_f16", "v_exp_legacy_f32", "v_log_legacy_f32")
 
 
+def check_row_walk_kernel(sym, insts):
+    """resize_stream_kernel<P, D, NT> (csrc/resize_stream.hpp): its ring loads are inline assembly the compiler does not track, waited for by a
+    hand-written `s_waitcnt vmcnt((D - 1) P)`.  The compiler believes a loaded register is valid the moment the load is issued: nothing may touch a
+    load's destination between the load and the next counted wait (a copy the register allocator slips in there would read stale data), and the
+    kernel must hold exactly the loads and waits the count assumes: 2 D P loads (prologue + loop), D counted waits, the final vmcnt(0)."""
+    m = re.search(r"resize_stream_kernelILi(\d+)ELi(\d+)E", sym)
+    P, D = int(m.group(1)), int(m.group(2))
+    bad = []
+    loads = [i for i, (op, _) in enumerate(insts) if op == "global_load_dwordx4"]
+    waits = [i for i, (op, args) in enumerate(insts) if op == "s_waitcnt" and re.search(r"vmcnt\((\d+)\)", args) and int(re.search(r"vmcnt\((\d+)\)", args).group(1)) == (D - 1) * P]
+    if len(loads) != 2 * D * P:
+        bad.append("%s: %d ring loads, expected %d" % (sym[:70], len(loads), 2 * D * P))
+    if len(waits) != D:
+        bad.append("%s: %d waits for vmcnt(%d), expected %d" % (sym[:70], len(waits), (D - 1) * P, D))
+    if not any(op == "s_waitcnt" and "vmcnt(0)" in args for op, args in insts[loads[-1]:] if loads):
+        bad.append("%s: no vmcnt(0) behind the last ring load" % sym[:70])
+    for i in loads:
+        dest = _vgprs(insts[i][1].split(",")[0])
+        for j in range(i + 1, len(insts)):
+            op, args = insts[j]
+            if op == "s_waitcnt" and "vmcnt" in args:
+                break
+            if op != "global_load_dwordx4" and _vgprs(args) & dest:
+                bad.append("%s: %s %s touches v%s between its load and the wait" % (sym[:60], op, args, sorted(dest)))
+                break
+    return "row_walk<%d, %d> %s  ring loads %d  counted waits %d" % (P, D, "nt" if "Lb1E" in sym else "plain", len(loads), len(waits)), bad
+
+
 def _vgprs(text):
     out = set()
     for m in re.finditer(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b", text):
@@ -284,6 +312,15 @@ def check(verbose=False):
             failures.append("an 8-pixel multi-light instantiation exists again (it does not fit 128 VGPRs and is never launched)")
         for s in xp:
             line, bad = check_xpose_kernel(s, fns[s], meta.get(s, {}))
+            report.append(line)
+            failures += bad
+        co = _code_object(os.path.join(CSRC, "resize.o"), tmp)
+        fns = _functions(co)
+        walk = sorted(s for s in fns if "resize_stream_kernelILi" in s)
+        if len(walk) != 2:
+            failures.append("expected 2 instantiations of resize_stream_kernel, found %d" % len(walk))
+        for s in walk:
+            line, bad = check_row_walk_kernel(s, fns[s])
             report.append(line)
             failures += bad
         # every kernel of every object: the trans-forwarding hazard (inline-assembly consumers are not covered by the compiler), and --

@@ -85,7 +85,7 @@ enum {
     PBR_TUNE_BWD_RUN = 8,               /* rounds of the streamed backward kernel for fp16 maps with one light (-1 = rule, 0 = the one-tile kernels) */
     PBR_TUNE_MSE_STREAM = 9,            /* rendering-loss step for fp16 maps with one light: the streamed kernel (1, default) or the one-tile kernels (0) */
     PBR_TUNE_TILE_REPEAT = 10,          /* tiled maps: every texel loaded and decoded once and evaluated / differentiated at all its repeats (-1 = rule: on, 0 = wrap-around addressing, gradients folded by a second kernel) */
-    PBR_TUNE_RESIZE_UP2 = 11,           /* the register-only resize kernels -- two taps for up-scales on both axes, the band walk for whole factors 2 ... 8 | 16 down, the row walk for other antialiased down-scales from 6.5 x up (1, default) -- or the strip kernels (0); 2 = as 1, with the row walk at every antialiased down-scale it can take (a test / measurement setting) */
+    PBR_TUNE_RESIZE_UP2 = 11,           /* the register-only resize kernels -- two taps for up-scales on both axes, the band walk for whole factors 2 ... 8 | 16 down, the row walk for other antialiased down-scales from 7 x up (1, default) -- or the strip kernels (0); 2 = as 1, with the row walk at every antialiased down-scale it can take (a test / measurement setting) */
     PBR_TUNE_COUNT = 12
 };
 /* (10 knobs in use since ABI 8.  ABI 6 carried 23 knobs; the 11 whose experiments are closed -- workgroup interleave, 16-byte streamed backward, the resize
@@ -403,7 +403,7 @@ enum {
     PBR_RESIZE_STRIP = 1,               /* one kernel, tile by tile through an LDS strip (csrc/resize.hip: resize_strip_kernel) */
     PBR_RESIZE_TWO_TAP = 2,             /* up-scales on both axes, registers only (resize_up2_kernel) */
     PBR_RESIZE_BAND_WALK = 3,           /* antialiased whole factors 2 ... 8 | 16, registers only (csrc/resize_down.hpp) */
-    PBR_RESIZE_ROW_WALK = 4             /* other antialiased down-scales from 6.5 x up (every one up to 16.5 x with the knob PBR_TUNE_RESIZE_UP2 at 2): every input row read once (csrc/resize_stream.hpp) */
+    PBR_RESIZE_ROW_WALK = 4             /* other antialiased down-scales from 7 x up, i.e. 17 ... 36 taps per axis (every one from 1.01 x to 17 x with the knob PBR_TUNE_RESIZE_UP2 at 2): every input row read once (csrc/resize_stream.hpp) */
 };
 int pbr_resize_form(const void *src, const void *dst, int64_t planes, int32_t h_in, int32_t w_in, int32_t h_out,
                     int32_t w_out, int antialias, const void *workspace);

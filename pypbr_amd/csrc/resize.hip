@@ -293,7 +293,7 @@ __device__ __forceinline__ void width_to_global_quads(const float *mid, float *d
 // upstream gradient.  Phase 0 copies the tile's slices of the tables into the same LDS arrays; phases 1 and 2 do not change.
 struct StripTables { const int *lo_x, *cnt_x, *lo_y, *cnt_y; const float *w_x, *w_y; int nx, ny, h_src; const float *band; const int *col_base; const float *col_w; };
 
-// WIDE: the instantiation for 17 ... 36 taps per axis (down-scales of 6.5x ... 16.5x; round 5) -- its own kernel, so that its registers (36 pieces of a column in
+// WIDE: the instantiation for 17 ... 36 taps per axis (down-scales of 7x ... 17x: (int)(2 s) + 3 taps; round 5) -- its own kernel, so that its registers (36 pieces of a column in
 // flight: 190 VGPRs) are not the occupancy of the common one (89).
 template <bool TABLES, bool QUADS, bool WIDE = false>
 __global__ __launch_bounds__(256) void resize_strip_kernel(const float *__restrict__ src, float *__restrict__ dst, int h_out,
@@ -1015,7 +1015,7 @@ static bool launch_down(const float *large, float *small, int64_t planes, int h_
     return true;
 }
 
-// Launch of resize_stream_kernel (resize_stream.hpp): antialiased down-scales by any factor 1.01 <= s <= 16.5 on both axes.  False when the shape is
+// Launch of resize_stream_kernel (resize_stream.hpp): antialiased down-scales by any factor 1.01 <= s < 17 on both axes.  False when the shape is
 // not the kernel's (the caller goes on to the strip form).  `workspace` holds the tables: pbr_resize_workspace_bytes is planes x h_in x w_out floats,
 // the tables need 5 h_in + 2 h_out + (kt + 2) w_out.
 static bool launch_stream(const float *src, float *dst, int64_t planes, int h_in, int w_in, int h_out, int w_out, const AxisFilter &fw, const AxisFilter &fh,
@@ -1119,13 +1119,14 @@ static int resize_forward(const void *src, void *dst, int64_t planes, int32_t h_
         const hipError_t e = hipGetLastError();
         return e == hipSuccess ? PBR_OK : 1000 + (int)e;
     }
-    // Antialiased down-scales from 6.5 x up that are not a whole factor (17 ... 36 taps per axis: the strip form's WIDE instantiation): every input row once
+    // Antialiased down-scales from 7 x up that are not a whole factor (17 ... 36 taps per axis, (int)(2 s) + 3: the strip form's WIDE instantiation): every input row once
     // (resize_stream.hpp).  tools/resize_stream_probe.py, us, walk | strip, after 150 ms of launches (settled clocks), every repetition on freshly allocated buffers:
     //   8 x 4096^2 -> 400^2  100 | 126     -> 300^2  97 | 128     3 x 4096^2 -> 400^2  35-40 | 44     -> 300^2  42 | 60
-    // The walk is built and bit-identical for every factor from 1.01 x (knob value 2 takes it wherever the shape allows) but NOT the rule below 6.5 x: it has more
+    // The walk is built and bit-identical for every factor from 1.01 x (knob value 2 takes it wherever the shape allows) but NOT the rule below 7 x: it has more
     // instructions per byte there (a width pass per 1.4 ... 6 input rows) and loses with the clocks -- at boost clocks (the first ~20 launches after an idle moment)
     // 8 x 4096^2 -> 2000^2 | 1365^2 | 1000^2 read 120 | 107 | 102 against the strip form's 140 | 119 | 108, after 150 ms of launches 139 | 125-132 | 107 against
-    // 140 | 117-122 | 108, and below 2 x 187-228 against 154-174; a cache-resident input (3 planes) between 2.2 x and 6.5 x is 2-6 % faster through the strip form.
+    // 140 | 117-122 | 108, and below 2 x 187-228 against 154-174; a cache-resident input (3 planes) between 2.2 x and 7 x is 2-6 % faster through the strip form.  (And the boxes differ: on one in four the walk's stores drain
+    // fast enough for it to win from 1.5 x up -- 106 against 117 at 1365^2, equally settled; the strip form's figures do not move.  profiles/EXPERIMENTS.md.)
     const bool walk = (int)(2.0f * fw.support) + 3 > 16 || (int)(2.0f * fh.support) + 3 > 16;
     if (g_resize_up2 && antialias && (walk || g_resize_up2 == 2) &&
         launch_stream(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_in, w_in, h_out, w_out, fw, fh, tmp, s, dry)) {
@@ -1137,7 +1138,7 @@ static int resize_forward(const void *src, void *dst, int64_t planes, int32_t h_
     {   // strip form: tap tables + the height-reduced strip [toh][pitch] of a toh x 64 output tile in LDS, up to 36 taps per axis
         const int kx = (int)(2.0f * fw.support) + 3, ky = (int)(2.0f * fh.support) + 3;      // taps per output: xsize <= 2 support + 2
         const bool vec_ok = w_in % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0;
-        if (kx <= 36 && ky <= 36) {                                                           // (round 5: 16 -> 36 taps, i.e. down-scales up to 16.5x keep the one-kernel form)
+        if (kx <= 36 && ky <= 36) {                                                           // (round 5: 16 -> 36 taps, i.e. down-scales below 17x keep the one-kernel form)
             const int cols_max = (int)(kTileW * fw.scale + 2.0f * fw.support) + 4 + 3;       // + 3: window start aligned down to 16 bytes
             const int pitch = ((cols_max + 3) & ~3) + 4;                                      // + 4 floats: rows land on different banks
             auto lds_for = [&](int rows) {
@@ -1172,7 +1173,7 @@ static int resize_forward(const void *src, void *dst, int64_t planes, int32_t h_
             }
         }
     }
-    // more than 36 taps per axis (down-scales beyond ~16.5x): two passes through `workspace`
+    // more than 36 taps per axis (down-scales from 17x): two passes through `workspace`
     *form = PBR_RESIZE_TWO_PASS;
     if (dry) return PBR_OK;
     hipLaunchKernelGGL(resize_width_kernel, dim3(stream_grid(planes * h_in * w_out)), dim3(256), 0, s,

@@ -1,4 +1,4 @@
-// resize_stream.hpp -- antialiased down-scale by ANY factor 1.01 <= s <= 16.5 on both axes: every input row read ONCE (round 6; the rule from 6.5 x up: resize.hip).
+// resize_stream.hpp -- antialiased down-scale by ANY factor 1.01 <= s < 17 on both axes: every input row read ONCE (round 6; the rule from 7 x up: resize.hip).
 //
 // What MaterialBase.resize (/root/reference/pypbr/materials/base.py:490-504) does when the target is not a whole fraction of the
 // texture (4096^2 -> 1365^2, -> 400^2, 2048^2 -> 1000^2 ...): torchvision's resize = F.interpolate(mode="bilinear", antialias=True), ATen's

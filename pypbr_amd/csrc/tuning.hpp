@@ -45,4 +45,4 @@ struct TuningScope {
 #define g_bwd_run          (::pbr::knob(PBR_TUNE_BWD_RUN))          // tiles per wave of the streamed backward kernel (fp16 maps, one light): -1 = rule, 0 = off
 #define g_mse_stream       (::pbr::knob(PBR_TUNE_MSE_STREAM))       // ct_loss.hip: streamed loss step for fp16 maps with one light (1) or the one-tile kernels (0)
 #define g_tile_repeat      (::pbr::knob(PBR_TUNE_TILE_REPEAT))      // tiled maps: the repeat-inner kernels, forward and backward (-1 = rule: on, 0 = the wrap-around form)
-#define g_resize_up2       (::pbr::knob(PBR_TUNE_RESIZE_UP2))       // resize.hip: the register-only kernels (two-tap up-scales, whole-factor down-scales) and the row walk from 6.5x down-scales up (1), the strip kernels (0), the row walk at every down-scale it can take (2)
+#define g_resize_up2       (::pbr::knob(PBR_TUNE_RESIZE_UP2))       // resize.hip: the register-only kernels (two-tap up-scales, whole-factor down-scales) and the row walk from 7x down-scales up (1), the strip kernels (0), the row walk at every down-scale it can take (2)

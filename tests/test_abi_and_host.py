@@ -684,3 +684,41 @@ def test_loader_keeps_samples_and_decodes_only_the_chosen_workflows_maps(tmp_pat
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             IO.load_material_from_folder(str(tmp_path), preferred_workflow="specular")
+
+
+def test_resize_form_names_the_family_that_serves_a_shape():
+    """pbr_resize_form (ABI 8) decides like pbr_resize_bilinear and launches nothing -- it only looks at the pointers' alignment -- so the dispatch rule of
+    csrc/resize.hip is host logic a box without a GPU can pin: up-scales -> the two-tap kernel, antialiased whole factors 2 ... 8 | 16 -> the band walk,
+    other antialiased down-scales from 7 x up -> the row walk (round 6), everything else -> the strip kernel, beyond 36 taps -> two passes; knob value 0
+    keeps the strip kernel, 2 takes the row walk at every factor it can; rows that are not whole 16-byte pieces, unaligned views and outputs too small for a
+    strip never reach the row walk.  MaterialBase.resize, /root/reference/pypbr/materials/base.py:490-504."""
+    from pypbr_amd import _native as N
+    lib = N.lib()
+    A, U = 0x7000000000, 0x7000000004            # a 16-byte aligned address and one that is not (never dereferenced)
+
+    def form(planes, hi, wi, ho, wo, aa=1, src=A, ws=A, knob=-1):
+        lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, knob)
+        try:
+            return lib.pbr_resize_form(src, A, planes, hi, wi, ho, wo, aa, ws)
+        finally:
+            lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, -1)
+
+    assert form(3, 4096, 4096, 6144, 6144, aa=0) == N.RESIZE_TWO_TAP and form(3, 512, 512, 512, 512) == N.RESIZE_TWO_TAP
+    for S in (2, 3, 4, 5, 6, 7, 8, 16):
+        out = 4096 // S // 4 * 4                  # (3, 5, 6, 7 do not divide 4096: 1364, 816, 680, 584 -- factors 3.003 ... 7.01)
+        want = N.RESIZE_BAND_WALK if 4096 % S == 0 else (N.RESIZE_ROW_WALK if int(2.0 * 4096 / out) + 3 > 16 else N.RESIZE_STRIP)
+        assert form(3, 4096, 4096, out, out) == want, S
+    assert form(3, 3 * 1024, 3 * 1024, 1024, 1024) == N.RESIZE_BAND_WALK and form(3, 7 * 512, 7 * 512, 512, 512) == N.RESIZE_BAND_WALK
+    assert form(8, 4096, 4096, 400, 400) == N.RESIZE_ROW_WALK and form(3, 4096, 4096, 300, 300) == N.RESIZE_ROW_WALK      # 10.24 x, 13.65 x
+    assert form(3, 4096, 4096, 580, 2000) == N.RESIZE_ROW_WALK and form(3, 4096, 4096, 590, 2000) == N.RESIZE_STRIP      # 7.06 x | 6.94 x down the rows, 2.05 x across: one axis with 17 taps is enough
+    assert form(8, 4096, 4096, 1365, 1365) == N.RESIZE_STRIP and form(3, 4096, 4096, 700, 700) == N.RESIZE_STRIP           # below 7 x: the strip kernel is the rule
+    assert form(8, 4096, 4096, 1365, 1365, knob=2) == N.RESIZE_ROW_WALK and form(3, 4096, 4096, 3000, 3000, knob=2) == N.RESIZE_ROW_WALK
+    assert form(8, 4096, 4096, 400, 400, knob=0) == N.RESIZE_STRIP and form(3, 4096, 4096, 2048, 2048, knob=0) == N.RESIZE_STRIP
+    assert form(1, 4096, 4096, 100, 100) == N.RESIZE_TWO_PASS                       # 41 x: more than 36 taps
+    assert form(3, 4096, 4096, 400, 400, aa=0) == N.RESIZE_STRIP                    # no antialiasing: two taps per output, no walk
+    assert form(3, 4096, 4094, 400, 400) == N.RESIZE_STRIP                          # rows that are not whole 16-byte pieces
+    assert form(3, 4096, 4096, 400, 400, src=U) == N.RESIZE_STRIP and form(3, 4096, 4096, 400, 400, ws=U) == N.RESIZE_STRIP
+    assert form(3, 4096, 4096, 400, 12) == N.RESIZE_TWO_PASS and form(3, 128, 128, 3, 12, knob=2) == N.RESIZE_TWO_PASS     # (341 x across; 42 x down the rows)
+    assert form(3, 200, 200, 20, 12, knob=2) == N.RESIZE_STRIP                      # a result narrower than a strip's minimum
+    assert form(3, 4096, 4096, 4000, 4090, knob=2) == N.RESIZE_STRIP                # a factor within 1 % of 1
+    assert form(0, 4096, 4096, 400, 400) == -1 and form(3, 4096, 4096, 0, 400) == -1 and lib.pbr_resize_form(0, A, 3, 64, 64, 32, 32, 1, A) == -1

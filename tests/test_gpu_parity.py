@@ -720,7 +720,7 @@ def test_fused_tile_gradients_and_material_api():
                                         ((1, 1024, 1024), (64, 64)), ((2, 700, 1100), (64, 100)), ((1, 640, 1024), (37, 64)), ((3, 512, 2048), (40, 128))])
 @pytest.mark.parametrize("antialias", [True, False])
 def test_resize_fused_and_two_pass_forms_against_aten(shape, size, antialias):
-    """The schedules of pbr_resize_bilinear (LDS-fused tile kernel, its instantiation for 17 ... 36 taps -- down-scales of 6.5x ... 16.5x, round 5 --, two
+    """The schedules of pbr_resize_bilinear (LDS-fused tile kernel, its instantiation for 17 ... 36 taps -- down-scales of 7x ... 17x, round 5 --, two
     passes beyond) against the op the reference ends up in: torch.nn.functional.interpolate(bilinear, align_corners=False, antialias) on CPU."""
     from pypbr_amd import functional as F
     g = torch.Generator().manual_seed(sum(shape) + size[0])

@@ -409,7 +409,7 @@ def test_row_walk_downscale_equals_the_strip_kernel_and_aten():
     (/root/reference/pypbr/materials/base.py:490-504) -- as a walk down the INPUT rows (csrc/resize_stream.hpp): every row read once, added to the (at most three)
     output rows whose windows hold it, finished rows through LDS to a second wave for the width pass.  The strip kernel's taps in the strip kernel's order:
     BIT-IDENTICAL to it at every factor (knob PBR_TUNE_RESIZE_UP2 = 2 takes the walk wherever the shape allows, 0 the strip form), <= 2e-6 from ATen's
-    antialiased interpolate.  The rule (knob 1) takes it from 6.5 x up; pbr_resize_form says which family serves a call, so the comparison cannot pass on
+    antialiased interpolate.  The rule (knob 1) takes it from 7 x up; pbr_resize_form says which family serves a call, so the comparison cannot pass on
     one kernel compared with itself.  Shapes: factors 1.02 ... 16.4 that differ per axis, one and several strips / bands, widths that leave the last strip a few
     columns, several planes, windows clipped at all four edges."""
     from pypbr_amd import _native as N
@@ -450,7 +450,7 @@ def test_row_walk_downscale_equals_the_strip_kernel_and_aten():
             walk, f2 = run(big, ho, ho, 2)
             strip, f0 = run(big, ho, ho, 0)
             assert f2 == N.RESIZE_ROW_WALK and f0 == N.RESIZE_STRIP and torch.equal(walk, strip), ho
-            assert run(big, ho, ho, 1)[1] == (N.RESIZE_ROW_WALK if ho == 400 else N.RESIZE_STRIP)      # the rule: the walk from 6.5 x up
+            assert run(big, ho, ho, 1)[1] == (N.RESIZE_ROW_WALK if ho == 400 else N.RESIZE_STRIP)      # the rule: the walk from 7 x up
         del big, walk, strip
         # infinities and NaNs poison exactly the outputs whose windows hold them: rows at weight 0 in front of a window's first tap, a slot's last row, do not leak
         x = torch.rand(1, 512, 512, generator=g)

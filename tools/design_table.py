@@ -60,8 +60,8 @@ print(f'''| kernel (4096² probe shape unless noted) | algorithmic bytes per pix
 | `unpack_dense_kernel<uint8,3,…>` — an RGB image's samples → 3 float32 planes (a normal map: decoded in the same pass) | 3 + 12 | {us('unpack_image 4096^2 RGB uint8 samples')} ({us('unpack_image 4096^2 RGB uint8 normal')}) | {fr('unpack_image 4096^2 RGB uint8 samples', 2)} ({fr('unpack_image 4096^2 RGB uint8 normal', 2)}) | 1.0001 | 0.41 (0.54) | HBM (writes) |
 | **`resize_down_kernel<S,…>`** — whole-factor down-scale, register-only band walk (round 5): ONE 3-plane 4096² map (201 MB: it stays in the 256 MB memory-side cache between launches) → 2048² / 1024² / 512² | 4 per input + 4 per output pixel | {us('resize 3 x 4096^2 -> 2048')} / {us('resize 3 x 4096^2 -> 1024')} / {us('resize 3 x 4096^2 -> 512')} | {fr('resize 3 x 4096^2 -> 2048', 2)} / {fr('resize 3 x 4096^2 -> 1024', 2)} / {fr('resize 3 x 4096^2 -> 512', 2)} | {tr('resize 3 x 4096^2 -> 2048', 3)} / {tr('resize 3 x 4096^2 -> 1024', 3)} / {tr('resize 3 x 4096^2 -> 512', 3)} | {vb('resize 3 x 4096^2 -> 2048')} | HBM + memory-side cache (round 4's strip kernel: 44.8 / 36.0; 8 ×: two passes, 185) |
 | same, 8 planes (537 MB: nothing survives a launch; 2 × and 4 ×: lanes of 16 bytes, non-temporal loads) | same | {us('resize 8 x 4096^2 -> 2048')} / {us('resize 8 x 4096^2 -> 1024')} / {us('resize 8 x 4096^2 -> 512')} | {fr('resize 8 x 4096^2 -> 2048', 2)} / {fr('resize 8 x 4096^2 -> 1024', 2)} / {fr('resize 8 x 4096^2 -> 512', 2)} | {tr('resize 8 x 4096^2 -> 2048', 3)} / {tr('resize 8 x 4096^2 -> 1024', 3)} / {tr('resize 8 x 4096^2 -> 512', 3)} | {vb('resize 8 x 4096^2 -> 2048')} | HBM: what its bare pattern streams at (`r06_membench_resize.txt`) |
-| `resize_strip_kernel` — other down-scales below 6.5 ×: 4096² → 1365², 3 / 8 planes | same | {us('resize 3 x 4096^2 -> 1365')} / {us('resize 8 x 4096^2 -> 1365')} | {fr('resize 3 x 4096^2 -> 1365', 2)} / {fr('resize 8 x 4096^2 -> 1365', 2)} | {tr('resize 3 x 4096^2 -> 1365', 3)} / {tr('resize 8 x 4096^2 -> 1365', 3)} | {vb('resize 3 x 4096^2 -> 1365')} | cached loads (read-only ceiling 5.6 TB/s = 0.70); three barrier-separated phases per tile |
-| **`resize_stream_kernel`** (round 6) — a walk down the INPUT rows, every row read once, two-wave workgroups (walk \| width pass + stores): antialiased down-scales that are not a whole factor, from 6.5 × up (17 … 36 taps; until round 6 the strip kernel's WIDE instantiation: 44 / 130 µs, 0.58 / 0.52 at 1.15 × traffic): 4096² → 400², 3 / 8 planes | same | **{us('resize 3 x 4096^2 -> 400')} / {us('resize 8 x 4096^2 -> 400')}** (+ its tables kernel: 5 µs) | **{fr('resize 3 x 4096^2 -> 400', 2)} / {fr('resize 8 x 4096^2 -> 400', 2)}** | {tr('resize 3 x 4096^2 -> 400', 3)} / {tr('resize 8 x 4096^2 -> 400', 3)} | {vb('resize 3 x 4096^2 -> 400')} | HBM: the bare patterns of the same box in `r06_membench_resize.txt` (read-only 8 planes; 105:1 over 8 planes) |
+| `resize_strip_kernel` — other down-scales below 7 ×: 4096² → 1365², 3 / 8 planes | same | {us('resize 3 x 4096^2 -> 1365')} / {us('resize 8 x 4096^2 -> 1365')} | {fr('resize 3 x 4096^2 -> 1365', 2)} / {fr('resize 8 x 4096^2 -> 1365', 2)} | {tr('resize 3 x 4096^2 -> 1365', 3)} / {tr('resize 8 x 4096^2 -> 1365', 3)} | {vb('resize 3 x 4096^2 -> 1365')} | cached loads (read-only ceiling 5.6 TB/s = 0.70); three barrier-separated phases per tile |
+| **`resize_stream_kernel`** (round 6) — a walk down the INPUT rows, every row read once, two-wave workgroups (walk \| width pass + stores): antialiased down-scales that are not a whole factor, from 7 × up (17 … 36 taps; until round 6 the strip kernel's WIDE instantiation: 44 / 130 µs, 0.58 / 0.52 at 1.15 × traffic): 4096² → 400², 3 / 8 planes | same | **{us('resize 3 x 4096^2 -> 400')} / {us('resize 8 x 4096^2 -> 400')}** (+ its tables kernel: 5 µs) | **{fr('resize 3 x 4096^2 -> 400', 2)} / {fr('resize 8 x 4096^2 -> 400', 2)}** | {tr('resize 3 x 4096^2 -> 400', 3)} / {tr('resize 8 x 4096^2 -> 400', 3)} | {vb('resize 3 x 4096^2 -> 400')} | HBM: the bare patterns of the same box in `r06_membench_resize.txt` (read-only 8 planes; 105:1 over 8 planes) |
 | same kernel where it is NOT the rule (knob value 2): 4096² → 1365², 3 / 8 planes — more instructions per byte (a width pass per three input rows): level with the strip kernel at boost clocks, behind it at settled ones (§3.6) | same | {us('resize_walk3')} / {us('resize_walk8')} | {fr('resize_walk3', 2)} / {fr('resize_walk8', 2)} | {tr('resize_walk3', 3)} / {tr('resize_walk8', 3)} | {vb('resize_walk3')} | VALU / LDS issue at settled clocks |
 | `resize_up2_kernel<8>` 3 × 4096² → 6144² | same | {us('resize 3 x 4096^2 -> 6144')} | {fr('resize 3 x 4096^2 -> 6144', 2)} | {tr('resize 3 x 4096^2 -> 6144', 3)} | {vb('resize 3 x 4096^2 -> 6144')} (round 4: 0.69) | writes |
 | `resize_down_kernel<2,4,2,3,true>` with the transposed two-tap weights — gradient of a 2× up-scale, 6 × 4096² upstream → 2048² (round 4's two-tap transpose: 0.71 at 1.17 × the bytes) | 4 per upstream + 4 per gradient pixel | {us('resize backward 6 x 4096^2')} | {fr('resize backward 6 x 4096^2', 2)} | {tr('resize backward 6 x 4096^2', 3)} | {vb('resize backward 6 x 4096^2')} | HBM |

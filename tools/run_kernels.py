@@ -247,7 +247,7 @@ if want("resize"):
     g = torch.Generator(device=DEV).manual_seed(0)
     a = torch.rand(3, S, S, device=DEV, generator=g)
     # whole factors 2 ... 8 | 16 down (what resize(512) of a 1024^2 ... 4096^2 texture is): the register-only band walk (round 5); any other down-scale: the
-    # strip kernel (4096 -> 1365: 3.0007x) below 6.5 x, the walk down the input rows (round 6: resize_stream.hpp; its time here is the call's: tables kernel + walk) from there up
+    # strip kernel (4096 -> 1365: 3.0007x) below 7 x, the walk down the input rows (round 6: resize_stream.hpp; its time here is the call's: tables kernel + walk) from there up
     # (4096 -> 400: 10.24x); up-scales: the two-tap register kernel.  THREE planes = one map, 201 MB: between launches it stays in the 256 MB
     # memory-side cache; EIGHT planes (537 MB) is the same kernel with nothing left from the launch before -- the HBM figure.
     for planes in (3, 8):
@@ -268,11 +268,11 @@ if want("resize"):
             report(f"resize {planes} x 4096^2 -> {ho}x{wo} antialias={aa}", kern, 4 * planes * (PX + ho * wo),
                    timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), planes, S, S, ho, wo, int(aa), ws.data_ptr(), stream)))
             del out, ws
-        # 4096^2 -> 1365^2 by the row walk, which is NOT the rule below 6.5 x (knob value 2): the figure behind that rule (resize.hip)
+        # 4096^2 -> 1365^2 by the row walk, which is NOT the rule below 7 x (knob value 2): the figure behind that rule (resize.hip)
         out = torch.empty(planes, 1365, 1365, device=DEV)
         ws = torch.empty(max(1, lib.pbr_resize_workspace_bytes(planes, S, 1365) // 4), device=DEV)
         lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, 2)
-        report(f"resize_walk{planes}: {planes} x 4096^2 -> 1365x1365 antialias=True by the row walk (knob value 2; the rule keeps the strip kernel below 6.5 x)",
+        report(f"resize_walk{planes}: {planes} x 4096^2 -> 1365x1365 antialias=True by the row walk (knob value 2; the rule keeps the strip kernel below 7 x)",
                "resize_stream_kernel<1, 4, %s>" % ("false" if planes == 3 else "true"), 4 * planes * (PX + 1365 * 1365),
                timed(lambda: lib.pbr_resize_bilinear(a.data_ptr(), out.data_ptr(), planes, S, S, 1365, 1365, 1, ws.data_ptr(), stream)))
         lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, -1)

@@ -475,3 +475,15 @@ def test_row_walk_downscale_equals_the_strip_kernel_and_aten():
             assert lib.pbr_resize_form(x.data_ptr(), out.data_ptr(), planes, hi, wi, ho, wo, aa, ws.data_ptr()) == want, (hi, wi, ho, wo, aa)
     finally:
         lib.pbr_set_tuning(N.TUNE_RESIZE_UP2, -1)
+
+
+def test_row_walk_fuzz():
+    """tools/resize_walk_fuzz.py: 120 random shapes (factors 1.02 ... 16.9 that differ per axis, 1-5 planes, ragged bands and strips) through the row walk
+    (knob value 2) and the strip kernel (knob value 0), bit for bit; pbr_resize_form tells them apart.  (A walk whose two waves disagreed about a barrier
+    would hang: the driver's per-test timeout is the guard.)"""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("resize_walk_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "resize_walk_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(120, seed=3, verbose=False) >= 80

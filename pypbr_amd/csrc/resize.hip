@@ -1122,11 +1122,13 @@ static int resize_forward(const void *src, void *dst, int64_t planes, int32_t h_
     // Antialiased down-scales from 7 x up that are not a whole factor (17 ... 36 taps per axis, (int)(2 s) + 3: the strip form's WIDE instantiation): every input row once
     // (resize_stream.hpp).  tools/resize_stream_probe.py, us, walk | strip, after 150 ms of launches (settled clocks), every repetition on freshly allocated buffers:
     //   8 x 4096^2 -> 400^2  100 | 126     -> 300^2  97 | 128     3 x 4096^2 -> 400^2  35-40 | 44     -> 300^2  42 | 60
-    // The walk is built and bit-identical for every factor from 1.01 x (knob value 2 takes it wherever the shape allows) but NOT the rule below 7 x: it has more
-    // instructions per byte there (a width pass per 1.4 ... 6 input rows) and loses with the clocks -- at boost clocks (the first ~20 launches after an idle moment)
-    // 8 x 4096^2 -> 2000^2 | 1365^2 | 1000^2 read 120 | 107 | 102 against the strip form's 140 | 119 | 108, after 150 ms of launches 139 | 125-132 | 107 against
-    // 140 | 117-122 | 108, and below 2 x 187-228 against 154-174; a cache-resident input (3 planes) between 2.2 x and 7 x is 2-6 % faster through the strip form.  (And the boxes differ: on one in four the walk's stores drain
-    // fast enough for it to win from 1.5 x up -- 106 against 117 at 1365^2, equally settled; the strip form's figures do not move.  profiles/EXPERIMENTS.md.)
+    // The walk is built and bit-identical for every factor from 1.01 x (knob value 2 takes it wherever the shape allows) but NOT the rule below 7 x, where
+    // its STORES decide: the walking wave alone streams 8 x 4096^2 at its read-only pattern (87-95 us) at every factor and clock, the width pass's arithmetic is free from
+    // 2 x up, and the result's stores cost 0.45-0.9 us per MB where the strip form pays 0.26 (not understood: DESIGN.md section 9).  At boost clocks (the first ~20 launches
+    // after an idle moment) 8 x 4096^2 -> 2000^2 | 1365^2 | 1000^2 read 120 | 107 | 102 against the strip form's 140 | 119 | 108; after 150 ms of launches 139 | 125-132 | 107
+    // against 140 | 117-122 | 108, and below 2 x 187-243 against 154-174 -- on three boxes of four: on the fourth the stores drain fast enough for the walk to win from 1.5 x up
+    // (106 against 117 at 1365^2, equally settled); the strip form's figures do not move.  A cache-resident input (3 planes) between 2.2 x and 7 x is 2-6 % faster
+    // through the strip form.  Every step: profiles/EXPERIMENTS.md.
     const bool walk = (int)(2.0f * fw.support) + 3 > 16 || (int)(2.0f * fh.support) + 3 > 16;
     if (g_resize_up2 && antialias && (walk || g_resize_up2 == 2) &&
         launch_stream(static_cast<const float *>(src), static_cast<float *>(dst), planes, h_in, w_in, h_out, w_out, fw, fh, tmp, s, dry)) {

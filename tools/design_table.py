@@ -62,7 +62,7 @@ print(f'''| kernel (4096² probe shape unless noted) | algorithmic bytes per pix
 | same, 8 planes (537 MB: nothing survives a launch; 2 × and 4 ×: lanes of 16 bytes, non-temporal loads) | same | {us('resize 8 x 4096^2 -> 2048')} / {us('resize 8 x 4096^2 -> 1024')} / {us('resize 8 x 4096^2 -> 512')} | {fr('resize 8 x 4096^2 -> 2048', 2)} / {fr('resize 8 x 4096^2 -> 1024', 2)} / {fr('resize 8 x 4096^2 -> 512', 2)} | {tr('resize 8 x 4096^2 -> 2048', 3)} / {tr('resize 8 x 4096^2 -> 1024', 3)} / {tr('resize 8 x 4096^2 -> 512', 3)} | {vb('resize 8 x 4096^2 -> 2048')} | HBM: what its bare pattern streams at (`r06_membench_resize.txt`) |
 | `resize_strip_kernel` — other down-scales below 7 ×: 4096² → 1365², 3 / 8 planes | same | {us('resize 3 x 4096^2 -> 1365')} / {us('resize 8 x 4096^2 -> 1365')} | {fr('resize 3 x 4096^2 -> 1365', 2)} / {fr('resize 8 x 4096^2 -> 1365', 2)} | {tr('resize 3 x 4096^2 -> 1365', 3)} / {tr('resize 8 x 4096^2 -> 1365', 3)} | {vb('resize 3 x 4096^2 -> 1365')} | cached loads (read-only ceiling 5.6 TB/s = 0.70); three barrier-separated phases per tile |
 | **`resize_stream_kernel`** (round 6) — a walk down the INPUT rows, every row read once, two-wave workgroups (walk \| width pass + stores): antialiased down-scales that are not a whole factor, from 7 × up (17 … 36 taps; until round 6 the strip kernel's WIDE instantiation: 44 / 130 µs, 0.58 / 0.52 at 1.15 × traffic): 4096² → 400², 3 / 8 planes | same | **{us('resize 3 x 4096^2 -> 400')} / {us('resize 8 x 4096^2 -> 400')}** (+ its tables kernel: 5 µs) | **{fr('resize 3 x 4096^2 -> 400', 2)} / {fr('resize 8 x 4096^2 -> 400', 2)}** | {tr('resize 3 x 4096^2 -> 400', 3)} / {tr('resize 8 x 4096^2 -> 400', 3)} | {vb('resize 3 x 4096^2 -> 400')} | HBM: the bare patterns of the same box in `r06_membench_resize.txt` (read-only 8 planes; 105:1 over 8 planes) |
-| same kernel where it is NOT the rule (knob value 2): 4096² → 1365², 3 / 8 planes — more instructions per byte (a width pass per three input rows): level with the strip kernel at boost clocks, behind it at settled ones (§3.6) | same | {us('resize_walk3')} / {us('resize_walk8')} | {fr('resize_walk3', 2)} / {fr('resize_walk8', 2)} | {tr('resize_walk3', 3)} / {tr('resize_walk8', 3)} | {vb('resize_walk3')} | VALU / LDS issue at settled clocks |
+| same kernel where it is NOT the rule (knob value 2): 4096² → 1365², 3 / 8 planes — its stores decide there: ahead of the strip kernel at boost clocks, level or behind at settled ones (§3.6, §9 #3) | same | {us('resize_walk3')} / {us('resize_walk8')} | {fr('resize_walk3', 2)} / {fr('resize_walk8', 2)} | {tr('resize_walk3', 3)} / {tr('resize_walk8', 3)} | {vb('resize_walk3')} | the result's stores (0.45 µs per MB against the strip kernel's 0.26) |
 | `resize_up2_kernel<8>` 3 × 4096² → 6144² | same | {us('resize 3 x 4096^2 -> 6144')} | {fr('resize 3 x 4096^2 -> 6144', 2)} | {tr('resize 3 x 4096^2 -> 6144', 3)} | {vb('resize 3 x 4096^2 -> 6144')} (round 4: 0.69) | writes |
 | `resize_down_kernel<2,4,2,3,true>` with the transposed two-tap weights — gradient of a 2× up-scale, 6 × 4096² upstream → 2048² (round 4's two-tap transpose: 0.71 at 1.17 × the bytes) | 4 per upstream + 4 per gradient pixel | {us('resize backward 6 x 4096^2')} | {fr('resize backward 6 x 4096^2', 2)} | {tr('resize backward 6 x 4096^2', 3)} | {vb('resize backward 6 x 4096^2')} | HBM |
 | `resize_up2_backward_kernel<8,4>` — gradient of a 1.5× up-scale, 3 × 6144² upstream → 4096² | same | {us('resize backward 3 x 6144^2')} | {fr('resize backward 3 x 6144^2', 2)} | {tr('resize backward 3 x 6144^2', 3)} | {vb('resize backward 3 x 6144^2')} | VALU (its column products) / cached loads |
